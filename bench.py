@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: photon packets/s on the 256^3 Stromgren problem.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" is one full iteration of the reference's loop
+(src/IonizationSimulation.cpp:359-643) on every rank:
+    reset_grid -> shoot `--packets` packets -> [sum all-reduce of the
+    accumulators over ranks] -> cell update.
+The grid is first brought to its converged ionization state with untimed
+low-statistics iterations (the cost of a packet depends on how far it travels,
+so a fully ionised start would be a different workload from the one the
+metric is quoted on).
+
+N > 1 is the replicated-grid mode of the reference's MPI path: every rank
+holds the whole grid and shoots `--packets` packets of its own (weak scaling),
+the [16][ncell] accumulator block is sum-reduced with one RCCL all-reduce.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# algorithmic HBM bytes per DDA step, H-only fp64: 16 B cell
+# record read {n x_H, n x_He} + 8 B read + 8 B write of the J_H accumulator
+BYTES_PER_STEP_H_ONLY = 32.
+
+
+def setup_engine(backend, ncell):
+    from cmacionize_amd import STROMGREN as S
+    eng = backend.engine
+    eng.set_sources(S["source_position"], S["source_weight"], S["luminosity"])
+    eng.set_spectrum_monochromatic(S["frequency"])
+    sigma = np.zeros(14)
+    sigma[0] = S["sigma_H"]
+    alpha = np.zeros(14)
+    alpha[0] = S["alpha_H"]
+    eng.set_cross_sections_fixed(sigma)
+    eng.set_recombination_rates_fixed(alpha)
+    n = ncell ** 3
+    x = np.zeros((14, n))
+    x[0] = S["xH"]
+    x[1] = S["xHe"]
+    eng.upload_cells(np.full(n, S["density"]), np.full(n, S["temperature"]), x)
+
+
+def cpu_baseline(ncell, xH, seconds=12.):
+    """The oracle's transport loop (OpenMP, all host cores) on a bounded
+    sample of the same workload: the converged x_H field of the GPU run."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle_lib.build()
+    sim = oracle_lib.stromgren_simulation(ncell, compact=True)
+    sim.x[0][:] = xH
+    cores = oracle_lib.num_threads()
+    n = 20000 * cores
+    t0 = time.perf_counter()
+    sim.shoot(42, 1000, 0, n)
+    dt = time.perf_counter() - t0
+    rate = n / dt
+    n2 = int(max(n, min(rate * seconds, 5e7)))
+    sim.reset()
+    t0 = time.perf_counter()
+    sim.shoot(42, 1001, 0, n2)
+    dt = time.perf_counter() - t0
+    return {"value": n2 / dt, "unit": "packets/s", "cores": cores,
+            "kind": "port",
+            "sample": "%d packets on the converged %d^3 stromgren field, "
+                      "transport only, OpenMP C oracle, %.1f s" %
+                      (n2, ncell, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ncell", type=int, default=256)
+    ap.add_argument("--packets", type=float, default=1e8,
+                    help="packets per rank per step")
+    ap.add_argument("--converge-iterations", type=int, default=12)
+    ap.add_argument("--converge-packets", type=float, default=1e7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from cmacionize_amd.simulation import GpuBackend, ReplicaIterationDriver
+    from cmacionize_amd import STROMGREN as S
+    from cmacionize_amd import engine as E
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" %
+              (args.gpus, world), file=sys.stderr)
+
+    ncell = args.ncell
+    npk = int(args.packets)
+    backend = GpuBackend((ncell,) * 3, S["anchor"], S["sides"], S["periodic"],
+                         device=local_rank, track_heating=False)
+    setup_engine(backend, ncell)
+    driver = ReplicaIterationDriver(backend, rank, world, dist)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # bring the grid to the converged state (untimed)
+    loop = 0
+    for _ in range(args.converge_iterations):
+        driver.iteration(loop, int(args.converge_packets) * world, 42)
+        loop += 1
+    # in the timed region every rank shoots npk packets: global = npk * world
+    for _ in range(args.warmup):
+        driver.iteration(loop, npk * world, 42)
+        loop += 1
+    barrier()
+    backend.engine.get_timing(reset=True)
+    nsteps_total = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        driver.iteration(loop, npk * world, 42)
+        nsteps_total += driver.nsteps
+        loop += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timing = backend.engine.get_timing(reset=True)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_packets = float(npk) * world * args.steps
+        value = total_packets / elapsed
+        shoot_s = timing["shoot_ms"] * 1e-3
+        launches = max(timing["shoot_launches"], 1)
+        # DDA steps executed by THIS rank's launches (nsteps is the global sum)
+        steps_per_launch = nsteps_total / world / launches
+        achieved = (steps_per_launch * BYTES_PER_STEP_H_ONLY /
+                    (shoot_s / launches)) / 1e9
+        xH = backend.engine.download_field(E.FIELD_IONIC_FRACTION)
+        out = {
+            "metric": "photon packets/sec, 256^3 stromgren",
+            "value": value,
+            "unit": "packets/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "stromgren.param %d^3 grid, %.0e packets per GPU "
+                            "per iteration, H-only, converged ionization "
+                            "state; step = reset + shoot + reduce + cell "
+                            "update" % (ncell, npk),
+                "parallelism": "replica x%d (sum all-reduce of accumulators)"
+                               % world,
+            },
+            "transport_only_packets_per_s": float(npk) * args.steps / shoot_s,
+            "dda_steps_per_packet": nsteps_total / total_packets,
+            "cell_update_ms_per_step": timing["update_ms"] /
+            max(timing["update_launches"], 1),
+            "ionized_volume_fraction": float((xH < 0.5).mean()),
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "shoot_kernel<H-only>",
+                "kernel_avg_ms": 1e3 * shoot_s / launches,
+                "bytes_per_dda_step": BYTES_PER_STEP_H_ONLY,
+                "dda_steps_per_launch": steps_per_launch,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ncell, xH)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+/*
+ * device_common.h - structures shared by the host side of the engine and its
+ * kernels (gfx950).
+ */
+#ifndef CMI_DEVICE_COMMON_H
+#define CMI_DEVICE_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CMI_NION 14
+#define CMI_NACC 16
+
+enum {
+  ION_H_n = 0,
+  ION_He_n,
+  ION_C_p1,
+  ION_C_p2,
+  ION_N_n,
+  ION_N_p1,
+  ION_N_p2,
+  ION_O_n,
+  ION_O_p1,
+  ION_Ne_n,
+  ION_Ne_p1,
+  ION_S_p1,
+  ION_S_p2,
+  ION_S_p3
+};
+
+enum { TYPE_PRIMARY = 0, TYPE_DIFFUSE_HI, TYPE_DIFFUSE_HeI, TYPE_ABSORBED };
+
+/* reference constants, src/PhysicalConstants.hpp:61-131 */
+#define CMI_PLANCK 6.626070040e-34
+#define CMI_BOLTZMANN 1.38064852e-23
+#define CMI_LIGHTSPEED 299792458.
+#define CMI_ELECTRONVOLT 1.6021766208e-19
+#define CMI_ELECTRON_MASS 9.10938356e-31
+
+#define CMI_MAX_SOURCES_INLINE 8
+
+/* Geometry of the regular grid (src/CartesianDensityGrid.cpp:40-95) */
+struct GridDev {
+  double anchor[3];
+  double box_sides[3];
+  double cellside[3];
+  double inv_cellside[3];
+  int32_t ncell[3];
+  int32_t periodic[3];
+  int64_t ncell_total;
+};
+
+/* one (ion, shell) term of the Verner cross section, converted as in
+ * src/VernerCrossSections.cpp:36-154 */
+struct VernerTermDev {
+  double E_th, einn;
+  double A_Plconst, A_E_0_inv, A_sigma_0, A_y_a_inv, A_P, A_y_w_sq;
+  double B_E_0_inv, B_sigma_0, B_y_a_inv, B_P, B_y_w_sq, B_y_0, B_y_1_sq;
+  int32_t ion, shell, ninn, ntot;
+};
+#define CMI_VERNER_NTERM_DEV 22
+
+/* radiative recombination fit of a metal ion
+ * (src/VernerRecombinationRates.cpp:104-130), rnew[2], rnew[3] pre-inverted */
+struct VernerRecDev {
+  double p[4];
+  int32_t kind;
+  int32_t pad;
+};
+
+/* charge transfer fit a * t^b * (1 + c exp(d t)) [* exp(e / t)]
+ * (src/ChargeTransferRates.cpp) */
+struct CTFitDev {
+  double a, b, c, d, e, lo, hi;
+  int32_t kind;
+  int32_t pad;
+};
+
+/* All read-only physics tables, one instance in device memory */
+struct TablesDev {
+  VernerTermDev verner[CMI_VERNER_NTERM_DEV];
+  VernerRecDev verner_rec[CMI_NION];
+  CTFitDev ct_recomb_H[CMI_NION];
+  CTFitDev ct_ion_H[CMI_NION];
+  CTFitDev ct_recomb_He[CMI_NION];
+};
+
+/* Physics set-up passed by value to the kernels */
+struct ModelDev {
+  /* sources */
+  int32_t nsource;
+  int32_t spectrum_type;
+  const double *source_position;   /* device [nsource][3] */
+  const double *source_cumulative; /* device [nsource] */
+  double total_luminosity;
+  double mono_frequency;
+  double planck_temperature;
+  /* cross sections / recombination */
+  int32_t xsec_verner;
+  int32_t recomb_verner;
+  double xsec_fixed[CMI_NION];
+  double recomb_fixed[CMI_NION];
+  /* abundances: He C N O Ne S */
+  double abundance[6];
+  /* reemission */
+  int32_t reemit_type;
+  int32_t pad0;
+  double reemit_fixed_probability;
+  double reemit_fixed_frequency;
+  /* thresholds in Hz, src/DensityGrid.hpp:219-222 */
+  double nu_H, nu_He;
+  const TablesDev *tables;
+};
+
+/* SoA cell state, all device pointers to [ncell] doubles */
+struct CellsDev {
+  double *number_density;
+  double *temperature;
+  double *x[CMI_NION];
+  double *acc[CMI_NACC]; /* 14 mean intensities + 2 heating terms */
+  /* transport record: {n * x_H, n * x_He}; .x < 0 marks a vacuum cell */
+  double2 *opacity;
+};
+
+/* packet counters accumulated by the transport kernel */
+struct CountersDev {
+  double totweight;
+  double typecount[4];
+  unsigned long long nsteps;
+};
+
+#endif

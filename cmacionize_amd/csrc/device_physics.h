@@ -1,0 +1,505 @@
+/*
+ * device_physics.h - device functions: packet RNG, atomic data, ionization
+ * balance. Each function cites the reference code it implements.
+ */
+#ifndef CMI_DEVICE_PHYSICS_H
+#define CMI_DEVICE_PHYSICS_H
+
+#include "device_common.h"
+
+/* ---------------------------------------------------------------- RNG -- */
+
+/* Philox4x32-10 counter-based generator. Replaces the per-thread sequential
+ * ranlxd2 stream of src/RandomGenerator.hpp:39-272: a packet's uniforms are a
+ * pure function of (seed, iteration, packet id, draw index), independent of
+ * which lane runs it. */
+struct PacketRng {
+  uint32_t seed, iteration;
+  uint32_t p_lo, p_hi;
+  uint32_t block; /* next Philox block to generate (= draws consumed / 2) */
+  uint32_t have;  /* the second double of the last block is still unused */
+  double cached;
+
+  __device__ __forceinline__ void init(uint32_t seed_, uint32_t iteration_,
+                                       uint64_t packet) {
+    seed = seed_;
+    iteration = iteration_;
+    p_lo = (uint32_t)packet;
+    p_hi = (uint32_t)(packet >> 32);
+    block = 0;
+    have = 0;
+    cached = 0.;
+  }
+
+  __device__ __forceinline__ static double to_unit(uint32_t lo, uint32_t hi) {
+    const uint64_t bits = (((uint64_t)hi << 32) | lo) >> 12;
+    /* 52 random bits + 1/2, scaled: strictly inside (0,1), exact in fp64 */
+    return ((double)bits + 0.5) * 0x1.0p-52;
+  }
+
+  /* draw d of the packet = word pair (d & 1) of block d / 2; draws are
+   * consumed strictly in order, so one cached double is enough */
+  __device__ __forceinline__ double next() {
+    if (have) {
+      have = 0;
+      return cached;
+    }
+    uint32_t c0 = p_lo, c1 = p_hi, c2 = block, c3 = 0u;
+    uint32_t k0 = seed, k1 = iteration;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      const uint32_t hi0 = __umulhi(0xD2511F53u, c0);
+      const uint32_t lo0 = 0xD2511F53u * c0;
+      const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2);
+      const uint32_t lo1 = 0xCD9E8D57u * c2;
+      c0 = hi1 ^ c1 ^ k0;
+      c1 = lo1;
+      c2 = hi0 ^ c3 ^ k1;
+      c3 = lo0;
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    ++block;
+    cached = to_unit(c2, c3);
+    have = 1;
+    return to_unit(c0, c1);
+  }
+};
+
+/* src/Utilities.hpp:726-742 (bisection, result in [0, length-2]) */
+__device__ __forceinline__ uint32_t cmi_locate(double x, const double *arr,
+                                               uint32_t length) {
+  uint32_t lo = 0, hi = length;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (x > arr[mid])
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return (lo == length - 1) ? lo - 1 : lo;
+}
+
+/* ------------------------------------------------ Verner cross section -- */
+
+/* VernerCrossSections::get_cross_section_verner,
+ * src/VernerCrossSections.cpp:166-245, for one (ion, shell) term */
+__device__ inline double verner_term_sigma(const VernerTermDev &t, double e) {
+  if (e < t.E_th)
+    return 0.;
+  const int is = t.shell;
+  const int nout = t.ntot;
+  if (is > nout)
+    return 0.;
+  const int nint = t.ninn;
+  const double einn = t.einn;
+  if (is < nout && is > nint && e < einn)
+    return 0.;
+  if (is <= nint || e >= einn) {
+    const double y = e * t.A_E_0_inv;
+    const double ym1 = y - 1.;
+    const double Fy = (ym1 * ym1 + t.A_y_w_sq) * pow(y, t.A_Plconst) *
+                      pow(1. + sqrt(y * t.A_y_a_inv), -t.A_P);
+    return t.A_sigma_0 * Fy;
+  } else {
+    const double x = e * t.B_E_0_inv - t.B_y_0;
+    const double y = sqrt(x * x + t.B_y_1_sq);
+    const double xm1 = x - 1.;
+    const double Fy = (xm1 * xm1 + t.B_y_w_sq) * pow(y, 0.5 * t.B_P - 5.5) *
+                      pow(1. + sqrt(y * t.B_y_a_inv), -t.B_P);
+    return t.B_sigma_0 * Fy;
+  }
+}
+
+/* all 14 cross sections of a packet: PhotonSource::set_cross_sections,
+ * src/PhotonSource.cpp:189-199 with CrossSections::get_cross_section
+ * (src/VernerCrossSections.cpp:259-322 or FixedValueCrossSections) */
+__device__ inline void cmi_cross_sections(const ModelDev &m, double nu,
+                                          double sigma[CMI_NION]) {
+  if (!m.xsec_verner) {
+#pragma unroll
+    for (int i = 0; i < CMI_NION; ++i)
+      sigma[i] = m.xsec_fixed[i];
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < CMI_NION; ++i)
+    sigma[i] = 0.;
+  const VernerTermDev *terms = m.tables->verner;
+  for (int k = 0; k < CMI_VERNER_NTERM_DEV; ++k) {
+    const double s = verner_term_sigma(terms[k], nu);
+    const int ion = terms[k].ion;
+    /* static indexing keeps sigma[] in registers */
+#pragma unroll
+    for (int i = 0; i < CMI_NION; ++i)
+      if (i == ion)
+        sigma[i] += s;
+  }
+}
+
+/* -------------------------------------------------- recombination rates -- */
+
+/* src/VernerRecombinationRates.cpp:104-130 */
+__device__ inline double verner_rec_fit(const VernerRecDev &r, double T) {
+  if (r.kind == 0) {
+    const double tt = sqrt(T * r.p[2]);
+    return r.p[0] / (tt * pow(tt + 1., 1. - r.p[1]) *
+                     pow(1. + sqrt(T * r.p[3]), 1. + r.p[1]));
+  } else {
+    const double tt = T * 1.e-4;
+    return r.p[0] * pow(tt, -r.p[1]);
+  }
+}
+
+/* RecombinationRates::get_recombination_rate,
+ * src/VernerRecombinationRates.cpp:140-333 */
+__device__ inline double cmi_recombination_rate(const ModelDev &m, int ion,
+                                                double temperature) {
+  if (!m.recomb_verner)
+    return m.recomb_fixed[ion];
+  const VernerRecDev *rec = m.tables->verner_rec;
+  double rate = 0.;
+  switch (ion) {
+  case ION_H_n: {
+    const double T1 = temperature / 3.148;
+    const double T2 = temperature / 7.036e5;
+    rate = 7.982e-11 / (sqrt(T1) * pow(1. + sqrt(T1), 0.252) *
+                        pow(1. + sqrt(T2), 1.748));
+    break;
+  }
+  case ION_He_n: {
+    const double T1 = temperature / 15.54;
+    const double T2 = temperature / 3.676e7;
+    rate = 3.294e-11 / (sqrt(T1) * pow(1. + sqrt(T1), 0.309) *
+                        pow(1. + sqrt(T2), 1.691));
+    break;
+  }
+  case ION_C_p1: {
+    const double T4 = temperature * 1.e-4;
+    const double T4_inv = 1. / T4;
+    rate = verner_rec_fit(rec[ion], temperature) +
+           1.e-12 *
+               (1.8267 * T4_inv + 4.1012 + 4.8443 * T4 + 0.2261 * T4 * T4) *
+               pow(T4, -1.5) * exp(-0.5960 * T4_inv);
+    break;
+  }
+  case ION_C_p2: {
+    const double T4 = temperature * 1.e-4;
+    const double T4_inv = 1. / T4;
+    rate = verner_rec_fit(rec[ion], temperature) +
+           1.e-12 *
+               (2.3196 * T4_inv + 10.7328 + 6.8830 * T4 - 0.1824 * T4 * T4) *
+               pow(T4, -1.5) * exp(-0.4101 * T4_inv);
+    break;
+  }
+  case ION_N_n: {
+    const double T4 = temperature * 1.e-4;
+    rate = verner_rec_fit(rec[ion], temperature) +
+           1.e-12 * (0.6310 + 0.1990 * T4 - 0.0197 * T4 * T4) *
+               pow(T4, -1.5) * exp(-0.4398 / T4);
+    break;
+  }
+  case ION_N_p1: {
+    const double T4 = temperature * 1.e-4;
+    const double T4_inv = 1. / T4;
+    rate = verner_rec_fit(rec[ion], temperature) +
+           1.e-12 *
+               (0.0320 * T4_inv - 0.6624 + 4.3191 * T4 + 0.0003 * T4 * T4) *
+               pow(T4, -1.5) * exp(-0.5946 * T4_inv);
+    break;
+  }
+  case ION_N_p2: {
+    const double T4 = temperature * 1.e-4;
+    const double T4_inv = 1. / T4;
+    rate = verner_rec_fit(rec[ion], temperature) +
+           1.e-12 *
+               (-0.8806 * T4_inv + 11.2406 + 30.7066 * T4 - 1.1721 * T4 * T4) *
+               pow(T4, -1.5) * exp(-0.6127 * T4_inv);
+    break;
+  }
+  case ION_O_n: {
+    const double T4 = temperature * 1.e-4;
+    const double T4_inv = 1. / T4;
+    rate = verner_rec_fit(rec[ion], temperature) +
+           1.e-12 *
+               (-0.0001 * T4_inv + 0.0001 + 0.0956 * T4 + 0.0193 * T4 * T4) *
+               pow(T4, -1.5) * exp(-0.4106 * T4_inv);
+    break;
+  }
+  case ION_O_p1: {
+    const double T4 = temperature * 1.e-4;
+    const double T4_inv = 1. / T4;
+    rate = verner_rec_fit(rec[ion], temperature) +
+           1.e-12 *
+               (-0.0036 * T4_inv + 0.7519 + 1.5252 * T4 - 0.0838 * T4 * T4) *
+               pow(T4, -1.5) * exp(-0.2769 * T4_inv);
+    break;
+  }
+  case ION_Ne_n:
+    rate = verner_rec_fit(rec[ion], temperature);
+    break;
+  case ION_Ne_p1: {
+    const double T4 = temperature * 1.e-4;
+    const double T4_inv = 1. / T4;
+    rate = verner_rec_fit(rec[ion], temperature) +
+           1.e-12 *
+               (0.0129 * T4_inv - 0.1779 + 0.9353 * T4 - 0.0682 * T4 * T4) *
+               pow(T4, -1.5) * exp(-0.4156 * T4_inv);
+    break;
+  }
+  case ION_S_p1: {
+    const double T_in_eV = temperature / 1.16045221e4;
+    rate = verner_rec_fit(rec[ion], temperature) +
+           1.37e-9 * exp(-14.95 / T_in_eV) * pow(T_in_eV, -1.5);
+    break;
+  }
+  case ION_S_p2: {
+    const double T_in_eV = temperature / 1.16045221e4;
+    const double T_in_eV_inv = 1. / T_in_eV;
+    rate = verner_rec_fit(rec[ion], temperature) +
+           (8.0729e-9 * exp(-17.56 * T_in_eV_inv) +
+            1.1012e-10 * exp(-7.07 * T_in_eV_inv)) *
+               pow(T_in_eV, -1.5);
+    break;
+  }
+  default: { /* ION_S_p3 */
+    const double T_inv = 1. / temperature;
+    rate = verner_rec_fit(rec[ion], temperature) +
+           (5.817e-7 * exp(-362.8 * T_inv) + 1.391e-6 * exp(-1058. * T_inv) +
+            1.123e-5 * exp(-7160. * T_inv) + 1.521e-4 * exp(-3.26e4 * T_inv) +
+            1.875e-3 * exp(-1.235e5 * T_inv) +
+            2.097e-2 * exp(-2.07e5 * T_inv)) *
+               pow(temperature, -1.5);
+    break;
+  }
+  }
+  rate *= 1.e-6;
+  return fmax(0., rate);
+}
+
+/* ------------------------------------------------------ charge transfer -- */
+
+/* src/ChargeTransferRates.cpp:44-395, table driven */
+__device__ inline double ct_eval(const CTFitDev &f, double T4) {
+  if (f.kind == 0)
+    return 0.;
+  if (f.kind == 1)
+    return f.a;
+  double t = fmax(T4, f.lo);
+  t = fmin(t, f.hi);
+  if (f.kind == 4)
+    return f.a * t * t;
+  const double base = f.a * pow(t, f.b) * (1. + f.c * exp(f.d * t));
+  if (f.kind == 3)
+    return base * exp(f.e / t);
+  return base;
+}
+
+/* ---------------------------------------------------- ionization balance -- */
+
+/* src/IonizationStateCalculator.cpp:802-820 */
+__device__ inline double cmi_ionization_state_hydrogen(double alphaH, double jH,
+                                                       double nH) {
+  if (jH > 0. && nH > 0.) {
+    const double aa = 0.5 * jH / (nH * alphaH);
+    const double bb = 2. / aa;
+    if (bb < 1.e-10) {
+      return fmax(1.e-14, 0.25 * bb);
+    } else {
+      const double cc = sqrt(bb + 1.);
+      return fmax(1.e-14, 1. + aa * (1. - cc));
+    }
+  }
+  return 1.;
+}
+
+/* src/IonizationStateCalculator.cpp:649-753 */
+__device__ inline void cmi_ionization_states_hydrogen_helium(
+    double alphaH, double alphaHe, double jH, double jHe, double nH,
+    double AHe, double T, double &h0, double &he0) {
+  if (jH < 1.e-20) {
+    h0 = 1.;
+    he0 = 1.;
+    return;
+  }
+  const double alpha_e_2sP = 4.17e-20 * pow(T * 1.e-4, -0.861);
+  const double ch1 = alphaH * nH / jH;
+  const double ch2 = AHe * alpha_e_2sP * nH / jH;
+  double che = 0.;
+  if (jHe > 0.)
+    che = alphaHe * nH / jHe;
+  double h0old = 0.99 * (1. - exp(-0.5 / ch1));
+  h0 = 0.9 * h0old;
+  double he0old = 1.;
+  if (che > 0.) {
+    he0old = 0.5 / che;
+    he0old = fmin(he0old, 1.);
+  }
+  he0 = 0.;
+  int niter = 0;
+  /* stops as soon as EITHER fraction has converged (&&), as the reference */
+  while (fabs(h0 - h0old) > 1.e-4 * h0old &&
+         fabs(he0 - he0old) > 1.e-4 * he0old) {
+    ++niter;
+    h0old = h0;
+    he0old = (he0 > 0.) ? he0 : 0.;
+    const double pHots = 1. / (1. + 77. * he0old / sqrt(T) / h0old);
+    const double ch = ch1 - ch2 * AHe * (1. - he0old) * pHots / (1. - h0old);
+    he0 = 1.;
+    if (che != 0.) {
+      const double bhe = (1. + 2. * AHe - h0) * che + 1.;
+      const double che_bhe = che / bhe;
+      const double opAHeh0 = 1. + AHe - h0;
+      const double t1he = 4. * AHe * opAHeh0 * che_bhe * che_bhe;
+      if (t1he < 1.e-3) {
+        he0 = opAHeh0 * che_bhe;
+      } else {
+        he0 = (bhe - sqrt(bhe * bhe - 4. * AHe * opAHeh0 * che * che)) /
+              (2. * AHe * che);
+      }
+    }
+    const double b = ch * (2. + AHe - he0 * AHe) + 1.;
+    const double ch_b = ch / b;
+    const double opAHeh0AHe = 1. + AHe - he0 * AHe;
+    const double t1 = 4. * ch_b * ch_b * opAHeh0AHe;
+    if (t1 < 1.e-3) {
+      h0 = ch_b * opAHeh0AHe;
+    } else {
+      h0 = (b - sqrt(b * b - 4. * ch * ch * opAHeh0AHe)) / (2. * ch);
+    }
+    if (niter > 10) {
+      h0 = 0.5 * (h0 + h0old);
+      he0 = 0.5 * (he0 + he0old);
+    }
+    if (niter > 20) {
+      /* the reference aborts here (cmac_error); the engine keeps the last
+       * iterate */
+      break;
+    }
+  }
+}
+
+/* src/IonizationStateCalculator.cpp:323-501; x[2..13] out */
+__device__ inline void cmi_ionization_states_metals(
+    const ModelDev &m, const double j[12], double ne, double T, double T4,
+    double nh0, double nhe0, double nhp, double x[CMI_NION]) {
+  const TablesDev *tb = m.tables;
+  double alpha[CMI_NION];
+#pragma unroll
+  for (int ion = ION_C_p1; ion < CMI_NION; ++ion)
+    alpha[ion] = cmi_recombination_rate(m, ion, T);
+#define CTRH(ion) ct_eval(tb->ct_recomb_H[ion], T4)
+#define CTIH(ion) ct_eval(tb->ct_ion_H[ion], T4)
+#define CTRHE(ion) ct_eval(tb->ct_recomb_He[ion], T4)
+  { /* carbon */
+    const double C21 = j[0] / (ne * alpha[ION_C_p1]);
+    const double C32 = j[1] / (ne * alpha[ION_C_p2] + nh0 * CTRH(ION_C_p2) +
+                               nhe0 * CTRHE(ION_C_p2));
+    const double C31 = C32 * C21;
+    const double s = 1. / (1. + C21 + C31);
+    x[ION_C_p1] = C21 * s;
+    x[ION_C_p2] = C31 * s;
+  }
+  { /* nitrogen */
+    const double N21 = (j[2] + nhp * CTIH(ION_N_n)) /
+                       (ne * alpha[ION_N_n] + nh0 * CTRH(ION_N_n));
+    const double N32 = j[3] / (ne * alpha[ION_N_p1] + nh0 * CTRH(ION_N_p1) +
+                               nhe0 * CTRHE(ION_N_p1));
+    const double N43 = j[4] / (ne * alpha[ION_N_p2] + nh0 * CTRH(ION_N_p2) +
+                               nhe0 * CTRHE(ION_N_p2));
+    const double N31 = N32 * N21;
+    const double N41 = N43 * N31;
+    const double s = 1. / (1. + N21 + N31 + N41);
+    x[ION_N_n] = N21 * s;
+    x[ION_N_p1] = N31 * s;
+    x[ION_N_p2] = N41 * s;
+  }
+  { /* oxygen */
+    const double O21 = (j[5] + nhp * CTIH(ION_O_n)) /
+                       (ne * alpha[ION_O_n] + nh0 * CTRH(ION_O_n));
+    const double O32 = j[6] / (ne * alpha[ION_O_p1] + nh0 * CTRH(ION_O_p1) +
+                               nhe0 * CTRHE(ION_O_p1));
+    const double O31 = O32 * O21;
+    const double s = 1. / (1. + O21 + O31);
+    x[ION_O_n] = O21 * s;
+    x[ION_O_p1] = O31 * s;
+  }
+  { /* neon */
+    const double Ne21 = j[7] / (ne * alpha[ION_Ne_n]);
+    const double Ne32 = j[8] / (ne * alpha[ION_Ne_p1] + nh0 * CTRH(ION_Ne_p1) +
+                                nhe0 * CTRHE(ION_Ne_p1));
+    const double Ne31 = Ne32 * Ne21;
+    const double s = 1. / (1. + Ne21 + Ne31);
+    x[ION_Ne_n] = Ne21 * s;
+    x[ION_Ne_p1] = Ne31 * s;
+  }
+  { /* sulphur */
+    const double S21 = j[9] / (ne * alpha[ION_S_p1] + nh0 * CTRH(ION_S_p1));
+    const double S32 = j[10] / (ne * alpha[ION_S_p2] + nh0 * CTRH(ION_S_p2) +
+                                nhe0 * CTRHE(ION_S_p2));
+    const double S43 = j[11] / (ne * alpha[ION_S_p3] + nh0 * CTRH(ION_S_p3) +
+                                nhe0 * CTRHE(ION_S_p3));
+    const double S31 = S32 * S21;
+    const double S41 = S43 * S31;
+    const double s = 1. / (1. + S21 + S31 + S41);
+    x[ION_S_p1] = S21 * s;
+    x[ION_S_p2] = S31 * s;
+    x[ION_S_p3] = S41 * s;
+  }
+#undef CTRH
+#undef CTIH
+#undef CTRHE
+}
+
+/* IonizationStateCalculator::calculate_ionization_state(jfac, hfac, vars),
+ * src/IonizationStateCalculator.cpp:70-272. J[14] un-normalised; heating[2]
+ * normalised in place; x[14] out. */
+__device__ inline void cmi_ionization_state_cell(const ModelDev &m, double jfac,
+                                                 double hfac, double ntot,
+                                                 double T,
+                                                 const double J[CMI_NION],
+                                                 double heating[2],
+                                                 double x[CMI_NION]) {
+  const double jH = jfac * J[ION_H_n];
+  const double jHe = jfac * J[ION_He_n];
+  heating[0] = hfac * heating[0];
+  heating[1] = hfac * heating[1];
+  if (jH > 0. && ntot > 0.) {
+    const double alphaH = cmi_recombination_rate(m, ION_H_n, T);
+    const double AHe = m.abundance[0];
+    double h0, he0 = 0.;
+    if (AHe != 0.) {
+      const double alphaHe = cmi_recombination_rate(m, ION_He_n, T);
+      cmi_ionization_states_hydrogen_helium(alphaH, alphaHe, jH, jHe, ntot,
+                                            AHe, T, h0, he0);
+    } else {
+      h0 = cmi_ionization_state_hydrogen(alphaH, jH, ntot);
+    }
+    x[ION_H_n] = h0;
+    x[ION_He_n] = he0;
+    const double nhp = ntot * (1. - h0);
+    const double ne = ntot * (1. - h0 + AHe * (1. - he0));
+    const double T4 = T * 1.e-4;
+    double jm[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+      jm[i] = jfac * J[ION_C_p1 + i];
+    const double nh0 = ntot * h0;
+    const double nhe0 = ntot * he0 * AHe;
+    cmi_ionization_states_metals(m, jm, ne, T, T4, nh0, nhe0, nhp, x);
+  } else {
+#pragma unroll
+    for (int i = 0; i < CMI_NION; ++i)
+      x[i] = 0.;
+    if (ntot > 0.) {
+      /* neutral gas: the tracked neutral stages are fully populated */
+      x[ION_H_n] = 1.;
+      x[ION_He_n] = 1.;
+      x[ION_N_n] = 1.;
+      x[ION_O_n] = 1.;
+      x[ION_Ne_n] = 1.;
+    }
+  }
+}
+
+#endif

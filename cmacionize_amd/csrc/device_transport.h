@@ -1,0 +1,179 @@
+/*
+ * device_transport.h - device functions for packet emission and the DDA
+ * march through the regular grid.
+ */
+#ifndef CMI_DEVICE_TRANSPORT_H
+#define CMI_DEVICE_TRANSPORT_H
+
+#include "device_physics.h"
+#include "device_spectra.h"
+
+#include <float.h>
+
+/* State of one packet in flight; Photon of src/Photon.hpp:36-69 minus the
+ * fields the path never reads (Stokes / direction parameters). FULL = all 14
+ * cross sections are carried; otherwise only hydrogen's. */
+template <bool FULL> struct Packet {
+  double pos[3];
+  double dir[3];
+  double inv_dir[3];
+  double tau;    /* remaining optical depth */
+  double nu;     /* frequency (Hz) */
+  double weight;
+  double sigma_H;
+  double sigma_He_corr; /* A_He * sigma_He */
+  double sigma[FULL ? CMI_NION : 1];
+  int32_t index[3];
+  int32_t type;
+};
+
+/* PhotonSource::get_random_direction + Photon::set_direction
+ * (src/PhotonSource.hpp:140-148, src/Photon.hpp:165-170) */
+template <bool FULL>
+__device__ __forceinline__ void random_direction(Packet<FULL> &p,
+                                                 PacketRng &rng) {
+  const double cost = 2. * rng.next() - 1.;
+  const double sint = sqrt(fmax(1. - cost * cost, 0.));
+  const double phi = 2. * M_PI * rng.next();
+  double sinp, cosp;
+  sincos(phi, &sinp, &cosp);
+  p.dir[0] = sint * cosp;
+  p.dir[1] = sint * sinp;
+  p.dir[2] = cost;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    p.inv_dir[a] = 1. / p.dir[a];
+}
+
+/* PhotonSource::set_cross_sections, src/PhotonSource.cpp:189-199 */
+template <bool FULL>
+__device__ __forceinline__ void set_cross_sections(const ModelDev &m,
+                                                   Packet<FULL> &p) {
+  if (FULL) {
+    double s[CMI_NION];
+    cmi_cross_sections(m, p.nu, s);
+#pragma unroll
+    for (int i = 0; i < CMI_NION; ++i)
+      p.sigma[FULL ? i : 0] = s[i];
+    p.sigma_H = s[ION_H_n];
+    p.sigma_He_corr = m.abundance[0] * s[ION_He_n];
+  } else {
+    /* only reached with FixedValueCrossSections and sigma[1..13] == 0 */
+    p.sigma_H = m.xsec_fixed[ION_H_n];
+    p.sigma_He_corr = m.abundance[0] * m.xsec_fixed[ION_He_n];
+    p.sigma[0] = p.sigma_H;
+  }
+}
+
+/* CartesianDensityGrid::get_cell_indices, src/CartesianDensityGrid.cpp:152-161
+ * (truncating conversion, like the reference's implicit double -> int) */
+template <bool FULL>
+__device__ __forceinline__ void locate_cell(const GridDev &g,
+                                            Packet<FULL> &p) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    p.index[a] = (int32_t)((p.pos[a] - g.anchor[a]) * g.inv_cellside[a]);
+}
+
+/* PhotonSource::get_random_photon (discrete branch) + the first optical depth
+ * of IonizationPhotonShootJob::execute
+ * (src/PhotonSource.cpp:208-249, src/IonizationPhotonShootJob.hpp:119-135) */
+template <bool FULL>
+__device__ inline void emit_packet(const GridDev &g, const ModelDev &m,
+                                   PacketRng &rng, Packet<FULL> &p) {
+  /* first uniform: continuous vs discrete source; no continuous source on
+   * this path, so it is drawn and ignored */
+  double x = rng.next();
+  x = rng.next();
+  int i = 0;
+  while (x > m.source_cumulative[i])
+    ++i;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    p.pos[a] = m.source_position[3 * i + a];
+  random_direction(p, rng);
+  p.nu = sample_source_spectrum(m, rng);
+  p.type = TYPE_PRIMARY;
+  set_cross_sections(m, p);
+  p.weight = 1.;
+  p.tau = -log(rng.next());
+  locate_cell(g, p);
+}
+
+/* CartesianDensityGrid::is_inside, src/CartesianDensityGrid.cpp:187-227 */
+template <bool FULL>
+__device__ __forceinline__ bool is_inside(const GridDev &g, Packet<FULL> &p) {
+  bool inside = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (!g.periodic[a]) {
+      inside &= (p.index[a] >= 0 && p.index[a] < g.ncell[a]);
+    } else {
+      if (p.index[a] < 0) {
+        p.index[a] = g.ncell[a] - 1;
+        p.pos[a] += g.box_sides[a];
+      }
+      if (p.index[a] >= g.ncell[a]) {
+        p.index[a] = 0;
+        p.pos[a] -= g.box_sides[a];
+      }
+    }
+  }
+  return inside;
+}
+
+/* One iteration of the loop of CartesianDensityGrid::interact
+ * (src/CartesianDensityGrid.cpp:396-432) with get_wall_intersection
+ * (:280-318) and get_optical_depth (src/DensityGrid.hpp:117-140) inlined.
+ * The caller has checked that the packet is inside and tau > 0.
+ * Returns the path length travelled in the cell; `cell` receives the long
+ * index, `kappa` the cell's transport record. */
+template <bool FULL>
+__device__ __forceinline__ double dda_step(const GridDev &g,
+                                           const double2 *__restrict__ opacity,
+                                           Packet<FULL> &p, int64_t &cell,
+                                           double2 &kappa) {
+  cell = ((int64_t)p.index[0] * g.ncell[1] + p.index[1]) * g.ncell[2] +
+         p.index[2];
+  kappa = opacity[cell];
+
+  double d[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double lo = g.anchor[a] + g.cellside[a] * p.index[a];
+    const double hi = lo + g.cellside[a];
+    d[a] = (p.dir[a] > 0.)
+               ? (hi - p.pos[a]) * p.inv_dir[a]
+               : ((p.dir[a] < 0.) ? (lo - p.pos[a]) * p.inv_dir[a] : DBL_MAX);
+  }
+  double ds = fmin(d[0], fmin(d[1], d[2]));
+  double wall[3];
+  int32_t step[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    /* every axis that ties the minimum advances (edges, corners) */
+    step[a] = (d[a] == ds) ? ((p.dir[a] > 0.) ? 1 : -1) : 0;
+    wall[a] = p.pos[a] + ds * p.dir[a];
+  }
+
+  /* kappa = {n x_H, n x_He}; a negative .x marks vacuum */
+  const double kH = fmax(kappa.x, 0.);
+  const double tau_cell = ds * (p.sigma_H * kH + p.sigma_He_corr * kappa.y);
+  p.tau -= tau_cell;
+  if (p.tau < 0.) {
+    const double Scorr = ds * p.tau / tau_cell;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      p.pos[a] += (wall[a] - p.pos[a]) * (ds + Scorr) / ds;
+    ds += Scorr;
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      p.pos[a] = wall[a];
+      p.index[a] += step[a];
+    }
+  }
+  return ds;
+}
+
+#endif

@@ -1,0 +1,814 @@
+/*
+ * engine.hip - host side of the MI355X photoionization engine and its C ABI
+ * (include/cmi_gpu.h). Owns the device memory, lowers the plugin descriptors
+ * into device tables and launches the kernels of kernels.h on one HIP stream.
+ */
+#include "../../include/cmi_gpu.h"
+
+#include "atomic_data.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                          \
+  do {                                                                         \
+    hipError_t err__ = (expr);                                                 \
+    if (err__ != hipSuccess)                                                   \
+      return fail(CMI_GPU_EDEVICE, "%s failed: %s (%s:%d)", #expr,             \
+                  hipGetErrorString(err__), __FILE__, __LINE__);               \
+  } while (0)
+
+struct EventPair {
+  hipEvent_t start, stop;
+};
+
+} // namespace
+
+struct cmi_gpu_engine {
+  cmi_gpu_config config;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cu = 0;
+
+  GridDev grid;
+  ModelDev model;
+  CellsDev cells;
+  int64_t ncell = 0;
+
+  /* device allocations */
+  double *state_block = nullptr;   /* n, T, x[14] : 16 fields */
+  double *acc_block = nullptr;     /* J[14], heating[2] : 16 fields */
+  bool own_acc = false;
+  double2 *opacity = nullptr;
+  CountersDev *counters = nullptr;
+  TablesDev *tables = nullptr;
+  double *source_position = nullptr;
+  double *source_cumulative = nullptr;
+
+  bool have_sources = false, have_spectrum = false, have_xsec = false,
+       have_recomb = false, have_cells = false;
+  bool full_ions = false; /* transport carries all 14 cross sections */
+  cmi_gpu_temperature_params tparams;
+
+  std::vector<EventPair> shoot_events, update_events;
+};
+
+namespace {
+
+double eV_to_Hz(double eV) {
+  /* UnitConverter::to_SI<QUANTITY_FREQUENCY>(eV, "eV"),
+   * src/UnitConverter.hpp:156-159,266-300 */
+  return eV * CMI_ELECTRONVOLT * (1. / CMI_PLANCK) / 1.;
+}
+
+double *field_pointer(cmi_gpu_engine *e, int field) {
+  if (field < 0 || field >= CMI_GPU_NFIELD)
+    return nullptr;
+  if (field < CMI_GPU_FIELD_MEAN_INTENSITY)
+    return e->state_block + (int64_t)field * e->ncell;
+  return e->acc_block + (int64_t)(field - CMI_GPU_FIELD_MEAN_INTENSITY) *
+                            e->ncell;
+}
+
+/* lower the generated raw tables into the device layout, applying the unit
+ * conversions of the reference constructors */
+void build_tables(TablesDev &t) {
+  memset(&t, 0, sizeof t);
+  /* src/VernerCrossSections.cpp:36-154 */
+  const double eV_to_Hz_fac = CMI_ELECTRONVOLT / CMI_PLANCK;
+  static_assert(CMI_VERNER_NTERM == CMI_VERNER_NTERM_DEV, "term count");
+  for (int i = 0; i < CMI_VERNER_NTERM; ++i) {
+    const cmi_verner_term &raw = cmi_verner_terms[i];
+    VernerTermDev &d = t.verner[i];
+    d.ion = raw.ion;
+    d.shell = raw.shell;
+    d.ninn = raw.ninn;
+    d.ntot = raw.ntot;
+    const double E_th = raw.A[0], E_0 = raw.A[1], sigma_0 = raw.A[2],
+                 y_a = raw.A[3], P = raw.A[4], y_w = raw.A[5];
+    d.E_th = E_th * eV_to_Hz_fac;
+    d.einn = (raw.N < 3) ? 1.e30 : raw.einn_eV * eV_to_Hz_fac;
+    d.A_Plconst = 0.5 * P - 5.5 - raw.l;
+    d.A_E_0_inv = 1. / (E_0 * eV_to_Hz_fac);
+    d.A_sigma_0 = 1.e-22 * sigma_0;
+    d.A_y_a_inv = 1. / y_a;
+    d.A_P = P;
+    d.A_y_w_sq = y_w * y_w;
+    d.B_E_0_inv = 1. / (raw.B[2] * eV_to_Hz_fac);
+    d.B_sigma_0 = 1.e-22 * raw.B[3];
+    d.B_y_a_inv = 1. / raw.B[4];
+    d.B_P = raw.B[5];
+    d.B_y_w_sq = raw.B[6] * raw.B[6];
+    d.B_y_0 = raw.B[7];
+    d.B_y_1_sq = raw.B[8] * raw.B[8];
+  }
+  /* src/VernerRecombinationRates.cpp:38-90 */
+  for (int i = 0; i < CMI_VERNER_NREC; ++i) {
+    const cmi_verner_rec &raw = cmi_verner_recs[i];
+    VernerRecDev &d = t.verner_rec[raw.ion];
+    d.kind = raw.kind;
+    d.p[0] = raw.p[0];
+    d.p[1] = raw.p[1];
+    d.p[2] = (raw.kind == 0 && raw.p[2] != 0.) ? 1. / raw.p[2] : raw.p[2];
+    d.p[3] = (raw.kind == 0 && raw.p[3] != 0.) ? 1. / raw.p[3] : raw.p[3];
+  }
+  /* src/ChargeTransferRates.cpp: {kind, a, b, c, d, e, lo, hi};
+   * kind 0 zero, 1 constant, 2 a t^b (1 + c e^{d t}), 3 same * e^{e/t},
+   * 4 a t^2 */
+  auto set = [](CTFitDev &f, int kind, double a, double b, double c, double d,
+                double e, double lo, double hi) {
+    f.kind = kind;
+    f.a = a;
+    f.b = b;
+    f.c = c;
+    f.d = d;
+    f.e = e;
+    f.lo = lo;
+    f.hi = hi;
+  };
+  /* recombination with H, :44-157 */
+  set(t.ct_recomb_H[ION_He_n], 2, 7.47e-21, 2.06, 9.93, -3.89, 0, 0.6, 10.);
+  set(t.ct_recomb_H[ION_C_p1], 2, 1.67e-19, 2.79, 304.74, -4.07, 0, 0.5, 5.);
+  set(t.ct_recomb_H[ION_C_p2], 2, 3.25e-15, 0.21, 0.19, -3.29, 0, 0.1, 10.);
+  set(t.ct_recomb_H[ION_N_n], 2, 1.01e-18, -0.29, -0.92, -8.38, 0, 0.01, 5.);
+  set(t.ct_recomb_H[ION_N_p1], 2, 3.05e-16, 0.6, 2.65, -0.93, 0, 0.1, 10.);
+  set(t.ct_recomb_H[ION_N_p2], 2, 4.54e-15, 0.57, -0.65, -0.89, 0, 0.001,
+      10.);
+  set(t.ct_recomb_H[ION_O_n], 2, 1.04e-15, 3.15e-2, -0.61, -9.73, 0, 0.001,
+      1.);
+  set(t.ct_recomb_H[ION_O_p1], 2, 1.04e-15, 0.27, 2.02, -5.92, 0, 0.01, 10.);
+  set(t.ct_recomb_H[ION_Ne_n], 0, 0, 0, 0, 0, 0, 0, 0);
+  set(t.ct_recomb_H[ION_Ne_p1], 1, 1.e-20, 0, 0, 0, 0, 0, 0);
+  set(t.ct_recomb_H[ION_S_p1], 1, 1.e-20, 0, 0, 0, 0, 0, 0);
+  set(t.ct_recomb_H[ION_S_p2], 2, 2.29e-15, 4.02e-2, 1.59, -6.06, 0, 0.1, 3.);
+  set(t.ct_recomb_H[ION_S_p3], 2, 6.44e-15, 0.13, 2.69, -5.69, 0, 0.1, 3.);
+  /* ionization by H+, :169-250 (all others zero) */
+  set(t.ct_ion_H[ION_N_n], 3, 4.55e-18, -0.29, -0.92, -8.38, -1.086, 0.01,
+      5.);
+  set(t.ct_ion_H[ION_O_n], 3, 7.4e-17, 0.47, 24.37, -0.74, -0.023, 0.001, 1.);
+  /* recombination with He, :262-395 */
+  set(t.ct_recomb_He[ION_C_p2], 4, 4.6e-17, 0, 0, 0, 0, 0.1, 3.);
+  set(t.ct_recomb_He[ION_N_p1], 2, 3.3e-16, 0.29, 1.3, -4.5, 0, 0.1, 3.);
+  set(t.ct_recomb_He[ION_N_p2], 1, 1.5e-16, 0, 0, 0, 0, 0, 0);
+  set(t.ct_recomb_He[ION_O_p1], 2, 2.e-16, 0.95, 0., 0., 0, 0.5, 5.);
+  set(t.ct_recomb_He[ION_Ne_p1], 1, 1.e-20, 0, 0, 0, 0, 0, 0);
+  set(t.ct_recomb_He[ION_S_p2], 2, 1.1e-15, 0.56, 0., 0., 0, 0.1, 3.);
+  set(t.ct_recomb_He[ION_S_p3], 2, 7.6e-19, 0.32, 3.4, -5.25, 0, 0.1, 3.);
+}
+
+int grid_blocks(cmi_gpu_engine *e, int64_t work_items, int blocks_per_cu) {
+  int64_t want = (work_items + CMI_BLOCK - 1) / CMI_BLOCK;
+  int64_t cap = (int64_t)e->num_cu * blocks_per_cu;
+  if (want < 1)
+    want = 1;
+  return (int)(want < cap ? want : cap);
+}
+
+void update_full_flag(cmi_gpu_engine *e) {
+  /* the light transport kernel is exact iff no ion other than H0 can ever
+   * have a non-zero cross section */
+  bool full = e->model.xsec_verner != 0;
+  if (!full)
+    for (int i = 1; i < CMI_NION; ++i)
+      if (e->model.xsec_fixed[i] != 0.)
+        full = true;
+  e->full_ions = full;
+}
+
+int rebuild_opacity(cmi_gpu_engine *e) {
+  opacity_kernel<<<grid_blocks(e, e->ncell, 8), CMI_BLOCK, 0, e->stream>>>(
+      e->cells, e->ncell);
+  HIP_TRY(hipGetLastError());
+  return CMI_GPU_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *cmi_gpu_last_error(void) { return g_last_error.c_str(); }
+
+int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
+  if (!config || !out)
+    return fail(CMI_GPU_EINVAL, "cmi_gpu_create: null argument");
+  for (int a = 0; a < 3; ++a) {
+    if (config->ncell[a] <= 0)
+      return fail(CMI_GPU_EINVAL, "number of cells must be positive");
+    if (!(config->sides[a] > 0.))
+      return fail(CMI_GPU_EINVAL, "box sides must be positive");
+  }
+  int ndev = 0;
+  hipError_t err = hipGetDeviceCount(&ndev);
+  if (err != hipSuccess || ndev == 0)
+    return fail(CMI_GPU_EDEVICE,
+                "no HIP device available (%s); this engine has no CPU path",
+                err == hipSuccess ? "device count is 0"
+                                  : hipGetErrorString(err));
+  if (config->device < 0 || config->device >= ndev)
+    return fail(CMI_GPU_EINVAL, "device %d out of range [0,%d)",
+                config->device, ndev);
+  HIP_TRY(hipSetDevice(config->device));
+
+  cmi_gpu_engine *e = new cmi_gpu_engine();
+  e->config = *config;
+  e->device = config->device;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+  e->num_cu = prop.multiProcessorCount;
+  if (config->stream) {
+    e->stream = (hipStream_t)config->stream;
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = true;
+  }
+
+  /* CartesianDensityGrid ctor, src/CartesianDensityGrid.cpp:72-79 */
+  GridDev &g = e->grid;
+  for (int a = 0; a < 3; ++a) {
+    g.anchor[a] = config->anchor[a];
+    g.box_sides[a] = config->sides[a];
+    g.ncell[a] = config->ncell[a];
+    g.periodic[a] = config->periodic[a] ? 1 : 0;
+    g.cellside[a] = config->sides[a] / config->ncell[a];
+    g.inv_cellside[a] = 1. / g.cellside[a];
+  }
+  e->ncell = (int64_t)g.ncell[0] * g.ncell[1] * g.ncell[2];
+  g.ncell_total = e->ncell;
+
+  const size_t field_bytes = (size_t)e->ncell * sizeof(double);
+  HIP_TRY(hipMalloc(&e->state_block, 16 * field_bytes));
+  HIP_TRY(hipMemsetAsync(e->state_block, 0, 16 * field_bytes, e->stream));
+  if (config->external_accumulators) {
+    e->acc_block = (double *)config->external_accumulators;
+  } else {
+    HIP_TRY(hipMalloc(&e->acc_block, CMI_NACC * field_bytes));
+    e->own_acc = true;
+  }
+  HIP_TRY(hipMemsetAsync(e->acc_block, 0, CMI_NACC * field_bytes, e->stream));
+  HIP_TRY(hipMalloc(&e->opacity, (size_t)e->ncell * sizeof(double2)));
+  HIP_TRY(hipMalloc(&e->counters, sizeof(CountersDev)));
+  HIP_TRY(hipMemsetAsync(e->counters, 0, sizeof(CountersDev), e->stream));
+  HIP_TRY(hipMalloc(&e->tables, sizeof(TablesDev)));
+  {
+    TablesDev *host = new TablesDev;
+    build_tables(*host);
+    hipError_t cerr =
+        hipMemcpy(e->tables, host, sizeof(TablesDev), hipMemcpyHostToDevice);
+    delete host;
+    HIP_TRY(cerr);
+  }
+
+  CellsDev &c = e->cells;
+  c.number_density = e->state_block;
+  c.temperature = e->state_block + e->ncell;
+  for (int i = 0; i < CMI_NION; ++i)
+    c.x[i] = e->state_block + (int64_t)(2 + i) * e->ncell;
+  for (int i = 0; i < CMI_NACC; ++i)
+    c.acc[i] = e->acc_block + (int64_t)i * e->ncell;
+  c.opacity = e->opacity;
+
+  ModelDev &m = e->model;
+  memset(&m, 0, sizeof m);
+  m.tables = e->tables;
+  /* DensityGrid ctor, src/DensityGrid.hpp:219-222 */
+  m.nu_H = eV_to_Hz(13.6);
+  m.nu_He = eV_to_Hz(24.6);
+  m.reemit_type = CMI_GPU_REEMIT_NONE;
+
+  cmi_gpu_temperature_params &tp = e->tparams;
+  tp.do_temperature_calculation = 0;
+  tp.minimum_number_of_iterations = 3;
+  tp.epsilon_convergence = 1.e-3;
+  tp.maximum_number_of_iterations = 100;
+  tp.pah_heating_factor = 0.;
+  tp.cosmic_ray_heating_factor = 0.;
+  tp.cosmic_ray_heating_limit = 0.75;
+  tp.cosmic_ray_heating_scale_length = 1.33333 * 3.086e19;
+  tp.minimum_ionized_temperature = 4000.;
+
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *out = e;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_destroy(cmi_gpu_engine *e) {
+  if (!e)
+    return CMI_GPU_OK;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  for (auto &p : e->shoot_events) {
+    (void)hipEventDestroy(p.start);
+    (void)hipEventDestroy(p.stop);
+  }
+  for (auto &p : e->update_events) {
+    (void)hipEventDestroy(p.start);
+    (void)hipEventDestroy(p.stop);
+  }
+  (void)hipFree(e->state_block);
+  if (e->own_acc)
+    (void)hipFree(e->acc_block);
+  (void)hipFree(e->opacity);
+  (void)hipFree(e->counters);
+  (void)hipFree(e->tables);
+  (void)hipFree(e->source_position);
+  (void)hipFree(e->source_cumulative);
+  if (e->own_stream)
+    (void)hipStreamDestroy(e->stream);
+  delete e;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_synchronize(cmi_gpu_engine *e) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return CMI_GPU_OK;
+}
+
+int64_t cmi_gpu_number_of_cells(const cmi_gpu_engine *e) {
+  return e ? e->ncell : -1;
+}
+
+int cmi_gpu_set_sources(cmi_gpu_engine *e, int32_t n, const double *positions,
+                        const double *weights, double total_luminosity) {
+  if (!e || n <= 0 || !positions || !weights)
+    return fail(CMI_GPU_EINVAL, "cmi_gpu_set_sources: bad argument");
+  /* PhotonSource ctor, src/PhotonSource.cpp:74-93 */
+  std::vector<double> cumulative(n);
+  for (int i = 0; i < n; ++i)
+    cumulative[i] = (i > 0 ? cumulative[i - 1] : 0.) + weights[i];
+  if (std::abs(cumulative.back() - 1.) > 1.e-9)
+    return fail(CMI_GPU_EINVAL,
+                "Discrete source weights do not sum to 1.0 (%g)!",
+                cumulative.back());
+  cumulative.back() = 1.;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(e->source_position);
+  (void)hipFree(e->source_cumulative);
+  HIP_TRY(hipMalloc(&e->source_position, sizeof(double) * 3 * n));
+  HIP_TRY(hipMalloc(&e->source_cumulative, sizeof(double) * n));
+  HIP_TRY(hipMemcpy(e->source_position, positions, sizeof(double) * 3 * n,
+                    hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->source_cumulative, cumulative.data(),
+                    sizeof(double) * n, hipMemcpyHostToDevice));
+  e->model.nsource = n;
+  e->model.source_position = e->source_position;
+  e->model.source_cumulative = e->source_cumulative;
+  e->model.total_luminosity = total_luminosity;
+  e->have_sources = true;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_spectrum_monochromatic(cmi_gpu_engine *e, double frequency) {
+  if (!e || !(frequency > 0.))
+    return fail(CMI_GPU_EINVAL, "monochromatic spectrum: bad argument");
+  e->model.spectrum_type = CMI_GPU_SPECTRUM_MONOCHROMATIC;
+  e->model.mono_frequency = frequency;
+  e->have_spectrum = true;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_spectrum_planck(cmi_gpu_engine *e, double temperature) {
+  (void)temperature;
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  return fail(CMI_GPU_ESTATE, "Planck spectrum not implemented yet");
+}
+
+int cmi_gpu_set_cross_sections_fixed(cmi_gpu_engine *e, const double *sigma) {
+  if (!e || !sigma)
+    return fail(CMI_GPU_EINVAL, "fixed cross sections: bad argument");
+  e->model.xsec_verner = 0;
+  for (int i = 0; i < CMI_NION; ++i)
+    e->model.xsec_fixed[i] = sigma[i];
+  e->have_xsec = true;
+  update_full_flag(e);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_cross_sections_verner(cmi_gpu_engine *e) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  e->model.xsec_verner = 1;
+  e->have_xsec = true;
+  update_full_flag(e);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_recombination_rates_fixed(cmi_gpu_engine *e,
+                                          const double *alpha) {
+  if (!e || !alpha)
+    return fail(CMI_GPU_EINVAL, "fixed recombination rates: bad argument");
+  e->model.recomb_verner = 0;
+  for (int i = 0; i < CMI_NION; ++i)
+    e->model.recomb_fixed[i] = alpha[i];
+  e->have_recomb = true;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_recombination_rates_verner(cmi_gpu_engine *e) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  e->model.recomb_verner = 1;
+  e->have_recomb = true;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_abundances(cmi_gpu_engine *e, const double *abundances) {
+  if (!e || !abundances)
+    return fail(CMI_GPU_EINVAL, "abundances: bad argument");
+  for (int i = 0; i < 6; ++i)
+    e->model.abundance[i] = abundances[i];
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_reemission(cmi_gpu_engine *e, int32_t type,
+                           double fixed_probability, double fixed_frequency) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  if (type != CMI_GPU_REEMIT_NONE)
+    return fail(CMI_GPU_ESTATE, "diffuse re-emission not implemented yet");
+  e->model.reemit_type = type;
+  e->model.reemit_fixed_probability = fixed_probability;
+  e->model.reemit_fixed_frequency = fixed_frequency;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_temperature_params(cmi_gpu_engine *e,
+                                   const cmi_gpu_temperature_params *params) {
+  if (!e || !params)
+    return fail(CMI_GPU_EINVAL, "temperature params: bad argument");
+  e->tparams = *params;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_upload_cells(cmi_gpu_engine *e, const double *number_density,
+                         const double *temperature,
+                         const double *ionic_fractions) {
+  if (!e || !number_density || !temperature)
+    return fail(CMI_GPU_EINVAL, "upload_cells: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t bytes = (size_t)e->ncell * sizeof(double);
+  HIP_TRY(hipMemcpyAsync(e->cells.number_density, number_density, bytes,
+                         hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->cells.temperature, temperature, bytes,
+                         hipMemcpyHostToDevice, e->stream));
+  if (ionic_fractions) {
+    HIP_TRY(hipMemcpyAsync(e->cells.x[0], ionic_fractions, CMI_NION * bytes,
+                           hipMemcpyHostToDevice, e->stream));
+  } else {
+    HIP_TRY(hipMemsetAsync(e->cells.x[0], 0, CMI_NION * bytes, e->stream));
+  }
+  int rc = rebuild_opacity(e);
+  if (rc)
+    return rc;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->have_cells = true;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_upload_field(cmi_gpu_engine *e, int32_t field,
+                         const double *values) {
+  if (!e || !values)
+    return fail(CMI_GPU_EINVAL, "upload_field: bad argument");
+  double *dst = field_pointer(e, field);
+  if (!dst)
+    return fail(CMI_GPU_EINVAL, "upload_field: unknown field %d", field);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(dst, values, (size_t)e->ncell * sizeof(double),
+                         hipMemcpyHostToDevice, e->stream));
+  if (field == CMI_GPU_FIELD_NUMBER_DENSITY ||
+      field == CMI_GPU_FIELD_IONIC_FRACTION + ION_H_n ||
+      field == CMI_GPU_FIELD_IONIC_FRACTION + ION_He_n) {
+    int rc = rebuild_opacity(e);
+    if (rc)
+      return rc;
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_download_field(cmi_gpu_engine *e, int32_t field, double *values) {
+  if (!e || !values)
+    return fail(CMI_GPU_EINVAL, "download_field: bad argument");
+  double *src = field_pointer(e, field);
+  if (!src)
+    return fail(CMI_GPU_EINVAL, "download_field: unknown field %d", field);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(values, src, (size_t)e->ncell * sizeof(double),
+                         hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return CMI_GPU_OK;
+}
+
+void *cmi_gpu_field_device_pointer(cmi_gpu_engine *e, int32_t field) {
+  if (!e)
+    return nullptr;
+  return field_pointer(e, field);
+}
+
+int cmi_gpu_reset_grid(cmi_gpu_engine *e) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemsetAsync(e->acc_block, 0,
+                         (size_t)CMI_NACC * e->ncell * sizeof(double),
+                         e->stream));
+  HIP_TRY(hipMemsetAsync(e->counters, 0, sizeof(CountersDev), e->stream));
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
+                  uint64_t first_packet, uint64_t n_packets) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  if (!e->have_sources || !e->have_spectrum || !e->have_xsec ||
+      !e->have_cells)
+    return fail(CMI_GPU_ESTATE,
+                "cmi_gpu_shoot: sources, spectrum, cross sections and cell "
+                "data must be set first");
+  if (n_packets == 0)
+    return CMI_GPU_OK;
+  HIP_TRY(hipSetDevice(e->device));
+
+  ShootArgs a;
+  a.grid = e->grid;
+  a.model = e->model;
+  a.cells = e->cells;
+  a.counters = e->counters;
+  a.first_packet = first_packet;
+  a.n_packets = n_packets;
+  a.seed = seed;
+  a.iteration = iteration;
+
+  const bool heat = e->config.track_heating != 0;
+  const bool reemit = e->model.reemit_type != CMI_GPU_REEMIT_NONE;
+  void (*kernel)(const ShootArgs) = nullptr;
+#define PICK(F, H, R)                                                          \
+  if (e->full_ions == F && heat == H && reemit == R)                           \
+    kernel = shoot_kernel<F, H, R>;
+  PICK(false, false, false)
+  PICK(false, false, true)
+  PICK(false, true, false)
+  PICK(false, true, true)
+  PICK(true, false, false)
+  PICK(true, false, true)
+  PICK(true, true, false)
+  PICK(true, true, true)
+#undef PICK
+
+  int blocks_per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel,
+                                                       CMI_BLOCK, 0));
+  if (blocks_per_cu < 1)
+    blocks_per_cu = 1;
+  if (blocks_per_cu > 8)
+    blocks_per_cu = 8;
+  const int blocks = grid_blocks(e, (int64_t)n_packets, blocks_per_cu);
+
+  EventPair ev;
+  HIP_TRY(hipEventCreate(&ev.start));
+  HIP_TRY(hipEventCreate(&ev.stop));
+  HIP_TRY(hipEventRecord(ev.start, e->stream));
+  kernel<<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev.stop, e->stream));
+  e->shoot_events.push_back(ev);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_get_counters(cmi_gpu_engine *e, double *totweight,
+                         double *typecount, uint64_t *nsteps) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  CountersDev host;
+  HIP_TRY(hipMemcpyAsync(&host, e->counters, sizeof host,
+                         hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (totweight)
+    *totweight = host.totweight;
+  if (typecount)
+    for (int i = 0; i < 4; ++i)
+      typecount[i] = host.typecount[i];
+  if (nsteps)
+    *nsteps = host.nsteps;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_update_cells(cmi_gpu_engine *e, uint32_t loop, double totweight) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  if (!e->have_sources || !e->have_recomb || !e->have_cells)
+    return fail(CMI_GPU_ESTATE,
+                "cmi_gpu_update_cells: sources, recombination rates and cell "
+                "data must be set first");
+  if (!(totweight > 0.))
+    return fail(CMI_GPU_EINVAL, "update_cells: totweight must be positive");
+  HIP_TRY(hipSetDevice(e->device));
+  if (e->tparams.do_temperature_calculation &&
+      loop > (uint32_t)e->tparams.minimum_number_of_iterations)
+    return fail(CMI_GPU_ESTATE, "temperature calculation not implemented yet");
+
+  UpdateArgs a;
+  a.grid = e->grid;
+  a.model = e->model;
+  a.cells = e->cells;
+  /* src/IonizationStateCalculator.cpp:519-522 and :136-137 */
+  const double jfac = e->model.total_luminosity / totweight;
+  const double hfac = jfac * CMI_PLANCK;
+  const double volume =
+      e->grid.cellside[0] * e->grid.cellside[1] * e->grid.cellside[2];
+  a.jfac = jfac / volume;
+  a.hfac = hfac / volume;
+
+  EventPair ev;
+  HIP_TRY(hipEventCreate(&ev.start));
+  HIP_TRY(hipEventCreate(&ev.stop));
+  HIP_TRY(hipEventRecord(ev.start, e->stream));
+  const int blocks = grid_blocks(e, e->ncell, 8);
+  if (e->full_ions)
+    ionization_kernel<true><<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
+  else
+    ionization_kernel<false><<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev.stop, e->stream));
+  e->update_events.push_back(ev);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_emit_packets(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
+                         uint64_t first_packet, uint64_t n, double *position,
+                         double *direction, double *frequency,
+                         double *cross_sections, double *tau) {
+  if (!e || !position || !direction || !frequency || !cross_sections || !tau)
+    return fail(CMI_GPU_EINVAL, "emit_packets: bad argument");
+  if (!e->have_sources || !e->have_spectrum || !e->have_xsec)
+    return fail(CMI_GPU_ESTATE, "emit_packets: model not complete");
+  if (n == 0)
+    return CMI_GPU_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  double *d = nullptr;
+  const size_t per = 3 + 3 + 1 + CMI_NION + 1;
+  HIP_TRY(hipMalloc(&d, sizeof(double) * per * n));
+  double *dpos = d, *ddir = d + 3 * n, *dnu = d + 6 * n, *dsig = d + 7 * n,
+         *dtau = d + (7 + CMI_NION) * n;
+  emit_probe_kernel<<<(unsigned)((n + 63) / 64), 64, 0, e->stream>>>(
+      e->grid, e->model, seed, iteration, first_packet, n, dpos, ddir, dnu,
+      dsig, dtau);
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess)
+    err = hipStreamSynchronize(e->stream);
+  if (err == hipSuccess)
+    err = hipMemcpy(position, dpos, sizeof(double) * 3 * n,
+                    hipMemcpyDeviceToHost);
+  if (err == hipSuccess)
+    err = hipMemcpy(direction, ddir, sizeof(double) * 3 * n,
+                    hipMemcpyDeviceToHost);
+  if (err == hipSuccess)
+    err = hipMemcpy(frequency, dnu, sizeof(double) * n, hipMemcpyDeviceToHost);
+  if (err == hipSuccess)
+    err = hipMemcpy(cross_sections, dsig, sizeof(double) * CMI_NION * n,
+                    hipMemcpyDeviceToHost);
+  if (err == hipSuccess)
+    err = hipMemcpy(tau, dtau, sizeof(double) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(err);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_trace_packets(cmi_gpu_engine *e, uint64_t n,
+                          const double *position, const double *direction,
+                          const double *tau, const double *sigma_H,
+                          const double *sigma_He_corr, int32_t max_steps,
+                          int64_t *out_cell, double *out_ds,
+                          int32_t *out_nsteps, int64_t *out_last_cell,
+                          double *out_position) {
+  if (!e || !position || !direction || !tau || !sigma_H || !sigma_He_corr ||
+      !out_cell || !out_ds || !out_nsteps || !out_last_cell || !out_position ||
+      max_steps <= 0)
+    return fail(CMI_GPU_EINVAL, "trace_packets: bad argument");
+  if (!e->have_cells)
+    return fail(CMI_GPU_ESTATE, "trace_packets: no cell data");
+  if (n == 0)
+    return CMI_GPU_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  char *buf = nullptr;
+  const size_t in_bytes = sizeof(double) * (3 + 3 + 1 + 1 + 1) * n;
+  const size_t cell_bytes = sizeof(int64_t) * (size_t)max_steps * n;
+  const size_t ds_bytes = sizeof(double) * (size_t)max_steps * n;
+  const size_t tail = (sizeof(int64_t) + 3 * sizeof(double)) * n +
+                      sizeof(int32_t) * n;
+  HIP_TRY(hipMalloc(&buf, in_bytes + cell_bytes + ds_bytes + tail));
+  double *dpos = (double *)buf, *ddir = dpos + 3 * n, *dtau = ddir + 3 * n,
+         *dsh = dtau + n, *dshe = dsh + n;
+  int64_t *dcell = (int64_t *)(buf + in_bytes);
+  double *dds = (double *)(buf + in_bytes + cell_bytes);
+  int64_t *dlast = (int64_t *)(buf + in_bytes + cell_bytes + ds_bytes);
+  double *dfinal = (double *)(dlast + n);
+  int32_t *dnsteps = (int32_t *)(dfinal + 3 * n);
+  hipError_t err = hipMemcpy(dpos, position, sizeof(double) * 3 * n,
+                             hipMemcpyHostToDevice);
+  if (err == hipSuccess)
+    err = hipMemcpy(ddir, direction, sizeof(double) * 3 * n,
+                    hipMemcpyHostToDevice);
+  if (err == hipSuccess)
+    err = hipMemcpy(dtau, tau, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (err == hipSuccess)
+    err = hipMemcpy(dsh, sigma_H, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (err == hipSuccess)
+    err = hipMemcpy(dshe, sigma_He_corr, sizeof(double) * n,
+                    hipMemcpyHostToDevice);
+  if (err == hipSuccess)
+    err = hipMemsetAsync(dcell, 0xff, cell_bytes, e->stream);
+  if (err == hipSuccess)
+    err = hipMemsetAsync(dds, 0, ds_bytes, e->stream);
+  if (err == hipSuccess) {
+    trace_probe_kernel<<<(unsigned)((n + 63) / 64), 64, 0, e->stream>>>(
+        e->grid, e->opacity, n, dpos, ddir, dtau, dsh, dshe, max_steps, dcell,
+        dds, dnsteps, dlast, dfinal);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess)
+    err = hipStreamSynchronize(e->stream);
+  if (err == hipSuccess)
+    err = hipMemcpy(out_cell, dcell, cell_bytes, hipMemcpyDeviceToHost);
+  if (err == hipSuccess)
+    err = hipMemcpy(out_ds, dds, ds_bytes, hipMemcpyDeviceToHost);
+  if (err == hipSuccess)
+    err = hipMemcpy(out_nsteps, dnsteps, sizeof(int32_t) * n,
+                    hipMemcpyDeviceToHost);
+  if (err == hipSuccess)
+    err = hipMemcpy(out_last_cell, dlast, sizeof(int64_t) * n,
+                    hipMemcpyDeviceToHost);
+  if (err == hipSuccess)
+    err = hipMemcpy(out_position, dfinal, sizeof(double) * 3 * n,
+                    hipMemcpyDeviceToHost);
+  (void)hipFree(buf);
+  HIP_TRY(err);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_get_timing(cmi_gpu_engine *e, int32_t reset, double *shoot_ms,
+                       uint64_t *shoot_launches, double *update_ms,
+                       uint64_t *update_launches) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  double s = 0., u = 0.;
+  for (auto &p : e->shoot_events) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p.start, p.stop));
+    s += ms;
+  }
+  for (auto &p : e->update_events) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p.start, p.stop));
+    u += ms;
+  }
+  if (shoot_ms)
+    *shoot_ms = s;
+  if (shoot_launches)
+    *shoot_launches = e->shoot_events.size();
+  if (update_ms)
+    *update_ms = u;
+  if (update_launches)
+    *update_launches = e->update_events.size();
+  if (reset) {
+    for (auto &p : e->shoot_events) {
+      (void)hipEventDestroy(p.start);
+      (void)hipEventDestroy(p.stop);
+    }
+    for (auto &p : e->update_events) {
+      (void)hipEventDestroy(p.start);
+      (void)hipEventDestroy(p.stop);
+    }
+    e->shoot_events.clear();
+    e->update_events.clear();
+  }
+  return CMI_GPU_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,306 @@
+"""ctypes binding of the engine's C ABI (include/cmi_gpu.h, libcmi_gpu.so).
+
+This is plumbing only: every method is one call through the C ABI. There is no
+Python or CPU implementation of the path behind it - if the HIP library is
+missing or no device is present, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcmi_gpu.so")
+
+NION = 14
+NACC = 16
+NTYPE = 4
+
+FIELD_NUMBER_DENSITY = 0
+FIELD_TEMPERATURE = 1
+FIELD_IONIC_FRACTION = 2
+FIELD_MEAN_INTENSITY = 16
+FIELD_HEATING = 30
+
+REEMIT_NONE, REEMIT_PHYSICAL, REEMIT_FIXED = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+
+
+class Config(C.Structure):
+    _fields_ = [("anchor", C.c_double * 3), ("sides", C.c_double * 3),
+                ("ncell", C.c_int32 * 3), ("periodic", C.c_int32 * 3),
+                ("device", C.c_int32), ("track_heating", C.c_int32),
+                ("stream", C.c_void_p),
+                ("external_accumulators", C.c_void_p)]
+
+
+class TemperatureParams(C.Structure):
+    _fields_ = [("do_temperature_calculation", C.c_int32),
+                ("minimum_number_of_iterations", C.c_int32),
+                ("epsilon_convergence", C.c_double),
+                ("maximum_number_of_iterations", C.c_int32),
+                ("pah_heating_factor", C.c_double),
+                ("cosmic_ray_heating_factor", C.c_double),
+                ("cosmic_ray_heating_limit", C.c_double),
+                ("cosmic_ray_heating_scale_length", C.c_double),
+                ("minimum_ionized_temperature", C.c_double)]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+# every symbol include/cmi_gpu.h declares
+EXPORTED_SYMBOLS = [
+    "cmi_gpu_create", "cmi_gpu_destroy", "cmi_gpu_last_error",
+    "cmi_gpu_synchronize", "cmi_gpu_number_of_cells", "cmi_gpu_set_sources",
+    "cmi_gpu_set_spectrum_monochromatic", "cmi_gpu_set_spectrum_planck",
+    "cmi_gpu_set_cross_sections_fixed", "cmi_gpu_set_cross_sections_verner",
+    "cmi_gpu_set_recombination_rates_fixed",
+    "cmi_gpu_set_recombination_rates_verner", "cmi_gpu_set_abundances",
+    "cmi_gpu_set_reemission", "cmi_gpu_set_temperature_params",
+    "cmi_gpu_upload_cells", "cmi_gpu_upload_field", "cmi_gpu_download_field",
+    "cmi_gpu_field_device_pointer", "cmi_gpu_reset_grid", "cmi_gpu_shoot",
+    "cmi_gpu_get_counters", "cmi_gpu_update_cells", "cmi_gpu_emit_packets",
+    "cmi_gpu_trace_packets", "cmi_gpu_get_timing",
+]
+
+_lib = None
+
+
+def load_library():
+    """Load libcmi_gpu.so (built by __graft_entry__.build()); no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            "HIP engine library not found at %s - build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C cmacionize_amd/csrc`. There is no CPU fallback." %
+            LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.cmi_gpu_last_error.restype = C.c_char_p
+    L.cmi_gpu_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.cmi_gpu_destroy.argtypes = [vp]
+    L.cmi_gpu_synchronize.argtypes = [vp]
+    L.cmi_gpu_number_of_cells.restype = C.c_int64
+    L.cmi_gpu_number_of_cells.argtypes = [vp]
+    L.cmi_gpu_set_sources.argtypes = [vp, C.c_int32, _dp, _dp, C.c_double]
+    L.cmi_gpu_set_spectrum_monochromatic.argtypes = [vp, C.c_double]
+    L.cmi_gpu_set_spectrum_planck.argtypes = [vp, C.c_double]
+    L.cmi_gpu_set_cross_sections_fixed.argtypes = [vp, _dp]
+    L.cmi_gpu_set_cross_sections_verner.argtypes = [vp]
+    L.cmi_gpu_set_recombination_rates_fixed.argtypes = [vp, _dp]
+    L.cmi_gpu_set_recombination_rates_verner.argtypes = [vp]
+    L.cmi_gpu_set_abundances.argtypes = [vp, _dp]
+    L.cmi_gpu_set_reemission.argtypes = [vp, C.c_int32, C.c_double,
+                                         C.c_double]
+    L.cmi_gpu_set_temperature_params.argtypes = [
+        vp, C.POINTER(TemperatureParams)]
+    L.cmi_gpu_upload_cells.argtypes = [vp, _dp, _dp, _dp]
+    L.cmi_gpu_upload_field.argtypes = [vp, C.c_int32, _dp]
+    L.cmi_gpu_download_field.argtypes = [vp, C.c_int32, _dp]
+    L.cmi_gpu_field_device_pointer.restype = C.c_void_p
+    L.cmi_gpu_field_device_pointer.argtypes = [vp, C.c_int32]
+    L.cmi_gpu_reset_grid.argtypes = [vp]
+    L.cmi_gpu_shoot.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64,
+                                C.c_uint64]
+    L.cmi_gpu_get_counters.argtypes = [vp, _dp, _dp, C.POINTER(C.c_uint64)]
+    L.cmi_gpu_update_cells.argtypes = [vp, C.c_uint32, C.c_double]
+    L.cmi_gpu_emit_packets.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64,
+                                       C.c_uint64, _dp, _dp, _dp, _dp, _dp]
+    L.cmi_gpu_trace_packets.argtypes = [
+        vp, C.c_uint64, _dp, _dp, _dp, _dp, _dp, C.c_int32,
+        C.POINTER(C.c_int64), _dp, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+        _dp]
+    L.cmi_gpu_get_timing.argtypes = [vp, C.c_int32, _dp, C.POINTER(C.c_uint64),
+                                     _dp, C.POINTER(C.c_uint64)]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class GpuEngine:
+    """One engine handle = one grid on one GPU."""
+
+    def __init__(self, ncell, anchor, sides, periodic=(0, 0, 0), device=0,
+                 track_heating=False, stream=None, external_accumulators=None):
+        self._lib = load_library()
+        cfg = Config()
+        for a in range(3):
+            cfg.anchor[a] = anchor[a]
+            cfg.sides[a] = sides[a]
+            cfg.ncell[a] = int(ncell[a])
+            cfg.periodic[a] = int(bool(periodic[a]))
+        cfg.device = device
+        cfg.track_heating = int(bool(track_heating))
+        cfg.stream = stream
+        cfg.external_accumulators = external_accumulators
+        self._h = C.c_void_p()
+        self._check(self._lib.cmi_gpu_create(C.byref(cfg), C.byref(self._h)))
+        self.ncell = tuple(int(n) for n in ncell)
+        self.n = int(np.prod(self.ncell))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError("cmi_gpu error %d: %s" % (
+                rc, self._lib.cmi_gpu_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.cmi_gpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # plugin descriptors -----------------------------------------------------
+    def set_sources(self, positions, weights, luminosity):
+        pos = _f64(positions).reshape(-1, 3)
+        w = _f64(weights)
+        self._check(self._lib.cmi_gpu_set_sources(self._h, len(w), _p(pos),
+                                                  _p(w), luminosity))
+
+    def set_spectrum_monochromatic(self, frequency):
+        self._check(self._lib.cmi_gpu_set_spectrum_monochromatic(self._h,
+                                                                 frequency))
+
+    def set_spectrum_planck(self, temperature):
+        self._check(self._lib.cmi_gpu_set_spectrum_planck(self._h,
+                                                          temperature))
+
+    def set_cross_sections_fixed(self, sigma):
+        s = _f64(sigma)
+        assert s.shape == (NION,)
+        self._check(self._lib.cmi_gpu_set_cross_sections_fixed(self._h, _p(s)))
+
+    def set_cross_sections_verner(self):
+        self._check(self._lib.cmi_gpu_set_cross_sections_verner(self._h))
+
+    def set_recombination_rates_fixed(self, alpha):
+        a = _f64(alpha)
+        assert a.shape == (NION,)
+        self._check(self._lib.cmi_gpu_set_recombination_rates_fixed(self._h,
+                                                                    _p(a)))
+
+    def set_recombination_rates_verner(self):
+        self._check(self._lib.cmi_gpu_set_recombination_rates_verner(self._h))
+
+    def set_abundances(self, abundances):
+        a = _f64(abundances)
+        assert a.shape == (6,)
+        self._check(self._lib.cmi_gpu_set_abundances(self._h, _p(a)))
+
+    def set_reemission(self, kind, probability=0., frequency=0.):
+        self._check(self._lib.cmi_gpu_set_reemission(self._h, kind,
+                                                     probability, frequency))
+
+    def set_temperature_params(self, **kw):
+        p = TemperatureParams(0, 3, 1.e-3, 100, 0., 0., 0.75,
+                              1.33333 * 3.086e19, 4000.)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        self._check(self._lib.cmi_gpu_set_temperature_params(self._h,
+                                                             C.byref(p)))
+
+    # cell data --------------------------------------------------------------
+    def upload_cells(self, number_density, temperature, ionic_fractions=None):
+        n = _f64(number_density).ravel()
+        t = _f64(temperature).ravel()
+        assert n.size == self.n and t.size == self.n
+        x = None
+        if ionic_fractions is not None:
+            x = _f64(ionic_fractions).reshape(NION, self.n)
+        self._check(self._lib.cmi_gpu_upload_cells(
+            self._h, _p(n), _p(t), _p(x) if x is not None else None))
+
+    def upload_field(self, field, values):
+        v = _f64(values).ravel()
+        assert v.size == self.n
+        self._check(self._lib.cmi_gpu_upload_field(self._h, field, _p(v)))
+
+    def download_field(self, field):
+        out = np.empty(self.n)
+        self._check(self._lib.cmi_gpu_download_field(self._h, field, _p(out)))
+        return out
+
+    def field_device_pointer(self, field):
+        return self._lib.cmi_gpu_field_device_pointer(self._h, field)
+
+    # iteration body -----------------------------------------------------------
+    def reset_grid(self):
+        self._check(self._lib.cmi_gpu_reset_grid(self._h))
+
+    def shoot(self, seed, iteration, first_packet, n_packets):
+        self._check(self._lib.cmi_gpu_shoot(self._h, seed, iteration,
+                                            first_packet, n_packets))
+
+    def get_counters(self):
+        tw = C.c_double()
+        tc = np.zeros(NTYPE)
+        ns = C.c_uint64()
+        self._check(self._lib.cmi_gpu_get_counters(self._h, C.byref(tw),
+                                                   _p(tc), C.byref(ns)))
+        return tw.value, tc, ns.value
+
+    def update_cells(self, loop, totweight):
+        self._check(self._lib.cmi_gpu_update_cells(self._h, loop, totweight))
+
+    def synchronize(self):
+        self._check(self._lib.cmi_gpu_synchronize(self._h))
+
+    # probes -------------------------------------------------------------------
+    def emit_packets(self, seed, iteration, first_packet, n):
+        pos = np.empty((n, 3))
+        dirn = np.empty((n, 3))
+        nu = np.empty(n)
+        sig = np.empty((n, NION))
+        tau = np.empty(n)
+        self._check(self._lib.cmi_gpu_emit_packets(
+            self._h, seed, iteration, first_packet, n, _p(pos), _p(dirn),
+            _p(nu), _p(sig), _p(tau)))
+        return pos, dirn, nu, sig, tau
+
+    def trace_packets(self, position, direction, tau, sigma_H, sigma_He_corr,
+                      max_steps):
+        pos = _f64(position).reshape(-1, 3)
+        n = pos.shape[0]
+        dirn = _f64(direction).reshape(n, 3)
+        tau = _f64(tau).reshape(n)
+        sh = _f64(sigma_H).reshape(n)
+        she = _f64(sigma_He_corr).reshape(n)
+        cells = np.empty((n, max_steps), dtype=np.int64)
+        ds = np.empty((n, max_steps))
+        nsteps = np.empty(n, dtype=np.int32)
+        last = np.empty(n, dtype=np.int64)
+        final = np.empty((n, 3))
+        self._check(self._lib.cmi_gpu_trace_packets(
+            self._h, n, _p(pos), _p(dirn), _p(tau), _p(sh), _p(she), max_steps,
+            cells.ctypes.data_as(C.POINTER(C.c_int64)), _p(ds),
+            nsteps.ctypes.data_as(C.POINTER(C.c_int32)),
+            last.ctypes.data_as(C.POINTER(C.c_int64)), _p(final)))
+        return cells, ds, nsteps, last, final
+
+    def get_timing(self, reset=True):
+        s = C.c_double()
+        u = C.c_double()
+        ns = C.c_uint64()
+        nu = C.c_uint64()
+        self._check(self._lib.cmi_gpu_get_timing(
+            self._h, int(reset), C.byref(s), C.byref(ns), C.byref(u),
+            C.byref(nu)))
+        return {"shoot_ms": s.value, "shoot_launches": ns.value,
+                "update_ms": u.value, "update_launches": nu.value}

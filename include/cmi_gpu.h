@@ -1,0 +1,258 @@
+/*
+ * cmi_gpu.h - C ABI of the MI355X photoionization engine (libcmi_gpu.so).
+ *
+ * This is the drop-in boundary for ONE path of CMacIonize: photon-packet
+ * transport through a regular Cartesian grid plus the per-cell ionization /
+ * temperature balance, i.e. the body of the iteration loop of
+ * IonizationSimulation::run (reference src/IonizationSimulation.cpp:359-643):
+ *
+ *     reset_grid -> shoot N packets -> [reduce] -> calculate_temperature
+ *
+ * Everything above that loop (parameter file, plugin objects, writers) stays
+ * on the host; the plugins are lowered once, at initialisation, into the flat
+ * descriptors passed through the cmi_gpu_set_* calls. Every entry point cites
+ * the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - plain C types only: opaque handle, pointers and sizes;
+ *  - every function returns 0 on success and a non-zero CMI_GPU_E* code on
+ *    failure; cmi_gpu_last_error() gives the message (thread local). Nothing
+ *    aborts (the reference's cmac_error aborts, src/Error.hpp:101-110);
+ *  - "host" pointers are caller-owned host memory, copied during the call;
+ *    "device" pointers are HIP device memory valid on the engine's device;
+ *  - all quantities in SI units, fp64, ion order of src/ElementNames.hpp:101-154
+ *    (H0 He0 C+ C2+ N0 N+ N2+ O0 O+ Ne0 Ne+ S+ S2+ S3+), cells row-major
+ *    ix*ny*nz + iy*nz + iz (src/CartesianDensityGrid.hpp:137-144);
+ *  - one host thread per handle; work is enqueued on the handle's HIP stream
+ *    and is asynchronous unless stated otherwise.
+ *  - there is no CPU fallback: without a HIP device cmi_gpu_create fails.
+ */
+#ifndef CMI_GPU_H
+#define CMI_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMI_GPU_NION 14
+#define CMI_GPU_NHEATING 2
+#define CMI_GPU_NTYPE 4 /* src/PhotonType.hpp:36-50 */
+/* mean-intensity + heating accumulators per cell (src/DensityGrid.hpp:150-197) */
+#define CMI_GPU_NACC (CMI_GPU_NION + CMI_GPU_NHEATING)
+
+enum {
+  CMI_GPU_OK = 0,
+  CMI_GPU_EINVAL = 1,   /* bad argument */
+  CMI_GPU_EDEVICE = 2,  /* HIP runtime error / no device */
+  CMI_GPU_ESTATE = 3,   /* call sequence error (e.g. shoot before sources) */
+  CMI_GPU_ENOMEM = 4
+};
+
+/* field ids for upload / download / device pointers */
+enum {
+  CMI_GPU_FIELD_NUMBER_DENSITY = 0, /* IonizationVariables::_number_density */
+  CMI_GPU_FIELD_TEMPERATURE = 1,    /* ::_temperature */
+  CMI_GPU_FIELD_IONIC_FRACTION = 2, /* + ion (14 fields) ::_ionic_fractions */
+  CMI_GPU_FIELD_MEAN_INTENSITY = 16, /* + ion (14 fields) ::_mean_intensity */
+  CMI_GPU_FIELD_HEATING = 30,        /* + 0 (H), 1 (He)  ::_heating */
+  CMI_GPU_NFIELD = 32
+};
+
+enum { CMI_GPU_SPECTRUM_MONOCHROMATIC = 0, CMI_GPU_SPECTRUM_PLANCK = 1 };
+enum { CMI_GPU_REEMIT_NONE = 0, CMI_GPU_REEMIT_PHYSICAL = 1,
+       CMI_GPU_REEMIT_FIXED = 2 };
+
+typedef struct cmi_gpu_engine cmi_gpu_engine;
+
+/* Geometry of the CartesianDensityGrid (src/CartesianDensityGrid.cpp:40-95:
+ * box anchor/sides, number of cells, periodicity flags) + engine options. */
+typedef struct {
+  double anchor[3];     /* SimulationBox:anchor (m) */
+  double sides[3];      /* SimulationBox:sides (m) */
+  int32_t ncell[3];     /* DensityGrid:number of cells */
+  int32_t periodic[3];  /* SimulationBox:periodicity */
+  int32_t device;       /* HIP device ordinal */
+  /* 1: also accumulate the two heating integrals during transport. The
+   * reference always does (src/DensityGrid.hpp:170-186); they are only used
+   * by the temperature solve, so a run with "do temperature calculation:
+   * false" may pass 0 and save two atomics per step. */
+  int32_t track_heating;
+  /* optional: HIP stream (hipStream_t) to enqueue on; NULL = own stream */
+  void *stream;
+  /* optional: caller-allocated device buffer for the CMI_GPU_NACC accumulator
+   * fields, contiguous [CMI_GPU_NACC][ncell] doubles (so that the caller can
+   * hand it to a collective, e.g. torch.distributed over RCCL); NULL = the
+   * engine allocates it. */
+  void *external_accumulators;
+} cmi_gpu_config;
+
+/* ------------------------------------------------------------ lifetime -- */
+
+/* replaces: DensityGridFactory::generate + CartesianDensityGrid ctor
+ * (src/DensityGridFactory.hpp:73-77, src/CartesianDensityGrid.cpp:40-95) */
+int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **engine);
+int cmi_gpu_destroy(cmi_gpu_engine *engine);
+const char *cmi_gpu_last_error(void);
+/* blocks until all enqueued work is done */
+int cmi_gpu_synchronize(cmi_gpu_engine *engine);
+int64_t cmi_gpu_number_of_cells(const cmi_gpu_engine *engine);
+
+/* ------------------------------------------------- plugin descriptors -- */
+
+/* replaces: PhotonSourceDistribution::{get_number_of_sources, get_position,
+ * get_weight, get_total_luminosity} as consumed by the PhotonSource ctor
+ * (src/PhotonSourceDistribution.hpp:54-80, src/PhotonSource.cpp:60-146).
+ * positions: host [n][3] (m); weights: host [n], must sum to 1 within 1e-9
+ * (same check as the reference); total_luminosity in s^-1. */
+int cmi_gpu_set_sources(cmi_gpu_engine *engine, int32_t n,
+                        const double *positions, const double *weights,
+                        double total_luminosity);
+
+/* replaces: PhotonSourceSpectrum::get_random_frequency for
+ * MonochromaticPhotonSourceSpectrum (src/MonochromaticPhotonSourceSpectrum.hpp:97-100) */
+int cmi_gpu_set_spectrum_monochromatic(cmi_gpu_engine *engine,
+                                       double frequency);
+/* ... for PlanckPhotonSourceSpectrum (src/PlanckPhotonSourceSpectrum.cpp:53-113,149-165) */
+int cmi_gpu_set_spectrum_planck(cmi_gpu_engine *engine, double temperature);
+
+/* replaces: CrossSections::get_cross_section for FixedValueCrossSections
+ * (src/FixedValueCrossSections.hpp:151-154); sigma: host [14] (m^2) */
+int cmi_gpu_set_cross_sections_fixed(cmi_gpu_engine *engine,
+                                     const double *sigma);
+/* ... for VernerCrossSections (src/VernerCrossSections.cpp:259-322) */
+int cmi_gpu_set_cross_sections_verner(cmi_gpu_engine *engine);
+
+/* replaces: RecombinationRates::get_recombination_rate for
+ * FixedValueRecombinationRates (src/FixedValueRecombinationRates.hpp:157-160);
+ * alpha: host [14] (m^3 s^-1), indexed by the recombined ion */
+int cmi_gpu_set_recombination_rates_fixed(cmi_gpu_engine *engine,
+                                          const double *alpha);
+/* ... for VernerRecombinationRates (src/VernerRecombinationRates.cpp:140-333) */
+int cmi_gpu_set_recombination_rates_verner(cmi_gpu_engine *engine);
+
+/* replaces: Abundances (src/Abundances.hpp) as filled by
+ * FixedValueAbundanceModel (src/FixedValueAbundanceModel.hpp:44-52);
+ * abundances: host [6] = He, C, N, O, Ne, S relative to H */
+int cmi_gpu_set_abundances(cmi_gpu_engine *engine, const double *abundances);
+
+/* replaces: DiffuseReemissionHandlerFactory::generate
+ * (src/DiffuseReemissionHandlerFactory.hpp:94-99): NONE, PHYSICAL
+ * (src/PhysicalDiffuseReemissionHandler.cpp) or FIXED
+ * (src/FixedValueDiffuseReemissionHandler.hpp, needs probability+frequency) */
+int cmi_gpu_set_reemission(cmi_gpu_engine *engine, int32_t type,
+                           double fixed_probability, double fixed_frequency);
+
+/* replaces: TemperatureCalculator ctor parameters
+ * (src/TemperatureCalculator.cpp:133-160) */
+typedef struct {
+  int32_t do_temperature_calculation; /* default 0 */
+  int32_t minimum_number_of_iterations; /* 3 */
+  double epsilon_convergence;           /* 1e-3 */
+  int32_t maximum_number_of_iterations; /* 100 */
+  double pah_heating_factor;            /* 0 */
+  double cosmic_ray_heating_factor;     /* 0 */
+  double cosmic_ray_heating_limit;      /* 0.75 */
+  double cosmic_ray_heating_scale_length; /* 1.33333 kpc in m */
+  double minimum_ionized_temperature;   /* 4000 K */
+} cmi_gpu_temperature_params;
+int cmi_gpu_set_temperature_params(cmi_gpu_engine *engine,
+                                   const cmi_gpu_temperature_params *params);
+
+/* ----------------------------------------------------------- cell data -- */
+
+/* replaces: DensityGrid::set_densities / DensityGridInitializationFunction
+ * (src/DensityGrid.cpp:40-62, src/DensityGrid.hpp:775-790): the host
+ * evaluates DensityFunction::operator() per cell and uploads SoA arrays.
+ * number_density, temperature: host [ncell]; ionic_fractions: host
+ * [14][ncell] or NULL (= all zero). Synchronous. */
+int cmi_gpu_upload_cells(cmi_gpu_engine *engine, const double *number_density,
+                         const double *temperature,
+                         const double *ionic_fractions);
+/* single field, host [ncell]; synchronous */
+int cmi_gpu_upload_field(cmi_gpu_engine *engine, int32_t field,
+                         const double *values);
+/* replaces: the DensityGrid iterator accessors a DensityGridWriter reads
+ * (src/DensityGridWriter.hpp:96-124); host [ncell]; synchronous */
+int cmi_gpu_download_field(cmi_gpu_engine *engine, int32_t field,
+                           double *values);
+/* device address of a field ([ncell] doubles); the 16 accumulator fields
+ * (MEAN_INTENSITY+0..13, HEATING+0..1) are contiguous in that order */
+void *cmi_gpu_field_device_pointer(cmi_gpu_engine *engine, int32_t field);
+
+/* ------------------------------------------------- the iteration body -- */
+
+/* replaces: DensityGrid::reset_grid (src/DensityGrid.hpp:803-807) and zeroes
+ * the packet counters (totweight, typecount, step counter) */
+int cmi_gpu_reset_grid(cmi_gpu_engine *engine);
+
+/* replaces: WorkDistributor::do_in_parallel(IonizationPhotonShootJobMarket) =
+ * IonizationPhotonShootJob::execute for packets [first_packet, first_packet +
+ * n_packets) of iteration `iteration` (src/IonizationSimulation.cpp:402,
+ * src/IonizationPhotonShootJob.hpp:117-146). Packet p draws its random
+ * numbers from Philox4x32-10(counter = {p, draw block}, key = {seed,
+ * iteration}), so any partition of the packet range over calls / devices
+ * gives the same packets. Accumulates into the mean-intensity (+heating)
+ * fields and the counters. Asynchronous. */
+int cmi_gpu_shoot(cmi_gpu_engine *engine, uint32_t seed, uint32_t iteration,
+                  uint64_t first_packet, uint64_t n_packets);
+
+/* replaces: IonizationPhotonShootJobMarket::update_counters
+ * (src/IonizationSimulation.cpp:406): totweight and typecount[4] summed over
+ * all shoot calls since the last reset; nsteps = number of cell crossings
+ * (DDA steps) executed. Synchronous. Any pointer may be NULL. */
+int cmi_gpu_get_counters(cmi_gpu_engine *engine, double *totweight,
+                         double *typecount, uint64_t *nsteps);
+
+/* replaces: TemperatureCalculator::calculate_temperature(loop, totweight,
+ * grid, block) (src/TemperatureCalculator.cpp:944-970), i.e. per cell either
+ * IonizationStateCalculator::calculate_ionization_state
+ * (src/IonizationStateCalculator.cpp:70-272) or the temperature solve
+ * (src/TemperatureCalculator.cpp:567-931). Reads the (reduced) accumulators,
+ * writes ionic fractions (+temperature) and the transport opacities.
+ * Asynchronous. */
+int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
+                         double totweight);
+
+/* --------------------------------------------------- test / measurement -- */
+
+/* Parity probe of PhotonSource::get_random_photon + the first optical depth
+ * (src/PhotonSource.cpp:208-249, src/IonizationPhotonShootJob.hpp:119-135)
+ * for packets [first_packet, first_packet + n): host outputs position [n][3],
+ * direction [n][3], frequency [n], cross_sections [n][14], tau [n].
+ * Synchronous. */
+int cmi_gpu_emit_packets(cmi_gpu_engine *engine, uint32_t seed,
+                         uint32_t iteration, uint64_t first_packet, uint64_t n,
+                         double *position, double *direction,
+                         double *frequency, double *cross_sections,
+                         double *tau);
+
+/* Parity probe of CartesianDensityGrid::interact
+ * (src/CartesianDensityGrid.cpp:375-452) for n caller-specified packets:
+ * position/direction host [n][3], tau host [n], sigma_H / sigma_He_corr host
+ * [n] (the two cross sections that enter the optical depth). For packet i up
+ * to max_steps (cell, ds) pairs are written to out_cell/out_ds
+ * [n][max_steps]; out_nsteps [n]; out_last_cell [n] (-1 = left the box);
+ * out_position [n][3] final position. Does NOT touch the accumulators.
+ * Synchronous. */
+int cmi_gpu_trace_packets(cmi_gpu_engine *engine, uint64_t n,
+                          const double *position, const double *direction,
+                          const double *tau, const double *sigma_H,
+                          const double *sigma_He_corr, int32_t max_steps,
+                          int64_t *out_cell, double *out_ds,
+                          int32_t *out_nsteps, int64_t *out_last_cell,
+                          double *out_position);
+
+/* Device time (HIP events on the engine's stream) spent in the transport and
+ * cell-update kernels since the last call with reset != 0. Synchronous. */
+int cmi_gpu_get_timing(cmi_gpu_engine *engine, int32_t reset,
+                       double *shoot_ms, uint64_t *shoot_launches,
+                       double *update_ms, uint64_t *update_launches);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CMI_GPU_H */

@@ -1,0 +1,253 @@
+/*
+ * cmio.h - CPU ORACLE for the photon-packet transport + ionization-balance
+ * hot path of CMacIonize.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE. Only tests/, the smoke test
+ * in __graft_entry__.py and the cpu_baseline leg of bench.py may load this
+ * library. The shipped engine (cmacionize_amd/csrc, include/cmi_gpu.h) never
+ * links, loads or calls it.
+ *
+ * It is a plain-C restatement of the reference's algorithm, function by
+ * function; every function cites the reference file:line it follows (paths
+ * relative to the reference's root). It is pinned against the reference's own
+ * known-answer fixtures (tests/golden/, copied from the reference's test/
+ * data files) - see tests/test_oracle_*.py. The reference itself cannot be
+ * built in this image without running its cmake build (it needs the generated
+ * Configuration.hpp and *DataLocation.hpp headers), so there is no
+ * oracle/_ref binary; parity is pinned through the fixtures.
+ *
+ * One deliberate difference from the reference: the random number generator.
+ * The reference uses a sequential ranlxd2 stream per thread
+ * (src/RandomGenerator.hpp:39-272), which cannot be reproduced by a
+ * packet-parallel device kernel. Oracle and engine instead share a
+ * counter-based Philox4x32-10 stream per packet (see cmio_rng_* below), so
+ * that both generate bit-identical uniform numbers for packet p. Everything
+ * downstream of the uniforms follows the reference.
+ */
+#ifndef CMIO_H
+#define CMIO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ion order: src/ElementNames.hpp:101-154 */
+enum {
+  CMIO_ION_H_n = 0,
+  CMIO_ION_He_n,
+  CMIO_ION_C_p1,
+  CMIO_ION_C_p2,
+  CMIO_ION_N_n,
+  CMIO_ION_N_p1,
+  CMIO_ION_N_p2,
+  CMIO_ION_O_n,
+  CMIO_ION_O_p1,
+  CMIO_ION_Ne_n,
+  CMIO_ION_Ne_p1,
+  CMIO_ION_S_p1,
+  CMIO_ION_S_p2,
+  CMIO_ION_S_p3,
+  CMIO_NION = 14
+};
+
+/* element order: src/ElementNames.hpp (ELEMENT_H ... ELEMENT_S) */
+enum {
+  CMIO_EL_H = 0,
+  CMIO_EL_He,
+  CMIO_EL_C,
+  CMIO_EL_N,
+  CMIO_EL_O,
+  CMIO_EL_Ne,
+  CMIO_EL_S,
+  CMIO_NELEMENT = 7
+};
+
+/* photon types: src/PhotonType.hpp:36-50 */
+enum {
+  CMIO_TYPE_PRIMARY = 0,
+  CMIO_TYPE_DIFFUSE_HI,
+  CMIO_TYPE_DIFFUSE_HeI,
+  CMIO_TYPE_ABSORBED,
+  CMIO_NTYPE = 4
+};
+
+enum { CMIO_SPECTRUM_MONOCHROMATIC = 0, CMIO_SPECTRUM_PLANCK = 1 };
+enum { CMIO_XSEC_FIXED = 0, CMIO_XSEC_VERNER = 1 };
+enum { CMIO_RECOMB_FIXED = 0, CMIO_RECOMB_VERNER = 1 };
+enum { CMIO_REEMIT_NONE = 0, CMIO_REEMIT_PHYSICAL = 1, CMIO_REEMIT_FIXED = 2 };
+
+/* ---------------------------------------------------------------- RNG -- */
+
+/* Philox4x32-10 (Salmon et al. 2011), the shared packet RNG. */
+void cmio_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2],
+                        uint32_t out[4]);
+
+/* draw number `draw` (0,1,2,...) of packet `packet` in iteration `iteration`
+ * for seed `seed`: uniform double in the open interval (0,1).
+ * Block b = draw/2 is Philox(ctr = {packet_lo, packet_hi, b, 0},
+ * key = {seed, iteration}); draw&1 selects words {0,1} or {2,3};
+ * u = ((hi:lo >> 12) + 0.5) * 2^-52 (exact in fp64). */
+double cmio_rng_uniform(uint32_t seed, uint32_t iteration, uint64_t packet,
+                        uint32_t draw);
+
+int cmio_num_threads(void);
+
+/* -------------------------------------------------------------- model -- */
+
+/* Regular Cartesian grid: src/CartesianDensityGrid.cpp:40-95 */
+typedef struct {
+  double anchor[3];
+  double sides[3];
+  int32_t ncell[3];
+  int32_t periodic[3];
+} cmio_grid;
+
+/* SoA cell state; mirrors src/IonizationVariables.hpp:81-118. All arrays have
+ * ncell[0]*ncell[1]*ncell[2] entries, row-major (ix*ny*nz + iy*nz + iz),
+ * src/CartesianDensityGrid.hpp:137-144. Owned by the caller. */
+typedef struct {
+  double *number_density;       /* m^-3 */
+  double *temperature;          /* K */
+  double *ionic_fraction[CMIO_NION];
+  double *mean_intensity[CMIO_NION]; /* un-normalised sum ds*w*sigma (m^3) */
+  double *heating[2];                /* H, He */
+} cmio_cells;
+
+/* Physics set-up: everything the reference's plugin objects hold. */
+typedef struct {
+  /* PhotonSource (src/PhotonSource.cpp:60-146): discrete sources only */
+  int32_t nsource;
+  const double *source_position;   /* [nsource][3] m */
+  const double *source_cumulative; /* [nsource] cumulative weights, last = 1 */
+  double total_luminosity;         /* s^-1 */
+
+  /* PhotonSourceSpectrum */
+  int32_t spectrum_type;
+  double mono_frequency;      /* Hz */
+  double planck_temperature;  /* K */
+
+  /* CrossSections / RecombinationRates */
+  int32_t xsec_type;
+  double xsec_fixed[CMIO_NION];   /* m^2 */
+  int32_t recomb_type;
+  double recomb_fixed[CMIO_NION]; /* m^3 s^-1 */
+
+  /* Abundances (src/Abundances.hpp), index = element, [H] unused */
+  double abundance[CMIO_NELEMENT];
+
+  /* DiffuseReemissionHandler */
+  int32_t reemit_type;
+  double reemit_fixed_probability; /* FixedValueDiffuseReemissionHandler */
+  double reemit_fixed_frequency;   /* Hz */
+
+  /* TemperatureCalculator parameters
+   * (src/TemperatureCalculator.cpp:133-160) */
+  int32_t do_temperature;
+  int32_t t_min_iteration;  /* "minimum number of iterations" (3) */
+  double t_epsilon;         /* 1e-3 */
+  int32_t t_max_iterations; /* 100 */
+  double pahfac, crfac, crlim, crscale;
+  double t_min_ionized;     /* 4000 K */
+} cmio_model;
+
+/* A photon packet: src/Photon.hpp:36-69 */
+typedef struct {
+  double position[3];
+  double direction[3];
+  double inverse_direction[3];
+  double energy; /* frequency, Hz */
+  double cross_section[CMIO_NION];
+  double cross_section_He_corr;
+  double weight;
+  int32_t type;
+} cmio_photon;
+
+/* ---------------------------------------------------------- transport -- */
+
+/* src/CartesianDensityGrid.cpp:280-318 */
+void cmio_wall_intersection(const double origin[3], const double direction[3],
+                            const double inverse_direction[3],
+                            const double cell_anchor[3],
+                            const double cell_sides[3], int32_t next_index[3],
+                            double *ds, double intersection[3]);
+
+/* src/CartesianDensityGrid.cpp:375-452. Returns the long index of the cell
+ * the photon was last in, or -1 if it left the box (DensityGrid::end()).
+ * If trace_cell/trace_ds are non-NULL, up to trace_cap (cell, ds) pairs are
+ * recorded and *trace_n receives the number of steps taken. */
+int64_t cmio_interact(const cmio_grid *grid, const cmio_model *model,
+                      cmio_cells *cells, cmio_photon *photon,
+                      double optical_depth, int64_t *trace_cell,
+                      double *trace_ds, int64_t trace_cap, int64_t *trace_n);
+
+/* src/IonizationPhotonShootJob.hpp:117-146 for packets
+ * [first_packet, first_packet + n_packets). Adds to totweight/typecount. */
+void cmio_shoot(const cmio_grid *grid, const cmio_model *model,
+                cmio_cells *cells, uint32_t seed, uint32_t iteration,
+                uint64_t first_packet, uint64_t n_packets, double *totweight,
+                double typecount[CMIO_NTYPE]);
+
+/* Generate packet `packet` (src/PhotonSource.cpp:208-249) - also returns the
+ * first optical depth tau = -ln(xi) and the number of draws consumed. */
+void cmio_emit(const cmio_model *model, uint32_t seed, uint32_t iteration,
+               uint64_t packet, cmio_photon *photon, double *tau,
+               uint32_t *draws);
+
+/* src/DensityGrid.hpp:803-807 */
+void cmio_reset_grid(const cmio_grid *grid, cmio_cells *cells);
+
+/* ----------------------------------------------------------- atomic data -- */
+
+/* src/VernerCrossSections.cpp:259-322 (m^2; frequency in Hz) */
+double cmio_verner_cross_section(int ion, double frequency);
+/* src/VernerRecombinationRates.cpp:140-333 (m^3 s^-1) */
+double cmio_verner_recombination_rate(int ion, double temperature);
+/* src/ChargeTransferRates.cpp:44-157, :169-250, :262-395; T4 = T / 1e4 K */
+double cmio_ct_recombination_rate_H(int ion, double T4);
+double cmio_ct_ionization_rate_H(int ion, double T4);
+double cmio_ct_recombination_rate_He(int ion, double T4);
+
+/* --------------------------------------------------------- cell update -- */
+
+/* src/IonizationStateCalculator.cpp:802-820 */
+double cmio_ionization_state_hydrogen(double alphaH, double jH, double nH);
+
+/* src/IonizationStateCalculator.cpp:649-753; returns 0, or 1 if the
+ * reference would have hit cmac_error (more than 20 iterations). */
+int cmio_ionization_states_hydrogen_helium(double alphaH, double alphaHe,
+                                           double jH, double jHe, double nH,
+                                           double AHe, double T, double *h0,
+                                           double *he0);
+
+/* src/IonizationStateCalculator.cpp:323-501; writes x[C_p1..S_p3] */
+void cmio_ionization_states_metals(const cmio_model *model,
+                                   const double j_metals[12], double ne,
+                                   double T, double T4, double nh0, double nhe0,
+                                   double nhp, double x[CMIO_NION]);
+
+/* src/IonizationStateCalculator.cpp:70-272 for one cell; heating[2] is
+ * normalised in place, x[14] receives the new ionic fractions. */
+void cmio_ionization_state_cell(const cmio_model *model, double jfac,
+                                double hfac, double ntot, double T,
+                                const double J[CMIO_NION], double heating[2],
+                                double x[CMIO_NION]);
+
+/* src/IonizationStateCalculator.cpp:511-530 over the whole grid */
+void cmio_calculate_ionization_state(const cmio_grid *grid,
+                                     const cmio_model *model,
+                                     cmio_cells *cells, double totweight);
+
+/* src/TemperatureCalculator.cpp:944-970 (dispatch) over the whole grid:
+ * ionization balance (src/IonizationStateCalculator.cpp:511-530,70-272) or
+ * temperature solve (src/TemperatureCalculator.cpp:567-931). */
+void cmio_update_cells(const cmio_grid *grid, const cmio_model *model,
+                       cmio_cells *cells, uint32_t loop, double totweight);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CMIO_H */

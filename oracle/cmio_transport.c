@@ -1,0 +1,311 @@
+/*
+ * cmio_transport.c - ORACLE (test infrastructure): photon packet emission and
+ * DDA transport through the regular Cartesian grid.
+ *
+ * Restates, in plain C over SoA arrays:
+ *   src/IonizationPhotonShootJob.hpp:117-146   (cmio_shoot)
+ *   src/PhotonSource.cpp:189-199,208-249,272-308 (emit / reemit)
+ *   src/PhotonSource.hpp:140-148                (random direction)
+ *   src/CartesianDensityGrid.cpp:152-161,170-176,187-227,280-318,375-452
+ *   src/DensityGrid.hpp:117-140,150-197         (optical depth, integrals)
+ */
+#include "cmio_internal.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+/* src/DensityGrid.hpp:219-222: ionization thresholds in Hz */
+static double ionization_energy_H(void) { return cmio_eV_to_Hz(13.6); }
+static double ionization_energy_He(void) { return cmio_eV_to_Hz(24.6); }
+
+/* src/PhotonSource.cpp:189-199 */
+static void set_cross_sections(const cmio_model *model, cmio_photon *photon,
+                               double energy) {
+  for (int ion = 0; ion < CMIO_NION; ++ion) {
+    photon->cross_section[ion] = cmio_cross_section(model, ion, energy);
+  }
+  photon->cross_section_He_corr =
+      model->abundance[CMIO_EL_He] * photon->cross_section[CMIO_ION_He_n];
+}
+
+/* src/PhotonSource.hpp:140-148 + src/Photon.hpp:165-170 */
+static void set_random_direction(cmio_photon *photon, cmio_rng *rng) {
+  const double cost = 2. * cmio_rng_next(rng) - 1.;
+  const double sint = sqrt(fmax(1. - cost * cost, 0.));
+  const double phi = 2. * M_PI * cmio_rng_next(rng);
+  const double cosp = cos(phi);
+  const double sinp = sin(phi);
+  photon->direction[0] = sint * cosp;
+  photon->direction[1] = sint * sinp;
+  photon->direction[2] = cost;
+  for (int a = 0; a < 3; ++a) {
+    photon->inverse_direction[a] = 1. / photon->direction[a];
+  }
+}
+
+/* src/PhotonSource.cpp:208-249, discrete branch (the continuous-source branch
+ * is out of scope: ContinuousPhotonSource type None in every config, so
+ * _continuous_probability = 0 and x >= 0 always holds). The first uniform is
+ * still drawn, as in the reference. */
+static void random_photon(const cmio_model *model, cmio_rng *rng,
+                          cmio_photon *photon) {
+  double x = cmio_rng_next(rng);
+  (void)x; /* x >= _continuous_probability (= 0) */
+  x = cmio_rng_next(rng);
+  int i = 0;
+  while (x > model->source_cumulative[i]) {
+    ++i;
+  }
+  for (int a = 0; a < 3; ++a) {
+    photon->position[a] = model->source_position[3 * i + a];
+  }
+  set_random_direction(photon, rng);
+  const double energy = cmio_spectrum_sample(model, rng);
+  photon->energy = energy;
+  photon->type = CMIO_TYPE_PRIMARY;
+  set_cross_sections(model, photon, energy);
+  photon->weight = 1.; /* _discrete_photon_weight */
+}
+
+void cmio_emit(const cmio_model *model, uint32_t seed, uint32_t iteration,
+               uint64_t packet, cmio_photon *photon, double *tau,
+               uint32_t *draws) {
+  cmio_rng rng = {seed, iteration, packet, 0};
+  random_photon(model, &rng, photon);
+  *tau = -log(cmio_rng_next(&rng));
+  if (draws)
+    *draws = rng.draw;
+}
+
+void cmio_wall_intersection(const double origin[3], const double direction[3],
+                            const double inverse_direction[3],
+                            const double cell_anchor[3],
+                            const double cell_sides[3], int32_t next_index[3],
+                            double *ds, double intersection[3]) {
+  double d[3];
+  for (int a = 0; a < 3; ++a) {
+    const double top = cell_anchor[a] + cell_sides[a];
+    if (direction[a] > 0.) {
+      d[a] = (top - origin[a]) * inverse_direction[a];
+    } else if (direction[a] < 0.) {
+      d[a] = (cell_anchor[a] - origin[a]) * inverse_direction[a];
+    } else {
+      d[a] = DBL_MAX;
+    }
+  }
+  const double dmin = fmin(d[0], fmin(d[1], d[2]));
+  for (int a = 0; a < 3; ++a) {
+    /* every axis that ties the minimum advances (edge / corner crossings) */
+    next_index[a] = (d[a] == dmin) ? ((direction[a] > 0.) ? 1 : -1) : 0;
+    intersection[a] = origin[a] + dmin * direction[a];
+  }
+  *ds = dmin;
+}
+
+/* src/CartesianDensityGrid.cpp:187-227 */
+static int is_inside(const cmio_grid *grid, int32_t index[3],
+                     double position[3]) {
+  int inside = 1;
+  for (int a = 0; a < 3; ++a) {
+    if (!grid->periodic[a]) {
+      inside &= (index[a] >= 0 && index[a] < grid->ncell[a]);
+    } else {
+      if (index[a] < 0) {
+        index[a] = grid->ncell[a] - 1;
+        position[a] += grid->sides[a];
+      }
+      if (index[a] >= grid->ncell[a]) {
+        index[a] = 0;
+        position[a] -= grid->sides[a];
+      }
+    }
+  }
+  return inside;
+}
+
+int64_t cmio_interact(const cmio_grid *grid, const cmio_model *model,
+                      cmio_cells *cells, cmio_photon *photon,
+                      double optical_depth, int64_t *trace_cell,
+                      double *trace_ds, int64_t trace_cap, int64_t *trace_n) {
+  (void)model;
+  double cellside[3], inverse_cellside[3];
+  for (int a = 0; a < 3; ++a) {
+    cellside[a] = grid->sides[a] / grid->ncell[a];
+    inverse_cellside[a] = 1. / cellside[a];
+  }
+  const double nuH = ionization_energy_H();
+  const double nuHe = ionization_energy_He();
+
+  double origin[3] = {photon->position[0], photon->position[1],
+                      photon->position[2]};
+  int32_t index[3];
+  for (int a = 0; a < 3; ++a) {
+    /* get_cell_indices: truncating conversion, :152-161 */
+    index[a] = (int32_t)((origin[a] - grid->anchor[a]) * inverse_cellside[a]);
+  }
+
+  int64_t nstep = 0;
+  int64_t last_cell = -1;
+  while (is_inside(grid, index, origin) && optical_depth > 0.) {
+    double cell_anchor[3];
+    for (int a = 0; a < 3; ++a) {
+      cell_anchor[a] = grid->anchor[a] + cellside[a] * index[a];
+    }
+    double ds;
+    int32_t next_index[3];
+    double next_wall[3];
+    cmio_wall_intersection(origin, photon->direction,
+                           photon->inverse_direction, cell_anchor, cellside,
+                           next_index, &ds, next_wall);
+
+    const int64_t cell = ((int64_t)index[0] * grid->ncell[1] + index[1]) *
+                             grid->ncell[2] +
+                         index[2];
+    last_cell = cell;
+
+    /* get_optical_depth, src/DensityGrid.hpp:117-140 (fixed abundances) */
+    const double tau =
+        ds * cells->number_density[cell] *
+        (photon->cross_section[CMIO_ION_H_n] *
+             cells->ionic_fraction[CMIO_ION_H_n][cell] +
+         photon->cross_section_He_corr *
+             cells->ionic_fraction[CMIO_ION_He_n][cell]);
+    optical_depth -= tau;
+
+    if (optical_depth < 0.) {
+      const double Scorr = ds * optical_depth / tau;
+      for (int a = 0; a < 3; ++a) {
+        origin[a] += (next_wall[a] - origin[a]) * (ds + Scorr) / ds;
+      }
+      ds += Scorr;
+    } else {
+      for (int a = 0; a < 3; ++a) {
+        origin[a] = next_wall[a];
+        index[a] += next_index[a];
+      }
+    }
+
+    /* update_integrals, src/DensityGrid.hpp:150-197 */
+    if (cells->number_density[cell] > 0.) {
+      const double dsw = ds * photon->weight;
+      for (int ion = 0; ion < CMIO_NION; ++ion) {
+        const double dj = dsw * photon->cross_section[ion];
+#pragma omp atomic
+        cells->mean_intensity[ion][cell] += dj;
+      }
+      const double dhH =
+          dsw * photon->cross_section[CMIO_ION_H_n] * (photon->energy - nuH);
+      const double dhHe =
+          dsw * photon->cross_section[CMIO_ION_He_n] * (photon->energy - nuHe);
+#pragma omp atomic
+      cells->heating[0][cell] += dhH;
+#pragma omp atomic
+      cells->heating[1][cell] += dhHe;
+    }
+
+    if (trace_cell && nstep < trace_cap) {
+      trace_cell[nstep] = cell;
+      trace_ds[nstep] = ds;
+    }
+    ++nstep;
+  }
+  if (trace_n)
+    *trace_n = nstep;
+
+  if (nstep == 0 && optical_depth > 0.) {
+    /* cmac_error in the reference, :436-442 */
+    fprintf(stderr,
+            "cmio_interact: photon leaves the system immediately "
+            "(position: %g %g %g, direction: %g %g %g)!\n",
+            origin[0], origin[1], origin[2], photon->direction[0],
+            photon->direction[1], photon->direction[2]);
+    abort();
+  }
+
+  for (int a = 0; a < 3; ++a) {
+    photon->position[a] = origin[a];
+  }
+  if (!is_inside(grid, index, origin)) {
+    last_cell = -1;
+  }
+  return last_cell;
+}
+
+/* src/PhotonSource.cpp:272-308 */
+static int reemit(const cmio_model *model, const cmio_cells *cells,
+                  int64_t cell, cmio_photon *photon, cmio_rng *rng) {
+  if (model->reemit_type == CMIO_REEMIT_NONE) {
+    photon->type = CMIO_TYPE_ABSORBED;
+    return 0;
+  }
+  int32_t type;
+  const double new_frequency = cmio_reemit_frequency(
+      model, photon, model->abundance[CMIO_EL_He], cells->temperature[cell],
+      cells->ionic_fraction[CMIO_ION_H_n][cell],
+      cells->ionic_fraction[CMIO_ION_He_n][cell], rng, &type);
+  photon->type = type;
+  if (new_frequency == 0.) {
+    return 0;
+  }
+  photon->energy = new_frequency;
+  set_random_direction(photon, rng);
+  set_cross_sections(model, photon, new_frequency);
+  return 1;
+}
+
+void cmio_shoot(const cmio_grid *grid, const cmio_model *model,
+                cmio_cells *cells, uint32_t seed, uint32_t iteration,
+                uint64_t first_packet, uint64_t n_packets, double *totweight,
+                double typecount[CMIO_NTYPE]) {
+  double tw = 0.;
+  double tc0 = 0., tc1 = 0., tc2 = 0., tc3 = 0.;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : tw, tc0, tc1, tc2, tc3)
+  for (uint64_t i = 0; i < n_packets; ++i) {
+    cmio_rng rng = {seed, iteration, first_packet + i, 0};
+    cmio_photon photon;
+    random_photon(model, &rng, &photon);
+    double tau = -log(cmio_rng_next(&rng));
+    int64_t cell =
+        cmio_interact(grid, model, cells, &photon, tau, NULL, NULL, 0, NULL);
+    while (cell >= 0 && reemit(model, cells, cell, &photon, &rng)) {
+      tau = -log(cmio_rng_next(&rng));
+      cell =
+          cmio_interact(grid, model, cells, &photon, tau, NULL, NULL, 0, NULL);
+    }
+    tw += photon.weight;
+    switch (photon.type) {
+    case CMIO_TYPE_PRIMARY:
+      tc0 += photon.weight;
+      break;
+    case CMIO_TYPE_DIFFUSE_HI:
+      tc1 += photon.weight;
+      break;
+    case CMIO_TYPE_DIFFUSE_HeI:
+      tc2 += photon.weight;
+      break;
+    default:
+      tc3 += photon.weight;
+      break;
+    }
+  }
+  *totweight += tw;
+  typecount[0] += tc0;
+  typecount[1] += tc1;
+  typecount[2] += tc2;
+  typecount[3] += tc3;
+}
+
+void cmio_reset_grid(const cmio_grid *grid, cmio_cells *cells) {
+  const int64_t ncell =
+      (int64_t)grid->ncell[0] * grid->ncell[1] * grid->ncell[2];
+  for (int ion = 0; ion < CMIO_NION; ++ion) {
+    for (int64_t i = 0; i < ncell; ++i)
+      cells->mean_intensity[ion][i] = 0.;
+  }
+  for (int h = 0; h < 2; ++h) {
+    for (int64_t i = 0; i < ncell; ++i)
+      cells->heating[h][i] = 0.;
+  }
+}

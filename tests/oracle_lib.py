@@ -1,0 +1,263 @@
+"""ctypes binding of the CPU oracle (oracle/libcmio.so).
+
+Test infrastructure only: imported by tests/, by __graft_entry__.smoke() and
+by the cpu_baseline leg of bench.py. The product package (cmacionize_amd)
+never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+NION = 14
+NELEMENT = 7
+NTYPE = 4
+
+ION_NAMES = ["H_n", "He_n", "C_p1", "C_p2", "N_n", "N_p1", "N_p2", "O_n",
+             "O_p1", "Ne_n", "Ne_p1", "S_p1", "S_p2", "S_p3"]
+
+SPECTRUM_MONOCHROMATIC, SPECTRUM_PLANCK = 0, 1
+XSEC_FIXED, XSEC_VERNER = 0, 1
+RECOMB_FIXED, RECOMB_VERNER = 0, 1
+REEMIT_NONE, REEMIT_PHYSICAL, REEMIT_FIXED = 0, 1, 2
+
+dp = C.POINTER(C.c_double)
+
+
+class Grid(C.Structure):
+    _fields_ = [("anchor", C.c_double * 3), ("sides", C.c_double * 3),
+                ("ncell", C.c_int32 * 3), ("periodic", C.c_int32 * 3)]
+
+
+class Cells(C.Structure):
+    _fields_ = [("number_density", dp), ("temperature", dp),
+                ("ionic_fraction", dp * NION), ("mean_intensity", dp * NION),
+                ("heating", dp * 2)]
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("nsource", C.c_int32),
+        ("source_position", dp),
+        ("source_cumulative", dp),
+        ("total_luminosity", C.c_double),
+        ("spectrum_type", C.c_int32),
+        ("mono_frequency", C.c_double),
+        ("planck_temperature", C.c_double),
+        ("xsec_type", C.c_int32),
+        ("xsec_fixed", C.c_double * NION),
+        ("recomb_type", C.c_int32),
+        ("recomb_fixed", C.c_double * NION),
+        ("abundance", C.c_double * NELEMENT),
+        ("reemit_type", C.c_int32),
+        ("reemit_fixed_probability", C.c_double),
+        ("reemit_fixed_frequency", C.c_double),
+        ("do_temperature", C.c_int32),
+        ("t_min_iteration", C.c_int32),
+        ("t_epsilon", C.c_double),
+        ("t_max_iterations", C.c_int32),
+        ("pahfac", C.c_double),
+        ("crfac", C.c_double),
+        ("crlim", C.c_double),
+        ("crscale", C.c_double),
+        ("t_min_ionized", C.c_double),
+    ]
+
+
+class Photon(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("direction", C.c_double * 3),
+                ("inverse_direction", C.c_double * 3), ("energy", C.c_double),
+                ("cross_section", C.c_double * NION),
+                ("cross_section_He_corr", C.c_double),
+                ("weight", C.c_double), ("type", C.c_int32)]
+
+
+_lib = None
+
+
+def build():
+    """(Re)build oracle/libcmio.so with gcc; cheap when up to date."""
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(ORACLE_DIR, "libcmio.so")
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    L.cmio_rng_uniform.restype = C.c_double
+    L.cmio_rng_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64,
+                                   C.c_uint32]
+    L.cmio_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+    L.cmio_interact.restype = C.c_int64
+    L.cmio_interact.argtypes = [C.POINTER(Grid), C.POINTER(Model),
+                                C.POINTER(Cells), C.POINTER(Photon),
+                                C.c_double, C.POINTER(C.c_int64), dp,
+                                C.c_int64, C.POINTER(C.c_int64)]
+    L.cmio_shoot.argtypes = [C.POINTER(Grid), C.POINTER(Model),
+                             C.POINTER(Cells), C.c_uint32, C.c_uint32,
+                             C.c_uint64, C.c_uint64, dp, dp]
+    L.cmio_emit.argtypes = [C.POINTER(Model), C.c_uint32, C.c_uint32,
+                            C.c_uint64, C.POINTER(Photon), dp,
+                            C.POINTER(C.c_uint32)]
+    L.cmio_reset_grid.argtypes = [C.POINTER(Grid), C.POINTER(Cells)]
+    L.cmio_update_cells.argtypes = [C.POINTER(Grid), C.POINTER(Model),
+                                    C.POINTER(Cells), C.c_uint32, C.c_double]
+    L.cmio_wall_intersection.argtypes = [dp, dp, dp, dp, dp,
+                                         C.POINTER(C.c_int32), dp, dp]
+    L.cmio_ionization_state_hydrogen.restype = C.c_double
+    L.cmio_ionization_state_hydrogen.argtypes = [C.c_double] * 3
+    L.cmio_ionization_states_hydrogen_helium.restype = C.c_int
+    L.cmio_ionization_states_hydrogen_helium.argtypes = [C.c_double] * 7 + [
+        dp, dp]
+    L.cmio_ionization_state_cell.argtypes = [C.POINTER(Model), C.c_double,
+                                             C.c_double, C.c_double,
+                                             C.c_double, dp, dp, dp]
+    for name in ("cmio_verner_cross_section",
+                 "cmio_verner_recombination_rate",
+                 "cmio_ct_recombination_rate_H", "cmio_ct_ionization_rate_H",
+                 "cmio_ct_recombination_rate_He"):
+        f = getattr(L, name)
+        f.restype = C.c_double
+        f.argtypes = [C.c_int, C.c_double]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(dp)
+
+
+# ---------------------------------------------------------------------------
+# unit conversions of the reference (src/UnitConverter.hpp:98-160)
+PC = 3.086e16
+ELECTRONVOLT = 1.6021766208e-19
+PLANCK = 6.626070040e-34
+
+
+def eV_to_Hz(ev):
+    return ev * ELECTRONVOLT * (1. / PLANCK) / 1.
+
+
+class OracleSimulation:
+    """SoA state + model for the oracle; numpy arrays are the storage.
+
+    Mirrors the subset of IonizationSimulation (src/IonizationSimulation.cpp)
+    that is on the hot path: reset_grid -> shoot -> update_cells per
+    iteration.
+    """
+
+    def __init__(self, ncell, anchor, sides, periodic=(0, 0, 0),
+                 compact=False):
+        """compact=True aliases the storage of all metal ions (fractions and
+        mean intensities) to one scratch array each: valid only when their
+        cross sections are zero (H-only runs); saves 24 of 32 arrays."""
+        self.grid = Grid()
+        for a in range(3):
+            self.grid.anchor[a] = anchor[a]
+            self.grid.sides[a] = sides[a]
+            self.grid.ncell[a] = ncell[a]
+            self.grid.periodic[a] = int(periodic[a])
+        self.ncell = tuple(int(n) for n in ncell)
+        n = int(np.prod(self.ncell))
+        self.n = n
+        self.number_density = np.zeros(n)
+        self.temperature = np.zeros(n)
+        nstore = 3 if compact else NION
+        self._xs = np.zeros((nstore, n))
+        self._Js = np.zeros((nstore, n))
+        if compact:
+            self.x = [self._xs[0], self._xs[1]] + [self._xs[2]] * 12
+            self.J = [self._Js[0], self._Js[1]] + [self._Js[2]] * 12
+        else:
+            self.x = self._xs
+            self.J = self._Js
+        self.heating = np.zeros((2, n))
+        self.cells = Cells()
+        self.cells.number_density = _ptr(self.number_density)
+        self.cells.temperature = _ptr(self.temperature)
+        for i in range(NION):
+            self.cells.ionic_fraction[i] = _ptr(self.x[i])
+            self.cells.mean_intensity[i] = _ptr(self.J[i])
+        for i in range(2):
+            self.cells.heating[i] = _ptr(self.heating[i])
+        self.model = Model()
+        m = self.model
+        m.t_min_iteration = 3
+        m.t_epsilon = 1.e-3
+        m.t_max_iterations = 100
+        m.crlim = 0.75
+        m.crscale = 1.33333 * 3.086e19
+        m.t_min_ionized = 4000.
+        self.totweight = 0.
+        self.typecount = np.zeros(NTYPE)
+
+    def set_sources(self, positions, weights, luminosity):
+        self._src_pos = np.ascontiguousarray(positions, dtype=np.float64)
+        self._src_cum = np.cumsum(np.asarray(weights, dtype=np.float64))
+        self._src_cum[-1] = 1.
+        self.model.nsource = len(self._src_cum)
+        self.model.source_position = _ptr(self._src_pos)
+        self.model.source_cumulative = _ptr(self._src_cum)
+        self.model.total_luminosity = luminosity
+
+    def set_homogeneous(self, density, temperature, xH=1.e-6, xHe=1.e-6):
+        """src/HomogeneousDensityFunction.hpp:99-107"""
+        self.number_density[:] = density
+        self.temperature[:] = temperature
+        self._xs[:] = 0.
+        self.x[0][:] = xH
+        self.x[1][:] = xHe
+
+    def reset(self):
+        lib().cmio_reset_grid(C.byref(self.grid), C.byref(self.cells))
+
+    def shoot(self, seed, iteration, first_packet, n_packets):
+        tw = C.c_double(0.)
+        tc = np.zeros(NTYPE)
+        lib().cmio_shoot(C.byref(self.grid), C.byref(self.model),
+                         C.byref(self.cells), seed, iteration, first_packet,
+                         n_packets, C.byref(tw), _ptr(tc))
+        self.totweight += tw.value
+        self.typecount += tc
+        return tw.value, tc
+
+    def update(self, loop, totweight):
+        lib().cmio_update_cells(C.byref(self.grid), C.byref(self.model),
+                                C.byref(self.cells), loop, totweight)
+
+    def run(self, n_packets, n_iterations, seed=42):
+        for loop in range(n_iterations):
+            self.reset()
+            self.totweight = 0.
+            self.typecount[:] = 0.
+            self.shoot(seed, loop, 0, n_packets)
+            self.update(loop, self.totweight)
+
+
+def num_threads():
+    return int(lib().cmio_num_threads())
+
+
+def stromgren_simulation(ncell=64, diffuse=False, compact=False):
+    """benchmarks/stromgren.param (and stromgren_diffuse.param)."""
+    sim = OracleSimulation((ncell,) * 3, (-5. * PC,) * 3, (10. * PC,) * 3,
+                           compact=compact)
+    sim.set_sources([[0., 0., 0.]], [1.], 4.26e49)
+    sim.set_homogeneous(100. * 1.e6, 8000.)
+    m = sim.model
+    m.spectrum_type = SPECTRUM_MONOCHROMATIC
+    m.mono_frequency = eV_to_Hz(13.6)
+    m.xsec_type = XSEC_FIXED
+    m.xsec_fixed[0] = 6.3e-18 * 1.e-4
+    m.recomb_type = RECOMB_FIXED
+    m.recomb_fixed[0] = 4.e-13 * 1.e-6
+    m.reemit_type = REEMIT_PHYSICAL if diffuse else REEMIT_NONE
+    m.do_temperature = 0
+    return sim

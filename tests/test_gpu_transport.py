@@ -1,0 +1,248 @@
+"""GPU parity tests of the transport path, through the C ABI, against the CPU
+oracle on the same seeds / inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(ncell, track_heating=True, xH=None, density=None,
+                periodic=(0, 0, 0)):
+    from cmacionize_amd import GpuEngine, STROMGREN as S
+    eng = GpuEngine((ncell,) * 3, S["anchor"], S["sides"], periodic, device=0,
+                    track_heating=track_heating)
+    eng.set_sources(S["source_position"], S["source_weight"], S["luminosity"])
+    eng.set_spectrum_monochromatic(S["frequency"])
+    sigma = np.zeros(14)
+    sigma[0] = S["sigma_H"]
+    alpha = np.zeros(14)
+    alpha[0] = S["alpha_H"]
+    eng.set_cross_sections_fixed(sigma)
+    eng.set_recombination_rates_fixed(alpha)
+    n = ncell ** 3
+    x = np.zeros((14, n))
+    x[0] = S["xH"] if xH is None else xH
+    x[1] = S["xHe"]
+    dens = np.full(n, S["density"]) if density is None else density
+    eng.upload_cells(dens, np.full(n, S["temperature"]), x)
+    return eng
+
+
+def test_library_loads_and_fails_loudly_without_cpu_path():
+    from cmacionize_amd import engine
+    lib = engine.load_library()
+    for name in engine.EXPORTED_SYMBOLS:
+        assert hasattr(lib, name)
+    with pytest.raises(engine.EngineError):
+        engine.GpuEngine((4, 4, 4), (0, 0, 0), (1, 1, 1), device=9999)
+
+
+def test_emission_matches_oracle(oracle):
+    """Same Philox stream -> same packets (direction within libm ulps)."""
+    import ctypes as C
+    eng = make_engine(8)
+    n = 4096
+    pos, dirn, nu, sig, tau = eng.emit_packets(42, 3, 1000, n)
+    sim = oracle.stromgren_simulation(8)
+    ph = oracle.Photon()
+    t = C.c_double()
+    for i in range(0, n, 7):
+        oracle.lib().cmio_emit(C.byref(sim.model), 42, 3, 1000 + i,
+                               C.byref(ph), C.byref(t), None)
+        assert np.allclose(dirn[i], list(ph.direction), rtol=0, atol=4e-16)
+        assert np.array_equal(pos[i], list(ph.position))
+        assert nu[i] == ph.energy
+        assert np.array_equal(sig[i], list(ph.cross_section))
+        assert abs(tau[i] - t.value) <= 4e-16 * abs(t.value)
+    # isotropy (testPhotonSource.cpp:107-126 tolerance scaled to n)
+    assert np.all(np.abs(dirn.mean(axis=0)) < 5. / np.sqrt(n))
+    eng.close()
+
+
+def random_field(ncell, seed):
+    rng = np.random.default_rng(seed)
+    n = ncell ** 3
+    xH = 10. ** rng.uniform(-6, 0, n)
+    dens = np.full(n, 1.e8)
+    dens[rng.uniform(size=n) < 0.05] = 0.  # vacuum cells
+    return xH, dens
+
+
+@pytest.mark.parametrize("ncell", [16, 33])
+def test_dda_traces_bit_exact(oracle, ncell):
+    """Identical (position, direction, tau, sigma) -> identical cell lists and
+    bit-identical path lengths (CartesianDensityGrid::interact)."""
+    import ctypes as C
+    from cmacionize_amd import STROMGREN as S
+    xH, dens = random_field(ncell, 1)
+    eng = make_engine(ncell, xH=xH, density=dens)
+    sim = oracle.stromgren_simulation(ncell)
+    sim.number_density[:] = dens
+    sim.x[0] = xH
+    sim.x[1] = 1.e-6
+
+    rng = np.random.default_rng(5)
+    n = 600
+    side = S["sides"][0]
+    pos = rng.uniform(-0.499, 0.499, (n, 3)) * side
+    # include packets starting exactly on cell corners / faces
+    pos[:50] = 0.
+    pos[50:100, 0] = 0.
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    d[100:120] = [1., 0., 0.]           # axis aligned (inverse = inf)
+    d[120:140] = np.array([0., 1., 1.]) / np.sqrt(2.)  # edge crossings
+    d[140:160] = np.array([1., 1., 1.]) / np.sqrt(3.)  # corner crossings
+    d[160:170] = np.array([-1., -1., 1.]) / np.sqrt(3.)
+    tau = -np.log(rng.uniform(size=n)) * 3.
+    tau[::10] = 1.e30  # never absorbed: crosses the whole box
+    sH = np.full(n, S["sigma_H"])
+    sHe = np.full(n, 0.3 * S["sigma_H"] * 0.1)
+    max_steps = 4 * ncell + 8
+
+    cells, ds, nsteps, last, final = eng.trace_packets(pos, d, tau, sH, sHe,
+                                                       max_steps)
+    tc = np.empty(max_steps, dtype=np.int64)
+    td = np.empty(max_steps)
+    nmatch = 0
+    for i in range(n):
+        ph = oracle.Photon()
+        for a in range(3):
+            ph.position[a] = pos[i, a]
+            ph.direction[a] = d[i, a]
+            with np.errstate(divide="ignore"):
+                ph.inverse_direction[a] = np.float64(1.) / np.float64(d[i, a])
+        ph.cross_section[0] = sH[i]
+        ph.cross_section_He_corr = sHe[i]
+        ph.weight = 1.
+        tn = C.c_int64()
+        sim.J[:] = 0.
+        lc = oracle.lib().cmio_interact(
+            C.byref(sim.grid), C.byref(sim.model), C.byref(sim.cells),
+            C.byref(ph), tau[i], tc.ctypes.data_as(C.POINTER(C.c_int64)),
+            td.ctypes.data_as(oracle.dp), max_steps, C.byref(tn))
+        k = tn.value
+        assert k == nsteps[i], (i, k, nsteps[i])
+        assert k <= max_steps
+        assert lc == last[i]
+        assert np.array_equal(cells[i, :k], tc[:k])
+        # the engine multiplies sigma by the pre-multiplied n*x record, the
+        # reference by n and x separately: the optical depth (hence only the
+        # LAST, shortened step) can differ by an ulp or two
+        assert np.array_equal(ds[i, :k - 1], td[:k - 1])
+        assert abs(ds[i, k - 1] - td[k - 1]) <= 1e-13 * abs(td[k - 1]) + 1e-300
+        assert np.allclose(final[i], list(ph.position), rtol=1e-13, atol=0)
+        nmatch += 1
+    assert nmatch == n
+    eng.close()
+
+
+def test_periodic_traces(oracle):
+    import ctypes as C
+    from cmacionize_amd import STROMGREN as S
+    ncell = 8
+    eng = make_engine(ncell, periodic=(1, 0, 1))
+    sim = oracle.stromgren_simulation(ncell)
+    for a, f in enumerate((1, 0, 1)):
+        sim.grid.periodic[a] = f
+    rng = np.random.default_rng(11)
+    n = 100
+    pos = rng.uniform(-0.49, 0.49, (n, 3)) * S["sides"][0]
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    tau = np.full(n, 2.e-4)  # x_H = 1e-6: the box is very thin -> many wraps
+    sH = np.full(n, S["sigma_H"])
+    sHe = np.zeros(n)
+    max_steps = 2000
+    cells, ds, nsteps, last, final = eng.trace_packets(pos, d, tau, sH, sHe,
+                                                       max_steps)
+    tc = np.empty(max_steps, dtype=np.int64)
+    td = np.empty(max_steps)
+    for i in range(n):
+        ph = oracle.Photon()
+        for a in range(3):
+            ph.position[a] = pos[i, a]
+            ph.direction[a] = d[i, a]
+            ph.inverse_direction[a] = 1. / d[i, a]
+        ph.cross_section[0] = sH[i]
+        ph.weight = 1.
+        tn = C.c_int64()
+        lc = oracle.lib().cmio_interact(
+            C.byref(sim.grid), C.byref(sim.model), C.byref(sim.cells),
+            C.byref(ph), tau[i], tc.ctypes.data_as(C.POINTER(C.c_int64)),
+            td.ctypes.data_as(oracle.dp), max_steps, C.byref(tn))
+        k = min(tn.value, max_steps)
+        assert tn.value == nsteps[i]
+        assert lc == last[i]
+        assert np.array_equal(cells[i, :k], tc[:k])
+        assert np.array_equal(ds[i, :k - 1], td[:k - 1])
+    eng.close()
+
+
+@pytest.mark.parametrize("ncell,npacket", [(16, 30000), (64, 100000)])
+def test_shoot_matches_oracle(oracle, ncell, npacket):
+    """Whole transport step on the same seed: J_H, heating and the packet
+    counters against the oracle; then the cell update."""
+    from cmacionize_amd import engine as E
+    eng = make_engine(ncell)
+    sim = oracle.stromgren_simulation(ncell)
+    seed = 42
+    for loop in range(3):
+        eng.reset_grid()
+        eng.shoot(seed, loop, 0, npacket)
+        tw, tc, nsteps = eng.get_counters()
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(seed, loop, 0, npacket)
+        assert tw == sim.totweight == npacket
+        assert np.array_equal(tc, sim.typecount)
+        J = eng.download_field(E.FIELD_MEAN_INTENSITY)
+        # summation order differs (atomics) and sin/cos/log differ by ulps
+        assert np.allclose(J, sim.J[0], rtol=1e-9, atol=0.)
+        assert abs(J.sum() - sim.J[0].sum()) <= 1e-12 * sim.J[0].sum()
+        for ion in range(1, 14):
+            assert not eng.download_field(E.FIELD_MEAN_INTENSITY + ion).any()
+        hH = eng.download_field(E.FIELD_HEATING)
+        assert np.allclose(hH, sim.heating[0], rtol=1e-9, atol=1e-30)
+        eng.update_cells(loop, tw)
+        sim.update(loop, sim.totweight)
+        xH = eng.download_field(E.FIELD_IONIC_FRACTION)
+        assert np.allclose(xH, sim.x[0], rtol=1e-8, atol=0.)
+    eng.close()
+
+
+def test_packet_range_partition_is_additive(oracle):
+    """Shooting [0,N) in one call or in pieces gives the same tallies: the
+    property the multi-GPU replica mode relies on."""
+    from cmacionize_amd import engine as E
+    eng = make_engine(16, track_heating=False)
+    eng.reset_grid()
+    eng.shoot(7, 0, 0, 50000)
+    J1 = eng.download_field(E.FIELD_MEAN_INTENSITY)
+    c1 = eng.get_counters()
+    eng.reset_grid()
+    for first, count in ((0, 12500), (12500, 12501), (25001, 24999)):
+        eng.shoot(7, 0, first, count)
+    J2 = eng.download_field(E.FIELD_MEAN_INTENSITY)
+    c2 = eng.get_counters()
+    assert c1[0] == c2[0] and np.array_equal(c1[1], c2[1]) and c1[2] == c2[2]
+    assert np.allclose(J1, J2, rtol=1e-12, atol=0.)
+    eng.close()
+
+
+def test_stromgren_converges_to_analytic_radius():
+    """benchmarks/stromgren.py: ionised volume against the analytic Stromgren
+    sphere (R_s = 4.42 pc in a 10 pc box -> 36.2 % of the volume)."""
+    from cmacionize_amd import engine as E
+    ncell = 64
+    eng = make_engine(ncell, track_heating=False)
+    for loop in range(12):
+        eng.reset_grid()
+        eng.shoot(42, loop, 0, 1000000)
+        tw, _, _ = eng.get_counters()
+        eng.update_cells(loop, tw)
+    xH = eng.download_field(E.FIELD_IONIC_FRACTION)
+    frac = (xH < 0.5).mean()
+    assert abs(frac - 0.3617) < 0.01, frac
+    eng.close()

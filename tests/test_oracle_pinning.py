@@ -1,0 +1,278 @@
+"""Pins the CPU oracle against the reference's own known-answer fixtures
+(tests/golden/*_testdata.txt are the data files of the reference's test/
+directory, generated from Kenny Wood's Fortran code) at the reference's own
+tolerances, and against the hand-computed geometry cases of
+test/testCartesianDensityGrid.cpp:310-475."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    rows = []
+    for line in open(os.path.join(GOLDEN, name)):
+        if line.lstrip().startswith("#") or not line.strip():
+            continue
+        rows.append([float(v) for v in line.split()])
+    return np.array(rows)
+
+
+def rel_ok(a, b, tol):
+    """assert_values_equal_rel of test/Assert.hpp:62-68"""
+    return abs(a - b) <= tol * abs(a + b)
+
+
+def test_philox_known_answers(oracle):
+    """Random123 kat_vectors for philox4x32-10."""
+    L = oracle.lib()
+    cases = [
+        ((0, 0, 0, 0), (0, 0),
+         (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff,) * 2,
+         (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+         (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    for ctr, key, expect in cases:
+        c = (C.c_uint32 * 4)(*ctr)
+        k = (C.c_uint32 * 2)(*key)
+        out = (C.c_uint32 * 4)()
+        L.cmio_philox4x32_10(c, k, out)
+        assert tuple(out) == expect
+
+
+def test_rng_uniform_statistics(oracle):
+    """testRandomGenerator.cpp:33-72 checks the mean of the uniforms; here with
+    1e5 draws (sigma of the mean = 9.1e-4) at 4 sigma, plus the open interval
+    and stream independence properties the engine relies on."""
+    L = oracle.lib()
+    u = np.array([L.cmio_rng_uniform(42, 0, p, d) for p in range(20000)
+                  for d in range(5)])
+    assert u.min() > 0. and u.max() < 1.
+    assert abs(u.mean() - 0.5) < 3.7e-3
+    assert abs(u.var() - 1. / 12.) < 1.e-3
+    # different packet / iteration / seed -> different numbers
+    a = L.cmio_rng_uniform(42, 0, 7, 0)
+    assert a != L.cmio_rng_uniform(42, 0, 8, 0)
+    assert a != L.cmio_rng_uniform(42, 1, 7, 0)
+    assert a != L.cmio_rng_uniform(43, 0, 7, 0)
+    assert a == L.cmio_rng_uniform(42, 0, 7, 0)
+
+
+def test_verner_cross_sections(oracle):
+    """testVernerCrossSections.cpp:46-164, tolerance 1e-9."""
+    L = oracle.lib()
+    data = load("verner_testdata.txt")
+    assert data.shape[1] == 15 and data.shape[0] >= 100
+    for row in data:
+        e = oracle.eV_to_Hz(row[0] * 13.6)
+        for ion in range(14):
+            sigma = L.cmio_verner_cross_section(ion, e)  # m^2
+            got = sigma / (0.01 * 0.01) * 1.e18          # 1e-18 cm^2
+            assert rel_ok(row[1 + ion], got, 1.e-9), (row[0], ion, got)
+
+
+def test_verner_recombination_rates(oracle):
+    """testVernerRecombinationRates.cpp:44-147. The reference asserts 1e-15
+    there against numbers printed by the same C++ code; our libm calls are the
+    same, but leave two ulps of room for pow/exp."""
+    L = oracle.lib()
+    data = load("verner_rec_testdata.txt")
+    assert data.shape[1] == 15 and data.shape[0] >= 100
+    for row in data:
+        T = row[0]
+        for ion in range(14):
+            alpha = L.cmio_verner_recombination_rate(ion, T)
+            got = alpha / (0.01 ** 3)
+            assert rel_ok(got, row[1 + ion], 1.e-14), (T, ion, got)
+
+
+def test_charge_transfer_rates(oracle):
+    """testChargeTransferRates.cpp:78-140, tolerance 1e-6."""
+    L = oracle.lib()
+    ion = {(6, 4): 3, (7, 1): 4, (7, 2): 4, (7, 3): 5, (7, 4): 6, (8, 1): 7,
+           (8, 2): 7, (8, 3): 8, (10, 3): 10, (16, 3): 11, (16, 4): 12,
+           (16, 5): 13}
+    data = load("KingdonFerland_testdata.txt")
+    ntested = 0
+    for stage, atom, T, rec, ionr in data:
+        key = (int(atom), int(stage))
+        if key not in ion:
+            continue
+        if stage > 1:
+            got = L.cmio_ct_recombination_rate_H(ion[key], T * 1.e-4) * 1.e6
+            assert rel_ok(rec, got, 1.e-6), (key, T, rec, got)
+            ntested += 1
+        if key in ((7, 1), (8, 1)):
+            got = L.cmio_ct_ionization_rate_H(ion[key], T * 1.e-4) * 1.e6
+            assert rel_ok(ionr, got, 1.e-6), (key, T, ionr, got)
+            ntested += 1
+    assert ntested > 1000
+
+
+def verner_model(oracle, AHe):
+    m = oracle.Model()
+    m.recomb_type = oracle.RECOMB_VERNER
+    m.xsec_type = oracle.XSEC_VERNER
+    m.abundance[1] = AHe
+    m.total_luminosity = 1.
+    return m
+
+
+def test_ionization_state_calculator(oracle):
+    """testIonizationStateCalculator.cpp:68-204: 14 J, T, n -> 14 fractions at
+    1e-9; and H-only closed form vs H/He iteration with A_He = 0 at 1e-4."""
+    L = oracle.lib()
+    data = load("h0_testdata.txt")
+    assert data.shape == (100, 30)
+    m = verner_model(oracle, 0.1)
+    for row in data:
+        J = np.ascontiguousarray(row[:14])
+        T, ntot = row[14], row[15] * 1.e6
+        expect = row[16:30]
+        heating = np.zeros(2)
+        x = np.zeros(14)
+        L.cmio_ionization_state_cell(C.byref(m), 1., 1., ntot, T,
+                                     J.ctypes.data_as(oracle.dp),
+                                     heating.ctypes.data_as(oracle.dp),
+                                     x.ctypes.data_as(oracle.dp))
+        for ion in range(14):
+            assert rel_ok(x[ion], expect[ion], 1.e-9), (ion, x[ion],
+                                                        expect[ion])
+        h0 = C.c_double()
+        he0 = C.c_double()
+        L.cmio_ionization_states_hydrogen_helium(
+            3.12e-13 * 1.e-6, 0., row[0], 0., ntot, 0., T, C.byref(h0),
+            C.byref(he0))
+        h0s = L.cmio_ionization_state_hydrogen(3.12e-13 * 1.e-6, row[0], ntot)
+        d = abs(h0.value - h0s)
+        assert d <= 1.e-4 or d <= 1.e-4 * abs(h0.value + h0s)
+
+
+def test_neutral_and_vacuum_cells(oracle):
+    """IonizationStateCalculator.cpp:186-268: no radiation -> neutral (N0, O0,
+    Ne0 = 1), vacuum -> all zero."""
+    L = oracle.lib()
+    m = verner_model(oracle, 0.1)
+    J = np.zeros(14)
+    h = np.zeros(2)
+    x = np.full(14, 7.)
+    L.cmio_ionization_state_cell(C.byref(m), 1., 1., 1.e8, 8000.,
+                                 J.ctypes.data_as(oracle.dp),
+                                 h.ctypes.data_as(oracle.dp),
+                                 x.ctypes.data_as(oracle.dp))
+    assert list(x) == [1, 1, 0, 0, 1, 0, 0, 1, 0, 1, 0, 0, 0, 0]
+    J[:] = 1.
+    L.cmio_ionization_state_cell(C.byref(m), 1., 1., 0., 8000.,
+                                 J.ctypes.data_as(oracle.dp),
+                                 h.ctypes.data_as(oracle.dp),
+                                 x.ctypes.data_as(oracle.dp))
+    assert not x.any()
+
+
+def wall(oracle, origin, direction, anchor, sides):
+    L = oracle.lib()
+    o = np.array(origin, dtype=np.float64)
+    d = np.array(direction, dtype=np.float64)
+    with np.errstate(divide="ignore"):
+        inv = 1. / d
+    a = np.array(anchor, dtype=np.float64)
+    s = np.array(sides, dtype=np.float64)
+    nxt = (C.c_int32 * 3)()
+    ds = C.c_double()
+    hit = np.zeros(3)
+    p = lambda v: v.ctypes.data_as(oracle.dp)
+    L.cmio_wall_intersection(p(o), p(d), p(inv), p(a), p(s), nxt, C.byref(ds),
+                             p(hit))
+    return tuple(nxt), ds.value, hit
+
+
+def test_wall_intersection_cases(oracle):
+    """testCartesianDensityGrid.cpp:310-465: unit box, 8^3 cells... the cell
+    [0.5, 0.5625]^3 with the photon at (0.51, 0.51, 0.51)."""
+    origin = (0.51, 0.51, 0.51)
+    anchor = (0.5, 0.5, 0.5)
+    sides = (1. / 16.,) * 3
+    hi = 0.5 + 1. / 16.
+    cases = [
+        ((1., 0., 0.), (1, 0, 0), (hi, 0.51, 0.51), 1. / 16. - 0.01),
+        ((-1., 0., 0.), (-1, 0, 0), (0.5, 0.51, 0.51), 0.01),
+        ((0., 1., 0.), (0, 1, 0), (0.51, hi, 0.51), 1. / 16. - 0.01),
+        ((0., -1., 0.), (0, -1, 0), (0.51, 0.5, 0.51), 0.01),
+        ((0., 0., 1.), (0, 0, 1), (0.51, 0.51, hi), 1. / 16. - 0.01),
+        ((0., 0., -1.), (0, 0, -1), (0.51, 0.51, 0.5), 0.01),
+    ]
+    for d, nxt, hit, ds in cases:
+        n, s, h = wall(oracle, origin, d, anchor, sides)
+        assert n == nxt
+        assert tuple(h) == hit  # exact, as in the reference test
+        assert abs(s - ds) < 1.e-15
+    # general direction: z wall closest
+    d = np.array([1., 2., -3.])
+    d /= np.sqrt((d * d).sum())
+    n, s, h = wall(oracle, origin, d, anchor, sides)
+    assert n == (0, 0, -1)
+    assert h[0] == 0.51 + 0.01 / 3. and h[1] == 0.51 + 0.02 / 3.
+    assert h[2] == 0.5
+    assert abs(s - 0.0124722) < 1.e-7
+    # edge: two walls at once
+    d = np.array([0., 1., 1.])
+    d /= np.sqrt((d * d).sum())
+    n, s, h = wall(oracle, origin, d, anchor, sides)
+    assert n == (0, 1, 1)
+    assert tuple(h) == (0.51, hi, hi)
+    assert abs(s - 0.0742462) < 1.e-7
+    # corner: three walls at once
+    d = np.array([1., 1., 1.])
+    d /= np.sqrt((d * d).sum())
+    n, s, h = wall(oracle, origin, d, anchor, sides)
+    assert n == (1, 1, 1)
+    assert tuple(h) == (hi, hi, hi)
+    assert abs(s - 0.0909327) < 1.e-7
+
+
+def test_interact_leaves_box(oracle):
+    """testCartesianDensityGrid.cpp:467-475: unit box, 8^3 cells, n = 1,
+    x_H = 1e-6, sigma_H = sigma_He = 1, tau = 0.125 -> the photon escapes."""
+    sim = oracle.OracleSimulation((8, 8, 8), (0., 0., 0.), (1., 1., 1.))
+    sim.set_homogeneous(1., 8000.)
+    ph = oracle.Photon()
+    for a in range(3):
+        ph.position[a] = 0.51
+        ph.direction[a] = (1., 0., 0.)[a]
+        with np.errstate(divide="ignore"):
+            ph.inverse_direction[a] = float(np.float64(1.) /
+                                            np.float64((1., 0., 0.)[a]))
+    ph.cross_section[0] = 1.
+    ph.cross_section[1] = 1.
+    ph.weight = 1.
+    last = oracle.lib().cmio_interact(
+        C.byref(sim.grid), C.byref(sim.model), C.byref(sim.cells),
+        C.byref(ph), 0.125, None, None, 0, None)
+    assert last == -1
+    # every crossed cell got ds * w * sigma (DensityGrid.hpp:162-166)
+    J = sim.J[0].reshape(8, 8, 8)
+    assert np.allclose(J[4:, 4, 4], [0.625 - 0.51, .125, .125, .125])
+    assert J.sum() == pytest.approx(0.49)
+
+
+def test_stromgren_oracle_physics(oracle):
+    """End to end: the oracle reproduces the analytic Stromgren sphere
+    (benchmarks/stromgren.py:60-79): ionised volume fraction 0.362 (coarse
+    32^3 grid: one cell is 7 % of the radius), and the defining balance
+    recombinations = ionising photons, sum n^2 (1-x)^2 alpha V = Q."""
+    sim = oracle.stromgren_simulation(32)
+    sim.run(200000, 14)
+    frac = (sim.x[0] < 0.5).mean()
+    assert abs(frac - 0.3617) < 0.02
+    assert sim.totweight == 200000
+    assert sim.typecount[3] > 0.99 * 200000  # everything absorbed
+    V = (10. * oracle.PC / 32) ** 3
+    nion = sim.number_density * (1. - sim.x[0])
+    recombinations = (nion * nion * 4.e-19 * V).sum()
+    assert abs(recombinations / 4.26e49 - 1.) < 0.02

@@ -127,6 +127,7 @@ struct CountersDev {
   double totweight;
   double typecount[4];
   unsigned long long nsteps;
+  unsigned long long natomics; /* atomic adds issued to the accumulators */
 };
 
 #endif

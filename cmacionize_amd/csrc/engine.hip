@@ -7,6 +7,7 @@
 
 #include "atomic_data.h"
 #include "kernels.h"
+#include "sort.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -69,6 +70,23 @@ struct cmi_gpu_engine {
        have_recomb = false, have_cells = false;
   bool full_ions = false; /* transport carries all 14 cross sections */
   cmi_gpu_temperature_params tparams;
+
+  /* direction sort of the packet order (keys/ids double buffered) */
+  uint32_t *sort_keys[2] = {nullptr, nullptr};
+  uint32_t *sort_ids[2] = {nullptr, nullptr};
+  void *sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  uint64_t sort_capacity = 0;
+
+  struct Tuning {
+    bool sort_packets = true;
+    bool aggregate = true;
+    int refill_threshold = CMI_REFILL_THRESHOLD;
+    uint32_t chunk = 256;
+    int max_blocks_per_cu = 8;
+    uint64_t max_packets_per_launch = 1ull << 27;
+    bool exp_no_atomics = false;
+  } tune;
 
   std::vector<EventPair> shoot_events, update_events;
 };
@@ -332,6 +350,8 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->tables);
   (void)hipFree(e->source_position);
   (void)hipFree(e->source_cumulative);
+  (void)hipFree(e->sort_keys[0]);
+  (void)hipFree(e->sort_temp);
   if (e->own_stream)
     (void)hipStreamDestroy(e->stream);
   delete e;
@@ -539,6 +559,54 @@ int cmi_gpu_reset_grid(cmi_gpu_engine *e) {
   return CMI_GPU_OK;
 }
 
+int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
+  if (!e || !key)
+    return fail(CMI_GPU_EINVAL, "set_tuning: bad argument");
+  const std::string k(key);
+  if (k == "sort_packets")
+    e->tune.sort_packets = value != 0;
+  else if (k == "aggregate")
+    e->tune.aggregate = value != 0;
+  else if (k == "refill_threshold")
+    e->tune.refill_threshold = (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
+  else if (k == "chunk")
+    e->tune.chunk = (uint32_t)(value < 64 ? 64 : value);
+  else if (k == "max_blocks_per_cu")
+    e->tune.max_blocks_per_cu = (int)(value < 1 ? 1 : value);
+  else if (k == "max_packets_per_launch")
+    e->tune.max_packets_per_launch =
+        (uint64_t)(value < 1024 ? 1024 : (value > (1ll << 30) ? (1ll << 30) : value));
+  else if (k == "exp_no_atomics")
+    e->tune.exp_no_atomics = value != 0;
+  else
+    return fail(CMI_GPU_EINVAL, "set_tuning: unknown key '%s'", key);
+  return CMI_GPU_OK;
+}
+
+/* make sure the sort buffers hold n packets */
+static int reserve_sort_buffers(cmi_gpu_engine *e, uint64_t n) {
+  if (e->sort_capacity >= n)
+    return CMI_GPU_OK;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(e->sort_keys[0]);
+  (void)hipFree(e->sort_temp);
+  e->sort_keys[0] = nullptr;
+  e->sort_temp = nullptr;
+  e->sort_capacity = 0;
+  uint32_t *block = nullptr;
+  HIP_TRY(hipMalloc(&block, sizeof(uint32_t) * 4 * n));
+  e->sort_keys[0] = block;
+  e->sort_keys[1] = block + n;
+  e->sort_ids[0] = block + 2 * n;
+  e->sort_ids[1] = block + 3 * n;
+  size_t bytes = 0;
+  HIP_TRY(cmi_sort_pairs_temp_bytes(n, 32, &bytes));
+  e->sort_temp_bytes = bytes;
+  HIP_TRY(hipMalloc(&e->sort_temp, bytes ? bytes : 16));
+  e->sort_capacity = n;
+  return CMI_GPU_OK;
+}
+
 int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                   uint64_t first_packet, uint64_t n_packets) {
   if (!e)
@@ -552,30 +620,30 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     return CMI_GPU_OK;
   HIP_TRY(hipSetDevice(e->device));
 
-  ShootArgs a;
-  a.grid = e->grid;
-  a.model = e->model;
-  a.cells = e->cells;
-  a.counters = e->counters;
-  a.first_packet = first_packet;
-  a.n_packets = n_packets;
-  a.seed = seed;
-  a.iteration = iteration;
-
   const bool heat = e->config.track_heating != 0;
   const bool reemit = e->model.reemit_type != CMI_GPU_REEMIT_NONE;
+  /* cross-lane aggregation keys are 32-bit cell indices */
+  const bool agg = e->tune.aggregate && e->ncell < (1ll << 31);
   void (*kernel)(const ShootArgs) = nullptr;
-#define PICK(F, H, R)                                                          \
-  if (e->full_ions == F && heat == H && reemit == R)                           \
-    kernel = shoot_kernel<F, H, R>;
-  PICK(false, false, false)
-  PICK(false, false, true)
-  PICK(false, true, false)
-  PICK(false, true, true)
-  PICK(true, false, false)
-  PICK(true, false, true)
-  PICK(true, true, false)
-  PICK(true, true, true)
+#define PICK(F, H, R, A)                                                       \
+  if (e->full_ions == F && heat == H && reemit == R && agg == A)               \
+    kernel = shoot_kernel<F, H, R, A>;
+  PICK(false, false, false, false)
+  PICK(false, false, true, false)
+  PICK(false, true, false, false)
+  PICK(false, true, true, false)
+  PICK(true, false, false, false)
+  PICK(true, false, true, false)
+  PICK(true, true, false, false)
+  PICK(true, true, true, false)
+  PICK(false, false, false, true)
+  PICK(false, false, true, true)
+  PICK(false, true, false, true)
+  PICK(false, true, true, true)
+  PICK(true, false, false, true)
+  PICK(true, false, true, true)
+  PICK(true, true, false, true)
+  PICK(true, true, true, true)
 #undef PICK
 
   int blocks_per_cu = 0;
@@ -583,18 +651,76 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                                                        CMI_BLOCK, 0));
   if (blocks_per_cu < 1)
     blocks_per_cu = 1;
-  if (blocks_per_cu > 8)
-    blocks_per_cu = 8;
-  const int blocks = grid_blocks(e, (int64_t)n_packets, blocks_per_cu);
+  if (blocks_per_cu > e->tune.max_blocks_per_cu)
+    blocks_per_cu = e->tune.max_blocks_per_cu;
 
-  EventPair ev;
-  HIP_TRY(hipEventCreate(&ev.start));
-  HIP_TRY(hipEventCreate(&ev.stop));
-  HIP_TRY(hipEventRecord(ev.start, e->stream));
-  kernel<<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ev.stop, e->stream));
-  e->shoot_events.push_back(ev);
+  const bool sorted = e->tune.sort_packets;
+  const uint64_t max_launch = e->tune.max_packets_per_launch;
+  if (sorted) {
+    int rc = reserve_sort_buffers(e, n_packets < max_launch ? n_packets
+                                                            : max_launch);
+    if (rc)
+      return rc;
+  }
+  /* bits of the sort key in use: 22 direction bits + the source index */
+  int key_bits = 22;
+  for (int s = e->model.nsource - 1; s > 0; s >>= 1)
+    ++key_bits;
+  if (key_bits > 32)
+    key_bits = 32;
+
+  for (uint64_t done = 0; done < n_packets; done += max_launch) {
+    const uint64_t n = n_packets - done < max_launch ? n_packets - done
+                                                     : max_launch;
+    ShootArgs a;
+    a.grid = e->grid;
+    a.model = e->model;
+    a.cells = e->cells;
+    a.counters = e->counters;
+    a.first_packet = first_packet + done;
+    a.n_packets = n;
+    a.order = nullptr;
+    a.chunk = e->tune.chunk;
+    a.seed = seed;
+    a.iteration = iteration;
+    a.refill_threshold = e->tune.refill_threshold;
+    a.exp_no_atomics = e->tune.exp_no_atomics ? 1 : 0;
+
+    EventPair ev;
+    HIP_TRY(hipEventCreate(&ev.start));
+    HIP_TRY(hipEventCreate(&ev.stop));
+    HIP_TRY(hipEventRecord(ev.start, e->stream));
+    if (sorted) {
+      KeyArgs k;
+      k.model = e->model;
+      k.first_packet = a.first_packet;
+      k.n_packets = n;
+      k.seed = seed;
+      k.iteration = iteration;
+      k.keys = e->sort_keys[0];
+      k.ids = e->sort_ids[0];
+      direction_key_kernel<<<grid_blocks(e, (int64_t)n, 8), CMI_BLOCK, 0,
+                             e->stream>>>(k);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(cmi_sort_pairs(e->sort_temp, e->sort_temp_bytes, e->sort_keys[0],
+                             e->sort_keys[1], e->sort_ids[0], e->sort_ids[1],
+                             n, key_bits, e->stream));
+      a.order = e->sort_ids[1];
+    }
+    /* enough chunks for every wave of a full grid, else fewer blocks */
+    const uint64_t nchunks = (n + a.chunk - 1) / a.chunk;
+    int64_t blocks = (int64_t)e->num_cu * blocks_per_cu;
+    const int64_t need = (int64_t)((nchunks + (CMI_BLOCK / 64) - 1) /
+                                   (CMI_BLOCK / 64));
+    if (blocks > need)
+      blocks = need;
+    if (blocks < 1)
+      blocks = 1;
+    kernel<<<(unsigned)blocks, CMI_BLOCK, 0, e->stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.stop, e->stream));
+    e->shoot_events.push_back(ev);
+  }
   return CMI_GPU_OK;
 }
 
@@ -614,6 +740,18 @@ int cmi_gpu_get_counters(cmi_gpu_engine *e, double *totweight,
       typecount[i] = host.typecount[i];
   if (nsteps)
     *nsteps = host.nsteps;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_get_atomic_count(cmi_gpu_engine *e, uint64_t *natomics) {
+  if (!e || !natomics)
+    return fail(CMI_GPU_EINVAL, "get_atomic_count: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  CountersDev host;
+  HIP_TRY(hipMemcpyAsync(&host, e->counters, sizeof host,
+                         hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *natomics = host.natomics;
   return CMI_GPU_OK;
 }
 

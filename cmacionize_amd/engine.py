@@ -63,7 +63,8 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_upload_cells", "cmi_gpu_upload_field", "cmi_gpu_download_field",
     "cmi_gpu_field_device_pointer", "cmi_gpu_reset_grid", "cmi_gpu_shoot",
     "cmi_gpu_get_counters", "cmi_gpu_update_cells", "cmi_gpu_emit_packets",
-    "cmi_gpu_trace_packets", "cmi_gpu_get_timing",
+    "cmi_gpu_trace_packets", "cmi_gpu_get_timing", "cmi_gpu_set_tuning",
+    "cmi_gpu_get_atomic_count",
 ]
 
 _lib = None
@@ -118,6 +119,8 @@ def load_library():
         _dp]
     L.cmi_gpu_get_timing.argtypes = [vp, C.c_int32, _dp, C.POINTER(C.c_uint64),
                                      _dp, C.POINTER(C.c_uint64)]
+    L.cmi_gpu_set_tuning.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.cmi_gpu_get_atomic_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -256,8 +259,18 @@ class GpuEngine:
                                                    _p(tc), C.byref(ns)))
         return tw.value, tc, ns.value
 
+    def get_atomic_count(self):
+        n = C.c_uint64()
+        self._check(self._lib.cmi_gpu_get_atomic_count(self._h, C.byref(n)))
+        return n.value
+
     def update_cells(self, loop, totweight):
         self._check(self._lib.cmi_gpu_update_cells(self._h, loop, totweight))
+
+    def set_tuning(self, **kw):
+        for k, v in kw.items():
+            self._check(self._lib.cmi_gpu_set_tuning(self._h, k.encode(),
+                                                     int(v)))
 
     def synchronize(self):
         self._check(self._lib.cmi_gpu_synchronize(self._h))

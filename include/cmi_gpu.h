@@ -206,6 +206,10 @@ int cmi_gpu_shoot(cmi_gpu_engine *engine, uint32_t seed, uint32_t iteration,
 int cmi_gpu_get_counters(cmi_gpu_engine *engine, double *totweight,
                          double *typecount, uint64_t *nsteps);
 
+/* number of atomic adds the transport kernels issued to the accumulator
+ * fields since the last reset (diagnostic of the cross-lane aggregation) */
+int cmi_gpu_get_atomic_count(cmi_gpu_engine *engine, uint64_t *natomics);
+
 /* replaces: TemperatureCalculator::calculate_temperature(loop, totweight,
  * grid, block) (src/TemperatureCalculator.cpp:944-970), i.e. per cell either
  * IonizationStateCalculator::calculate_ionization_state
@@ -215,6 +219,18 @@ int cmi_gpu_get_counters(cmi_gpu_engine *engine, double *totweight,
  * Asynchronous. */
 int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
                          double totweight);
+
+/* Performance knobs (no effect on what is computed, only on how):
+ *   "sort_packets" (1)      process the packets of a launch in emission-
+ *                           direction order, so that the lanes of a wave cross
+ *                           the same cells
+ *   "aggregate" (1)         sum the contributions of lanes in the same cell
+ *                           across the wave before the atomic
+ *   "refill_threshold" (64) idle lanes of a wave that trigger a refill
+ *   "chunk" (256)           consecutive packets a wave takes at a time
+ *   "max_blocks_per_cu" (8), "max_packets_per_launch" (2^27)
+ *   "exp_no_atomics" (0)    EXPERIMENT ONLY: skip the accumulation */
+int cmi_gpu_set_tuning(cmi_gpu_engine *engine, const char *key, int64_t value);
 
 /* --------------------------------------------------- test / measurement -- */
 

@@ -245,6 +245,41 @@ def test_packet_range_partition_is_additive(oracle):
     eng.close()
 
 
+def test_tuning_does_not_change_results():
+    """Direction sorting, cross-lane aggregation, refill threshold, chunking
+    and launch splitting only reorder the work: same tallies up to the
+    summation order; the aggregation must actually cut the atomics."""
+    from cmacionize_amd import engine as E
+    eng = make_engine(32, track_heating=True)
+    results = []
+    for kw in (dict(sort_packets=0, aggregate=0, refill_threshold=16),
+               dict(sort_packets=1, aggregate=1, refill_threshold=64),
+               dict(sort_packets=1, aggregate=1, refill_threshold=20,
+                    chunk=64, max_packets_per_launch=30000),
+               dict(sort_packets=0, aggregate=1, refill_threshold=1,
+                    chunk=1000, max_blocks_per_cu=1)):
+        base = dict(sort_packets=1, aggregate=1, refill_threshold=64,
+                    chunk=256, max_blocks_per_cu=8,
+                    max_packets_per_launch=1 << 27)
+        base.update(kw)
+        eng.set_tuning(**base)
+        eng.reset_grid()
+        eng.shoot(11, 2, 5, 100001)
+        tw, tc, ns = eng.get_counters()
+        results.append((tw, tc, ns, eng.download_field(E.FIELD_MEAN_INTENSITY),
+                        eng.download_field(E.FIELD_HEATING),
+                        eng.get_atomic_count()))
+    tw0, tc0, ns0, J0, h0, na0 = results[0]
+    assert na0 == 2 * ns0  # one atomic per step and accumulator
+    for tw, tc, ns, J, h, na in results[1:]:
+        assert tw == tw0 == 100001 and ns == ns0
+        assert np.array_equal(tc, tc0)
+        assert np.allclose(J, J0, rtol=1e-11, atol=1e-13 * J0.max())
+        assert np.allclose(h, h0, rtol=1e-11, atol=1e-13 * np.abs(h0).max())
+    assert results[1][5] < 0.5 * na0
+    eng.close()
+
+
 def test_stromgren_converges_to_analytic_radius():
     """benchmarks/stromgren.py: ionised volume against the analytic Stromgren
     sphere (R_s = 4.42 pc in a 10 pc box -> 36.2 % of the volume)."""

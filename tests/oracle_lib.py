@@ -154,7 +154,7 @@ class OracleSimulation:
     """
 
     def __init__(self, ncell, anchor, sides, periodic=(0, 0, 0),
-                 compact=False):
+                 compact=False, accumulators=None):
         """compact=True aliases the storage of all metal ions (fractions and
         mean intensities) to one scratch array each: valid only when their
         cross sections are zero (H-only runs); saves 24 of 32 arrays."""
@@ -171,14 +171,21 @@ class OracleSimulation:
         self.temperature = np.zeros(n)
         nstore = 3 if compact else NION
         self._xs = np.zeros((nstore, n))
-        self._Js = np.zeros((nstore, n))
+        if accumulators is not None:
+            # caller-owned contiguous [16][n] block (14 J + 2 heating), the
+            # layout of the engine's accumulator block
+            assert accumulators.shape == (NION + 2, n) and not compact
+            self._Js = accumulators[:NION]
+            self.heating = accumulators[NION:]
+        else:
+            self._Js = np.zeros((nstore, n))
+            self.heating = np.zeros((2, n))
         if compact:
             self.x = [self._xs[0], self._xs[1]] + [self._xs[2]] * 12
             self.J = [self._Js[0], self._Js[1]] + [self._Js[2]] * 12
         else:
             self.x = self._xs
             self.J = self._Js
-        self.heating = np.zeros((2, n))
         self.cells = Cells()
         self.cells.number_density = _ptr(self.number_density)
         self.cells.temperature = _ptr(self.temperature)
@@ -245,10 +252,11 @@ def num_threads():
     return int(lib().cmio_num_threads())
 
 
-def stromgren_simulation(ncell=64, diffuse=False, compact=False):
+def stromgren_simulation(ncell=64, diffuse=False, compact=False,
+                         accumulators=None):
     """benchmarks/stromgren.param (and stromgren_diffuse.param)."""
     sim = OracleSimulation((ncell,) * 3, (-5. * PC,) * 3, (10. * PC,) * 3,
-                           compact=compact)
+                           compact=compact, accumulators=accumulators)
     sim.set_sources([[0., 0., 0.]], [1.], 4.26e49)
     sim.set_homogeneous(100. * 1.e6, 8000.)
     m = sim.model

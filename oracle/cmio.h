@@ -151,7 +151,43 @@ typedef struct {
   int32_t t_max_iterations; /* 100 */
   double pahfac, crfac, crlim, crscale;
   double t_min_ionized;     /* 4000 K */
+
+  /* sampling tables built by cmio_tables_create (needed for the Planck
+   * spectrum and for physical re-emission) */
+  const struct cmio_tables *tables;
 } cmio_model;
+
+#define CMIO_NFREQ 1000 /* frequency bins of every sampled spectrum */
+#define CMIO_NTEMP 100  /* temperature bins of the Lyman continua */
+
+/* src/PlanckPhotonSourceSpectrum.hpp, src/HydrogenLymanContinuumSpectrum.hpp,
+ * src/HeliumLymanContinuumSpectrum.hpp,
+ * src/HeliumTwoPhotonContinuumSpectrum.hpp: the members of these classes */
+typedef struct cmio_tables {
+  double planck_logfreq[CMIO_NFREQ];
+  double planck_cdf[CMIO_NFREQ];
+  double planck_logcdf[CMIO_NFREQ];
+  double lyc_T[CMIO_NTEMP];
+  double lyc_freq[2][CMIO_NFREQ];            /* [H, He] */
+  double lyc_cdf[2][CMIO_NTEMP][CMIO_NFREQ]; /* [H, He][T][nu] */
+  double he2pc_freq[CMIO_NFREQ];
+  double he2pc_cdf[CMIO_NFREQ];
+} cmio_tables;
+
+/* builds every table from the model's spectrum and cross sections */
+cmio_tables *cmio_tables_create(const cmio_model *model);
+void cmio_tables_free(cmio_tables *tables);
+
+/* n samples of spectrum `kind` (0 Planck, 1 H Lyc, 2 He Lyc, 3 He 2-photon)
+ * at `temperature`; sample i uses packet stream i of `seed` */
+void cmio_sample_spectrum(const cmio_model *model, int kind,
+                          double temperature, uint32_t seed, uint64_t n,
+                          double *out);
+/* src/HeliumTwoPhotonContinuumSpectrum.cpp:144-160 */
+double cmio_he2pc_integral(void);
+/* src/PhysicalDiffuseReemissionHandler.hpp:66-105: p[0] = P(H Lyc),
+ * p[1..4] = cumulative He channel probabilities */
+void cmio_reemission_probabilities(double temperature, double p[5]);
 
 /* A photon packet: src/Photon.hpp:36-69 */
 typedef struct {
@@ -239,6 +275,41 @@ void cmio_ionization_state_cell(const cmio_model *model, double jfac,
 void cmio_calculate_ionization_state(const cmio_grid *grid,
                                      const cmio_model *model,
                                      cmio_cells *cells, double totweight);
+
+/* ---------------------------------------------------------- line cooling -- */
+
+/* src/LineCoolingData.cpp:1492-1555; A and B are overwritten, B = solution */
+int cmio_solve_5x5(double A[5][5], double B[5]);
+/* src/LineCoolingData.cpp:1767-1847: cooling rate per hydrogen atom (J s^-1
+ * = kg m^2 s^-3); abundances[13] in the element order NI NII OI OII OIII NeIII
+ * SII SIII CII CIII NIII NeII SIV (src/LineCoolingData.hpp:38-80) */
+double cmio_line_cooling(double temperature, double electron_density,
+                         const double abundances[13]);
+/* accessors used to pin the data table (src/LineCoolingData.cpp:1410-1450) */
+double cmio_lc_energy_difference(int element, int transition);
+double cmio_lc_transition_probability(int element, int transition);
+double cmio_lc_statistical_weight(int element, int level);
+
+/* -------------------------------------------------------- thermal balance -- */
+
+/* src/TemperatureCalculator.cpp:207-501; j[14], h[2] normalised integrals;
+ * x[2..13] receive the metal fractions at temperature T */
+void cmio_cooling_and_heating_balance(const cmio_model *model, double *h0,
+                                      double *he0, double *gain, double *loss,
+                                      double T, double n, double midpoint_z,
+                                      const double j[CMIO_NION],
+                                      const double h[2], double pahfac,
+                                      double crfac, double crscale,
+                                      double x[CMIO_NION]);
+/* src/TemperatureCalculator.cpp:567-931 for one cell: J[14], heating[2]
+ * un-normalised; *temperature in/out; x[14] in/out */
+void cmio_temperature_cell(const cmio_model *model, double jfac, double hfac,
+                           double ntot, double midpoint_z, double *temperature,
+                           const double J[CMIO_NION], double heating[2],
+                           double x[CMIO_NION]);
+/* src/TemperatureCalculator.cpp:944-970, temperature branch */
+void cmio_calculate_temperature(const cmio_grid *grid, const cmio_model *model,
+                                cmio_cells *cells, double totweight);
 
 /* src/TemperatureCalculator.cpp:944-970 (dispatch) over the whole grid:
  * ionization balance (src/IonizationStateCalculator.cpp:511-530,70-272) or

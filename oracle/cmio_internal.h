@@ -25,6 +25,7 @@ static inline double cmio_rng_next(cmio_rng *rng) {
 #define CMIO_LIGHTSPEED 299792458.
 #define CMIO_ELECTRONVOLT 1.6021766208e-19
 #define CMIO_ELECTRON_MASS 9.10938356e-31
+#define CMIO_RYDBERG 2.179872325e-18
 
 /* UnitConverter::to_SI<QUANTITY_FREQUENCY>(x, "eV"):
  * src/UnitConverter.hpp:156-159,266-300 */

@@ -64,6 +64,7 @@ class Model(C.Structure):
         ("crlim", C.c_double),
         ("crscale", C.c_double),
         ("t_min_ionized", C.c_double),
+        ("tables", C.c_void_p),
     ]
 
 
@@ -119,6 +120,30 @@ def lib():
     L.cmio_ionization_state_cell.argtypes = [C.POINTER(Model), C.c_double,
                                              C.c_double, C.c_double,
                                              C.c_double, dp, dp, dp]
+    L.cmio_num_threads.restype = C.c_int
+    L.cmio_tables_create.restype = C.c_void_p
+    L.cmio_tables_create.argtypes = [C.POINTER(Model)]
+    L.cmio_tables_free.argtypes = [C.c_void_p]
+    L.cmio_sample_spectrum.argtypes = [C.POINTER(Model), C.c_int, C.c_double,
+                                       C.c_uint32, C.c_uint64, dp]
+    L.cmio_he2pc_integral.restype = C.c_double
+    L.cmio_reemission_probabilities.argtypes = [C.c_double, dp]
+    L.cmio_solve_5x5.restype = C.c_int
+    L.cmio_solve_5x5.argtypes = [dp, dp]
+    L.cmio_line_cooling.restype = C.c_double
+    L.cmio_line_cooling.argtypes = [C.c_double, C.c_double, dp]
+    for name in ("cmio_lc_energy_difference",
+                 "cmio_lc_transition_probability",
+                 "cmio_lc_statistical_weight"):
+        f = getattr(L, name)
+        f.restype = C.c_double
+        f.argtypes = [C.c_int, C.c_int]
+    L.cmio_cooling_and_heating_balance.argtypes = [
+        C.POINTER(Model), dp, dp, dp, dp, C.c_double, C.c_double, C.c_double,
+        dp, dp, C.c_double, C.c_double, C.c_double, dp]
+    L.cmio_temperature_cell.argtypes = [
+        C.POINTER(Model), C.c_double, C.c_double, C.c_double, C.c_double, dp,
+        dp, dp, dp]
     for name in ("cmio_verner_cross_section",
                  "cmio_verner_recombination_rate",
                  "cmio_ct_recombination_rate_H", "cmio_ct_ionization_rate_H",
@@ -225,7 +250,18 @@ class OracleSimulation:
     def reset(self):
         lib().cmio_reset_grid(C.byref(self.grid), C.byref(self.cells))
 
+    def build_tables(self):
+        """(Re)build the sampling tables after the spectrum / cross sections
+        / re-emission settings of the model are final."""
+        if self.model.tables:
+            lib().cmio_tables_free(self.model.tables)
+        self.model.tables = lib().cmio_tables_create(C.byref(self.model))
+
     def shoot(self, seed, iteration, first_packet, n_packets):
+        if not self.model.tables and (
+                self.model.spectrum_type == SPECTRUM_PLANCK or
+                self.model.reemit_type == REEMIT_PHYSICAL):
+            self.build_tables()
         tw = C.c_double(0.)
         tc = np.zeros(NTYPE)
         lib().cmio_shoot(C.byref(self.grid), C.byref(self.model),
@@ -268,4 +304,66 @@ def stromgren_simulation(ncell=64, diffuse=False, compact=False,
     m.recomb_fixed[0] = 4.e-13 * 1.e-6
     m.reemit_type = REEMIT_PHYSICAL if diffuse else REEMIT_NONE
     m.do_temperature = 0
+    return sim
+
+
+def block_syntax_density(ncell, anchor, sides, blocks):
+    """BlockSyntaxDensityFunction::operator() on the cell midpoints
+    (src/BlockSyntaxDensityFunction.hpp:150-190, BlockSyntaxBlock.hpp:91-105).
+    blocks: list of (origin[3], sides[3], exponent, density, temperature,
+    neutral_fraction_H); later blocks override earlier ones."""
+    ax = [anchor[a] + (np.arange(ncell[a]) + 0.5) * (sides[a] / ncell[a])
+          for a in range(3)]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    pos = [X.ravel(), Y.ravel(), Z.ravel()]
+    n = np.full(X.size, -1.)
+    T = np.full(X.size, -1.)
+    xH = np.full(X.size, -1.)
+    for origin, bsides, exponent, density, temperature, nfH in blocks:
+        r = np.zeros(X.size)
+        for a in range(3):
+            x = 2. * np.abs(pos[a] - origin[a]) / bsides[a]
+            if exponent < 10.:
+                r += x ** exponent
+            else:
+                r = np.maximum(r, x)
+        if exponent < 10.:
+            r = r ** (1. / exponent)
+        inside = r <= 1.
+        n[inside] = density
+        T[inside] = temperature
+        xH[inside] = nfH
+    assert n.min() >= 0. and T.min() >= 0.
+    return n, T, xH
+
+
+LEXINGTON_ABUNDANCES = dict(He=0.1, C=2.2e-4, N=4.e-5, O=3.3e-4, Ne=5.e-5,
+                            S=9.e-6)
+
+
+def lexington_simulation(ncell=32, star_temperature=40000.):
+    """benchmarks/lexingtonHII40.param + lexingtonHII40.yml."""
+    anchor = (-5. * PC,) * 3
+    sides = (10. * PC,) * 3
+    sim = OracleSimulation((ncell,) * 3, anchor, sides)
+    sim.set_sources([[0., 0., 0.]], [1.], 4.26e49)
+    n, T, xH = block_syntax_density(
+        (ncell,) * 3, anchor, sides,
+        [((0., 0., 0.), (10. * PC,) * 3, 10., 100. * 1.e6, 8000., 1.e-6),
+         ((0., 0., 0.), (6.e18 * 0.01,) * 3, 2., 0., 0., 1.e-6)])
+    sim.number_density[:] = n
+    sim.temperature[:] = T
+    sim._xs[:] = 0.
+    sim.x[0][:] = xH
+    sim.x[1][:] = 1.e-6
+    m = sim.model
+    m.spectrum_type = SPECTRUM_PLANCK
+    m.planck_temperature = star_temperature
+    m.xsec_type = XSEC_VERNER
+    m.recomb_type = RECOMB_VERNER
+    for i, el in enumerate(("He", "C", "N", "O", "Ne", "S")):
+        m.abundance[1 + i] = LEXINGTON_ABUNDANCES[el]
+    m.reemit_type = REEMIT_PHYSICAL
+    m.do_temperature = 1
+    m.pahfac = 0.
     return sim

@@ -76,6 +76,25 @@ struct CTFitDev {
   int32_t pad;
 };
 
+/* line cooling data, converted as in src/LineCoolingData.cpp:42-1399:
+ * 10 five-level ions (NI NII OI OII OIII NeIII SII SIII CII CIII) and 3
+ * two-level ions (NIII NeII SIV); transitions 0-1 0-2 0-3 0-4 1-2 1-3 1-4
+ * 2-3 2-4 3-4 */
+#define CMI_LC_NFIVE_DEV 10
+#define CMI_LC_NTWO_DEV 3
+#define CMI_LC_NTRANS_DEV 10
+struct LineCoolingDev {
+  double energy[CMI_LC_NFIVE_DEV][CMI_LC_NTRANS_DEV]; /* K */
+  double A[CMI_LC_NFIVE_DEV][CMI_LC_NTRANS_DEV];      /* s^-1 */
+  double cs[CMI_LC_NFIVE_DEV][CMI_LC_NTRANS_DEV][7];  /* Omega(T) fit */
+  double inv_weight[CMI_LC_NFIVE_DEV][5];
+  double two_energy[CMI_LC_NTWO_DEV];
+  double two_A[CMI_LC_NTWO_DEV];
+  double two_cs[CMI_LC_NTWO_DEV][7];
+  double two_inv_weight[CMI_LC_NTWO_DEV][2];
+  double prefactor; /* h^2 / (sqrt(k) (2 pi m_e)^1.5) */
+};
+
 /* All read-only physics tables, one instance in device memory */
 struct TablesDev {
   VernerTermDev verner[CMI_VERNER_NTERM_DEV];
@@ -83,6 +102,23 @@ struct TablesDev {
   CTFitDev ct_recomb_H[CMI_NION];
   CTFitDev ct_ion_H[CMI_NION];
   CTFitDev ct_recomb_He[CMI_NION];
+  LineCoolingDev lc;
+};
+
+/* CDF tables of the sampled spectra: the members of
+ * PlanckPhotonSourceSpectrum, Hydrogen/HeliumLymanContinuumSpectrum and
+ * HeliumTwoPhotonContinuumSpectrum. 1.65 MB, lives in HBM (L2 resident). */
+#define CMI_NFREQ 1000
+#define CMI_NTEMP 100
+struct SpectraDev {
+  double planck_logfreq[CMI_NFREQ];
+  double planck_cdf[CMI_NFREQ];
+  double planck_logcdf[CMI_NFREQ];
+  double lyc_T[CMI_NTEMP];
+  double lyc_freq[2][CMI_NFREQ];           /* [H, He] */
+  double lyc_cdf[2][CMI_NTEMP][CMI_NFREQ]; /* [H, He][T][nu] */
+  double he2pc_freq[CMI_NFREQ];
+  double he2pc_cdf[CMI_NFREQ];
 };
 
 /* Physics set-up passed by value to the kernels */
@@ -110,6 +146,13 @@ struct ModelDev {
   /* thresholds in Hz, src/DensityGrid.hpp:219-222 */
   double nu_H, nu_He;
   const TablesDev *tables;
+  const SpectraDev *spectra; /* NULL until a sampled spectrum is needed */
+  /* TemperatureCalculator parameters, src/TemperatureCalculator.cpp:133-160 */
+  double t_epsilon;
+  double pahfac, crfac, crlim, crscale;
+  double t_min_ionized;
+  int32_t t_max_iterations;
+  int32_t pad1;
 };
 
 /* SoA cell state, all device pointers to [ncell] doubles */

@@ -84,7 +84,8 @@ __device__ __forceinline__ uint32_t cmi_locate(double x, const double *arr,
 
 /* VernerCrossSections::get_cross_section_verner,
  * src/VernerCrossSections.cpp:166-245, for one (ion, shell) term */
-__device__ inline double verner_term_sigma(const VernerTermDev &t, double e) {
+__host__ __device__ inline double verner_term_sigma(const VernerTermDev &t,
+                                                    double e) {
   if (e < t.E_th)
     return 0.;
   const int is = t.shell;
@@ -114,8 +115,9 @@ __device__ inline double verner_term_sigma(const VernerTermDev &t, double e) {
 /* all 14 cross sections of a packet: PhotonSource::set_cross_sections,
  * src/PhotonSource.cpp:189-199 with CrossSections::get_cross_section
  * (src/VernerCrossSections.cpp:259-322 or FixedValueCrossSections) */
-__device__ inline void cmi_cross_sections(const ModelDev &m, double nu,
-                                          double sigma[CMI_NION]) {
+/* (host + device: the host uses it to tabulate the Lyman continua) */
+__host__ __device__ inline void cmi_cross_sections(const ModelDev &m, double nu,
+                                                   double sigma[CMI_NION]) {
   if (!m.xsec_verner) {
 #pragma unroll
     for (int i = 0; i < CMI_NION; ++i)

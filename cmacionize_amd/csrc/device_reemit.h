@@ -6,16 +6,133 @@
 
 #include "device_transport.h"
 
+/* PhysicalDiffuseReemissionHandler::set_reemission_probabilities,
+ * src/PhysicalDiffuseReemissionHandler.hpp:66-105. The reference stores the
+ * five numbers per cell at the start of every iteration
+ * (src/IonizationSimulation.cpp:380-383); they only depend on the cell's
+ * temperature, which does not change while packets fly, so they are evaluated
+ * where needed instead of costing 5 fields of HBM. */
+__device__ inline void reemission_probabilities(double temperature,
+                                                double &pH, double pHe[4]) {
+  const double T4 = temperature * 1.e-4;
+  const double alpha_1_H = 1.58e-13 * pow(T4, -0.53);
+  const double alpha_A_agn = 4.18e-13 * pow(T4, -0.7);
+  pH = alpha_1_H / alpha_A_agn;
+  const double alpha_1_He = 1.54e-13 * pow(T4, -0.486);
+  const double alpha_e_2tS = 2.1e-13 * pow(T4, -0.381);
+  const double alpha_e_2sS = 2.06e-14 * pow(T4, -0.451);
+  const double alpha_e_2sP = 4.17e-14 * pow(T4, -0.695);
+  const double alphaHe = alpha_1_He + alpha_e_2tS + alpha_e_2sS + alpha_e_2sP;
+  pHe[0] = alpha_1_He / alphaHe;
+  pHe[1] = pHe[0] + alpha_e_2tS / alphaHe;
+  pHe[2] = pHe[1] + alpha_e_2sS / alphaHe;
+  pHe[3] = pHe[2] + alpha_e_2sP / alphaHe;
+}
+
+/* PhysicalDiffuseReemissionHandler::reemit,
+ * src/PhysicalDiffuseReemissionHandler.cpp:219-370 (Wood, Mathis & Ercolano
+ * 2004, section 3.3). Returns the new frequency, 0 = absorbed for good. */
+__device__ inline double physical_reemit(const ModelDev &m, double sigma_H,
+                                         double sigma_He, double T, double xH,
+                                         double xHe, PacketRng &rng,
+                                         int32_t &type) {
+  const SpectraDev *s = m.spectra;
+  const double AHe = m.abundance[0];
+  const double nH0anuH0 = xH * sigma_H;
+  const double nHe0anuHe0 = xHe * AHe * sigma_He;
+  const double pHabs = nH0anuH0 / (nH0anuH0 + nHe0anuHe0);
+  double new_frequency = 0.;
+  type = TYPE_ABSORBED;
+
+  double x = rng.next();
+  if (x <= pHabs) {
+    /* absorbed by hydrogen: Lyman continuum photon or lost */
+    const double pH = (1.58e-13 * pow(T * 1.e-4, -0.53)) /
+                      (4.18e-13 * pow(T * 1.e-4, -0.7));
+    x = rng.next();
+    if (x <= pH) {
+      new_frequency = sample_lyman_continuum(s, 0, T, rng);
+      type = TYPE_DIFFUSE_HI;
+    }
+  } else {
+    /* absorbed by helium: pick the recombination channel */
+    double pH, pHe[4];
+    reemission_probabilities(T, pH, pHe);
+    x = rng.next();
+    if (x <= pHe[0]) {
+      new_frequency = sample_lyman_continuum(s, 1, T, rng);
+      type = TYPE_DIFFUSE_HeI;
+    } else if (x <= pHe[1]) {
+      new_frequency = 4.788e15; /* 2^3S -> 1^1S, 19.8 eV */
+      type = TYPE_DIFFUSE_HeI;
+    } else if (x <= pHe[2]) {
+      /* two-photon continuum: 56 % chance of an H-ionizing photon */
+      x = rng.next();
+      if (x < 0.56) {
+        new_frequency = sample_he_two_photon(s, rng);
+        type = TYPE_DIFFUSE_HeI;
+      }
+    } else if (x <= pHe[3]) {
+      /* He Lyman alpha: absorbed on the spot by H, or two-photon decay */
+      const double sqrtTnH0 = sqrt(T) * xH;
+      const double pHots = sqrtTnH0 / (sqrtTnH0 + 77. * xHe);
+      x = rng.next();
+      if (x < pHots) {
+        x = rng.next();
+        if (x <= pH) {
+          new_frequency = sample_lyman_continuum(s, 0, T, rng);
+          type = TYPE_DIFFUSE_HI;
+        }
+      } else {
+        x = rng.next();
+        if (x < 0.56) {
+          new_frequency = sample_he_two_photon(s, rng);
+          type = TYPE_DIFFUSE_HeI;
+        }
+      }
+    }
+  }
+  return new_frequency;
+}
+
 /* PhotonSource::reemit (src/PhotonSource.cpp:272-308): decide whether the
  * packet absorbed in `cell` is re-emitted as ionizing radiation; if so give it
- * a new frequency, direction, cross sections and optical depth. */
+ * a new frequency, direction, cross sections and optical depth
+ * (src/IonizationPhotonShootJob.hpp:137-142). */
 template <bool FULL>
 __device__ inline bool reemit_packet(const GridDev &g, const ModelDev &m,
                                      const CellsDev &cells, int64_t cell,
                                      PacketRng &rng, Packet<FULL> &p) {
-  (void)g; (void)m; (void)cells; (void)cell; (void)rng;
-  p.type = TYPE_ABSORBED;
-  return false;
+  double new_frequency;
+  int32_t type;
+  if (m.reemit_type == 2) {
+    /* FixedValueDiffuseReemissionHandler::reemit,
+     * src/FixedValueDiffuseReemissionHandler.hpp:73-86 */
+    const double u = rng.next();
+    if (u < m.reemit_fixed_probability) {
+      type = TYPE_DIFFUSE_HI;
+      new_frequency = m.reemit_fixed_frequency;
+    } else {
+      type = TYPE_ABSORBED;
+      new_frequency = 0.;
+    }
+  } else {
+    const double sigma_He =
+        FULL ? p.sigma[FULL ? ION_He_n : 0] : m.xsec_fixed[ION_He_n];
+    new_frequency = physical_reemit(
+        m, p.sigma_H, sigma_He, cells.temperature[cell],
+        cells.x[ION_H_n][cell], cells.x[ION_He_n][cell], rng, type);
+  }
+  p.type = type;
+  if (new_frequency == 0.)
+    return false;
+  p.nu = new_frequency;
+  random_direction(p, rng);
+  set_cross_sections(m, p);
+  p.tau = -log(rng.next());
+  /* interact() starts from the cell that contains the packet's position */
+  locate_cell(g, p);
+  return true;
 }
 
 #endif

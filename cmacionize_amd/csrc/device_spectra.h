@@ -1,19 +1,65 @@
 /*
- * device_spectra.h - device samplers for source spectra and diffuse
- * re-emission.
+ * device_spectra.h - device samplers for the source spectrum and the diffuse
+ * re-emission spectra. The CDF tables (SpectraDev) are built on the host at
+ * initialisation - the lowering of the reference's PhotonSourceSpectrum
+ * plugins into device descriptors.
  */
 #ifndef CMI_DEVICE_SPECTRA_H
 #define CMI_DEVICE_SPECTRA_H
 
 #include "device_physics.h"
 
-/* PhotonSourceSpectrum::get_random_frequency */
+/* PlanckPhotonSourceSpectrum::get_random_frequency,
+ * src/PlanckPhotonSourceSpectrum.cpp:149-165: log-log interpolation */
+__device__ inline double sample_planck(const SpectraDev *s, PacketRng &rng) {
+  const double x = rng.next();
+  const uint32_t ix = cmi_locate(x, s->planck_cdf, CMI_NFREQ);
+  const double log_random_frequency =
+      (log10(x) - s->planck_logcdf[ix]) /
+          (s->planck_logcdf[ix + 1] - s->planck_logcdf[ix]) *
+          (s->planck_logfreq[ix + 1] - s->planck_logfreq[ix]) +
+      s->planck_logfreq[ix];
+  const double frequency = pow(10., log_random_frequency);
+  return frequency * 3.288465385e15;
+}
+
+/* Hydrogen/HeliumLymanContinuumSpectrum::get_random_frequency,
+ * src/HydrogenLymanContinuumSpectrum.cpp:136-153 (which = 0) and
+ * src/HeliumLymanContinuumSpectrum.cpp:147-164 (which = 1): the same uniform
+ * is located in the two bracketing temperature rows, the frequencies are
+ * interpolated linearly in T */
+__device__ inline double sample_lyman_continuum(const SpectraDev *s, int which,
+                                                double temperature,
+                                                PacketRng &rng) {
+  const uint32_t iT = cmi_locate(temperature, s->lyc_T, CMI_NTEMP);
+  const double x = rng.next();
+  const uint32_t inu1 = cmi_locate(x, s->lyc_cdf[which][iT], CMI_NFREQ);
+  const uint32_t inu2 = cmi_locate(x, s->lyc_cdf[which][iT + 1], CMI_NFREQ);
+  const double *nu = s->lyc_freq[which];
+  return nu[inu1] + (temperature - s->lyc_T[iT]) * (nu[inu2] - nu[inu1]) /
+                        (s->lyc_T[iT + 1] - s->lyc_T[iT]);
+}
+
+/* HeliumTwoPhotonContinuumSpectrum::get_random_frequency,
+ * src/HeliumTwoPhotonContinuumSpectrum.cpp:167-180 */
+__device__ inline double sample_he_two_photon(const SpectraDev *s,
+                                              PacketRng &rng) {
+  const double x = rng.next();
+  const uint32_t inu = cmi_locate(x, s->he2pc_cdf, CMI_NFREQ);
+  return s->he2pc_freq[inu] + (s->he2pc_freq[inu + 1] - s->he2pc_freq[inu]) *
+                                  (x - s->he2pc_cdf[inu]) /
+                                  (s->he2pc_cdf[inu + 1] - s->he2pc_cdf[inu]);
+}
+
+/* PhotonSourceSpectrum::get_random_frequency of the discrete sources */
 __device__ inline double sample_source_spectrum(const ModelDev &m,
                                                 PacketRng &rng) {
-  (void)rng;
-  /* MonochromaticPhotonSourceSpectrum: no random number is drawn
-   * (src/MonochromaticPhotonSourceSpectrum.hpp:97-100) */
-  return m.mono_frequency;
+  if (m.spectrum_type == 0) {
+    /* MonochromaticPhotonSourceSpectrum: no random number is drawn
+     * (src/MonochromaticPhotonSourceSpectrum.hpp:97-100) */
+    return m.mono_frequency;
+  }
+  return sample_planck(m.spectra, rng);
 }
 
 #endif

@@ -6,6 +6,7 @@
 #include "../../include/cmi_gpu.h"
 
 #include "atomic_data.h"
+#include "linecooling_data.h"
 #include "kernels.h"
 #include "sort.h"
 
@@ -63,6 +64,9 @@ struct cmi_gpu_engine {
   double2 *opacity = nullptr;
   CountersDev *counters = nullptr;
   TablesDev *tables = nullptr;
+  TablesDev *host_tables = nullptr; /* host copy, for host-side tabulation */
+  SpectraDev *spectra = nullptr;
+  bool spectra_dirty = true; /* cross sections / spectrum changed */
   double *source_position = nullptr;
   double *source_cumulative = nullptr;
 
@@ -192,6 +196,189 @@ void build_tables(TablesDev &t) {
   set(t.ct_recomb_He[ION_Ne_p1], 1, 1.e-20, 0, 0, 0, 0, 0, 0);
   set(t.ct_recomb_He[ION_S_p2], 2, 1.1e-15, 0.56, 0., 0., 0, 0.1, 3.);
   set(t.ct_recomb_He[ION_S_p3], 2, 7.6e-19, 0.32, 3.4, -5.25, 0, 0.1, 3.);
+
+  /* line cooling data, src/LineCoolingData.cpp:42-1399: energy levels to
+   * energy differences in K, everything else copied */
+  static_assert(CMI_LC_NFIVE == CMI_LC_NFIVE_DEV && CMI_LC_NTWO == CMI_LC_NTWO_DEV,
+                "line cooling element counts");
+  auto unit_factor = [](int unit) {
+    /* :46-61: cm^-1, eV, Ry -> K */
+    if (unit == 0)
+      return 100. * CMI_PLANCK * CMI_LIGHTSPEED / CMI_BOLTZMANN;
+    if (unit == 1)
+      return CMI_ELECTRONVOLT / CMI_BOLTZMANN;
+    return 2.179872325e-18 / CMI_BOLTZMANN;
+  };
+  static const int TR[5][5] = {{-1, 0, 1, 2, 3},
+                               {-1, -1, 4, 5, 6},
+                               {-1, -1, -1, 7, 8},
+                               {-1, -1, -1, -1, 9},
+                               {-1, -1, -1, -1, -1}};
+  LineCoolingDev &lc = t.lc;
+  for (int el = 0; el < CMI_LC_NFIVE; ++el) {
+    const cmi_lc_five_level &d = cmi_lc_five[el];
+    const double f = unit_factor(d.unit);
+    for (int j = 1; j < 5; ++j) {
+      lc.energy[el][TR[0][j]] = d.levels[j - 1] * f;
+      for (int i = 1; i < j; ++i)
+        lc.energy[el][TR[i][j]] = (d.levels[j - 1] - d.levels[i - 1]) * f;
+    }
+    for (int tr = 0; tr < CMI_LC_NTRANS; ++tr) {
+      lc.A[el][tr] = d.A[tr];
+      for (int k = 0; k < 7; ++k)
+        lc.cs[el][tr][k] = d.cs[tr][k];
+    }
+    for (int k = 0; k < 5; ++k)
+      lc.inv_weight[el][k] = d.inv_weight[k];
+  }
+  for (int el = 0; el < CMI_LC_NTWO; ++el) {
+    const cmi_lc_two_level &d = cmi_lc_two[el];
+    lc.two_energy[el] = d.energy * unit_factor(d.unit);
+    lc.two_A[el] = d.A;
+    for (int k = 0; k < 7; ++k)
+      lc.two_cs[el][k] = d.cs[k];
+    lc.two_inv_weight[el][0] = d.inv_weight[0];
+    lc.two_inv_weight[el][1] = d.inv_weight[1];
+  }
+  /* :1390-1398 */
+  lc.prefactor = CMI_PLANCK * CMI_PLANCK /
+                 (std::sqrt(CMI_BOLTZMANN) *
+                  std::pow(2. * M_PI * CMI_ELECTRON_MASS, 1.5));
+}
+
+/* Tabulate the sampled spectra on the host: the constructors of
+ * PlanckPhotonSourceSpectrum (src/PlanckPhotonSourceSpectrum.cpp:53-113),
+ * Hydrogen/HeliumLymanContinuumSpectrum
+ * (src/HydrogenLymanContinuumSpectrum.cpp:40-122,
+ * src/HeliumLymanContinuumSpectrum.cpp:45-133) and
+ * HeliumTwoPhotonContinuumSpectrum
+ * (src/HeliumTwoPhotonContinuumSpectrum.cpp:44-101). */
+void build_spectra(const ModelDev &host_model, SpectraDev &s) {
+  memset(&s, 0, sizeof s);
+  const double h = CMI_PLANCK, k = CMI_BOLTZMANN;
+  if (host_model.spectrum_type == CMI_GPU_SPECTRUM_PLANCK) {
+    const double temperature = host_model.planck_temperature;
+    const double max_frequency = 4.;
+    const double min_frequency = 3.289e15;
+    std::vector<double> frequency(CMI_NFREQ), luminosity(CMI_NFREQ);
+    for (int i = 0; i < CMI_NFREQ; ++i) {
+      frequency[i] = 1. + i * (max_frequency - 1.) / (CMI_NFREQ - 1.);
+      luminosity[i] = frequency[i] * frequency[i] * frequency[i] /
+                      (std::exp(h * frequency[i] * min_frequency /
+                                (k * temperature)) -
+                       1.);
+    }
+    s.planck_cdf[0] = 0.;
+    for (int i = 1; i < CMI_NFREQ; ++i)
+      s.planck_cdf[i] = s.planck_cdf[i - 1] +
+                        0.5 *
+                            (luminosity[i] / frequency[i] +
+                             luminosity[i - 1] / frequency[i - 1]) *
+                            (frequency[i] - frequency[i - 1]);
+    s.planck_logcdf[0] = -10.;
+    s.planck_logfreq[0] = 0.;
+    for (int i = 1; i < CMI_NFREQ; ++i) {
+      s.planck_cdf[i] /= s.planck_cdf[CMI_NFREQ - 1];
+      s.planck_logcdf[i] = std::log10(s.planck_cdf[i]);
+      s.planck_logfreq[i] = std::log10(frequency[i]);
+    }
+  }
+  for (int which = 0; which < 2; ++which) {
+    const int ion = which == 0 ? ION_H_n : ION_He_n;
+    const double min_frequency =
+        which == 0 ? 3.289e15 : 1.81 * 3.288465385e15;
+    const double max_frequency =
+        which == 0 ? 4. * min_frequency : 4. * 3.288465385e15;
+    double *nu = s.lyc_freq[which];
+    std::vector<double> xsec(CMI_NFREQ);
+    for (int i = 0; i < CMI_NFREQ; ++i) {
+      nu[i] = min_frequency +
+              i * (max_frequency - min_frequency) / (CMI_NFREQ - 1.);
+      double sigma[CMI_NION];
+      cmi_cross_sections(host_model, nu[i], sigma);
+      xsec[i] = sigma[ion];
+    }
+    for (int iT = 0; iT < CMI_NTEMP; ++iT) {
+      double *cdf = s.lyc_cdf[which][iT];
+      cdf[0] = 0.;
+      s.lyc_T[iT] = 1500. + (iT + 0.5) * 13500. / CMI_NTEMP;
+      for (int inu = 1; inu < CMI_NFREQ; ++inu) {
+        const double j1 =
+            nu[inu - 1] * nu[inu - 1] * nu[inu - 1] * xsec[inu - 1] *
+            std::exp(-(h * (nu[inu - 1] - min_frequency)) / (k * s.lyc_T[iT]));
+        const double j2 =
+            nu[inu] * nu[inu] * nu[inu] * xsec[inu] *
+            std::exp(-(h * (nu[inu] - min_frequency)) / (k * s.lyc_T[iT]));
+        cdf[inu] =
+            0.5 * (j1 / nu[inu] + j2 / nu[inu - 1]) * (nu[inu] - nu[inu - 1]);
+      }
+      for (int inu = 1; inu < CMI_NFREQ; ++inu)
+        cdf[inu] = cdf[inu - 1] + cdf[inu];
+      const double total = cdf[CMI_NFREQ - 1];
+      for (int inu = 0; inu < CMI_NFREQ; ++inu)
+        cdf[inu] /= total; /* NaN rows if the ion's cross section is zero */
+    }
+  }
+  {
+    const double min_frequency = 3.288465385e15;
+    const double max_frequency = 1.6 * min_frequency;
+    const double nu0 = 4.98e15;
+    auto A_of = [](double y) {
+      if (!(y < 1.))
+        return 0.;
+      /* Utilities::locate on the 41-point table + linear interpolation */
+      uint32_t lo = 0, hi = CMI_HE2Q_N;
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (y > cmi_he2q_y[mid])
+          lo = mid;
+        else
+          hi = mid;
+      }
+      if (lo == CMI_HE2Q_N - 1)
+        --lo;
+      const double f =
+          (y - cmi_he2q_y[lo]) / (cmi_he2q_y[lo + 1] - cmi_he2q_y[lo]);
+      return cmi_he2q_A[lo] + f * (cmi_he2q_A[lo + 1] - cmi_he2q_A[lo]);
+    };
+    for (int i = 0; i < CMI_NFREQ; ++i)
+      s.he2pc_freq[i] = min_frequency + i * (max_frequency - min_frequency) /
+                                            (CMI_NFREQ - 1.);
+    s.he2pc_cdf[0] = 0.;
+    for (int i = 1; i < CMI_NFREQ; ++i) {
+      const double A1 = A_of(s.he2pc_freq[i - 1] / nu0);
+      const double A2 = A_of(s.he2pc_freq[i] / nu0);
+      s.he2pc_cdf[i] =
+          0.5 * (A1 + A2) * (s.he2pc_freq[i] - s.he2pc_freq[i - 1]);
+    }
+    for (int i = 1; i < CMI_NFREQ; ++i)
+      s.he2pc_cdf[i] = s.he2pc_cdf[i - 1] + s.he2pc_cdf[i];
+    const double total = s.he2pc_cdf[CMI_NFREQ - 1];
+    for (int i = 0; i < CMI_NFREQ; ++i)
+      s.he2pc_cdf[i] /= total;
+  }
+}
+
+/* (re)build and upload the spectra tables if a sampled spectrum is in use */
+int ensure_spectra(cmi_gpu_engine *e) {
+  const bool needed = e->model.spectrum_type == CMI_GPU_SPECTRUM_PLANCK ||
+                      e->model.reemit_type == CMI_GPU_REEMIT_PHYSICAL;
+  if (!needed || !e->spectra_dirty)
+    return CMI_GPU_OK;
+  if (!e->spectra)
+    HIP_TRY(hipMalloc(&e->spectra, sizeof(SpectraDev)));
+  ModelDev host_model = e->model;
+  host_model.tables = e->host_tables;
+  SpectraDev *host = new SpectraDev;
+  build_spectra(host_model, *host);
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  hipError_t err =
+      hipMemcpy(e->spectra, host, sizeof(SpectraDev), hipMemcpyHostToDevice);
+  delete host;
+  HIP_TRY(err);
+  e->model.spectra = e->spectra;
+  e->spectra_dirty = false;
+  return CMI_GPU_OK;
 }
 
 int grid_blocks(cmi_gpu_engine *e, int64_t work_items, int blocks_per_cu) {
@@ -288,12 +475,10 @@ int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
   HIP_TRY(hipMemsetAsync(e->counters, 0, sizeof(CountersDev), e->stream));
   HIP_TRY(hipMalloc(&e->tables, sizeof(TablesDev)));
   {
-    TablesDev *host = new TablesDev;
-    build_tables(*host);
-    hipError_t cerr =
-        hipMemcpy(e->tables, host, sizeof(TablesDev), hipMemcpyHostToDevice);
-    delete host;
-    HIP_TRY(cerr);
+    e->host_tables = new TablesDev;
+    build_tables(*e->host_tables);
+    HIP_TRY(hipMemcpy(e->tables, e->host_tables, sizeof(TablesDev),
+                      hipMemcpyHostToDevice));
   }
 
   CellsDev &c = e->cells;
@@ -323,6 +508,11 @@ int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
   tp.cosmic_ray_heating_limit = 0.75;
   tp.cosmic_ray_heating_scale_length = 1.33333 * 3.086e19;
   tp.minimum_ionized_temperature = 4000.;
+  m.t_epsilon = tp.epsilon_convergence;
+  m.t_max_iterations = tp.maximum_number_of_iterations;
+  m.crlim = tp.cosmic_ray_heating_limit;
+  m.crscale = tp.cosmic_ray_heating_scale_length;
+  m.t_min_ionized = tp.minimum_ionized_temperature;
 
   HIP_TRY(hipStreamSynchronize(e->stream));
   *out = e;
@@ -348,6 +538,8 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->opacity);
   (void)hipFree(e->counters);
   (void)hipFree(e->tables);
+  (void)hipFree(e->spectra);
+  delete e->host_tables;
   (void)hipFree(e->source_position);
   (void)hipFree(e->source_cumulative);
   (void)hipFree(e->sort_keys[0]);
@@ -410,10 +602,13 @@ int cmi_gpu_set_spectrum_monochromatic(cmi_gpu_engine *e, double frequency) {
 }
 
 int cmi_gpu_set_spectrum_planck(cmi_gpu_engine *e, double temperature) {
-  (void)temperature;
-  if (!e)
-    return fail(CMI_GPU_EINVAL, "null engine");
-  return fail(CMI_GPU_ESTATE, "Planck spectrum not implemented yet");
+  if (!e || !(temperature > 0.))
+    return fail(CMI_GPU_EINVAL, "Planck spectrum: bad argument");
+  e->model.spectrum_type = CMI_GPU_SPECTRUM_PLANCK;
+  e->model.planck_temperature = temperature;
+  e->have_spectrum = true;
+  e->spectra_dirty = true;
+  return CMI_GPU_OK;
 }
 
 int cmi_gpu_set_cross_sections_fixed(cmi_gpu_engine *e, const double *sigma) {
@@ -423,6 +618,7 @@ int cmi_gpu_set_cross_sections_fixed(cmi_gpu_engine *e, const double *sigma) {
   for (int i = 0; i < CMI_NION; ++i)
     e->model.xsec_fixed[i] = sigma[i];
   e->have_xsec = true;
+  e->spectra_dirty = true;
   update_full_flag(e);
   return CMI_GPU_OK;
 }
@@ -432,6 +628,7 @@ int cmi_gpu_set_cross_sections_verner(cmi_gpu_engine *e) {
     return fail(CMI_GPU_EINVAL, "null engine");
   e->model.xsec_verner = 1;
   e->have_xsec = true;
+  e->spectra_dirty = true;
   update_full_flag(e);
   return CMI_GPU_OK;
 }
@@ -467,9 +664,12 @@ int cmi_gpu_set_reemission(cmi_gpu_engine *e, int32_t type,
                            double fixed_probability, double fixed_frequency) {
   if (!e)
     return fail(CMI_GPU_EINVAL, "null engine");
-  if (type != CMI_GPU_REEMIT_NONE)
-    return fail(CMI_GPU_ESTATE, "diffuse re-emission not implemented yet");
+  if (type != CMI_GPU_REEMIT_NONE && type != CMI_GPU_REEMIT_PHYSICAL &&
+      type != CMI_GPU_REEMIT_FIXED)
+    return fail(CMI_GPU_EINVAL,
+                "Unknown DiffuseReemissionHandler type: %d", type);
   e->model.reemit_type = type;
+  e->spectra_dirty = true;
   e->model.reemit_fixed_probability = fixed_probability;
   e->model.reemit_fixed_frequency = fixed_frequency;
   return CMI_GPU_OK;
@@ -480,6 +680,14 @@ int cmi_gpu_set_temperature_params(cmi_gpu_engine *e,
   if (!e || !params)
     return fail(CMI_GPU_EINVAL, "temperature params: bad argument");
   e->tparams = *params;
+  ModelDev &m = e->model;
+  m.t_epsilon = params->epsilon_convergence;
+  m.t_max_iterations = params->maximum_number_of_iterations;
+  m.pahfac = params->pah_heating_factor;
+  m.crfac = params->cosmic_ray_heating_factor;
+  m.crlim = params->cosmic_ray_heating_limit;
+  m.crscale = params->cosmic_ray_heating_scale_length;
+  m.t_min_ionized = params->minimum_ionized_temperature;
   return CMI_GPU_OK;
 }
 
@@ -619,6 +827,11 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   if (n_packets == 0)
     return CMI_GPU_OK;
   HIP_TRY(hipSetDevice(e->device));
+  {
+    int rc = ensure_spectra(e);
+    if (rc)
+      return rc;
+  }
 
   const bool heat = e->config.track_heating != 0;
   const bool reemit = e->model.reemit_type != CMI_GPU_REEMIT_NONE;
@@ -765,9 +978,9 @@ int cmi_gpu_update_cells(cmi_gpu_engine *e, uint32_t loop, double totweight) {
   if (!(totweight > 0.))
     return fail(CMI_GPU_EINVAL, "update_cells: totweight must be positive");
   HIP_TRY(hipSetDevice(e->device));
-  if (e->tparams.do_temperature_calculation &&
-      loop > (uint32_t)e->tparams.minimum_number_of_iterations)
-    return fail(CMI_GPU_ESTATE, "temperature calculation not implemented yet");
+  const bool solve_temperature =
+      e->tparams.do_temperature_calculation &&
+      loop > (uint32_t)e->tparams.minimum_number_of_iterations;
 
   UpdateArgs a;
   a.grid = e->grid;
@@ -786,7 +999,9 @@ int cmi_gpu_update_cells(cmi_gpu_engine *e, uint32_t loop, double totweight) {
   HIP_TRY(hipEventCreate(&ev.stop));
   HIP_TRY(hipEventRecord(ev.start, e->stream));
   const int blocks = grid_blocks(e, e->ncell, 8);
-  if (e->full_ions)
+  if (solve_temperature)
+    temperature_kernel<<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
+  else if (e->full_ions)
     ionization_kernel<true><<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
   else
     ionization_kernel<false><<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
@@ -807,6 +1022,11 @@ int cmi_gpu_emit_packets(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   if (n == 0)
     return CMI_GPU_OK;
   HIP_TRY(hipSetDevice(e->device));
+  {
+    int rc = ensure_spectra(e);
+    if (rc)
+      return rc;
+  }
   double *d = nullptr;
   const size_t per = 3 + 3 + 1 + CMI_NION + 1;
   HIP_TRY(hipMalloc(&d, sizeof(double) * per * n));
@@ -904,6 +1124,86 @@ int cmi_gpu_trace_packets(cmi_gpu_engine *e, uint64_t n,
     err = hipMemcpy(out_position, dfinal, sizeof(double) * 3 * n,
                     hipMemcpyDeviceToHost);
   (void)hipFree(buf);
+  HIP_TRY(err);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_sample_spectrum(cmi_gpu_engine *e, int32_t kind,
+                            double temperature, uint32_t seed, uint64_t n,
+                            double *frequencies) {
+  if (!e || !frequencies || kind < 0 || kind > 3)
+    return fail(CMI_GPU_EINVAL, "sample_spectrum: bad argument");
+  if (!e->have_xsec)
+    return fail(CMI_GPU_ESTATE, "sample_spectrum: cross sections not set");
+  if (n == 0)
+    return CMI_GPU_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  /* force the tables even if no sampled spectrum is configured */
+  const int32_t saved = e->model.reemit_type;
+  e->model.reemit_type = CMI_GPU_REEMIT_PHYSICAL;
+  int rc = ensure_spectra(e);
+  e->model.reemit_type = saved;
+  if (rc)
+    return rc;
+  if (kind == 0 && e->model.spectrum_type != CMI_GPU_SPECTRUM_PLANCK)
+    return fail(CMI_GPU_ESTATE, "sample_spectrum: no Planck spectrum set");
+  double *d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(double) * n));
+  spectrum_probe_kernel<<<(unsigned)((n + 255) / 256), 256, 0, e->stream>>>(
+      e->model, kind, temperature, seed, n, d);
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess)
+    err = hipStreamSynchronize(e->stream);
+  if (err == hipSuccess)
+    err = hipMemcpy(frequencies, d, sizeof(double) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(err);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_thermal_probe(cmi_gpu_engine *e, int64_t n, int32_t solve,
+                          const double *J, const double *heating,
+                          const double *temperature,
+                          const double *number_density, double *out_fractions,
+                          double *out_temperature, double *out_pair) {
+  if (!e || n <= 0 || !J || !heating || !temperature || !number_density ||
+      !out_fractions || !out_temperature || !out_pair)
+    return fail(CMI_GPU_EINVAL, "thermal_probe: bad argument");
+  if (!e->have_recomb)
+    return fail(CMI_GPU_ESTATE, "thermal_probe: recombination rates not set");
+  HIP_TRY(hipSetDevice(e->device));
+  double *d = nullptr;
+  const size_t in_count = (size_t)n * (CMI_NION + 2 + 1 + 1);
+  const size_t out_count = (size_t)n * (CMI_NION + 1 + 2);
+  HIP_TRY(hipMalloc(&d, sizeof(double) * (in_count + out_count)));
+  double *dJ = d, *dh = dJ + CMI_NION * n, *dT = dh + 2 * n, *dn = dT + n,
+         *dx = dn + n, *dTo = dx + CMI_NION * n, *dp = dTo + n;
+  hipError_t err =
+      hipMemcpy(dJ, J, sizeof(double) * CMI_NION * n, hipMemcpyHostToDevice);
+  if (err == hipSuccess)
+    err = hipMemcpy(dh, heating, sizeof(double) * 2 * n, hipMemcpyHostToDevice);
+  if (err == hipSuccess)
+    err = hipMemcpy(dT, temperature, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (err == hipSuccess)
+    err = hipMemcpy(dn, number_density, sizeof(double) * n,
+                    hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    thermal_probe_kernel<<<(unsigned)((n + 63) / 64), 64, 0, e->stream>>>(
+        e->model, n, solve, dJ, dh, dT, dn, dx, dTo, dp);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess)
+    err = hipStreamSynchronize(e->stream);
+  if (err == hipSuccess)
+    err = hipMemcpy(out_fractions, dx, sizeof(double) * CMI_NION * n,
+                    hipMemcpyDeviceToHost);
+  if (err == hipSuccess)
+    err = hipMemcpy(out_temperature, dTo, sizeof(double) * n,
+                    hipMemcpyDeviceToHost);
+  if (err == hipSuccess)
+    err = hipMemcpy(out_pair, dp, sizeof(double) * 2 * n,
+                    hipMemcpyDeviceToHost);
+  (void)hipFree(d);
   HIP_TRY(err);
   return CMI_GPU_OK;
 }

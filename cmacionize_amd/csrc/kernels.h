@@ -6,6 +6,7 @@
 
 #include "device_transport.h"
 #include "device_reemit.h"
+#include "device_thermal.h"
 
 #define CMI_BLOCK 256
 /* idle lanes of a wave are refilled with new packets once this many of them
@@ -356,6 +357,98 @@ __global__ void __launch_bounds__(CMI_BLOCK)
                              ? make_double2(ntot * x[ION_H_n], ntot * x[ION_He_n])
                              : make_double2(-1., 0.);
   }
+}
+
+/* TemperatureCalculator::calculate_temperature over the grid, temperature
+ * branch (src/TemperatureCalculator.cpp:944-964 -> :567-931): one cell per
+ * lane. fp64-ALU / transcendental bound (up to 100 x 3 balance evaluations,
+ * each with ten 5x5 level-population solves). */
+__global__ void __launch_bounds__(CMI_BLOCK)
+    temperature_kernel(const UpdateArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       c < a.grid.ncell_total; c += stride) {
+    const double ntot = a.cells.number_density[c];
+    double T = a.cells.temperature[c];
+    double J[CMI_NION], heating[2], x[CMI_NION];
+#pragma unroll
+    for (int i = 0; i < CMI_NION; ++i) {
+      J[i] = a.cells.acc[i][c];
+      x[i] = a.cells.x[i][c];
+    }
+    heating[0] = a.cells.acc[CMI_NION][c];
+    heating[1] = a.cells.acc[CMI_NION + 1][c];
+    /* z of the cell midpoint, src/CartesianDensityGrid.hpp:85-89 */
+    const int64_t iz = c % a.grid.ncell[2];
+    const double zmid = (a.grid.anchor[2] + a.grid.cellside[2] * iz) +
+                        0.5 * a.grid.cellside[2];
+    temperature_cell(a.model, a.jfac, a.hfac, ntot, zmid, T, J, heating, x);
+    a.cells.temperature[c] = T;
+#pragma unroll
+    for (int i = 0; i < CMI_NION; ++i)
+      a.cells.x[i][c] = x[i];
+    a.cells.acc[CMI_NION][c] = heating[0];
+    a.cells.acc[CMI_NION + 1][c] = heating[1];
+    a.cells.opacity[c] = (ntot > 0.)
+                             ? make_double2(ntot * x[ION_H_n], ntot * x[ION_He_n])
+                             : make_double2(-1., 0.);
+  }
+}
+
+/* probe: one balance evaluation / one temperature solve per input row */
+__global__ void thermal_probe_kernel(const ModelDev model, int64_t n,
+                                     int32_t solve, const double *J,
+                                     const double *heating, const double *T_in,
+                                     const double *ntot, double *x_out,
+                                     double *T_out, double *gain_loss) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  double j[CMI_NION], h[2], x[CMI_NION];
+  for (int k = 0; k < CMI_NION; ++k) {
+    j[k] = J[CMI_NION * i + k];
+    x[k] = 0.;
+  }
+  h[0] = heating[2 * i];
+  h[1] = heating[2 * i + 1];
+  double T = T_in[i];
+  if (solve) {
+    temperature_cell(model, 1., 1., ntot[i], 0.5, T, j, h, x);
+    gain_loss[2 * i] = h[0];
+    gain_loss[2 * i + 1] = h[1];
+  } else {
+    double h0, he0, gain, loss;
+    cooling_and_heating_balance(model, h0, he0, gain, loss, T, ntot[i], 0.5, j,
+                                h, x);
+    x[ION_H_n] = h0;
+    x[ION_He_n] = he0;
+    gain_loss[2 * i] = gain;
+    gain_loss[2 * i + 1] = loss;
+  }
+  T_out[i] = T;
+  for (int k = 0; k < CMI_NION; ++k)
+    x_out[CMI_NION * i + k] = x[k];
+}
+
+/* probe: n samples of one of the sampled spectra */
+__global__ void spectrum_probe_kernel(const ModelDev model, int32_t kind,
+                                      double temperature, uint32_t seed,
+                                      uint64_t n, double *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  PacketRng rng;
+  rng.init(seed, 0u, i);
+  double nu;
+  if (kind == 0)
+    nu = sample_planck(model.spectra, rng);
+  else if (kind == 1)
+    nu = sample_lyman_continuum(model.spectra, 0, temperature, rng);
+  else if (kind == 2)
+    nu = sample_lyman_continuum(model.spectra, 1, temperature, rng);
+  else
+    nu = sample_he_two_photon(model.spectra, rng);
+  out[i] = nu;
 }
 
 /* build the transport records from n, x_H, x_He (after an upload) */

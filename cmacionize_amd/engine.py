@@ -64,7 +64,8 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_field_device_pointer", "cmi_gpu_reset_grid", "cmi_gpu_shoot",
     "cmi_gpu_get_counters", "cmi_gpu_update_cells", "cmi_gpu_emit_packets",
     "cmi_gpu_trace_packets", "cmi_gpu_get_timing", "cmi_gpu_set_tuning",
-    "cmi_gpu_get_atomic_count",
+    "cmi_gpu_get_atomic_count", "cmi_gpu_sample_spectrum",
+    "cmi_gpu_thermal_probe",
 ]
 
 _lib = None
@@ -121,6 +122,10 @@ def load_library():
                                      _dp, C.POINTER(C.c_uint64)]
     L.cmi_gpu_set_tuning.argtypes = [vp, C.c_char_p, C.c_int64]
     L.cmi_gpu_get_atomic_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.cmi_gpu_sample_spectrum.argtypes = [vp, C.c_int32, C.c_double,
+                                          C.c_uint32, C.c_uint64, _dp]
+    L.cmi_gpu_thermal_probe.argtypes = [vp, C.c_int64, C.c_int32, _dp, _dp,
+                                        _dp, _dp, _dp, _dp, _dp]
     _lib = L
     return L
 
@@ -306,6 +311,26 @@ class GpuEngine:
             nsteps.ctypes.data_as(C.POINTER(C.c_int32)),
             last.ctypes.data_as(C.POINTER(C.c_int64)), _p(final)))
         return cells, ds, nsteps, last, final
+
+    def sample_spectrum(self, kind, temperature, seed, n):
+        out = np.empty(n)
+        self._check(self._lib.cmi_gpu_sample_spectrum(
+            self._h, kind, temperature, seed, n, _p(out)))
+        return out
+
+    def thermal_probe(self, solve, J, heating, temperature, number_density):
+        J = _f64(J).reshape(-1, NION)
+        n = J.shape[0]
+        heating = _f64(heating).reshape(n, 2)
+        T = _f64(temperature).reshape(n)
+        dens = _f64(number_density).reshape(n)
+        x = np.empty((n, NION))
+        Tout = np.empty(n)
+        pair = np.empty((n, 2))
+        self._check(self._lib.cmi_gpu_thermal_probe(
+            self._h, n, int(solve), _p(J), _p(heating), _p(T), _p(dens),
+            _p(x), _p(Tout), _p(pair)))
+        return x, Tout, pair
 
     def get_timing(self, reset=True):
         s = C.c_double()

@@ -261,6 +261,30 @@ int cmi_gpu_trace_packets(cmi_gpu_engine *engine, uint64_t n,
                           int32_t *out_nsteps, int64_t *out_last_cell,
                           double *out_position);
 
+/* Parity probe of the spectrum samplers (get_random_frequency of
+ * PlanckPhotonSourceSpectrum kind 0, HydrogenLymanContinuumSpectrum 1,
+ * HeliumLymanContinuumSpectrum 2, HeliumTwoPhotonContinuumSpectrum 3): n
+ * frequencies (Hz) at `temperature`, sample i from packet stream i of `seed`.
+ * Synchronous. */
+int cmi_gpu_sample_spectrum(cmi_gpu_engine *engine, int32_t kind,
+                            double temperature, uint32_t seed, uint64_t n,
+                            double *frequencies);
+
+/* Parity probe of the thermal balance for n independent cells given as rows:
+ * J [n][14] and heating [n][2] already normalised (jfac = hfac = 1),
+ * temperature [n], number_density [n].
+ * solve = 0: one TemperatureCalculator::compute_cooling_and_heating_balance
+ *   (src/TemperatureCalculator.cpp:207-501) at the given temperature;
+ *   out_pair [n][2] = {gain, loss}, out_fractions [n][14] = {h0, he0, metals};
+ * solve = 1: TemperatureCalculator::calculate_temperature (:567-931);
+ *   out_temperature [n], out_fractions [n][14], out_pair = heating terms.
+ * Synchronous. */
+int cmi_gpu_thermal_probe(cmi_gpu_engine *engine, int64_t n, int32_t solve,
+                          const double *J, const double *heating,
+                          const double *temperature,
+                          const double *number_density, double *out_fractions,
+                          double *out_temperature, double *out_pair);
+
 /* Device time (HIP events on the engine's stream) spent in the transport and
  * cell-update kernels since the last call with reset != 0. Synchronous. */
 int cmi_gpu_get_timing(cmi_gpu_engine *engine, int32_t reset,

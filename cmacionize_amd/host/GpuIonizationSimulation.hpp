@@ -1,0 +1,519 @@
+/*
+ * GpuIonizationSimulation.hpp - the driver of the path, shaped like the
+ * reference's IonizationSimulation (src/IonizationSimulation.hpp public
+ * section; src/IonizationSimulation.cpp:101-231 ctor, :239-325 initialize,
+ * :334-680 run): same constructor / initialize(DensityFunction*) /
+ * run(DensityGridWriter*) trio with the same two injection hooks, same
+ * parameter keys and defaults, same log lines for the timers - but the
+ * iteration body runs on the MI355X engine through the C ABI.
+ */
+#ifndef CMI_HOST_GPUIONIZATIONSIMULATION_HPP
+#define CMI_HOST_GPUIONIZATIONSIMULATION_HPP
+
+#include "Plugins.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <iomanip>
+#include <iostream>
+#include <memory>
+#include <sstream>
+
+namespace cmi {
+
+/* Host mirror of the grid for writers: the iterator surface of DensityGrid a
+ * DensityGridWriter uses (src/DensityGrid.hpp:298-418,707-714,
+ * src/CartesianDensityGrid.hpp:85-100) over SoA arrays downloaded from the
+ * engine. */
+class DensityGrid {
+public:
+  struct IonizationVariables {
+    const DensityGrid *grid;
+    int64_t index;
+    double get_number_density() const { return grid->_number_density[index]; }
+    double get_temperature() const { return grid->_temperature[index]; }
+    double get_ionic_fraction(int ion) const {
+      return grid->_ionic_fraction[ion][index];
+    }
+    double get_mean_intensity(int ion) const {
+      return grid->_mean_intensity[ion][index];
+    }
+    double get_heating(int term) const { return grid->_heating[term][index]; }
+  };
+  class iterator : public Cell {
+    const DensityGrid *_grid;
+    int64_t _index;
+
+  public:
+    iterator(const DensityGrid *grid, int64_t index)
+        : _grid(grid), _index(index) {}
+    CoordinateVector get_cell_midpoint() const override {
+      return _grid->get_cell_midpoint(_index);
+    }
+    double get_volume() const override { return _grid->get_cell_volume(); }
+    IonizationVariables get_ionization_variables() const {
+      return IonizationVariables{_grid, _index};
+    }
+    int64_t get_index() const { return _index; }
+    iterator &operator++() {
+      ++_index;
+      return *this;
+    }
+    bool operator!=(const iterator &o) const { return _index != o._index; }
+    bool operator==(const iterator &o) const { return _index == o._index; }
+  };
+
+  DensityGrid(const SimulationBox &box, const std::array<long long, 3> &ncell)
+      : _box(box), _ncell(ncell) {
+    /* CartesianDensityGrid ctor, src/CartesianDensityGrid.cpp:72-79 */
+    for (int a = 0; a < 3; ++a)
+      _cellside[a] = box.sides[a] / ncell[a];
+    const int64_t n = get_number_of_cells();
+    _number_density.assign(n, 0.);
+    _temperature.assign(n, 0.);
+    for (auto &f : _ionic_fraction)
+      f.assign(n, 0.);
+    for (auto &f : _mean_intensity)
+      f.assign(n, 0.);
+    for (auto &f : _heating)
+      f.assign(n, 0.);
+  }
+  int64_t get_number_of_cells() const {
+    return (int64_t)_ncell[0] * _ncell[1] * _ncell[2];
+  }
+  CoordinateVector get_cell_midpoint(int64_t index) const {
+    /* get_indices + get_cell + midpoint, src/CartesianDensityGrid.hpp:85-89 */
+    const int64_t ix = index / (_ncell[1] * _ncell[2]);
+    const int64_t rest = index - ix * _ncell[1] * _ncell[2];
+    const int64_t iy = rest / _ncell[2];
+    const int64_t iz = rest - iy * _ncell[2];
+    const int64_t idx[3] = {ix, iy, iz};
+    CoordinateVector m;
+    for (int a = 0; a < 3; ++a)
+      m[a] = (_box.anchor[a] + _cellside[a] * idx[a]) + 0.5 * _cellside[a];
+    return m;
+  }
+  double get_cell_volume() const {
+    return _cellside[0] * _cellside[1] * _cellside[2];
+  }
+  iterator begin() const { return iterator(this, 0); }
+  iterator end() const { return iterator(this, get_number_of_cells()); }
+
+  const SimulationBox &box() const { return _box; }
+  const std::array<long long, 3> &ncell() const { return _ncell; }
+
+  /* SoA storage, filled by the driver */
+  std::vector<double> _number_density, _temperature;
+  std::array<std::vector<double>, NUMBER_OF_IONNAMES> _ionic_fraction,
+      _mean_intensity;
+  std::array<std::vector<double>, 2> _heating;
+
+private:
+  SimulationBox _box;
+  std::array<long long, 3> _ncell;
+  double _cellside[3];
+};
+
+/* src/DensityGridWriter.hpp:96-124 (the DensityGrid overload) */
+class DensityGridWriter {
+protected:
+  std::string _output_folder;
+
+public:
+  explicit DensityGridWriter(const std::string &output_folder)
+      : _output_folder(output_folder) {}
+  virtual ~DensityGridWriter() {}
+  virtual void write(DensityGrid &grid, uint_fast32_t iteration,
+                     ParameterFile &params, double time = 0.) = 0;
+};
+
+/* Utilities::compose_filename, src/Utilities.hpp:756-775 */
+inline std::string compose_filename(const std::string &folder,
+                                    const std::string &prefix,
+                                    const std::string &extension,
+                                    uint_fast32_t counter,
+                                    uint_fast32_t padding) {
+  std::stringstream name;
+  if (!folder.empty())
+    name << folder << "/";
+  name << prefix << std::setfill('0') << std::setw((int)padding) << counter
+       << "." << extension;
+  return name.str();
+}
+
+/* src/AsciiFileDensityGridWriter.cpp:36-84: x y z n volume x_H per cell */
+class AsciiFileDensityGridWriter : public DensityGridWriter {
+  std::string _prefix;
+
+public:
+  AsciiFileDensityGridWriter(const std::string &prefix,
+                             const std::string &output_folder)
+      : DensityGridWriter(output_folder), _prefix(prefix) {}
+  AsciiFileDensityGridWriter(const std::string &output_folder,
+                             ParameterFile &params)
+      : AsciiFileDensityGridWriter(
+            params.get_string("DensityGridWriter:prefix", "snapshot"),
+            output_folder) {}
+  void write(DensityGrid &grid, uint_fast32_t iteration, ParameterFile &,
+             double = 0.) override {
+    const std::string filename =
+        compose_filename(_output_folder, _prefix, "txt", iteration, 3);
+    std::ofstream file(filename);
+    file << "#x (m)\ty (m)\tz (m)\tn (m^-3)\tvolume (m^3)\tneutral H "
+            "fraction\n";
+    for (auto it = grid.begin(); it != grid.end(); ++it) {
+      const CoordinateVector x = it.get_cell_midpoint();
+      const double n = it.get_ionization_variables().get_number_density();
+      const double frac =
+          it.get_ionization_variables().get_ionic_fraction(ION_H_n);
+      file << x.x() << "\t" << x.y() << "\t" << x.z() << "\t" << n << "\t"
+           << it.get_volume() << "\t" << frac << "\n";
+    }
+  }
+};
+
+/* Raw SoA dump of every field (n, T, 14 fractions) as fp64, for checkers;
+ * the role the Gadget/HDF5 writer plays in the reference (no HDF5 in this
+ * image). Layout: int64 ncell[3], then 16 arrays of ncell doubles. */
+class BinaryDensityGridWriter : public DensityGridWriter {
+  std::string _prefix;
+
+public:
+  BinaryDensityGridWriter(const std::string &output_folder,
+                          ParameterFile &params)
+      : DensityGridWriter(output_folder),
+        _prefix(params.get_string("DensityGridWriter:prefix", "snapshot")) {}
+  void write(DensityGrid &grid, uint_fast32_t iteration, ParameterFile &,
+             double = 0.) override {
+    const std::string filename =
+        compose_filename(_output_folder, _prefix, "bin", iteration, 3);
+    std::ofstream file(filename, std::ios::binary);
+    const int64_t nc[3] = {grid.ncell()[0], grid.ncell()[1], grid.ncell()[2]};
+    file.write((const char *)nc, sizeof nc);
+    const size_t bytes = sizeof(double) * grid.get_number_of_cells();
+    file.write((const char *)grid._number_density.data(), bytes);
+    file.write((const char *)grid._temperature.data(), bytes);
+    for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+      file.write((const char *)grid._ionic_fraction[ion].data(), bytes);
+  }
+};
+
+/* src/DensityGridWriterFactory.hpp:100-103. The reference's default, Gadget,
+ * needs HDF5, which this image does not have (listed as "next" in SURVEY 8f). */
+inline DensityGridWriter *generate_writer(const std::string &output_folder,
+                                          ParameterFile &params) {
+  const std::string type = params.get_string("DensityGridWriter:type", "Gadget");
+  if (type == "AsciiFile")
+    return new AsciiFileDensityGridWriter(output_folder, params);
+  if (type == "Binary")
+    return new BinaryDensityGridWriter(output_folder, params);
+  if (type == "Gadget")
+    throw ParameterError(
+        "DensityGridWriter type Gadget needs HDF5, which this build does not "
+        "have; use AsciiFile or Binary");
+  throw ParameterError("Unknown DensityGridWriter type: \"" + type + "\"");
+}
+
+class GpuIonizationSimulation {
+  const bool _every_iteration_output;
+  const bool _output_statistics;
+  const bool _verbose;
+  ParameterFile _parameter_file;
+  uint_fast32_t _number_of_iterations;
+  uint_fast64_t _number_of_photons;
+  uint_fast64_t _number_of_photons_init;
+  int32_t _random_seed;
+
+  Abundances _abundances;
+  std::unique_ptr<CrossSections> _cross_sections;
+  std::unique_ptr<RecombinationRates> _recombination_rates;
+  std::unique_ptr<DensityFunction> _density_function;
+  SimulationBox _simulation_box;
+  std::array<long long, 3> _ncell;
+  std::unique_ptr<PhotonSourceDistribution> _photon_source_distribution;
+  std::unique_ptr<PhotonSourceSpectrum> _photon_source_spectrum;
+  DiffuseReemission _reemission;
+  cmi_gpu_temperature_params _temperature_params;
+  std::unique_ptr<DensityGridWriter> _density_grid_writer;
+  std::unique_ptr<DensityGrid> _density_grid;
+
+  cmi_gpu_engine *_engine = nullptr;
+  double _shoot_seconds = 0., _update_seconds = 0.;
+  double _last_totweight = 0.;
+  double _last_typecount[4] = {0., 0., 0., 0.};
+
+  void check(int rc, const char *what) const {
+    if (rc != CMI_GPU_OK)
+      throw std::runtime_error(std::string(what) + ": " + cmi_gpu_last_error());
+  }
+  void status(const std::string &message) const {
+    if (_verbose)
+      std::cout << message << std::endl;
+  }
+  void download_state() {
+    DensityGrid &g = *_density_grid;
+    check(cmi_gpu_download_field(_engine, CMI_GPU_FIELD_NUMBER_DENSITY,
+                                 g._number_density.data()),
+          "download");
+    check(cmi_gpu_download_field(_engine, CMI_GPU_FIELD_TEMPERATURE,
+                                 g._temperature.data()),
+          "download");
+    for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+      check(cmi_gpu_download_field(_engine, CMI_GPU_FIELD_IONIC_FRACTION + ion,
+                                   g._ionic_fraction[ion].data()),
+            "download");
+  }
+
+public:
+  /* IonizationSimulation ctor, src/IonizationSimulation.cpp:101-231.
+   * num_thread is accepted for command-line compatibility; the device id
+   * replaces it as the degree of freedom. */
+  GpuIonizationSimulation(const bool write_output,
+                          const bool every_iteration_output,
+                          const bool output_statistics,
+                          const int_fast32_t num_thread,
+                          const std::string &parameterfile,
+                          const int device = 0, const bool verbose = true,
+                          const bool create_engine = true)
+      : _every_iteration_output(every_iteration_output),
+        _output_statistics(output_statistics), _verbose(verbose),
+        _parameter_file(parameterfile),
+        _number_of_iterations((uint_fast32_t)_parameter_file.get_integer(
+            "IonizationSimulation:number of iterations", 10)),
+        _number_of_photons((uint_fast64_t)_parameter_file.get_integer(
+            "IonizationSimulation:number of photons", 100000)),
+        _number_of_photons_init((uint_fast64_t)_parameter_file.get_integer(
+            "IonizationSimulation:number of photons first loop",
+            (long long)_number_of_photons)),
+        _random_seed(0), _abundances(_parameter_file),
+        _cross_sections(generate_cross_sections(_parameter_file)),
+        _recombination_rates(generate_recombination_rates(_parameter_file)),
+        _density_function(generate_density_function(_parameter_file)),
+        _simulation_box(_parameter_file),
+        _ncell(_parameter_file.get_integer_vector("DensityGrid:number of cells",
+                                                  {64, 64, 64})),
+        _photon_source_distribution(
+            generate_photon_source_distribution(_parameter_file)),
+        _photon_source_spectrum(generate_photon_source_spectrum(
+            "PhotonSourceSpectrum", _parameter_file)),
+        _reemission(_parameter_file) {
+    (void)num_thread;
+    const std::string grid_type =
+        _parameter_file.get_string("DensityGrid:type", "Cartesian");
+    if (grid_type != "Cartesian")
+      throw ParameterError("DensityGrid type \"" + grid_type +
+                           "\" is not on this path (Cartesian only)");
+    const std::string continuous =
+        _parameter_file.get_string("ContinuousPhotonSource:type", "None");
+    if (continuous != "None")
+      throw ParameterError("ContinuousPhotonSource type \"" + continuous +
+                           "\" is not on this path");
+    if (_photon_source_distribution && !_photon_source_spectrum)
+      throw ParameterError(
+          "No spectrum provided for the discrete photon sources!");
+
+    const std::string output_folder = _parameter_file.get_string(
+        "IonizationSimulation:output folder", ".");
+    if (write_output)
+      _density_grid_writer.reset(generate_writer(output_folder, _parameter_file));
+
+    /* TemperatureCalculator parameters, src/TemperatureCalculator.cpp:133-160 */
+    cmi_gpu_temperature_params &t = _temperature_params;
+    t.do_temperature_calculation = _parameter_file.get_bool(
+        "TemperatureCalculator:do temperature calculation", false);
+    t.minimum_number_of_iterations = (int32_t)_parameter_file.get_integer(
+        "TemperatureCalculator:minimum number of iterations", 3);
+    t.epsilon_convergence = _parameter_file.get_double(
+        "TemperatureCalculator:epsilon convergence", 1.e-3);
+    t.maximum_number_of_iterations = (int32_t)_parameter_file.get_integer(
+        "TemperatureCalculator:maximum number of iterations", 100);
+    t.pah_heating_factor =
+        _parameter_file.get_double("TemperatureCalculator:PAH heating factor", 0.);
+    t.cosmic_ray_heating_factor = _parameter_file.get_double(
+        "TemperatureCalculator:cosmic ray heating factor", 0.);
+    t.cosmic_ray_heating_limit = _parameter_file.get_double(
+        "TemperatureCalculator:cosmic ray heating limit", 0.75);
+    t.cosmic_ray_heating_scale_length = _parameter_file.get_physical_value(
+        QUANTITY_LENGTH, "TemperatureCalculator:cosmic ray heating scale length",
+        "1.33333 kpc");
+    t.minimum_ionized_temperature = _parameter_file.get_physical_value(
+        QUANTITY_TEMPERATURE, "TemperatureCalculator:minimum ionized temperature",
+        "4000. K");
+
+    _random_seed =
+        (int32_t)_parameter_file.get_integer("IonizationSimulation:random seed", 42);
+    if (_parameter_file.get_bool("IonizationSimulation:enable trackers", false))
+      throw ParameterError("Trackers are not on this path");
+
+    /* all parameters read: dump them (src/IonizationSimulation.cpp:218-226) */
+    if (write_output) {
+      std::ofstream pfile(parameterfile + ".used-values");
+      _parameter_file.print_contents(pfile);
+      status("Wrote used parameters to " + parameterfile + ".used-values.");
+    }
+
+    _density_grid.reset(new DensityGrid(_simulation_box, _ncell));
+
+    if (create_engine) {
+      cmi_gpu_config config;
+      for (int a = 0; a < 3; ++a) {
+        config.anchor[a] = _simulation_box.anchor[a];
+        config.sides[a] = _simulation_box.sides[a];
+        config.ncell[a] = (int32_t)_ncell[a];
+        config.periodic[a] = _simulation_box.periodicity[a] ? 1 : 0;
+      }
+      config.device = device;
+      config.track_heating = t.do_temperature_calculation;
+      config.stream = nullptr;
+      config.external_accumulators = nullptr;
+      check(cmi_gpu_create(&config, &_engine), "cmi_gpu_create");
+      if (_photon_source_distribution)
+        check(_photon_source_distribution->lower(_engine), "sources");
+      check(_photon_source_spectrum->lower(_engine), "spectrum");
+      check(_cross_sections->lower(_engine), "cross sections");
+      check(_recombination_rates->lower(_engine), "recombination rates");
+      check(_abundances.lower(_engine), "abundances");
+      check(_reemission.lower(_engine), "reemission");
+      check(cmi_gpu_set_temperature_params(_engine, &_temperature_params),
+            "temperature parameters");
+    }
+  }
+
+  ~GpuIonizationSimulation() {
+    if (_engine)
+      cmi_gpu_destroy(_engine);
+  }
+
+  ParameterFile &parameter_file() { return _parameter_file; }
+  DensityGrid &grid() { return *_density_grid; }
+  uint_fast32_t number_of_iterations() const { return _number_of_iterations; }
+  uint_fast64_t number_of_photons() const { return _number_of_photons; }
+  const cmi_gpu_temperature_params &temperature_params() const {
+    return _temperature_params;
+  }
+  const DiffuseReemission &reemission() const { return _reemission; }
+  const Abundances &abundances() const { return _abundances; }
+  PhotonSourceDistribution *sources() { return _photon_source_distribution.get(); }
+  PhotonSourceSpectrum *spectrum() { return _photon_source_spectrum.get(); }
+  CrossSections *cross_sections() { return _cross_sections.get(); }
+  RecombinationRates *recombination_rates() { return _recombination_rates.get(); }
+  int32_t random_seed() const { return _random_seed; }
+
+  /* IonizationSimulation::initialize, src/IonizationSimulation.cpp:239-325:
+   * evaluate the DensityFunction on every cell (host), upload SoA arrays */
+  void initialize(DensityFunction *density_function = nullptr) {
+    if (density_function == nullptr)
+      density_function = _density_function.get();
+    status("Initializing DensityFunction...");
+    density_function->initialize();
+    status("Done.");
+    DensityGrid &g = *_density_grid;
+    const int64_t n = g.get_number_of_cells();
+    std::vector<double> x((size_t)NUMBER_OF_IONNAMES * n);
+    /* DensityGridInitializationFunction, src/DensityGrid.hpp:775-790 */
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      DensityGrid::iterator cell(&g, i);
+      const DensityValues vals = (*density_function)(cell);
+      g._number_density[i] = vals.get_number_density();
+      g._temperature[i] = vals.get_temperature();
+      for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion) {
+        g._ionic_fraction[ion][i] = vals.get_ionic_fraction(ion);
+        x[(size_t)ion * n + i] = vals.get_ionic_fraction(ion);
+      }
+    }
+    density_function->free();
+    if (_engine)
+      check(cmi_gpu_upload_cells(_engine, g._number_density.data(),
+                                 g._temperature.data(), x.data()),
+            "cmi_gpu_upload_cells");
+  }
+
+  /* IonizationSimulation::run, src/IonizationSimulation.cpp:334-680 */
+  void run(DensityGridWriter *density_grid_writer = nullptr) {
+    if (!_engine)
+      throw std::runtime_error("run() needs an engine (not a dry run)");
+    if (_density_grid_writer)
+      _density_grid_writer->write(*_density_grid, 0, _parameter_file);
+
+    uint_fast32_t loop = 0;
+    while (loop < _number_of_iterations) {
+      status("Starting loop " + std::to_string(loop) + ".");
+      uint_fast64_t lnumphoton = _number_of_photons;
+      if (loop == 0)
+        lnumphoton = _number_of_photons_init;
+
+      check(cmi_gpu_reset_grid(_engine), "reset_grid");
+      status("Start shooting " + std::to_string(lnumphoton) + " photons...");
+      auto t0 = std::chrono::steady_clock::now();
+      check(cmi_gpu_shoot(_engine, (uint32_t)_random_seed, loop, 0, lnumphoton),
+            "shoot");
+      double totweight = 0.;
+      double typecount[4] = {0., 0., 0., 0.};
+      check(cmi_gpu_get_counters(_engine, &totweight, typecount, nullptr),
+            "get_counters");
+      auto t1 = std::chrono::steady_clock::now();
+      _shoot_seconds += std::chrono::duration<double>(t1 - t0).count();
+      _last_totweight = totweight;
+      for (int i = 0; i < 4; ++i)
+        _last_typecount[i] = typecount[i];
+      status("Done shooting photons.");
+      if (_output_statistics) {
+        /* src/IonizationSimulation.cpp:418-447 */
+        std::ostringstream s;
+        s << 100. * typecount[3] / totweight
+          << "% of photons were reemitted as non-ionizing photons.\n"
+          << 100. * (typecount[1] + typecount[2]) / totweight
+          << "% of photons were scattered.\n"
+          << "Escape fraction: "
+          << std::max(0., 100. * (totweight - typecount[3]) / totweight)
+          << "%.\n"
+          << "Diffuse HI escape fraction: " << 100. * typecount[1] / totweight
+          << "%.\n"
+          << "Diffuse HeI escape fraction: " << 100. * typecount[2] / totweight
+          << "%.";
+        status(s.str());
+      }
+
+      status("Calculating ionization state after shooting " +
+             std::to_string(lnumphoton) + " photons...");
+      t0 = std::chrono::steady_clock::now();
+      check(cmi_gpu_update_cells(_engine, loop, totweight), "update_cells");
+      check(cmi_gpu_synchronize(_engine), "synchronize");
+      t1 = std::chrono::steady_clock::now();
+      _update_seconds += std::chrono::duration<double>(t1 - t0).count();
+      status("Done calculating ionization state.");
+
+      ++loop;
+      if (_density_grid_writer && _every_iteration_output &&
+          loop < _number_of_iterations) {
+        download_state();
+        _density_grid_writer->write(*_density_grid, loop, _parameter_file);
+      }
+    }
+    if (loop == _number_of_iterations)
+      status("Maximum number of iterations (" +
+             std::to_string(_number_of_iterations) + ") reached, stopping.");
+
+    download_state();
+    if (_density_grid_writer)
+      _density_grid_writer->write(*_density_grid, _number_of_iterations,
+                                  _parameter_file);
+    if (density_grid_writer)
+      density_grid_writer->write(*_density_grid, _number_of_iterations,
+                                 _parameter_file);
+    /* the reference's own packets/s instrument,
+     * src/IonizationSimulation.cpp:667-674 */
+    std::ostringstream s;
+    s << "Total photon shooting time: " << _shoot_seconds << " s.\n"
+      << "Total cell update time: " << _update_seconds << " s.";
+    status(s.str());
+  }
+
+  double shoot_seconds() const { return _shoot_seconds; }
+  double update_seconds() const { return _update_seconds; }
+};
+
+} // namespace cmi
+
+#endif

@@ -1,0 +1,565 @@
+/*
+ * Plugins.hpp - the host-side plugin surfaces of the path, with the
+ * reference's virtual signatures, the concrete plugins the benchmark configs
+ * select, and their factories keyed on "<Block>:type".
+ *
+ * In the reference these objects are called per packet / per cell through
+ * virtual functions. Here they run on the host once, at initialisation, and
+ * are LOWERED into the flat descriptors of the C ABI (include/cmi_gpu.h):
+ * every concrete class below has a lower() that makes the matching
+ * cmi_gpu_set_* call. A third-party plugin ports by recompiling against these
+ * headers and adding its lower().
+ *
+ * Reference interfaces mirrored (signatures kept):
+ *   Cell                         src/Cell.hpp
+ *   DensityValues                src/DensityValues.hpp:36-120
+ *   DensityFunction              src/DensityFunction.hpp:35-65
+ *   PhotonSourceDistribution     src/PhotonSourceDistribution.hpp:54-80
+ *   PhotonSourceSpectrum         src/PhotonSourceSpectrum.hpp:48-56
+ *   CrossSections                src/CrossSections.hpp:49-50
+ *   RecombinationRates           src/RecombinationRates.hpp:49
+ *   AbundanceModel / Abundances  src/FixedValueAbundanceModel.hpp:44-66
+ *   DiffuseReemissionHandler     src/DiffuseReemissionHandlerFactory.hpp:94-99
+ *   SimulationBox                src/SimulationBox.hpp
+ */
+#ifndef CMI_HOST_PLUGINS_HPP
+#define CMI_HOST_PLUGINS_HPP
+
+#include "../../include/cmi_gpu.h"
+#include "ParameterFile.hpp"
+
+#include <array>
+#include <cmath>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace cmi {
+
+constexpr int NUMBER_OF_IONNAMES = 14;
+/* src/ElementNames.hpp:101-154 */
+enum IonName {
+  ION_H_n = 0, ION_He_n, ION_C_p1, ION_C_p2, ION_N_n, ION_N_p1, ION_N_p2,
+  ION_O_n, ION_O_p1, ION_Ne_n, ION_Ne_p1, ION_S_p1, ION_S_p2, ION_S_p3
+};
+/* parameter names of the ions (src/ElementNames.hpp get_ion_name) */
+inline const char *ion_name(int ion) {
+  static const char *names[NUMBER_OF_IONNAMES] = {
+      "H", "He", "C+", "C++", "N", "N+", "N++", "O", "O+", "Ne", "Ne+", "S+",
+      "S++", "S+++"};
+  return names[ion];
+}
+
+struct CoordinateVector {
+  double v[3];
+  CoordinateVector() : v{0., 0., 0.} {}
+  CoordinateVector(double x, double y, double z) : v{x, y, z} {}
+  double x() const { return v[0]; }
+  double y() const { return v[1]; }
+  double z() const { return v[2]; }
+  double operator[](int i) const { return v[i]; }
+  double &operator[](int i) { return v[i]; }
+};
+
+class Cell {
+public:
+  virtual ~Cell() {}
+  virtual CoordinateVector get_cell_midpoint() const = 0;
+  virtual double get_volume() const = 0;
+};
+
+class DensityValues {
+  double _number_density = 0.;
+  double _ionic_fraction[NUMBER_OF_IONNAMES] = {0.};
+  double _temperature = 0.;
+
+public:
+  void set_number_density(double n) { _number_density = n; }
+  void set_ionic_fraction(int ion, double x) { _ionic_fraction[ion] = x; }
+  void set_temperature(double T) { _temperature = T; }
+  double get_number_density() const { return _number_density; }
+  double get_ionic_fraction(int ion) const { return _ionic_fraction[ion]; }
+  double get_temperature() const { return _temperature; }
+};
+
+/* ------------------------------------------------------- DensityFunction */
+
+class DensityFunction {
+public:
+  virtual ~DensityFunction() {}
+  virtual void initialize() {}
+  virtual void free() {}
+  virtual DensityValues operator()(const Cell &cell) = 0;
+};
+
+/* src/HomogeneousDensityFunction.hpp:41-107 */
+class HomogeneousDensityFunction : public DensityFunction {
+  const double _density, _temperature, _neutral_fraction_H;
+
+public:
+  HomogeneousDensityFunction(double density = 1., double temperature = 8000.,
+                             double neutral_fraction_H = 1.e-6)
+      : _density(density), _temperature(temperature),
+        _neutral_fraction_H(neutral_fraction_H) {}
+  explicit HomogeneousDensityFunction(ParameterFile &params)
+      : HomogeneousDensityFunction(
+            params.get_physical_value(QUANTITY_NUMBER_DENSITY,
+                                      "DensityFunction:density", "100. cm^-3"),
+            params.get_physical_value(QUANTITY_TEMPERATURE,
+                                      "DensityFunction:temperature",
+                                      "8000. K"),
+            params.get_double("DensityFunction:neutral fraction H", 1.e-6)) {}
+  DensityValues operator()(const Cell &) override {
+    DensityValues values;
+    values.set_number_density(_density);
+    values.set_temperature(_temperature);
+    values.set_ionic_fraction(ION_H_n, _neutral_fraction_H);
+    values.set_ionic_fraction(ION_He_n, 1.e-6);
+    return values;
+  }
+};
+
+/* src/BlockSyntaxDensityFunction.hpp:45-195, src/BlockSyntaxBlock.hpp:91-105 */
+class BlockSyntaxDensityFunction : public DensityFunction {
+  struct Block {
+    std::array<double, 3> origin, sides;
+    double exponent, density, temperature, neutral_fraction_H;
+    bool is_inside(const CoordinateVector &p) const {
+      double r = 0.;
+      for (int i = 0; i < 3; ++i) {
+        const double x = 2. * std::abs(p[i] - origin[i]) / sides[i];
+        if (exponent < 10.)
+          r += std::pow(x, exponent);
+        else
+          r = std::max(r, x);
+      }
+      if (exponent < 10.)
+        r = std::pow(r, 1. / exponent);
+      return r <= 1.;
+    }
+  };
+  std::vector<Block> _blocks;
+
+  static double get_exponent(const std::string &type) {
+    if (type == "rhombus")
+      return 1.;
+    if (type == "sphere")
+      return 2.;
+    if (type == "cube")
+      return 10.;
+    throw ParameterError("Unknown block type: \"" + type + "\"!");
+  }
+
+public:
+  explicit BlockSyntaxDensityFunction(const std::string &filename) {
+    ParameterFile blockfile(filename);
+    const long long numblock = blockfile.get_integer("number of blocks", -1);
+    if (numblock < 0)
+      throw ParameterError("Parameter \"number of blocks\" not found!");
+    for (long long i = 0; i < numblock; ++i) {
+      const std::string b = "block[" + std::to_string(i) + "]:";
+      Block block;
+      block.origin = blockfile.get_physical_vector(
+          QUANTITY_LENGTH, b + "origin", "[0. m, 0. m, 0. m]");
+      block.sides = blockfile.get_physical_vector(QUANTITY_LENGTH, b + "sides",
+                                                  "[1. m, 1. m, 1. m]");
+      block.exponent = get_exponent(blockfile.get_string(b + "type", "cube"));
+      if (blockfile.has_value(b + "number density")) {
+        block.density = blockfile.get_physical_value(
+            QUANTITY_NUMBER_DENSITY, b + "number density", "0. m^-3");
+      } else {
+        block.density = blockfile.get_physical_value(
+                            QUANTITY_DENSITY, b + "density", "0. kg m^-3") /
+                        constants::proton_mass;
+      }
+      block.temperature = blockfile.get_physical_value(
+          QUANTITY_TEMPERATURE, b + "initial temperature", "0. K");
+      block.neutral_fraction_H =
+          blockfile.get_double(b + "neutral fraction H", 1.e-6);
+      if (block.density < 0.)
+        throw ParameterError("Negative density given for block " +
+                             std::to_string(i) + "!");
+      if (block.temperature < 0.)
+        throw ParameterError("Negative temperature given for block " +
+                             std::to_string(i) + "!");
+      _blocks.push_back(block);
+    }
+    std::ofstream ofile(filename + ".used-values");
+    blockfile.print_contents(ofile);
+  }
+  explicit BlockSyntaxDensityFunction(ParameterFile &params)
+      : BlockSyntaxDensityFunction(
+            params.get_filename("DensityFunction:filename")) {}
+
+  DensityValues operator()(const Cell &cell) override {
+    const CoordinateVector position = cell.get_cell_midpoint();
+    double density = -1., temperature = -1., neutral_fraction_H = -1.;
+    for (const Block &b : _blocks) {
+      if (b.is_inside(position)) {
+        density = b.density;
+        temperature = b.temperature;
+        neutral_fraction_H = b.neutral_fraction_H;
+      }
+    }
+    if (density < 0. || temperature < 0. || neutral_fraction_H < 0.)
+      throw ParameterError("No block found containing a cell midpoint!");
+    DensityValues values;
+    values.set_number_density(density);
+    values.set_temperature(temperature);
+    values.set_ionic_fraction(ION_H_n, neutral_fraction_H);
+    values.set_ionic_fraction(ION_He_n, 1.e-6);
+    return values;
+  }
+};
+
+/* src/DensityFunctionFactory.hpp:138-172 (types on this path) */
+inline DensityFunction *generate_density_function(ParameterFile &params) {
+  const std::string type =
+      params.get_string("DensityFunction:type", "Homogeneous");
+  if (type == "Homogeneous")
+    return new HomogeneousDensityFunction(params);
+  if (type == "BlockSyntax")
+    return new BlockSyntaxDensityFunction(params);
+  throw ParameterError("Unknown DensityFunction type: \"" + type +
+                       "\" (this engine provides Homogeneous and BlockSyntax; "
+                       "pass your own DensityFunction to initialize())");
+}
+
+/* ---------------------------------------------- PhotonSourceDistribution */
+
+typedef uint_fast32_t photonsourcenumber_t;
+
+class PhotonSourceDistribution {
+public:
+  virtual ~PhotonSourceDistribution() {}
+  virtual photonsourcenumber_t get_number_of_sources() const = 0;
+  virtual CoordinateVector get_position(photonsourcenumber_t index) = 0;
+  virtual double get_weight(photonsourcenumber_t index) const = 0;
+  virtual double get_total_luminosity() const = 0;
+
+  /* generic lowering: works for any implementation of the four getters */
+  int lower(cmi_gpu_engine *engine) {
+    const photonsourcenumber_t n = get_number_of_sources();
+    std::vector<double> pos(3 * n), w(n);
+    for (photonsourcenumber_t i = 0; i < n; ++i) {
+      const CoordinateVector p = get_position(i);
+      for (int a = 0; a < 3; ++a)
+        pos[3 * i + a] = p[a];
+      w[i] = get_weight(i);
+    }
+    return cmi_gpu_set_sources(engine, (int32_t)n, pos.data(), w.data(),
+                               get_total_luminosity());
+  }
+};
+
+/* src/SingleStarPhotonSourceDistribution.hpp:41-100 */
+class SingleStarPhotonSourceDistribution : public PhotonSourceDistribution {
+  const CoordinateVector _position;
+  const double _luminosity;
+
+public:
+  SingleStarPhotonSourceDistribution(CoordinateVector position,
+                                     double luminosity)
+      : _position(position), _luminosity(luminosity) {}
+  explicit SingleStarPhotonSourceDistribution(ParameterFile &params)
+      : _position([&] {
+          const auto p = params.get_physical_vector(
+              QUANTITY_LENGTH, "PhotonSourceDistribution:position",
+              "[0. pc, 0. pc, 0. pc]");
+          return CoordinateVector(p[0], p[1], p[2]);
+        }()),
+        _luminosity(params.get_physical_value(
+            QUANTITY_FREQUENCY, "PhotonSourceDistribution:luminosity",
+            "4.26e49 s^-1")) {}
+  photonsourcenumber_t get_number_of_sources() const override { return 1; }
+  CoordinateVector get_position(photonsourcenumber_t) override {
+    return _position;
+  }
+  double get_weight(photonsourcenumber_t) const override { return 1.; }
+  double get_total_luminosity() const override { return _luminosity; }
+};
+
+inline PhotonSourceDistribution *
+generate_photon_source_distribution(ParameterFile &params) {
+  const std::string type =
+      params.get_string("PhotonSourceDistribution:type", "SingleStar");
+  if (type == "SingleStar")
+    return new SingleStarPhotonSourceDistribution(params);
+  if (type == "None")
+    return nullptr;
+  throw ParameterError("Unknown PhotonSourceDistribution type: \"" + type +
+                       "\"");
+}
+
+/* -------------------------------------------------- PhotonSourceSpectrum */
+
+class RandomGenerator; /* per-packet streams live on the device */
+
+class PhotonSourceSpectrum {
+public:
+  virtual ~PhotonSourceSpectrum() {}
+  /* per-packet virtual of the reference; on this path spectra are sampled on
+   * the device from the descriptor set by lower() */
+  virtual double get_random_frequency(RandomGenerator &random_generator,
+                                      double temperature = 0.) const = 0;
+  virtual double get_total_flux() const = 0;
+  virtual int lower(cmi_gpu_engine *engine) const = 0;
+};
+
+/* src/MonochromaticPhotonSourceSpectrum.hpp:40-113 */
+class MonochromaticPhotonSourceSpectrum : public PhotonSourceSpectrum {
+  const double _frequency, _total_flux;
+
+public:
+  explicit MonochromaticPhotonSourceSpectrum(double frequency,
+                                             double total_flux = -1.)
+      : _frequency(frequency), _total_flux(total_flux) {}
+  MonochromaticPhotonSourceSpectrum(const std::string &role,
+                                    ParameterFile &params)
+      : MonochromaticPhotonSourceSpectrum(
+            params.get_physical_value(QUANTITY_FREQUENCY, role + ":frequency",
+                                      "13.6 eV"),
+            params.get_physical_value(QUANTITY_FLUX, role + ":total flux",
+                                      "-1. m^-2 s^-1")) {}
+  double get_random_frequency(RandomGenerator &, double = 0.) const override {
+    return _frequency;
+  }
+  double get_total_flux() const override { return _total_flux; }
+  double get_frequency() const { return _frequency; }
+  int lower(cmi_gpu_engine *engine) const override {
+    return cmi_gpu_set_spectrum_monochromatic(engine, _frequency);
+  }
+};
+
+/* src/PlanckPhotonSourceSpectrum.cpp:53-147 */
+class PlanckPhotonSourceSpectrum : public PhotonSourceSpectrum {
+  const double _temperature, _ionizing_flux;
+
+public:
+  explicit PlanckPhotonSourceSpectrum(double temperature,
+                                      double ionizing_flux = -1.)
+      : _temperature(temperature), _ionizing_flux(ionizing_flux) {}
+  PlanckPhotonSourceSpectrum(const std::string &role, ParameterFile &params)
+      : PlanckPhotonSourceSpectrum(
+            params.get_physical_value(QUANTITY_TEMPERATURE,
+                                      role + ":temperature", "4.e4 K"),
+            params.get_physical_value(QUANTITY_FLUX, role + ":ionizing flux",
+                                      "-1. m^-2 s^-1")) {}
+  double get_random_frequency(RandomGenerator &, double = 0.) const override {
+    throw ParameterError("Planck spectrum is sampled on the device");
+  }
+  double get_total_flux() const override { return _ionizing_flux; }
+  double get_temperature() const { return _temperature; }
+  int lower(cmi_gpu_engine *engine) const override {
+    return cmi_gpu_set_spectrum_planck(engine, _temperature);
+  }
+};
+
+/* src/PhotonSourceSpectrumFactory.hpp:93-113 (types on this path) */
+inline PhotonSourceSpectrum *
+generate_photon_source_spectrum(const std::string &role,
+                                ParameterFile &params) {
+  const std::string type = params.get_string(role + ":type", "Monochromatic");
+  if (type == "Monochromatic")
+    return new MonochromaticPhotonSourceSpectrum(role, params);
+  if (type == "Planck")
+    return new PlanckPhotonSourceSpectrum(role, params);
+  if (type == "None")
+    return nullptr;
+  throw ParameterError("Unknown PhotonSourceSpectrum type: \"" + type + "\"");
+}
+
+/* -------------------------------------- CrossSections / RecombinationRates */
+
+class CrossSections {
+public:
+  virtual ~CrossSections() {}
+  virtual double get_cross_section(const int_fast32_t ion,
+                                   const double energy) const = 0;
+  virtual int lower(cmi_gpu_engine *engine) const = 0;
+};
+
+/* parameter key of an ion's cross section / of the ion that recombines INTO
+ * it (src/FixedValueCrossSections.hpp:113-146,
+ * src/FixedValueRecombinationRates.hpp:113-150) */
+inline const char *xsec_key(int ion) {
+  static const char *k[NUMBER_OF_IONNAMES] = {
+      "hydrogen_0", "helium_0", "carbon_1", "carbon_2", "nitrogen_0",
+      "nitrogen_1", "nitrogen_2", "oxygen_0", "oxygen_1", "neon_0", "neon_1",
+      "sulphur_1", "sulphur_2", "sulphur_3"};
+  return k[ion];
+}
+inline const char *recomb_key(int ion) {
+  static const char *k[NUMBER_OF_IONNAMES] = {
+      "hydrogen_1", "helium_1", "carbon_2", "carbon_3", "nitrogen_1",
+      "nitrogen_2", "nitrogen_3", "oxygen_1", "oxygen_2", "neon_1", "neon_2",
+      "sulphur_2", "sulphur_3", "sulphur_4"};
+  return k[ion];
+}
+
+class FixedValueCrossSections : public CrossSections {
+  double _cross_sections[NUMBER_OF_IONNAMES];
+
+public:
+  explicit FixedValueCrossSections(ParameterFile &params) {
+    for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+      _cross_sections[ion] = params.get_physical_value(
+          QUANTITY_SURFACE_AREA, std::string("CrossSections:") + xsec_key(ion),
+          ion == ION_H_n ? "6.3e-18 cm^2" : "0. m^2");
+  }
+  double get_cross_section(const int_fast32_t ion,
+                           const double) const override {
+    return _cross_sections[ion];
+  }
+  int lower(cmi_gpu_engine *engine) const override {
+    return cmi_gpu_set_cross_sections_fixed(engine, _cross_sections);
+  }
+};
+
+class VernerCrossSections : public CrossSections {
+public:
+  double get_cross_section(const int_fast32_t, const double) const override {
+    throw ParameterError("Verner cross sections are evaluated on the device");
+  }
+  int lower(cmi_gpu_engine *engine) const override {
+    return cmi_gpu_set_cross_sections_verner(engine);
+  }
+};
+
+/* src/CrossSectionsFactory.hpp:69-73 */
+inline CrossSections *generate_cross_sections(ParameterFile &params) {
+  const std::string type = params.get_string("CrossSections:type", "Verner");
+  if (type == "FixedValue")
+    return new FixedValueCrossSections(params);
+  if (type == "Verner")
+    return new VernerCrossSections();
+  throw ParameterError("Unknown CrossSections type: \"" + type + "\"");
+}
+
+class RecombinationRates {
+public:
+  virtual ~RecombinationRates() {}
+  virtual double get_recombination_rate(const int_fast32_t ion,
+                                        const double temperature) const = 0;
+  virtual int lower(cmi_gpu_engine *engine) const = 0;
+};
+
+class FixedValueRecombinationRates : public RecombinationRates {
+  double _rates[NUMBER_OF_IONNAMES];
+
+public:
+  explicit FixedValueRecombinationRates(ParameterFile &params) {
+    for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+      _rates[ion] = params.get_physical_value(
+          QUANTITY_REACTION_RATE,
+          std::string("RecombinationRates:") + recomb_key(ion),
+          ion == ION_H_n ? "4.e-13 cm^3 s^-1" : "0. m^3 s^-1");
+  }
+  double get_recombination_rate(const int_fast32_t ion,
+                                const double) const override {
+    return _rates[ion];
+  }
+  int lower(cmi_gpu_engine *engine) const override {
+    return cmi_gpu_set_recombination_rates_fixed(engine, _rates);
+  }
+};
+
+class VernerRecombinationRates : public RecombinationRates {
+public:
+  double get_recombination_rate(const int_fast32_t,
+                                const double) const override {
+    throw ParameterError("Verner rates are evaluated on the device");
+  }
+  int lower(cmi_gpu_engine *engine) const override {
+    return cmi_gpu_set_recombination_rates_verner(engine);
+  }
+};
+
+/* src/RecombinationRatesFactory.hpp:65-67 */
+inline RecombinationRates *generate_recombination_rates(ParameterFile &params) {
+  const std::string type =
+      params.get_string("RecombinationRates:type", "Verner");
+  if (type == "FixedValue")
+    return new FixedValueRecombinationRates(params);
+  if (type == "Verner")
+    return new VernerRecombinationRates();
+  throw ParameterError("Unknown RecombinationRates type: \"" + type + "\"");
+}
+
+/* ------------------------------------------------------------ Abundances */
+
+/* src/FixedValueAbundanceModel.hpp:44-52: "AbundanceModel:<element>",
+ * default 0; elements He C N O Ne S */
+struct Abundances {
+  double value[6] = {0., 0., 0., 0., 0., 0.};
+  explicit Abundances(ParameterFile &params) {
+    const std::string type =
+        params.get_string("AbundanceModel:type", "FixedValue");
+    if (type != "FixedValue")
+      throw ParameterError("Unknown AbundanceModel type: \"" + type + "\"");
+    static const char *el[6] = {"He", "C", "N", "O", "Ne", "S"};
+    for (int i = 0; i < 6; ++i)
+      value[i] =
+          params.get_double(std::string("AbundanceModel:") + el[i], 0.);
+  }
+  int lower(cmi_gpu_engine *engine) const {
+    return cmi_gpu_set_abundances(engine, value);
+  }
+};
+
+/* ----------------------------------------------- DiffuseReemissionHandler */
+
+/* src/DiffuseReemissionHandlerFactory.hpp:60-110 incl. the deprecated
+ * "PhotonSource:diffuse field" switch */
+struct DiffuseReemission {
+  int type = CMI_GPU_REEMIT_NONE;
+  double probability = 0.364;
+  double frequency = 0.;
+  explicit DiffuseReemission(ParameterFile &params) {
+    if (!params.has_value("DiffuseReemissionHandler:type") &&
+        params.has_value("PhotonSource:diffuse field")) {
+      const bool diffuse = params.get_bool("PhotonSource:diffuse field", false);
+      params.add_value("DiffuseReemissionHandler:type",
+                       diffuse ? "Physical" : "None");
+    }
+    const std::string t =
+        params.get_string("DiffuseReemissionHandler:type", "None");
+    if (t == "FixedValue") {
+      type = CMI_GPU_REEMIT_FIXED;
+      probability = params.get_double(
+          "DiffuseReemissionHandler:reemission probability", 0.364);
+      frequency = params.get_physical_value(
+          QUANTITY_FREQUENCY, "DiffuseReemissionHandler:reemission frequency",
+          "19.8 eV");
+    } else if (t == "Physical") {
+      type = CMI_GPU_REEMIT_PHYSICAL;
+    } else if (t == "None") {
+      type = CMI_GPU_REEMIT_NONE;
+    } else {
+      throw ParameterError("Unknown DiffuseReemissionHandler type: \"" + t +
+                           "\"!");
+    }
+  }
+  int lower(cmi_gpu_engine *engine) const {
+    return cmi_gpu_set_reemission(engine, type, probability, frequency);
+  }
+};
+
+/* ---------------------------------------------------------- SimulationBox */
+
+struct SimulationBox {
+  std::array<double, 3> anchor, sides;
+  std::array<bool, 3> periodicity;
+  explicit SimulationBox(ParameterFile &params)
+      : anchor(params.get_physical_vector(QUANTITY_LENGTH,
+                                          "SimulationBox:anchor",
+                                          "[0. m, 0. m, 0. m]")),
+        sides(params.get_physical_vector(QUANTITY_LENGTH, "SimulationBox:sides",
+                                         "[1. m, 1. m, 1. m]")),
+        periodicity(params.get_bool_vector("SimulationBox:periodicity",
+                                           {false, false, false})) {}
+};
+
+} // namespace cmi
+
+#endif

@@ -1,0 +1,196 @@
+"""Tests of the C++ host layer above the C ABI (cmacionize_amd/host): the
+.param parser with units and defaults, the plugin factories and their
+lowering, and - on the GPU - the cmi-gpu executable end to end against the
+oracle.
+
+Mirrors the reference's testParameterFile.cpp / testUnitConverter.cpp in
+spirit (same grammar, same unit arithmetic)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "cmacionize_amd", "cmi-gpu")
+BENCH = os.path.join(ROOT, "benchmarks")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    if not os.path.exists(EXE):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "cmacionize_amd",
+                                                   "csrc")], check=True)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "cmacionize_amd",
+                                                   "host")], check=True)
+    return EXE
+
+
+def describe(exe, param, cwd):
+    out = subprocess.run([exe, "--params", param, "--dry-run", "--describe"],
+                         check=True, capture_output=True, text=True, cwd=cwd)
+    return json.loads(out.stdout)
+
+
+def unit_power(value, power):
+    """Unit::operator^=, src/Unit.hpp:124-150"""
+    if power >= 0:
+        v = value
+        for _ in range(1, power):
+            v *= value
+        return v
+    v = 1.
+    for _ in range(-power):
+        v /= value
+    return v
+
+
+def test_stromgren_param_is_lowered_like_the_reference(exe, tmp_path):
+    d = describe(exe, os.path.join(BENCH, "stromgren.param"), str(tmp_path))
+    pc = 3.086e16
+    assert d["anchor"] == [-5. * pc] * 3
+    assert d["sides"] == [10. * pc] * 3
+    assert d["periodicity"] == [0, 0, 0]
+    assert d["ncell"] == [64, 64, 64]
+    assert d["number_of_iterations"] == 20
+    assert d["number_of_photons"] == 1000000
+    assert d["random_seed"] == 42  # default
+    assert d["sources"] == [{"position": [0, 0, 0], "weight": 1}]
+    assert d["total_luminosity"] == 4.26e49
+    eV, h = 1.6021766208e-19, 6.626070040e-34
+    assert d["spectrum"] == {"type": "Monochromatic",
+                             "frequency": 13.6 * eV * (1. / h) / 1.}
+    assert d["cross_sections"][0] == 6.3e-18 * unit_power(0.01, 2)
+    assert d["cross_sections"][1:] == [0] * 13
+    assert d["recombination_rates"][0] == 4.e-13 * (unit_power(0.01, 3) * 1.)
+    assert d["abundances"] == [0] * 6  # FixedValueAbundanceModel default 0
+    assert d["reemission"]["type"] == 0
+    assert d["temperature"]["do"] == 0
+    assert d["temperature"]["cr_scale"] == 1.33333 * 3.086e19
+    assert not os.path.exists(os.path.join(BENCH,
+                                           "stromgren.param.used-values"))
+
+
+def test_diffuse_and_lexington_params(exe, tmp_path):
+    d = describe(exe, os.path.join(BENCH, "stromgren_diffuse.param"),
+                 str(tmp_path))
+    assert d["reemission"]["type"] == 1
+    d = describe(exe, os.path.join(BENCH, "lexingtonHII40.param"),
+                 str(tmp_path))
+    assert d["spectrum"] == {"type": "Planck", "temperature": 40000.}
+    assert d["cross_sections"] == "Verner"
+    assert d["recombination_rates"] == "Verner"
+    assert d["abundances"] == [0.1, 2.2e-4, 4.e-5, 3.3e-4, 5.e-5, 9.e-6]
+    assert d["number_of_photons"] == 100000000  # "1e8"
+    assert d["temperature"]["do"] == 1 and d["temperature"]["pah"] == 0
+    assert d["reemission"]["type"] == 1
+
+
+PARAM = """# comment line
+SimulationBox:
+  anchor: [0. m, -1. cm, 2. km]   # trailing comment
+  sides: [1. kpc, 1. pc, 1. au]
+  periodicity: [true, no, Y]
+DensityGrid:
+  number of cells: [8, 4, 2]
+DensityFunction:
+  type: Homogeneous
+  density: 5. cm^-3
+PhotonSourceSpectrum:
+  type: Monochromatic
+  frequency: 912. angstrom
+IonizationSimulation:
+  number of photons: 2e3
+  random seed: 7
+CrossSections:
+  type: FixedValue
+RecombinationRates:
+  type: FixedValue
+DiffuseReemissionHandler:
+  type: FixedValue
+  reemission probability: 0.25
+DensityGridWriter:
+  type: AsciiFile
+"""
+
+
+def test_parameter_grammar_units_and_defaults(exe, tmp_path):
+    p = tmp_path / "t.param"
+    p.write_text(PARAM)
+    d = describe(exe, str(p), str(tmp_path))
+    assert d["anchor"] == [0., -0.01, 2000.]
+    assert d["sides"] == [3.086e19, 3.086e16, 149597870700.]
+    assert d["periodicity"] == [1, 0, 1]
+    assert d["ncell"] == [8, 4, 2]
+    assert d["number_of_photons"] == 2000
+    assert d["number_of_iterations"] == 10  # default
+    assert d["random_seed"] == 7
+    # wavelength -> frequency: c / lambda (src/UnitConverter.hpp:276-280)
+    assert d["spectrum"]["frequency"] == (1. / (912. * 1.e-10)) * 299792458.
+    # defaults of the FixedValue plugins
+    assert d["cross_sections"][0] == 6.3e-18 * unit_power(0.01, 2)
+    assert d["recombination_rates"][0] == 4.e-13 * unit_power(0.01, 3)
+    assert d["reemission"] == {"type": 2, "probability": 0.25,
+                               "frequency": 19.8 * 1.6021766208e-19 *
+                               (1. / 6.626070040e-34)}
+
+
+def test_errors_are_reported_not_aborted(exe, tmp_path):
+    p = tmp_path / "bad.param"
+    p.write_text("DensityGrid:\n  type: Voronoi\nDensityGridWriter:\n"
+                 "  type: AsciiFile\n")
+    r = subprocess.run([exe, "--params", str(p), "--dry-run"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 1 and "not on this path" in r.stderr
+    p.write_text("SimulationBox:\n  anchor: [0. furlong, 0. m, 0. m]\n")
+    r = subprocess.run([exe, "--params", str(p), "--dry-run"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 1 and "Unknown unit" in r.stderr
+    r = subprocess.run([exe, "--params", str(tmp_path / "missing.param")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1
+
+
+@pytest.mark.gpu
+def test_cmi_gpu_executable_end_to_end(exe, tmp_path, oracle):
+    """stromgren at 16^3 through the executable: used-values file, initial and
+    final AsciiFile snapshots (reference column layout), result equal to the
+    oracle driven with the same lowered values and seeds."""
+    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = text.replace("[64, 64, 64]", "[16, 16, 16]")
+    text = text.replace("number of photons: 1e6", "number of photons: 20000")
+    text = text.replace("number of iterations: 20", "number of iterations: 3")
+    p = tmp_path / "small.param"
+    p.write_text(text)
+    r = subprocess.run([exe, "--params", str(p), "--output-statistics"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert "Total photon shooting time" in r.stdout
+    assert "Escape fraction" in r.stdout
+    used = open(str(p) + ".used-values").read()
+    assert "random seed: 42 # (default value)" in used
+    assert "number of photons: 20000 # (20000)" in used
+    first = np.loadtxt(tmp_path / "stromgren_000.txt")
+    last = np.loadtxt(tmp_path / "stromgren_003.txt")
+    assert first.shape == (4096, 6) and last.shape == (4096, 6)
+    assert np.all(first[:, 5] == 1.e-6)
+    d = describe(exe, str(p), str(tmp_path))
+    sim = oracle.OracleSimulation((16,) * 3, d["anchor"], d["sides"])
+    sim.set_sources([[0., 0., 0.]], [1.], d["total_luminosity"])
+    sim.set_homogeneous(100. * (1. / 0.01 / 0.01 / 0.01), 8000.)
+    m = sim.model
+    m.spectrum_type = oracle.SPECTRUM_MONOCHROMATIC
+    m.mono_frequency = d["spectrum"]["frequency"]
+    m.xsec_type = oracle.XSEC_FIXED
+    m.recomb_type = oracle.RECOMB_FIXED
+    for i in range(14):
+        m.xsec_fixed[i] = d["cross_sections"][i]
+        m.recomb_fixed[i] = d["recombination_rates"][i]
+    sim.run(20000, 3, seed=42)
+    # text output has 6 significant digits; iteration-to-iteration rounding
+    # feedback as in test_replica_distributed
+    assert np.allclose(last[:, 5], sim.x[0], rtol=2e-3, atol=0.)
+    mid = (np.arange(16) + 0.5) * (d["sides"][0] / 16) + d["anchor"][0]
+    assert np.allclose(last[:16, 2], mid, rtol=1e-5)
+    assert np.allclose(last[:, 4], (d["sides"][0] / 16) ** 3, rtol=1e-5)

@@ -99,7 +99,7 @@ __device__ inline double physical_reemit(const ModelDev &m, double sigma_H,
  * packet absorbed in `cell` is re-emitted as ionizing radiation; if so give it
  * a new frequency, direction, cross sections and optical depth
  * (src/IonizationPhotonShootJob.hpp:137-142). */
-template <bool FULL>
+template <bool FULL, bool EXACT>
 __device__ inline bool reemit_packet(const GridDev &g, const ModelDev &m,
                                      const CellsDev &cells, int64_t cell,
                                      PacketRng &rng, Packet<FULL> &p) {
@@ -127,11 +127,13 @@ __device__ inline bool reemit_packet(const GridDev &g, const ModelDev &m,
   if (new_frequency == 0.)
     return false;
   p.nu = new_frequency;
+  if (!EXACT)
+    end_flight(p); /* position of the absorption, along the OLD direction */
   random_direction(p, rng);
   set_cross_sections(m, p);
   p.tau = -log(rng.next());
   /* interact() starts from the cell that contains the packet's position */
-  locate_cell(g, p);
+  start_flight<FULL, EXACT>(g, p);
   return true;
 }
 

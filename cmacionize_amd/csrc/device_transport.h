@@ -1,6 +1,24 @@
 /*
  * device_transport.h - device functions for packet emission and the DDA
  * march through the regular grid.
+ *
+ * Two marchers implement CartesianDensityGrid::interact
+ * (src/CartesianDensityGrid.cpp:375-452):
+ *
+ *  EXACT  restates the reference's arithmetic operation by operation: every
+ *         step recomputes the cell walls from the cell index and the wall
+ *         distances from the current position. Path lengths are bit-identical
+ *         to the CPU oracle's. Used by the trace probe and selectable for the
+ *         transport kernel (tuning "exact_dda").
+ *
+ *  FAST   the incremental form of the same traversal (Amanatides & Woo): the
+ *         ray is parametrised as origin + t * direction, the parameter of the
+ *         next wall crossing per axis is initialised exactly like the
+ *         reference's first step and then advanced by cellside / |direction|.
+ *         Same cells, same tie rule (every axis that ties the minimum
+ *         advances), path lengths equal to the reference's up to rounding
+ *         (tested: |ds - ds_exact| <= 1e-12 x cellside). ~5x fewer
+ *         instructions per step; the default.
  */
 #ifndef CMI_DEVICE_TRANSPORT_H
 #define CMI_DEVICE_TRANSPORT_H
@@ -12,9 +30,10 @@
 
 /* State of one packet in flight; Photon of src/Photon.hpp:36-69 minus the
  * fields the path never reads (Stokes / direction parameters). FULL = all 14
- * cross sections are carried; otherwise only hydrogen's. */
+ * cross sections are carried; otherwise only hydrogen's. Members a kernel
+ * variant does not use cost no registers. */
 template <bool FULL> struct Packet {
-  double pos[3];
+  double pos[3]; /* EXACT: current position; FAST: origin of the flight */
   double dir[3];
   double inv_dir[3];
   double tau;    /* remaining optical depth */
@@ -23,6 +42,12 @@ template <bool FULL> struct Packet {
   double sigma_H;
   double sigma_He_corr; /* A_He * sigma_He */
   double sigma[FULL ? CMI_NION : 1];
+  /* FAST marcher */
+  double t;         /* path parameter reached so far */
+  double tmax[3];   /* parameter of the next wall crossing per axis */
+  double tdelta[3]; /* parameter distance between walls per axis */
+  int32_t cell;     /* long index of the current cell */
+  int32_t inside;
   int32_t index[3];
   int32_t type;
 };
@@ -75,31 +100,6 @@ __device__ __forceinline__ void locate_cell(const GridDev &g,
     p.index[a] = (int32_t)((p.pos[a] - g.anchor[a]) * g.inv_cellside[a]);
 }
 
-/* PhotonSource::get_random_photon (discrete branch) + the first optical depth
- * of IonizationPhotonShootJob::execute
- * (src/PhotonSource.cpp:208-249, src/IonizationPhotonShootJob.hpp:119-135) */
-template <bool FULL>
-__device__ inline void emit_packet(const GridDev &g, const ModelDev &m,
-                                   PacketRng &rng, Packet<FULL> &p) {
-  /* first uniform: continuous vs discrete source; no continuous source on
-   * this path, so it is drawn and ignored */
-  double x = rng.next();
-  x = rng.next();
-  int i = 0;
-  while (x > m.source_cumulative[i])
-    ++i;
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-    p.pos[a] = m.source_position[3 * i + a];
-  random_direction(p, rng);
-  p.nu = sample_source_spectrum(m, rng);
-  p.type = TYPE_PRIMARY;
-  set_cross_sections(m, p);
-  p.weight = 1.;
-  p.tau = -log(rng.next());
-  locate_cell(g, p);
-}
-
 /* CartesianDensityGrid::is_inside, src/CartesianDensityGrid.cpp:187-227 */
 template <bool FULL>
 __device__ __forceinline__ bool is_inside(const GridDev &g, Packet<FULL> &p) {
@@ -122,7 +122,57 @@ __device__ __forceinline__ bool is_inside(const GridDev &g, Packet<FULL> &p) {
   return inside;
 }
 
-/* One iteration of the loop of CartesianDensityGrid::interact
+/* Begin a flight from p.pos along p.dir: interact() starts from the cell that
+ * contains the position (src/CartesianDensityGrid.cpp:386). FAST also sets up
+ * the wall-crossing parameters, with the first crossing computed exactly as
+ * the reference's first get_wall_intersection (:280-318). */
+template <bool FULL, bool EXACT>
+__device__ __forceinline__ void start_flight(const GridDev &g,
+                                             Packet<FULL> &p) {
+  locate_cell(g, p);
+  if (!EXACT) {
+    p.inside = is_inside(g, p) ? 1 : 0;
+    p.t = 0.;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double lo = g.anchor[a] + g.cellside[a] * p.index[a];
+      const double hi = lo + g.cellside[a];
+      p.tmax[a] =
+          (p.dir[a] > 0.)
+              ? (hi - p.pos[a]) * p.inv_dir[a]
+              : ((p.dir[a] < 0.) ? (lo - p.pos[a]) * p.inv_dir[a] : DBL_MAX);
+      p.tdelta[a] = g.cellside[a] * fabs(p.inv_dir[a]);
+    }
+    p.cell = (p.index[0] * g.ncell[1] + p.index[1]) * g.ncell[2] + p.index[2];
+  }
+}
+
+/* PhotonSource::get_random_photon (discrete branch) + the first optical depth
+ * of IonizationPhotonShootJob::execute
+ * (src/PhotonSource.cpp:208-249, src/IonizationPhotonShootJob.hpp:119-135) */
+template <bool FULL, bool EXACT>
+__device__ inline void emit_packet(const GridDev &g, const ModelDev &m,
+                                   PacketRng &rng, Packet<FULL> &p) {
+  /* first uniform: continuous vs discrete source; no continuous source on
+   * this path, so it is drawn and ignored */
+  double x = rng.next();
+  x = rng.next();
+  int i = 0;
+  while (x > m.source_cumulative[i])
+    ++i;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    p.pos[a] = m.source_position[3 * i + a];
+  random_direction(p, rng);
+  p.nu = sample_source_spectrum(m, rng);
+  p.type = TYPE_PRIMARY;
+  set_cross_sections(m, p);
+  p.weight = 1.;
+  p.tau = -log(rng.next());
+  start_flight<FULL, EXACT>(g, p);
+}
+
+/* EXACT: one iteration of the loop of CartesianDensityGrid::interact
  * (src/CartesianDensityGrid.cpp:396-432) with get_wall_intersection
  * (:280-318) and get_optical_depth (src/DensityGrid.hpp:117-140) inlined.
  * The caller has checked that the packet is inside and tau > 0.
@@ -174,6 +224,62 @@ __device__ __forceinline__ double dda_step(const GridDev &g,
     }
   }
   return ds;
+}
+
+/* FAST: the same loop iteration in incremental form. Precondition: p.inside
+ * and tau > 0. On absorption (tau < 0 on return) p.t is the parameter of the
+ * absorption point; call end_flight() to get the position. */
+template <bool FULL>
+__device__ __forceinline__ double fast_step(const GridDev &g,
+                                            const double2 *__restrict__ opacity,
+                                            Packet<FULL> &p, int64_t &cell,
+                                            double2 &kappa) {
+  cell = p.cell;
+  kappa = opacity[p.cell];
+  const double tmin = fmin(p.tmax[0], fmin(p.tmax[1], p.tmax[2]));
+  double ds = tmin - p.t;
+  const double kH = fmax(kappa.x, 0.);
+  const double tau_cell = ds * (p.sigma_H * kH + p.sigma_He_corr * kappa.y);
+  p.tau -= tau_cell;
+  if (p.tau < 0.) {
+    ds += ds * p.tau / tau_cell; /* Scorr */
+    p.t += ds;
+  } else {
+    p.t = tmin;
+    bool inside = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (p.tmax[a] == tmin) { /* every tied axis advances */
+        const int32_t s = (p.dir[a] > 0.) ? 1 : -1;
+        int32_t i = p.index[a] + s;
+        p.tmax[a] += p.tdelta[a];
+        if (i < 0 || i >= g.ncell[a]) {
+          if (g.periodic[a]) {
+            /* is_inside(): wrap the index and shift the position by a box
+             * side - here the flight origin, so that origin + t * dir stays
+             * the wrapped position */
+            i -= s * g.ncell[a];
+            p.pos[a] -= s * g.box_sides[a];
+          } else {
+            inside = false;
+          }
+        }
+        p.index[a] = i;
+      }
+    }
+    p.inside = inside ? 1 : 0;
+    p.cell = (p.index[0] * g.ncell[1] + p.index[1]) * g.ncell[2] + p.index[2];
+  }
+  return ds;
+}
+
+/* FAST: materialise the current position (end of a flight) */
+template <bool FULL>
+__device__ __forceinline__ void end_flight(Packet<FULL> &p) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    p.pos[a] = p.pos[a] + p.t * p.dir[a];
+  p.t = 0.;
 }
 
 #endif

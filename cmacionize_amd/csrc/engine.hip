@@ -90,6 +90,7 @@ struct cmi_gpu_engine {
     int max_blocks_per_cu = 8;
     uint64_t max_packets_per_launch = 1ull << 27;
     bool exp_no_atomics = false;
+    bool exact_dda = false;
   } tune;
 
   std::vector<EventPair> shoot_events, update_events;
@@ -786,6 +787,8 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
         (uint64_t)(value < 1024 ? 1024 : (value > (1ll << 30) ? (1ll << 30) : value));
   else if (k == "exp_no_atomics")
     e->tune.exp_no_atomics = value != 0;
+  else if (k == "exact_dda")
+    e->tune.exact_dda = value != 0;
   else
     return fail(CMI_GPU_EINVAL, "set_tuning: unknown key '%s'", key);
   return CMI_GPU_OK;
@@ -835,12 +838,15 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
 
   const bool heat = e->config.track_heating != 0;
   const bool reemit = e->model.reemit_type != CMI_GPU_REEMIT_NONE;
-  /* cross-lane aggregation keys are 32-bit cell indices */
-  const bool agg = e->tune.aggregate && e->ncell < (1ll << 31);
+  /* cross-lane aggregation keys and the fast marcher use 32-bit cell
+   * indices */
+  const bool small_grid = e->ncell < (1ll << 31);
+  const bool agg = e->tune.aggregate && small_grid;
+  const bool exact = e->tune.exact_dda || !small_grid;
   void (*kernel)(const ShootArgs) = nullptr;
-#define PICK(F, H, R, A)                                                       \
-  if (e->full_ions == F && heat == H && reemit == R && agg == A)               \
-    kernel = shoot_kernel<F, H, R, A>;
+#define PICK(F, H, R, X)                                                       \
+  if (e->full_ions == F && heat == H && reemit == R && exact == X)             \
+    kernel = shoot_kernel<F, H, R, X>;
   PICK(false, false, false, false)
   PICK(false, false, true, false)
   PICK(false, true, false, false)
@@ -898,6 +904,7 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     a.iteration = iteration;
     a.refill_threshold = e->tune.refill_threshold;
     a.exp_no_atomics = e->tune.exp_no_atomics ? 1 : 0;
+    a.aggregate = agg ? 1 : 0;
 
     EventPair ev;
     HIP_TRY(hipEventCreate(&ev.start));
@@ -1103,9 +1110,15 @@ int cmi_gpu_trace_packets(cmi_gpu_engine *e, uint64_t n,
   if (err == hipSuccess)
     err = hipMemsetAsync(dds, 0, ds_bytes, e->stream);
   if (err == hipSuccess) {
-    trace_probe_kernel<<<(unsigned)((n + 63) / 64), 64, 0, e->stream>>>(
-        e->grid, e->opacity, n, dpos, ddir, dtau, dsh, dshe, max_steps, dcell,
-        dds, dnsteps, dlast, dfinal);
+    if (e->tune.exact_dda || e->ncell >= (1ll << 31))
+      trace_probe_kernel<true><<<(unsigned)((n + 63) / 64), 64, 0, e->stream>>>(
+          e->grid, e->opacity, n, dpos, ddir, dtau, dsh, dshe, max_steps,
+          dcell, dds, dnsteps, dlast, dfinal);
+    else
+      trace_probe_kernel<false>
+          <<<(unsigned)((n + 63) / 64), 64, 0, e->stream>>>(
+              e->grid, e->opacity, n, dpos, ddir, dtau, dsh, dshe, max_steps,
+              dcell, dds, dnsteps, dlast, dfinal);
     err = hipGetLastError();
   }
   if (err == hipSuccess)

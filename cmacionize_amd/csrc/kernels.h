@@ -9,6 +9,9 @@
 #include "device_thermal.h"
 
 #define CMI_BLOCK 256
+/* slots of a wave's write-combining cache for accumulator updates */
+#define CMI_CACHE_BITS 8
+#define CMI_CACHE_SLOTS (1 << CMI_CACHE_BITS)
 /* idle lanes of a wave are refilled with new packets once this many of them
  * are waiting (or when the whole wave is idle). 64 = a wave always carries one
  * group of 64 direction-sorted packets: its lanes stay in the same cells, so
@@ -46,6 +49,7 @@ struct ShootArgs {
   uint32_t iteration;
   int32_t refill_threshold;
   int32_t exp_no_atomics; /* experiment: skip the accumulation */
+  int32_t aggregate;      /* cross-lane run sums before the atomics */
 };
 
 /* update_integrals, src/DensityGrid.hpp:150-197: every crossed non-vacuum
@@ -74,31 +78,95 @@ __device__ __forceinline__ void update_integrals(const ShootArgs &a,
   }
 }
 
-/* Sum `v` over runs of consecutive lanes that hold the same `key` (segmented
- * inclusive scan, 6 rounds). On return the LAST lane of every run holds the
+/* DPP lane moves (gfx9 family): no LDS round trip, VALU latency only.
+ * Lanes without a source lane keep their own value (bound_ctrl = 0). */
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = dpp_i32<CTRL, ROW_MASK>(__double2loint(v));
+  const int hi = dpp_i32<CTRL, ROW_MASK>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+#define CMI_DPP_ROW_SHR(n) (0x110 + (n))
+#define CMI_DPP_WAVE_SHL1 0x130
+#define CMI_DPP_WAVE_SHR1 0x138
+#define CMI_DPP_ROW_BCAST15 0x142
+#define CMI_DPP_ROW_BCAST31 0x143
+
+/* Sum `v` over runs of consecutive lanes that hold the same `key`: segmented
+ * inclusive scan in the 6 DPP rounds of a wave64 scan (row_shr 1, 2, 4, 8
+ * inside each row of 16 lanes, then row_bcast15 into rows 1 and 3 and
+ * row_bcast31 into rows 2 and 3). The flag of a lane says "a run starts inside
+ * the prefix I have summed so far"; a lane adds the incoming partial sum only
+ * while its flag is clear. On return the LAST lane of every run holds the
  * run's total and is flagged in `tail`. Must be called by all 64 lanes. */
 template <int N>
 __device__ __forceinline__ void run_sums(int32_t key, double (&v)[N],
                                          bool &tail) {
   const int lane = threadIdx.x & 63;
-  const int32_t prev = __shfl_up(key, 1, 64);
-  const int32_t next = __shfl_down(key, 1, 64);
+  const int32_t prev = dpp_i32<CMI_DPP_WAVE_SHR1, 0xf>(key);
+  const int32_t next = dpp_i32<CMI_DPP_WAVE_SHL1, 0xf>(key);
   int flag = (lane == 0) || (key != prev); /* run starts here */
   tail = (lane == 63) || (key != next);
+#define CMI_SCAN_ROUND(CTRL, ROW_MASK, COND)                                   \
+  {                                                                            \
+    double up[N];                                                              \
+    _Pragma("unroll") for (int k = 0; k < N; ++k) up[k] =                      \
+        dpp_f64<CTRL, ROW_MASK>(v[k]);                                         \
+    const int flag_up = dpp_i32<CTRL, ROW_MASK>(flag);                         \
+    if (COND) {                                                                \
+      _Pragma("unroll") for (int k = 0; k < N; ++k) v[k] +=                    \
+          flag ? 0. : up[k];                                                   \
+      flag |= flag_up;                                                         \
+    }                                                                          \
+  }
+  const int in_row = lane & 15;
+  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(1), 0xf, in_row >= 1)
+  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(2), 0xf, in_row >= 2)
+  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(4), 0xf, in_row >= 4)
+  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(8), 0xf, in_row >= 8)
+  CMI_SCAN_ROUND(CMI_DPP_ROW_BCAST15, 0xa, (lane & 16) != 0)
+  CMI_SCAN_ROUND(CMI_DPP_ROW_BCAST31, 0xc, lane >= 32)
+#undef CMI_SCAN_ROUND
+}
+
+/* cross-lane sums of the 14 mean-intensity terms (+2 heating terms) of lanes
+ * in the same cell, four values per scan to bound the register footprint */
+template <bool FULL, bool HEAT>
+__device__ __forceinline__ void
+aggregate_full(const ShootArgs &a, const Packet<FULL> &p, int32_t key,
+               bool accumulate, int64_t cell, double ds,
+               unsigned int &natomics) {
+  const double dsw = accumulate ? ds * p.weight : 0.;
+  bool tail;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    double up[N];
+  for (int g4 = 0; g4 < CMI_NION; g4 += 4) {
+    double v[4];
 #pragma unroll
-    for (int k = 0; k < N; ++k)
-      up[k] = __shfl_up(v[k], d, 64);
-    const int flag_up = __shfl_up(flag, d, 64);
-    if (lane >= d) {
-      if (!flag) {
+    for (int k = 0; k < 4; ++k)
+      v[k] = (g4 + k < CMI_NION) ? dsw * p.sigma[FULL ? (g4 + k < CMI_NION ? g4 + k : 0) : 0] : 0.;
+    if (g4 + 4 > CMI_NION && HEAT) {
+      /* last group: ions 12, 13 and the two heating terms */
+      v[2] = dsw * p.sigma[ION_H_n] * (p.nu - a.model.nu_H);
+      v[3] = dsw * p.sigma[FULL ? ION_He_n : 0] * (p.nu - a.model.nu_He);
+    }
+    run_sums<4>(key, v, tail);
+    if (tail && accumulate) {
 #pragma unroll
-        for (int k = 0; k < N; ++k)
-          v[k] += up[k];
+      for (int k = 0; k < 4; ++k) {
+        if (g4 + k < CMI_NION) {
+          atomic_add_f64(a.cells.acc[g4 + k] + cell, v[k]);
+          ++natomics;
+        }
       }
-      flag |= flag_up;
+      if (g4 + 4 > CMI_NION && HEAT) {
+        atomic_add_f64(a.cells.acc[CMI_NION] + cell, v[2]);
+        atomic_add_f64(a.cells.acc[CMI_NION + 1] + cell, v[3]);
+        natomics += 2;
+      }
     }
   }
 }
@@ -113,13 +181,14 @@ __device__ __forceinline__ void run_sums(int32_t key, double (&v)[N],
  * wait - the emission code is long and divergent, so it should not run for a
  * lane or two at a time. The positions are mapped to packet ids through
  * `order`, which the host has sorted by emission direction: the lanes of a
- * wave then travel through the same cells, their loads coalesce and (AGG)
- * their contributions to the same cell are summed across the wave before one
- * lane issues the atomic (update_integrals, src/DensityGrid.hpp:150-197: the
- * reference does one locked read-modify-write per packet and cell; sums are
- * associative up to rounding).
+ * wave then travel through the same cells, their loads coalesce and (with
+ * a.aggregate) their contributions to the same cell are summed across the
+ * wave before one lane issues the atomic (update_integrals,
+ * src/DensityGrid.hpp:150-197: the reference does one locked
+ * read-modify-write per packet and cell; sums are associative up to
+ * rounding). EXACT selects the marcher (device_transport.h).
  */
-template <bool FULL, bool HEAT, bool REEMIT, bool AGG>
+template <bool FULL, bool HEAT, bool REEMIT, bool EXACT>
 __global__ void __launch_bounds__(CMI_BLOCK)
     shoot_kernel(const ShootArgs a) {
   const int lane = threadIdx.x & 63;
@@ -143,7 +212,76 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   int64_t last_cell = -1;
 
   double tw = 0., tc0 = 0., tc1 = 0., tc2 = 0., tc3 = 0.;
-  unsigned long long nsteps = 0, natomics = 0;
+  unsigned int nsteps = 0, natomics = 0; /* per lane and launch: < 2^32 */
+
+  /* H-only: per-wave write-combining cache in LDS. Scattered fp64 atomics
+   * execute at the memory side at a chip-wide rate of a few 1e10 per second
+   * whatever the schedule (measured: the kernel's time follows the number of
+   * atomics, not the number of steps), so contributions are first combined on
+   * chip: a run total goes into a direct-mapped table of (cell, partial sum)
+   * with LDS atomics; only an entry that is evicted by another cell - or
+   * flushed when the wave ends - costs a global atomic. A wave follows one
+   * bundle of neighbouring rays, so consecutive steps (and the next bundle of
+   * the wave's chunk) keep hitting the same few cells. The table is private to
+   * the wave: no barriers, LDS operations of a wave execute in order. */
+  __shared__ volatile int32_t cache_tag[CMI_BLOCK / 64][CMI_CACHE_SLOTS];
+  __shared__ volatile int32_t cache_owner[CMI_BLOCK / 64][CMI_CACHE_SLOTS];
+  __shared__ double cache_val[CMI_BLOCK / 64]
+                             [(HEAT ? 2 : 1) * CMI_CACHE_SLOTS];
+  const int wib = threadIdx.x >> 6;
+#define CMI_TAG(k) cache_tag[wib][k]
+#define CMI_OWNER(k) cache_owner[wib][k]
+#define CMI_VAL(k) cache_val[wib][k]
+/* compiler barrier: LDS values written by other lanes must be re-read */
+#define CMI_LDS_FENCE() asm volatile("" ::: "memory")
+  if (!FULL) {
+    for (int k = lane; k < CMI_CACHE_SLOTS; k += 64)
+      CMI_TAG(k) = -1;
+  }
+  /* add (v0[, v1]) to `cell` through the cache; called by all 64 lanes, lanes
+   * with add == false only take part in the wave-uniform control flow */
+  auto cache_add = [&](bool add, int32_t cell, double v0, double v1) {
+    const uint32_t slot =
+        ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_CACHE_BITS);
+    const int32_t t = add ? CMI_TAG(slot) : -2;
+    const bool hit = add && (t == cell);
+    if (hit) {
+      atomicAdd(&CMI_VAL(slot), v0); /* ds_add_f64 */
+      if (HEAT)
+        atomicAdd(&CMI_VAL(CMI_CACHE_SLOTS + slot), v1);
+    }
+    const bool miss = add && !hit;
+    if (__ballot(miss) != 0ull) {
+      /* several missing lanes can map to one slot: the last writer owns it */
+      if (miss)
+        CMI_OWNER(slot) = lane;
+      const bool winner = miss && (CMI_OWNER(slot) == lane);
+      if (winner) {
+        if (t >= 0) {
+          /* evict the resident cell: this is where HBM sees an atomic */
+          CMI_LDS_FENCE();
+          const double old0 = CMI_VAL(slot);
+          atomic_add_f64(a.cells.acc[ION_H_n] + t, old0);
+          if (HEAT) {
+            const double old1 = CMI_VAL(CMI_CACHE_SLOTS + slot);
+            atomic_add_f64(a.cells.acc[CMI_NION] + t, old1);
+          }
+          natomics += HEAT ? 2 : 1;
+        }
+        CMI_VAL(slot) = v0;
+        if (HEAT)
+          CMI_VAL(CMI_CACHE_SLOTS + slot) = v1;
+        CMI_TAG(slot) = cell;
+        CMI_LDS_FENCE();
+      } else if (miss) {
+        /* lost the slot to another lane in the same step: add directly */
+        atomic_add_f64(a.cells.acc[ION_H_n] + cell, v0);
+        if (HEAT)
+          atomic_add_f64(a.cells.acc[CMI_NION] + cell, v1);
+        natomics += HEAT ? 2 : 1;
+      }
+    }
+  };
 
   for (;;) {
     const unsigned long long active_mask = __ballot(active);
@@ -165,90 +303,120 @@ __global__ void __launch_bounds__(CMI_BLOCK)
         const uint64_t i = pos + rank;
         const uint64_t id = a.order ? (uint64_t)a.order[i] : i;
         rng.init(a.seed, a.iteration, a.first_packet + id);
-        emit_packet(a.grid, a.model, rng, p);
+        emit_packet<FULL, EXACT>(a.grid, a.model, rng, p);
         active = true;
         last_cell = -1;
       }
       const uint64_t taken = __popcll(idle_mask);
       pos += taken < avail ? taken : avail;
     }
+    /* more positions left for this wave (in this or a later chunk)? */
+    const uint64_t avail_after =
+        (pos_end - pos) + (chunk_begin + nwaves * chunk < a.n_packets ? 1 : 0);
 
-    /* ---- one DDA step for every lane that can take one ---- */
-    const bool inside = active && is_inside(a.grid, p);
-    const bool stepping = inside && p.tau > 0.;
-    double ds = 0.;
-    bool accumulate = false;
-    if (stepping) {
-      double2 kappa;
-      ds = dda_step(a.grid, a.cells.opacity, p, last_cell, kappa);
-      ++nsteps;
-      accumulate = (kappa.x >= 0.); /* number density > 0 */
-    }
-    if (!a.exp_no_atomics) {
-      if (AGG && !FULL) {
-        /* lanes in the same cell: one atomic for the whole run */
-        const int32_t key = accumulate ? (int32_t)last_cell : ~lane;
-        const double dsw = accumulate ? ds * p.weight : 0.;
-        bool tail;
-        if (HEAT) {
-          double v[2] = {dsw * p.sigma_H,
-                         dsw * p.sigma_H * (p.nu - a.model.nu_H)};
-          run_sums<2>(key, v, tail);
-          if (tail && accumulate) {
-            atomic_add_f64(a.cells.acc[ION_H_n] + last_cell, v[0]);
-            atomic_add_f64(a.cells.acc[CMI_NION] + last_cell, v[1]);
-            natomics += 2;
-          }
-        } else {
-          double v[1] = {dsw * p.sigma_H};
-          run_sums<1>(key, v, tail);
-          if (tail && accumulate) {
-            atomic_add_f64(a.cells.acc[ION_H_n] + last_cell, v[0]);
-            natomics += 1;
-          }
-        }
-      } else if (accumulate) {
-        update_integrals<FULL, HEAT>(a, p, last_cell, ds);
-        natomics += (FULL ? CMI_NION : 1) + (HEAT ? (FULL ? 2 : 1) : 0);
-      }
-    }
-
-    if (active) {
-      bool absorbed = false, done = false;
+    /* ---- hot loop: march until the wave is due for a refill (or done) ---- */
+    unsigned long long still_active;
+    do {
+      /* ---- one DDA step for every lane that can take one ---- */
+      const bool inside =
+          active && (EXACT ? is_inside(a.grid, p) : (p.inside != 0));
+      const bool stepping = inside && p.tau > 0.;
+      double ds = 0.;
+      bool accumulate = false;
       if (stepping) {
-        /* tau < 0: absorbed inside last_cell (the index was not advanced, so
-         * the packet is still inside the box) */
-        absorbed = (p.tau < 0.);
-      } else if (inside) {
-        /* tau hit 0 exactly on a wall, packet still inside: interact()
-         * returns the last traversed cell */
-        absorbed = (last_cell >= 0);
-        done = !absorbed;
-      } else {
-        done = true; /* left the box: DensityGrid::end() */
+        double2 kappa;
+        ds = EXACT ? dda_step(a.grid, a.cells.opacity, p, last_cell, kappa)
+                   : fast_step(a.grid, a.cells.opacity, p, last_cell, kappa);
+        ++nsteps;
+        accumulate = (kappa.x >= 0.); /* number density > 0 */
       }
-      if (absorbed) {
-        /* PhotonSource::reemit, src/PhotonSource.cpp:272-308 */
-        bool again = false;
-        if (REEMIT) {
-          again = reemit_packet(a.grid, a.model, a.cells, last_cell, rng, p);
-        } else {
-          p.type = TYPE_ABSORBED;
+      if (!a.exp_no_atomics) {
+        if (a.aggregate) {
+          /* lanes in the same cell: one atomic for the whole run */
+          const int32_t key = accumulate ? (int32_t)last_cell : ~lane;
+          if (FULL) {
+            aggregate_full<FULL, HEAT>(a, p, key, accumulate, last_cell, ds,
+                                       natomics);
+          } else {
+            const double dsw = accumulate ? ds * p.weight : 0.;
+            bool tail;
+            if (HEAT) {
+              double v[2] = {dsw * p.sigma_H,
+                             dsw * p.sigma_H * (p.nu - a.model.nu_H)};
+              run_sums<2>(key, v, tail);
+              cache_add(tail && accumulate, (int32_t)last_cell, v[0], v[1]);
+            } else {
+              double v[1] = {dsw * p.sigma_H};
+              run_sums<1>(key, v, tail);
+              cache_add(tail && accumulate, (int32_t)last_cell, v[0], 0.);
+            }
+          }
+        } else if (accumulate) {
+          update_integrals<FULL, HEAT>(a, p, last_cell, ds);
+          natomics += (FULL ? CMI_NION : 1) + (HEAT ? (FULL ? 2 : 1) : 0);
         }
-        last_cell = -1;
-        done = !again;
       }
-      if (done) {
-        tw += p.weight;
-        tc0 += (p.type == TYPE_PRIMARY) ? p.weight : 0.;
-        tc1 += (p.type == TYPE_DIFFUSE_HI) ? p.weight : 0.;
-        tc2 += (p.type == TYPE_DIFFUSE_HeI) ? p.weight : 0.;
-        tc3 += (p.type == TYPE_ABSORBED) ? p.weight : 0.;
-        active = false;
+
+      if (active) {
+        bool absorbed = false, done = false;
+        if (stepping) {
+          /* tau < 0: absorbed inside last_cell (the index was not advanced, so
+           * the packet is still inside the box) */
+          absorbed = (p.tau < 0.);
+        } else if (inside) {
+          /* tau hit 0 exactly on a wall, packet still inside: interact()
+           * returns the last traversed cell */
+          absorbed = (last_cell >= 0);
+          done = !absorbed;
+        } else {
+          done = true; /* left the box: DensityGrid::end() */
+        }
+        if (absorbed) {
+          /* PhotonSource::reemit, src/PhotonSource.cpp:272-308 */
+          bool again = false;
+          if (REEMIT) {
+            again = reemit_packet<FULL, EXACT>(a.grid, a.model, a.cells,
+                                               last_cell, rng, p);
+          } else {
+            p.type = TYPE_ABSORBED;
+          }
+          last_cell = -1;
+          done = !again;
+        }
+        if (done) {
+          tw += p.weight;
+          tc0 += (p.type == TYPE_PRIMARY) ? p.weight : 0.;
+          tc1 += (p.type == TYPE_DIFFUSE_HI) ? p.weight : 0.;
+          tc2 += (p.type == TYPE_DIFFUSE_HeI) ? p.weight : 0.;
+          tc3 += (p.type == TYPE_ABSORBED) ? p.weight : 0.;
+          active = false;
+        }
+      }
+
+      still_active = __ballot(active);
+    } while (still_active != 0ull &&
+             (avail_after == 0 ||
+              __popcll(~still_active) < a.refill_threshold));
+  }
+  if (!FULL) {
+    /* write the wave's resident partial sums back */
+    for (int k = lane; k < CMI_CACHE_SLOTS; k += 64) {
+      const int32_t t = CMI_TAG(k);
+      CMI_LDS_FENCE();
+      if (t >= 0) {
+        atomic_add_f64(a.cells.acc[ION_H_n] + t, CMI_VAL(k));
+        if (HEAT)
+          atomic_add_f64(a.cells.acc[CMI_NION] + t,
+                         CMI_VAL(CMI_CACHE_SLOTS + k));
+        natomics += HEAT ? 2 : 1;
       }
     }
   }
 
+#undef CMI_TAG
+#undef CMI_OWNER
+#undef CMI_VAL
+#undef CMI_LDS_FENCE
   /* IonizationPhotonShootJobMarket::update_counters */
   tw = wave_sum(tw);
   tc0 = wave_sum(tc0);
@@ -478,7 +646,7 @@ __global__ void emit_probe_kernel(const GridDev grid, const ModelDev model,
   PacketRng rng;
   rng.init(seed, iteration, first + i);
   Packet<true> p;
-  emit_packet(grid, model, rng, p);
+  emit_packet<true, true>(grid, model, rng, p);
   for (int a = 0; a < 3; ++a) {
     position[3 * i + a] = p.pos[a];
     direction[3 * i + a] = p.dir[a];
@@ -489,6 +657,7 @@ __global__ void emit_probe_kernel(const GridDev grid, const ModelDev model,
   tau[i] = p.tau;
 }
 
+template <bool EXACT>
 __global__ void trace_probe_kernel(const GridDev grid, const double2 *opacity,
                                    uint64_t n, const double *position,
                                    const double *direction, const double *tau,
@@ -511,13 +680,14 @@ __global__ void trace_probe_kernel(const GridDev grid, const double2 *opacity,
   p.sigma_H = sigma_H[i];
   p.sigma_He_corr = sigma_He_corr[i];
   p.weight = 1.;
-  locate_cell(grid, p);
+  start_flight<false, EXACT>(grid, p);
   int32_t steps = 0;
   int64_t last = -1;
-  while (is_inside(grid, p) && p.tau > 0.) {
+  while ((EXACT ? is_inside(grid, p) : (p.inside != 0)) && p.tau > 0.) {
     int64_t cell;
     double2 kappa;
-    const double ds = dda_step(grid, opacity, p, cell, kappa);
+    const double ds = EXACT ? dda_step(grid, opacity, p, cell, kappa)
+                            : fast_step(grid, opacity, p, cell, kappa);
     last = cell;
     if (steps < max_steps) {
       out_cell[(uint64_t)max_steps * i + steps] = cell;
@@ -525,8 +695,10 @@ __global__ void trace_probe_kernel(const GridDev grid, const double2 *opacity,
     }
     ++steps;
   }
-  if (!is_inside(grid, p))
+  if (!(EXACT ? is_inside(grid, p) : (p.inside != 0)))
     last = -1;
+  if (!EXACT)
+    end_flight(p);
   out_nsteps[i] = steps;
   out_last_cell[i] = last;
   for (int a = 0; a < 3; ++a)

@@ -229,6 +229,9 @@ int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
  *   "refill_threshold" (64) idle lanes of a wave that trigger a refill
  *   "chunk" (256)           consecutive packets a wave takes at a time
  *   "max_blocks_per_cu" (8), "max_packets_per_launch" (2^27)
+ *   "exact_dda" (0)         march with the reference's per-step arithmetic
+ *                           (bit-identical path lengths) instead of the
+ *                           incremental marcher (equal up to rounding)
  *   "exp_no_atomics" (0)    EXPERIMENT ONLY: skip the accumulation */
 int cmi_gpu_set_tuning(cmi_gpu_engine *engine, const char *key, int64_t value);
 
@@ -252,7 +255,7 @@ int cmi_gpu_emit_packets(cmi_gpu_engine *engine, uint32_t seed,
  * to max_steps (cell, ds) pairs are written to out_cell/out_ds
  * [n][max_steps]; out_nsteps [n]; out_last_cell [n] (-1 = left the box);
  * out_position [n][3] final position. Does NOT touch the accumulators.
- * Synchronous. */
+ * Uses the marcher selected by the "exact_dda" tuning knob. Synchronous. */
 int cmi_gpu_trace_packets(cmi_gpu_engine *engine, uint64_t n,
                           const double *position, const double *direction,
                           const double *tau, const double *sigma_H,

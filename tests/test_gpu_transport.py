@@ -68,14 +68,18 @@ def random_field(ncell, seed):
     return xH, dens
 
 
+@pytest.mark.parametrize("exact", [1, 0])
 @pytest.mark.parametrize("ncell", [16, 33])
-def test_dda_traces_bit_exact(oracle, ncell):
-    """Identical (position, direction, tau, sigma) -> identical cell lists and
-    bit-identical path lengths (CartesianDensityGrid::interact)."""
+def test_dda_traces(oracle, ncell, exact):
+    """Identical (position, direction, tau, sigma) -> identical cell lists.
+    exact_dda=1 (the reference's per-step arithmetic): bit-identical path
+    lengths. exact_dda=0 (incremental marcher, the default): path lengths
+    within 1e-12 x cellside."""
     import ctypes as C
     from cmacionize_amd import STROMGREN as S
     xH, dens = random_field(ncell, 1)
     eng = make_engine(ncell, xH=xH, density=dens)
+    eng.set_tuning(exact_dda=exact)
     sim = oracle.stromgren_simulation(ncell)
     sim.number_density[:] = dens
     sim.x[0] = xH
@@ -129,9 +133,13 @@ def test_dda_traces_bit_exact(oracle, ncell):
         # the engine multiplies sigma by the pre-multiplied n*x record, the
         # reference by n and x separately: the optical depth (hence only the
         # LAST, shortened step) can differ by an ulp or two
-        assert np.array_equal(ds[i, :k - 1], td[:k - 1])
-        # (absolute error ~ eps * cell size: the shortened step is a difference)
         cellside = S["sides"][0] / ncell
+        if exact:
+            assert np.array_equal(ds[i, :k - 1], td[:k - 1])
+        else:
+            assert np.allclose(ds[i, :k - 1], td[:k - 1], rtol=0,
+                               atol=1e-12 * cellside)
+        # (absolute error ~ eps * cell size: the shortened step is a difference)
         assert abs(ds[i, k - 1] - td[k - 1]) <= 1e-12 * cellside
         assert np.allclose(final[i], list(ph.position), rtol=0,
                            atol=1e-12 * cellside)
@@ -145,6 +153,7 @@ def test_periodic_traces(oracle):
     from cmacionize_amd import STROMGREN as S
     ncell = 8
     eng = make_engine(ncell, periodic=(1, 0, 1))
+    eng.set_tuning(exact_dda=1)
     sim = oracle.stromgren_simulation(ncell)
     for a, f in enumerate((1, 0, 1)):
         sim.grid.periodic[a] = f
@@ -179,6 +188,37 @@ def test_periodic_traces(oracle):
         assert lc == last[i]
         assert np.array_equal(cells[i, :k], tc[:k])
         assert np.array_equal(ds[i, :k - 1], td[:k - 1])
+    eng.close()
+
+
+def test_periodic_traces_fast_marcher(oracle):
+    """The incremental marcher wraps indices and shifts the flight origin:
+    same cells and final (wrapped) positions as the exact marcher."""
+    from cmacionize_amd import STROMGREN as S
+    ncell = 8
+    eng = make_engine(ncell, periodic=(1, 1, 0))
+    rng = np.random.default_rng(12)
+    n = 200
+    pos = rng.uniform(-0.49, 0.49, (n, 3)) * S["sides"][0]
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    tau = np.full(n, 0.1)  # ~40 cells at 2.4e-3 per cell: crosses the box
+    sH = np.full(n, S["sigma_H"])
+    sHe = np.zeros(n)
+    out = []
+    for exact in (1, 0):
+        eng.set_tuning(exact_dda=exact)
+        out.append(eng.trace_packets(pos, d, tau, sH, sHe, 1500))
+    (c1, ds1, n1, l1, f1), (c0, ds0, n0, l0, f0) = out
+    assert np.array_equal(n1, n0) and np.array_equal(l1, l0)
+    assert n1.max() > 3 * ncell  # the paths do wrap around
+    cellside = S["sides"][0] / ncell
+    for i in range(n):
+        k = min(n1[i], 1500)
+        assert np.array_equal(c1[i, :k], c0[i, :k])
+        assert np.allclose(ds1[i, :k], ds0[i, :k], rtol=0,
+                           atol=1e-11 * cellside)
+    assert np.allclose(f1, f0, rtol=0, atol=1e-10 * cellside)
     eng.close()
 
 
@@ -257,9 +297,10 @@ def test_tuning_does_not_change_results():
                dict(sort_packets=1, aggregate=1, refill_threshold=20,
                     chunk=64, max_packets_per_launch=30000),
                dict(sort_packets=0, aggregate=1, refill_threshold=1,
-                    chunk=1000, max_blocks_per_cu=1)):
+                    chunk=1000, max_blocks_per_cu=1),
+               dict(exact_dda=1)):
         base = dict(sort_packets=1, aggregate=1, refill_threshold=64,
-                    chunk=256, max_blocks_per_cu=8,
+                    chunk=256, max_blocks_per_cu=8, exact_dda=0,
                     max_packets_per_launch=1 << 27)
         base.update(kw)
         eng.set_tuning(**base)

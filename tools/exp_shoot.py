@@ -57,8 +57,9 @@ def main():
     for cfg in configs:
         kw = dict((k, int(v)) for k, v in
                   (item.split("=") for item in cfg.split(",")))
-        base = dict(sort_packets=1, aggregate=1, refill_threshold=16,
-                    chunk=1024, max_blocks_per_cu=8, exp_no_atomics=0)
+        base = dict(sort_packets=1, aggregate=1, refill_threshold=64,
+                    chunk=256, max_blocks_per_cu=8, exp_no_atomics=0,
+                    exact_dda=0)
         base.update(kw)
         eng.set_tuning(**base)
         times = []

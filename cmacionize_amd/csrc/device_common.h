@@ -160,9 +160,33 @@ struct CellsDev {
   double *number_density;
   double *temperature;
   double *x[CMI_NION];
-  double *acc[CMI_NACC]; /* 14 mean intensities + 2 heating terms */
+  /* accumulators: 14 mean intensities + 2 heating terms; element (field f,
+   * cell c) lives at acc_base[f * acc_field_stride + c * acc_cell_stride].
+   * SoA ([16][ncell]: strides ncell, 1) for H-only runs, AoS ([ncell][16]:
+   * strides 1, 16) when all 16 are updated per step */
+  double *acc_base;
+  int64_t acc_field_stride;
+  int64_t acc_cell_stride;
   /* transport record: {n * x_H, n * x_He}; .x < 0 marks a vacuum cell */
   double2 *opacity;
+};
+
+__host__ __device__ __forceinline__ double *acc_at(const CellsDev &cells,
+                                                   int field, int64_t cell) {
+  return cells.acc_base + field * cells.acc_field_stride +
+         cell * cells.acc_cell_stride;
+}
+
+/* Queue of re-emitted packets between two transport passes (SoA). An entry is
+ * a packet right after the re-emission decision: where it is, its new
+ * frequency and type, and how far its random stream has been consumed. */
+struct QueueDev {
+  double *pos[3];
+  double *nu;
+  uint32_t *id;   /* packet id relative to the launch's first packet */
+  uint32_t *meta; /* bits 0-23 rng blocks consumed, bit 24 rng cache valid,
+                     bits 28-31 photon type */
+  unsigned int *count;
 };
 
 /* packet counters accumulated by the transport kernel */

@@ -37,6 +37,20 @@ struct PacketRng {
     return ((double)bits + 0.5) * 0x1.0p-52;
   }
 
+  /* resume a stream that has consumed `block_` blocks; if `have_` the second
+   * double of block block_ - 1 is still unused and is regenerated */
+  __device__ __forceinline__ void resume(uint32_t seed_, uint32_t iteration_,
+                                         uint64_t packet, uint32_t block_,
+                                         uint32_t have_) {
+    init(seed_, iteration_, packet);
+    if (have_) {
+      block = block_ - 1;
+      (void)next(); /* regenerates the block, caches its second double */
+    } else {
+      block = block_;
+    }
+  }
+
   /* draw d of the packet = word pair (d & 1) of block d / 2; draws are
    * consumed strictly in order, so one cached double is enough */
   __device__ __forceinline__ double next() {

@@ -95,14 +95,14 @@ __device__ inline double physical_reemit(const ModelDev &m, double sigma_H,
   return new_frequency;
 }
 
-/* PhotonSource::reemit (src/PhotonSource.cpp:272-308): decide whether the
- * packet absorbed in `cell` is re-emitted as ionizing radiation; if so give it
- * a new frequency, direction, cross sections and optical depth
- * (src/IonizationPhotonShootJob.hpp:137-142). */
+/* First half of PhotonSource::reemit (src/PhotonSource.cpp:272-308): the
+ * handler's decision. Returns the new frequency (0 = the packet ends here) and
+ * sets p.type. On re-emission the packet's position is materialised: it is
+ * where the next flight starts. */
 template <bool FULL, bool EXACT>
-__device__ inline bool reemit_packet(const GridDev &g, const ModelDev &m,
-                                     const CellsDev &cells, int64_t cell,
-                                     PacketRng &rng, Packet<FULL> &p) {
+__device__ inline double reemit_decide(const ModelDev &m, const CellsDev &cells,
+                                       int64_t cell, PacketRng &rng,
+                                       Packet<FULL> &p) {
   double new_frequency;
   int32_t type;
   if (m.reemit_type == 2) {
@@ -117,24 +117,30 @@ __device__ inline bool reemit_packet(const GridDev &g, const ModelDev &m,
       new_frequency = 0.;
     }
   } else {
-    const double sigma_He =
-        FULL ? p.sigma[FULL ? ION_He_n : 0] : m.xsec_fixed[ION_He_n];
     new_frequency = physical_reemit(
-        m, p.sigma_H, sigma_He, cells.temperature[cell],
+        m, p.sigma_H, p.sigma_He, cells.temperature[cell],
         cells.x[ION_H_n][cell], cells.x[ION_He_n][cell], rng, type);
   }
   p.type = type;
-  if (new_frequency == 0.)
-    return false;
-  p.nu = new_frequency;
-  if (!EXACT)
+  if (new_frequency != 0. && !EXACT)
     end_flight(p); /* position of the absorption, along the OLD direction */
+  return new_frequency;
+}
+
+/* Second half of PhotonSource::reemit + IonizationPhotonShootJob::execute
+ * (src/PhotonSource.cpp:296-303, src/IonizationPhotonShootJob.hpp:139-141):
+ * new isotropic direction, cross sections at the new frequency, new optical
+ * depth; the flight starts from the cell that contains p.pos. */
+template <bool FULL, bool EXACT>
+__device__ inline void reemit_launch(const GridDev &g, const ModelDev &m,
+                                     double new_frequency, PacketRng &rng,
+                                     Packet<FULL> &p,
+                                     double (&weights)[CMI_NACC]) {
+  p.nu = new_frequency;
   random_direction(p, rng);
-  set_cross_sections(m, p);
+  set_cross_sections(m, p, weights);
   p.tau = -log(rng.next());
-  /* interact() starts from the cell that contains the packet's position */
   start_flight<FULL, EXACT>(g, p);
-  return true;
 }
 
 #endif

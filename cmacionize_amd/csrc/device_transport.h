@@ -41,7 +41,7 @@ template <bool FULL> struct Packet {
   double weight;
   double sigma_H;
   double sigma_He_corr; /* A_He * sigma_He */
-  double sigma[FULL ? CMI_NION : 1];
+  double sigma_He;      /* for the re-emission decision */
   /* FAST marcher */
   double t;         /* path parameter reached so far */
   double tmax[3];   /* parameter of the next wall crossing per axis */
@@ -70,23 +70,30 @@ __device__ __forceinline__ void random_direction(Packet<FULL> &p,
     p.inv_dir[a] = 1. / p.dir[a];
 }
 
-/* PhotonSource::set_cross_sections, src/PhotonSource.cpp:189-199 */
+/* PhotonSource::set_cross_sections, src/PhotonSource.cpp:189-199. The packet
+ * keeps only what the march needs (sigma_H, A_He sigma_He); the 16 per-step
+ * accumulation weights of DensityGrid::update_integrals
+ * (src/DensityGrid.hpp:162-173) - sigma_ion for the 14 ions, and
+ * sigma_H (nu - nu_H), sigma_He (nu - nu_He) for the two heating terms - are
+ * returned in `weights` for the caller to keep where it accumulates from. */
 template <bool FULL>
-__device__ __forceinline__ void set_cross_sections(const ModelDev &m,
-                                                   Packet<FULL> &p) {
+__device__ __forceinline__ void
+set_cross_sections(const ModelDev &m, Packet<FULL> &p,
+                   double (&weights)[CMI_NACC]) {
   if (FULL) {
-    double s[CMI_NION];
-    cmi_cross_sections(m, p.nu, s);
-#pragma unroll
-    for (int i = 0; i < CMI_NION; ++i)
-      p.sigma[FULL ? i : 0] = s[i];
-    p.sigma_H = s[ION_H_n];
-    p.sigma_He_corr = m.abundance[0] * s[ION_He_n];
+    cmi_cross_sections(m, p.nu, weights);
+    p.sigma_H = weights[ION_H_n];
+    p.sigma_He = weights[ION_He_n];
+    p.sigma_He_corr = m.abundance[0] * p.sigma_He;
+    weights[CMI_NION] = p.sigma_H * (p.nu - m.nu_H);
+    weights[CMI_NION + 1] = p.sigma_He * (p.nu - m.nu_He);
   } else {
     /* only reached with FixedValueCrossSections and sigma[1..13] == 0 */
     p.sigma_H = m.xsec_fixed[ION_H_n];
-    p.sigma_He_corr = m.abundance[0] * m.xsec_fixed[ION_He_n];
-    p.sigma[0] = p.sigma_H;
+    p.sigma_He = m.xsec_fixed[ION_He_n];
+    p.sigma_He_corr = m.abundance[0] * p.sigma_He;
+    weights[ION_H_n] = p.sigma_H;
+    weights[CMI_NION] = p.sigma_H * (p.nu - m.nu_H);
   }
 }
 
@@ -152,7 +159,8 @@ __device__ __forceinline__ void start_flight(const GridDev &g,
  * (src/PhotonSource.cpp:208-249, src/IonizationPhotonShootJob.hpp:119-135) */
 template <bool FULL, bool EXACT>
 __device__ inline void emit_packet(const GridDev &g, const ModelDev &m,
-                                   PacketRng &rng, Packet<FULL> &p) {
+                                   PacketRng &rng, Packet<FULL> &p,
+                                   double (&weights)[CMI_NACC]) {
   /* first uniform: continuous vs discrete source; no continuous source on
    * this path, so it is drawn and ignored */
   double x = rng.next();
@@ -166,7 +174,7 @@ __device__ inline void emit_packet(const GridDev &g, const ModelDev &m,
   random_direction(p, rng);
   p.nu = sample_source_spectrum(m, rng);
   p.type = TYPE_PRIMARY;
-  set_cross_sections(m, p);
+  set_cross_sections(m, p, weights);
   p.weight = 1.;
   p.tau = -log(rng.next());
   start_flight<FULL, EXACT>(g, p);

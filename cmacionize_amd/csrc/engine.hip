@@ -82,6 +82,12 @@ struct cmi_gpu_engine {
   size_t sort_temp_bytes = 0;
   uint64_t sort_capacity = 0;
 
+  /* re-emission queues (ping-pong) */
+  double *queue_block = nullptr;
+  uint64_t queue_capacity = 0;
+  QueueDev queue[2];
+  unsigned int *queue_counts = nullptr; /* [2] */
+
   struct Tuning {
     bool sort_packets = true;
     bool aggregate = true;
@@ -91,6 +97,10 @@ struct cmi_gpu_engine {
     uint64_t max_packets_per_launch = 1ull << 27;
     bool exp_no_atomics = false;
     bool exact_dda = false;
+    bool reemit_passes = true;
+    int refill_threshold_reemit = 16;
+    uint64_t reemit_inline_below = 4096;
+    int reemit_max_passes = 12;
   } tune;
 
   std::vector<EventPair> shoot_events, update_events;
@@ -110,7 +120,13 @@ double *field_pointer(cmi_gpu_engine *e, int field) {
   if (field < CMI_GPU_FIELD_MEAN_INTENSITY)
     return e->state_block + (int64_t)field * e->ncell;
   return e->acc_block + (int64_t)(field - CMI_GPU_FIELD_MEAN_INTENSITY) *
-                            e->ncell;
+                            e->cells.acc_field_stride;
+}
+
+/* element stride of a field: 1 for the state fields, the accumulator layout's
+ * cell stride for the accumulator fields */
+int64_t field_stride(cmi_gpu_engine *e, int field) {
+  return field < CMI_GPU_FIELD_MEAN_INTENSITY ? 1 : e->cells.acc_cell_stride;
 }
 
 /* lower the generated raw tables into the device layout, applying the unit
@@ -382,6 +398,21 @@ int ensure_spectra(cmi_gpu_engine *e) {
   return CMI_GPU_OK;
 }
 
+__global__ void gather_strided_kernel(const double *src, int64_t stride,
+                                      double *dst, int64_t n) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += step)
+    dst[i] = src[i * stride];
+}
+__global__ void scatter_strided_kernel(const double *src, double *dst,
+                                       int64_t stride, int64_t n) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += step)
+    dst[i * stride] = src[i];
+}
+
 int grid_blocks(cmi_gpu_engine *e, int64_t work_items, int blocks_per_cu) {
   int64_t want = (work_items + CMI_BLOCK - 1) / CMI_BLOCK;
   int64_t cap = (int64_t)e->num_cu * blocks_per_cu;
@@ -399,6 +430,17 @@ void update_full_flag(cmi_gpu_engine *e) {
       if (e->model.xsec_fixed[i] != 0.)
         full = true;
   e->full_ions = full;
+  /* accumulator layout follows the transport kernel: [16][ncell] when only
+   * hydrogen is accumulated (neighbouring cells share 64-B lines), [ncell][16]
+   * when every step updates all 16 values of a cell. The block is zeroed by
+   * every reset_grid, so switching between iterations is safe. */
+  if (full) {
+    e->cells.acc_field_stride = 1;
+    e->cells.acc_cell_stride = CMI_NACC;
+  } else {
+    e->cells.acc_field_stride = e->ncell;
+    e->cells.acc_cell_stride = 1;
+  }
 }
 
 int rebuild_opacity(cmi_gpu_engine *e) {
@@ -487,8 +529,9 @@ int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
   c.temperature = e->state_block + e->ncell;
   for (int i = 0; i < CMI_NION; ++i)
     c.x[i] = e->state_block + (int64_t)(2 + i) * e->ncell;
-  for (int i = 0; i < CMI_NACC; ++i)
-    c.acc[i] = e->acc_block + (int64_t)i * e->ncell;
+  c.acc_base = e->acc_block;
+  c.acc_field_stride = e->ncell; /* SoA until all 16 fields are in use */
+  c.acc_cell_stride = 1;
   c.opacity = e->opacity;
 
   ModelDev &m = e->model;
@@ -545,6 +588,8 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->source_cumulative);
   (void)hipFree(e->sort_keys[0]);
   (void)hipFree(e->sort_temp);
+  (void)hipFree(e->queue_block);
+  (void)hipFree(e->queue_counts);
   if (e->own_stream)
     (void)hipStreamDestroy(e->stream);
   delete e;
@@ -725,8 +770,26 @@ int cmi_gpu_upload_field(cmi_gpu_engine *e, int32_t field,
   if (!dst)
     return fail(CMI_GPU_EINVAL, "upload_field: unknown field %d", field);
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipMemcpyAsync(dst, values, (size_t)e->ncell * sizeof(double),
-                         hipMemcpyHostToDevice, e->stream));
+  const int64_t stride = field_stride(e, field);
+  if (stride == 1) {
+    HIP_TRY(hipMemcpyAsync(dst, values, (size_t)e->ncell * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+  } else {
+    double *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)e->ncell * sizeof(double)));
+    hipError_t err = hipMemcpyAsync(tmp, values,
+                                    (size_t)e->ncell * sizeof(double),
+                                    hipMemcpyHostToDevice, e->stream);
+    if (err == hipSuccess) {
+      scatter_strided_kernel<<<grid_blocks(e, e->ncell, 8), CMI_BLOCK, 0,
+                               e->stream>>>(tmp, dst, stride, e->ncell);
+      err = hipGetLastError();
+    }
+    if (err == hipSuccess)
+      err = hipStreamSynchronize(e->stream);
+    (void)hipFree(tmp);
+    HIP_TRY(err);
+  }
   if (field == CMI_GPU_FIELD_NUMBER_DENSITY ||
       field == CMI_GPU_FIELD_IONIC_FRACTION + ION_H_n ||
       field == CMI_GPU_FIELD_IONIC_FRACTION + ION_He_n) {
@@ -745,9 +808,36 @@ int cmi_gpu_download_field(cmi_gpu_engine *e, int32_t field, double *values) {
   if (!src)
     return fail(CMI_GPU_EINVAL, "download_field: unknown field %d", field);
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipMemcpyAsync(values, src, (size_t)e->ncell * sizeof(double),
-                         hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  const int64_t stride = field_stride(e, field);
+  if (stride == 1) {
+    HIP_TRY(hipMemcpyAsync(values, src, (size_t)e->ncell * sizeof(double),
+                           hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  } else {
+    double *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)e->ncell * sizeof(double)));
+    gather_strided_kernel<<<grid_blocks(e, e->ncell, 8), CMI_BLOCK, 0,
+                            e->stream>>>(src, stride, tmp, e->ncell);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess)
+      err = hipMemcpyAsync(values, tmp, (size_t)e->ncell * sizeof(double),
+                           hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess)
+      err = hipStreamSynchronize(e->stream);
+    (void)hipFree(tmp);
+    HIP_TRY(err);
+  }
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_accumulator_layout(cmi_gpu_engine *e, int64_t *field_stride_out,
+                               int64_t *cell_stride_out) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  if (field_stride_out)
+    *field_stride_out = e->cells.acc_field_stride;
+  if (cell_stride_out)
+    *cell_stride_out = e->cells.acc_cell_stride;
   return CMI_GPU_OK;
 }
 
@@ -789,6 +879,15 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
     e->tune.exp_no_atomics = value != 0;
   else if (k == "exact_dda")
     e->tune.exact_dda = value != 0;
+  else if (k == "reemit_passes")
+    e->tune.reemit_passes = value != 0;
+  else if (k == "refill_threshold_reemit")
+    e->tune.refill_threshold_reemit =
+        (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
+  else if (k == "reemit_inline_below")
+    e->tune.reemit_inline_below = (uint64_t)(value < 0 ? 0 : value);
+  else if (k == "reemit_max_passes")
+    e->tune.reemit_max_passes = (int)(value < 1 ? 1 : value);
   else
     return fail(CMI_GPU_EINVAL, "set_tuning: unknown key '%s'", key);
   return CMI_GPU_OK;
@@ -815,6 +914,32 @@ static int reserve_sort_buffers(cmi_gpu_engine *e, uint64_t n) {
   e->sort_temp_bytes = bytes;
   HIP_TRY(hipMalloc(&e->sort_temp, bytes ? bytes : 16));
   e->sort_capacity = n;
+  return CMI_GPU_OK;
+}
+
+/* make sure the two re-emission queues hold n packets each */
+static int reserve_queues(cmi_gpu_engine *e, uint64_t n) {
+  if (e->queue_capacity >= n)
+    return CMI_GPU_OK;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(e->queue_block);
+  e->queue_block = nullptr;
+  e->queue_capacity = 0;
+  /* per queue: 4 double arrays + 2 uint32 arrays = 5 doubles per packet */
+  HIP_TRY(hipMalloc(&e->queue_block, sizeof(double) * 10 * n));
+  if (!e->queue_counts) {
+    HIP_TRY(hipMalloc(&e->queue_counts, 2 * sizeof(unsigned int)));
+  }
+  for (int q = 0; q < 2; ++q) {
+    double *base = e->queue_block + (size_t)q * 5 * n;
+    for (int a = 0; a < 3; ++a)
+      e->queue[q].pos[a] = base + (size_t)a * n;
+    e->queue[q].nu = base + (size_t)3 * n;
+    e->queue[q].id = (uint32_t *)(base + (size_t)4 * n);
+    e->queue[q].meta = e->queue[q].id + n;
+    e->queue[q].count = e->queue_counts + q;
+  }
+  e->queue_capacity = n;
   return CMI_GPU_OK;
 }
 
@@ -881,6 +1006,14 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     if (rc)
       return rc;
   }
+  const bool passes = reemit && e->tune.reemit_passes;
+  if (passes) {
+    int rc = reserve_queues(e, n_packets < max_launch ? n_packets : max_launch);
+    if (rc)
+      return rc;
+  }
+  const QueueDev no_queue = {{nullptr, nullptr, nullptr}, nullptr, nullptr,
+                             nullptr, nullptr};
   /* bits of the sort key in use: 22 direction bits + the source index */
   int key_bits = 22;
   for (int s = e->model.nsource - 1; s > 0; s >>= 1)
@@ -905,6 +1038,13 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     a.refill_threshold = e->tune.refill_threshold;
     a.exp_no_atomics = e->tune.exp_no_atomics ? 1 : 0;
     a.aggregate = agg ? 1 : 0;
+    a.qin = no_queue;
+    a.qout = no_queue;
+    if (passes) {
+      HIP_TRY(hipMemsetAsync(e->queue_counts, 0, 2 * sizeof(unsigned int),
+                             e->stream));
+      a.qout = e->queue[0];
+    }
 
     EventPair ev;
     HIP_TRY(hipEventCreate(&ev.start));
@@ -938,6 +1078,41 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       blocks = 1;
     kernel<<<(unsigned)blocks, CMI_BLOCK, 0, e->stream>>>(a);
     HIP_TRY(hipGetLastError());
+    /* later generations: the re-emitted packets of the previous pass. Their
+     * flights start all over the grid in random directions, so these passes
+     * refill eagerly instead of keeping ray bundles together. */
+    for (int gen = 0; passes; ++gen) {
+      unsigned int count = 0;
+      HIP_TRY(hipMemcpyAsync(&count, e->queue[gen & 1].count,
+                             sizeof(unsigned int), hipMemcpyDeviceToHost,
+                             e->stream));
+      HIP_TRY(hipStreamSynchronize(e->stream));
+      if (count == 0)
+        break;
+      const bool last = count < e->tune.reemit_inline_below ||
+                        gen + 2 >= e->tune.reemit_max_passes;
+      ShootArgs b = a;
+      b.order = nullptr;
+      b.n_packets = count;
+      b.refill_threshold = e->tune.refill_threshold_reemit;
+      b.qin = e->queue[gen & 1];
+      b.qout = last ? no_queue : e->queue[(gen + 1) & 1];
+      if (!last)
+        HIP_TRY(hipMemsetAsync(e->queue[(gen + 1) & 1].count, 0,
+                               sizeof(unsigned int), e->stream));
+      const uint64_t nch = ((uint64_t)count + b.chunk - 1) / b.chunk;
+      int64_t nb = (int64_t)e->num_cu * blocks_per_cu;
+      const int64_t nneed =
+          (int64_t)((nch + (CMI_BLOCK / 64) - 1) / (CMI_BLOCK / 64));
+      if (nb > nneed)
+        nb = nneed;
+      if (nb < 1)
+        nb = 1;
+      kernel<<<(unsigned)nb, CMI_BLOCK, 0, e->stream>>>(b);
+      HIP_TRY(hipGetLastError());
+      if (last)
+        break;
+    }
     HIP_TRY(hipEventRecord(ev.stop, e->stream));
     e->shoot_events.push_back(ev);
   }

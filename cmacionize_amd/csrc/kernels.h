@@ -50,32 +50,25 @@ struct ShootArgs {
   int32_t refill_threshold;
   int32_t exp_no_atomics; /* experiment: skip the accumulation */
   int32_t aggregate;      /* cross-lane run sums before the atomics */
+  /* re-emission in passes: qin.id != NULL: this launch continues the packets
+   * of qin instead of emitting new ones; qout.id != NULL: packets that are
+   * re-emitted are parked in qout instead of being followed in place */
+  QueueDev qin, qout;
 };
 
-/* update_integrals, src/DensityGrid.hpp:150-197: every crossed non-vacuum
- * cell receives ds * w * sigma_ion for each ion, and the two heating terms. */
-template <bool FULL, bool HEAT>
-__device__ __forceinline__ void update_integrals(const ShootArgs &a,
-                                                 const Packet<FULL> &p,
-                                                 int64_t cell, double ds) {
-  const double dsw = ds * p.weight;
-  if (FULL) {
-#pragma unroll
-    for (int i = 0; i < CMI_NION; ++i)
-      atomic_add_f64(a.cells.acc[i] + cell, dsw * p.sigma[FULL ? i : 0]);
-    if (HEAT) {
-      atomic_add_f64(a.cells.acc[CMI_NION] + cell,
-                     dsw * p.sigma[ION_H_n] * (p.nu - a.model.nu_H));
-      atomic_add_f64(a.cells.acc[CMI_NION + 1] + cell,
-                     dsw * p.sigma[FULL ? ION_He_n : 0] *
-                         (p.nu - a.model.nu_He));
-    }
-  } else {
-    atomic_add_f64(a.cells.acc[ION_H_n] + cell, dsw * p.sigma_H);
-    if (HEAT)
-      atomic_add_f64(a.cells.acc[CMI_NION] + cell,
-                     dsw * p.sigma_H * (p.nu - a.model.nu_H));
-  }
+/* update_integrals, src/DensityGrid.hpp:150-197, hydrogen-only form without
+ * cross-lane aggregation: the crossed non-vacuum cell receives ds * w *
+ * sigma_H, and the hydrogen heating term. */
+template <bool HEAT>
+__device__ __forceinline__ void update_integrals_H(const ShootArgs &a,
+                                                   double sigma_H, double nu,
+                                                   double weight, int64_t cell,
+                                                   double ds) {
+  const double dsw = ds * weight;
+  atomic_add_f64(acc_at(a.cells, ION_H_n, cell), dsw * sigma_H);
+  if (HEAT)
+    atomic_add_f64(acc_at(a.cells, CMI_NION, cell),
+                   dsw * sigma_H * (nu - a.model.nu_H));
 }
 
 /* DPP lane moves (gfx9 family): no LDS round trip, VALU latency only.
@@ -133,42 +126,61 @@ __device__ __forceinline__ void run_sums(int32_t key, double (&v)[N],
 #undef CMI_SCAN_ROUND
 }
 
-/* cross-lane sums of the 14 mean-intensity terms (+2 heating terms) of lanes
- * in the same cell, four values per scan to bound the register footprint */
-template <bool FULL, bool HEAT>
+/* FULL mode (all 14 ions + 2 heating terms per step): update_integrals as a
+ * cooperative, transposed accumulation. A lane's 16 accumulation weights
+ * (sigma_ion, sigma (nu - nu_0)) are constants of its packet and live in LDS,
+ * [lane][16]; per step only ds * w changes. Runs of consecutive lanes in the
+ * same cell are found with one neighbour compare; then 16 lanes per run - one
+ * per accumulator - sum  ds_l w_l * weight[l][i]  over the run's lanes out of
+ * LDS and issue the atomic. With the accumulators stored [cell][16] (AoS,
+ * 128 B per cell) one wave instruction adds 4 cells x 16 values as four
+ * contiguous 128-B segments = 8 memory-side 64-B requests instead of 64:
+ * float atomics execute at the memory side in 64-B requests and their count,
+ * not the bytes, bounds this kernel. (A 16-value segmented scan costs ~10x
+ * the instructions of this form.) */
+struct FullStage {
+  double weight[64][CMI_NACC];
+  double dsw[64];
+  int32_t start[65];
+  int32_t cell[64];
+};
+
+template <bool HEAT>
 __device__ __forceinline__ void
-aggregate_full(const ShootArgs &a, const Packet<FULL> &p, int32_t key,
-               bool accumulate, int64_t cell, double ds,
-               unsigned int &natomics) {
-  const double dsw = accumulate ? ds * p.weight : 0.;
-  bool tail;
-#pragma unroll
-  for (int g4 = 0; g4 < CMI_NION; g4 += 4) {
-    double v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      v[k] = (g4 + k < CMI_NION) ? dsw * p.sigma[FULL ? (g4 + k < CMI_NION ? g4 + k : 0) : 0] : 0.;
-    if (g4 + 4 > CMI_NION && HEAT) {
-      /* last group: ions 12, 13 and the two heating terms */
-      v[2] = dsw * p.sigma[ION_H_n] * (p.nu - a.model.nu_H);
-      v[3] = dsw * p.sigma[FULL ? ION_He_n : 0] * (p.nu - a.model.nu_He);
-    }
-    run_sums<4>(key, v, tail);
-    if (tail && accumulate) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (g4 + k < CMI_NION) {
-          atomic_add_f64(a.cells.acc[g4 + k] + cell, v[k]);
-          ++natomics;
-        }
-      }
-      if (g4 + 4 > CMI_NION && HEAT) {
-        atomic_add_f64(a.cells.acc[CMI_NION] + cell, v[2]);
-        atomic_add_f64(a.cells.acc[CMI_NION + 1] + cell, v[3]);
-        natomics += 2;
+accumulate_full(const ShootArgs &a, FullStage &st, bool aggregate,
+                bool accumulate, int32_t cell, double dsw,
+                unsigned int &natomics) {
+  const int lane = threadIdx.x & 63;
+  const int32_t key = accumulate ? cell : ~lane;
+  const int32_t prev = dpp_i32<CMI_DPP_WAVE_SHR1, 0xf>(key);
+  const bool head = (lane == 0) || (key != prev) || !aggregate;
+  const unsigned long long heads = __ballot(head);
+  const int run = __popcll(heads & ((2ull << lane) - 1ull)) - 1;
+  const int nruns = __popcll(heads);
+  st.dsw[lane] = accumulate ? dsw : 0.;
+  if (head) {
+    st.start[run] = lane;
+    st.cell[run] = accumulate ? cell : -1;
+  }
+  if (lane == 0)
+    st.start[nruns] = 64;
+  asm volatile("" ::: "memory"); /* written by other lanes: re-read */
+  const int i = lane & 15;
+  for (int e0 = 0; e0 < nruns; e0 += 4) {
+    const int e = e0 + (lane >> 4);
+    if (e < nruns) {
+      const int32_t c = st.cell[e];
+      if (c >= 0 && (HEAT || i < CMI_NION)) {
+        const int l1 = st.start[e + 1];
+        double sum = 0.;
+        for (int l = st.start[e]; l < l1; ++l)
+          sum += st.dsw[l] * st.weight[l][i];
+        atomic_add_f64(acc_at(a.cells, i, c), sum);
+        ++natomics;
       }
     }
   }
+  asm volatile("" ::: "memory");
 }
 
 /*
@@ -208,6 +220,7 @@ __global__ void __launch_bounds__(CMI_BLOCK)
 
   Packet<FULL> p;
   PacketRng rng;
+  uint32_t packet_id = 0;
   bool active = false;
   int64_t last_cell = -1;
 
@@ -224,11 +237,15 @@ __global__ void __launch_bounds__(CMI_BLOCK)
    * bundle of neighbouring rays, so consecutive steps (and the next bundle of
    * the wave's chunk) keep hitting the same few cells. The table is private to
    * the wave: no barriers, LDS operations of a wave execute in order. */
-  __shared__ volatile int32_t cache_tag[CMI_BLOCK / 64][CMI_CACHE_SLOTS];
-  __shared__ volatile int32_t cache_owner[CMI_BLOCK / 64][CMI_CACHE_SLOTS];
-  __shared__ double cache_val[CMI_BLOCK / 64]
-                             [(HEAT ? 2 : 1) * CMI_CACHE_SLOTS];
+  constexpr int cache_slots = FULL ? 64 : CMI_CACHE_SLOTS; /* unused if FULL */
+  __shared__ volatile int32_t cache_tag[CMI_BLOCK / 64][cache_slots];
+  __shared__ volatile int32_t cache_owner[CMI_BLOCK / 64][cache_slots];
+  __shared__ double cache_val[CMI_BLOCK / 64][(HEAT ? 2 : 1) * cache_slots];
   const int wib = threadIdx.x >> 6;
+  /* FULL: per-wave accumulation weights and per-step scratch in LDS */
+  __shared__ FullStage full_stage[FULL ? CMI_BLOCK / 64 : 1];
+  FullStage &stage = full_stage[FULL ? wib : 0];
+  double weights[CMI_NACC];
 #define CMI_TAG(k) cache_tag[wib][k]
 #define CMI_OWNER(k) cache_owner[wib][k]
 #define CMI_VAL(k) cache_val[wib][k]
@@ -261,10 +278,10 @@ __global__ void __launch_bounds__(CMI_BLOCK)
           /* evict the resident cell: this is where HBM sees an atomic */
           CMI_LDS_FENCE();
           const double old0 = CMI_VAL(slot);
-          atomic_add_f64(a.cells.acc[ION_H_n] + t, old0);
+          atomic_add_f64(acc_at(a.cells, ION_H_n, t), old0);
           if (HEAT) {
             const double old1 = CMI_VAL(CMI_CACHE_SLOTS + slot);
-            atomic_add_f64(a.cells.acc[CMI_NION] + t, old1);
+            atomic_add_f64(acc_at(a.cells, CMI_NION, t), old1);
           }
           natomics += HEAT ? 2 : 1;
         }
@@ -275,9 +292,9 @@ __global__ void __launch_bounds__(CMI_BLOCK)
         CMI_LDS_FENCE();
       } else if (miss) {
         /* lost the slot to another lane in the same step: add directly */
-        atomic_add_f64(a.cells.acc[ION_H_n] + cell, v0);
+        atomic_add_f64(acc_at(a.cells, ION_H_n, cell), v0);
         if (HEAT)
-          atomic_add_f64(a.cells.acc[CMI_NION] + cell, v1);
+          atomic_add_f64(acc_at(a.cells, CMI_NION, cell), v1);
         natomics += HEAT ? 2 : 1;
       }
     }
@@ -301,9 +318,29 @@ __global__ void __launch_bounds__(CMI_BLOCK)
       const uint64_t rank = __popcll(idle_mask & lane_lt);
       if (!active && rank < avail) {
         const uint64_t i = pos + rank;
-        const uint64_t id = a.order ? (uint64_t)a.order[i] : i;
-        rng.init(a.seed, a.iteration, a.first_packet + id);
-        emit_packet<FULL, EXACT>(a.grid, a.model, rng, p);
+        if (REEMIT && a.qin.id != nullptr) {
+          /* continue a re-emitted packet of the previous pass */
+          packet_id = a.qin.id[i];
+          const uint32_t meta = a.qin.meta[i];
+          rng.resume(a.seed, a.iteration, a.first_packet + packet_id,
+                     meta & 0xffffffu, (meta >> 24) & 1u);
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax)
+            p.pos[ax] = a.qin.pos[ax][i];
+          p.type = (int32_t)(meta >> 28);
+          p.weight = 1.;
+          reemit_launch<FULL, EXACT>(a.grid, a.model, a.qin.nu[i], rng, p,
+                                     weights);
+        } else {
+          packet_id = a.order ? a.order[i] : (uint32_t)i;
+          rng.init(a.seed, a.iteration, a.first_packet + packet_id);
+          emit_packet<FULL, EXACT>(a.grid, a.model, rng, p, weights);
+        }
+        if (FULL) {
+#pragma unroll
+          for (int i = 0; i < CMI_NACC; ++i)
+            stage.weight[lane][i] = weights[i];
+        }
         active = true;
         last_cell = -1;
       }
@@ -331,13 +368,13 @@ __global__ void __launch_bounds__(CMI_BLOCK)
         accumulate = (kappa.x >= 0.); /* number density > 0 */
       }
       if (!a.exp_no_atomics) {
-        if (a.aggregate) {
+        if (FULL) {
+          accumulate_full<HEAT>(a, stage, a.aggregate != 0, accumulate,
+                                (int32_t)last_cell, ds * p.weight, natomics);
+        } else if (a.aggregate) {
           /* lanes in the same cell: one atomic for the whole run */
           const int32_t key = accumulate ? (int32_t)last_cell : ~lane;
-          if (FULL) {
-            aggregate_full<FULL, HEAT>(a, p, key, accumulate, last_cell, ds,
-                                       natomics);
-          } else {
+          {
             const double dsw = accumulate ? ds * p.weight : 0.;
             bool tail;
             if (HEAT) {
@@ -352,8 +389,8 @@ __global__ void __launch_bounds__(CMI_BLOCK)
             }
           }
         } else if (accumulate) {
-          update_integrals<FULL, HEAT>(a, p, last_cell, ds);
-          natomics += (FULL ? CMI_NION : 1) + (HEAT ? (FULL ? 2 : 1) : 0);
+          update_integrals_H<HEAT>(a, p.sigma_H, p.nu, p.weight, last_cell, ds);
+          natomics += HEAT ? 2 : 1;
         }
       }
 
@@ -371,17 +408,49 @@ __global__ void __launch_bounds__(CMI_BLOCK)
         } else {
           done = true; /* left the box: DensityGrid::end() */
         }
+        double new_frequency = 0.;
         if (absorbed) {
           /* PhotonSource::reemit, src/PhotonSource.cpp:272-308 */
-          bool again = false;
-          if (REEMIT) {
-            again = reemit_packet<FULL, EXACT>(a.grid, a.model, a.cells,
-                                               last_cell, rng, p);
-          } else {
+          if (REEMIT)
+            new_frequency = reemit_decide<FULL, EXACT>(a.model, a.cells,
+                                                       last_cell, rng, p);
+          else
             p.type = TYPE_ABSORBED;
-          }
           last_cell = -1;
-          done = !again;
+          done = (new_frequency == 0.);
+        }
+        if (REEMIT) {
+          const bool again = absorbed && new_frequency != 0.;
+          if (a.qout.id != nullptr) {
+            /* park the re-emitted packets for the next pass: their flights
+             * share nothing with this wave's ray bundle */
+            const unsigned long long parked = __ballot(again);
+            if (parked != 0ull) {
+              unsigned int base = 0;
+              if (lane == __ffsll((long long)parked) - 1)
+                base = atomicAdd(a.qout.count, (unsigned int)__popcll(parked));
+              base = __shfl(base, __ffsll((long long)parked) - 1, 64);
+              if (again) {
+                const unsigned int q = base + __popcll(parked & lane_lt);
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax)
+                  a.qout.pos[ax][q] = p.pos[ax];
+                a.qout.nu[q] = new_frequency;
+                a.qout.id[q] = packet_id;
+                a.qout.meta[q] = (rng.block & 0xffffffu) | (rng.have << 24) |
+                                 ((uint32_t)p.type << 28);
+                active = false; /* leaves this launch, not finished */
+              }
+            }
+          } else if (again) {
+            reemit_launch<FULL, EXACT>(a.grid, a.model, new_frequency, rng, p,
+                                       weights);
+            if (FULL) {
+#pragma unroll
+              for (int i = 0; i < CMI_NACC; ++i)
+                stage.weight[lane][i] = weights[i];
+            }
+          }
         }
         if (done) {
           tw += p.weight;
@@ -404,9 +473,9 @@ __global__ void __launch_bounds__(CMI_BLOCK)
       const int32_t t = CMI_TAG(k);
       CMI_LDS_FENCE();
       if (t >= 0) {
-        atomic_add_f64(a.cells.acc[ION_H_n] + t, CMI_VAL(k));
+        atomic_add_f64(acc_at(a.cells, ION_H_n, t), CMI_VAL(k));
         if (HEAT)
-          atomic_add_f64(a.cells.acc[CMI_NION] + t,
+          atomic_add_f64(acc_at(a.cells, CMI_NION, t),
                          CMI_VAL(CMI_CACHE_SLOTS + k));
         natomics += HEAT ? 2 : 1;
       }
@@ -506,21 +575,21 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     if (FULL) {
 #pragma unroll
       for (int i = 0; i < CMI_NION; ++i)
-        J[i] = a.cells.acc[i][c];
+        J[i] = (*acc_at(a.cells, i, c));
     } else {
-      J[0] = a.cells.acc[0][c];
+      J[0] = (*acc_at(a.cells, 0, c));
 #pragma unroll
       for (int i = 1; i < CMI_NION; ++i)
         J[i] = 0.;
     }
-    heating[0] = a.cells.acc[CMI_NION][c];
-    heating[1] = a.cells.acc[CMI_NION + 1][c];
+    heating[0] = (*acc_at(a.cells, CMI_NION, c));
+    heating[1] = (*acc_at(a.cells, CMI_NION + 1, c));
     cmi_ionization_state_cell(a.model, a.jfac, a.hfac, ntot, T, J, heating, x);
 #pragma unroll
     for (int i = 0; i < CMI_NION; ++i)
       a.cells.x[i][c] = x[i];
-    a.cells.acc[CMI_NION][c] = heating[0];
-    a.cells.acc[CMI_NION + 1][c] = heating[1];
+    (*acc_at(a.cells, CMI_NION, c)) = heating[0];
+    (*acc_at(a.cells, CMI_NION + 1, c)) = heating[1];
     a.cells.opacity[c] = (ntot > 0.)
                              ? make_double2(ntot * x[ION_H_n], ntot * x[ION_He_n])
                              : make_double2(-1., 0.);
@@ -541,11 +610,11 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     double J[CMI_NION], heating[2], x[CMI_NION];
 #pragma unroll
     for (int i = 0; i < CMI_NION; ++i) {
-      J[i] = a.cells.acc[i][c];
+      J[i] = (*acc_at(a.cells, i, c));
       x[i] = a.cells.x[i][c];
     }
-    heating[0] = a.cells.acc[CMI_NION][c];
-    heating[1] = a.cells.acc[CMI_NION + 1][c];
+    heating[0] = (*acc_at(a.cells, CMI_NION, c));
+    heating[1] = (*acc_at(a.cells, CMI_NION + 1, c));
     /* z of the cell midpoint, src/CartesianDensityGrid.hpp:85-89 */
     const int64_t iz = c % a.grid.ncell[2];
     const double zmid = (a.grid.anchor[2] + a.grid.cellside[2] * iz) +
@@ -555,8 +624,8 @@ __global__ void __launch_bounds__(CMI_BLOCK)
 #pragma unroll
     for (int i = 0; i < CMI_NION; ++i)
       a.cells.x[i][c] = x[i];
-    a.cells.acc[CMI_NION][c] = heating[0];
-    a.cells.acc[CMI_NION + 1][c] = heating[1];
+    (*acc_at(a.cells, CMI_NION, c)) = heating[0];
+    (*acc_at(a.cells, CMI_NION + 1, c)) = heating[1];
     a.cells.opacity[c] = (ntot > 0.)
                              ? make_double2(ntot * x[ION_H_n], ntot * x[ION_He_n])
                              : make_double2(-1., 0.);
@@ -646,14 +715,15 @@ __global__ void emit_probe_kernel(const GridDev grid, const ModelDev model,
   PacketRng rng;
   rng.init(seed, iteration, first + i);
   Packet<true> p;
-  emit_packet<true, true>(grid, model, rng, p);
+  double weights[CMI_NACC];
+  emit_packet<true, true>(grid, model, rng, p, weights);
   for (int a = 0; a < 3; ++a) {
     position[3 * i + a] = p.pos[a];
     direction[3 * i + a] = p.dir[a];
   }
   frequency[i] = p.nu;
   for (int k = 0; k < CMI_NION; ++k)
-    sigma[CMI_NION * i + k] = p.sigma[k];
+    sigma[CMI_NION * i + k] = weights[k];
   tau[i] = p.tau;
 }
 

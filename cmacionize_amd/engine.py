@@ -65,7 +65,7 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_get_counters", "cmi_gpu_update_cells", "cmi_gpu_emit_packets",
     "cmi_gpu_trace_packets", "cmi_gpu_get_timing", "cmi_gpu_set_tuning",
     "cmi_gpu_get_atomic_count", "cmi_gpu_sample_spectrum",
-    "cmi_gpu_thermal_probe",
+    "cmi_gpu_thermal_probe", "cmi_gpu_accumulator_layout",
 ]
 
 _lib = None
@@ -124,6 +124,8 @@ def load_library():
     L.cmi_gpu_get_atomic_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.cmi_gpu_sample_spectrum.argtypes = [vp, C.c_int32, C.c_double,
                                           C.c_uint32, C.c_uint64, _dp]
+    L.cmi_gpu_accumulator_layout.argtypes = [vp, C.POINTER(C.c_int64),
+                                             C.POINTER(C.c_int64)]
     L.cmi_gpu_thermal_probe.argtypes = [vp, C.c_int64, C.c_int32, _dp, _dp,
                                         _dp, _dp, _dp, _dp, _dp]
     _lib = L
@@ -244,6 +246,12 @@ class GpuEngine:
         out = np.empty(self.n)
         self._check(self._lib.cmi_gpu_download_field(self._h, field, _p(out)))
         return out
+
+    def accumulator_layout(self):
+        fs, cs = C.c_int64(), C.c_int64()
+        self._check(self._lib.cmi_gpu_accumulator_layout(
+            self._h, C.byref(fs), C.byref(cs)))
+        return fs.value, cs.value
 
     def field_device_pointer(self, field):
         return self._lib.cmi_gpu_field_device_pointer(self._h, field)

@@ -178,9 +178,17 @@ int cmi_gpu_upload_field(cmi_gpu_engine *engine, int32_t field,
  * (src/DensityGridWriter.hpp:96-124); host [ncell]; synchronous */
 int cmi_gpu_download_field(cmi_gpu_engine *engine, int32_t field,
                            double *values);
-/* device address of a field ([ncell] doubles); the 16 accumulator fields
- * (MEAN_INTENSITY+0..13, HEATING+0..1) are contiguous in that order */
+/* device address of the first element of a field. State fields are [ncell]
+ * contiguous doubles. The 16 accumulator fields (MEAN_INTENSITY+0..13,
+ * HEATING+0..1) share ONE contiguous block of 16 * ncell doubles starting at
+ * the pointer of MEAN_INTENSITY+0 - that block is what a multi-process caller
+ * sum-reduces; inside it element (field f, cell c) is at
+ * f * field_stride + c * cell_stride, with the strides reported by
+ * cmi_gpu_accumulator_layout ([16][ncell] for hydrogen-only transport,
+ * [ncell][16] when all ions are transported). */
 void *cmi_gpu_field_device_pointer(cmi_gpu_engine *engine, int32_t field);
+int cmi_gpu_accumulator_layout(cmi_gpu_engine *engine, int64_t *field_stride,
+                               int64_t *cell_stride);
 
 /* ------------------------------------------------- the iteration body -- */
 
@@ -229,6 +237,14 @@ int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
  *   "refill_threshold" (64) idle lanes of a wave that trigger a refill
  *   "chunk" (256)           consecutive packets a wave takes at a time
  *   "max_blocks_per_cu" (8), "max_packets_per_launch" (2^27)
+ *   "reemit_passes" (1)     with diffuse re-emission: park re-emitted packets
+ *                           in a queue and follow them in later passes of the
+ *                           kernel (keeps the primary ray bundles together);
+ *                           0 = follow them in place
+ *   "refill_threshold_reemit" (16), "reemit_inline_below" (4096),
+ *   "reemit_max_passes" (12)  refill threshold of the later passes; a pass
+ *                           with fewer packets than this, or the last allowed
+ *                           pass, follows re-emissions in place
  *   "exact_dda" (0)         march with the reference's per-step arithmetic
  *                           (bit-identical path lengths) instead of the
  *                           incremental marcher (equal up to rounding)

@@ -134,7 +134,14 @@ def test_temperature_solve_fixture(oracle):
     eng.close()
 
 
-def test_diffuse_stromgren_shoot_matches_oracle(oracle):
+@pytest.mark.parametrize("tuning", [
+    dict(reemit_passes=1),
+    dict(reemit_passes=0),
+    dict(reemit_passes=1, reemit_inline_below=0, reemit_max_passes=3,
+         refill_threshold_reemit=1, max_packets_per_launch=25000),
+    dict(reemit_passes=1, exact_dda=1, aggregate=0, sort_packets=0),
+])
+def test_diffuse_stromgren_shoot_matches_oracle(oracle, tuning):
     """benchmarks/stromgren_diffuse.param: physical re-emission with fixed
     cross sections (H branch only) - packets, counters and J against the
     oracle on the same seeds."""
@@ -143,6 +150,7 @@ def test_diffuse_stromgren_shoot_matches_oracle(oracle):
     ncell, npacket = 32, 60000
     eng = make_engine(ncell)
     eng.set_reemission(1)
+    eng.set_tuning(**tuning)
     sim = oracle.stromgren_simulation(ncell, diffuse=True)
     for loop in range(3):
         eng.reset_grid()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: photon packets/s on the 256^3 Stromgren problem.
+"""Benchmark of the hot path: photon packets/s on the 256^3 benchmark grids.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+                    [--config stromgren|stromgren_diffuse|lexington]
 
 One "step" is one full iteration of the reference's loop
 (src/IonizationSimulation.cpp:359-643) on every rank:
@@ -12,9 +13,13 @@ low-statistics iterations (the cost of a packet depends on how far it travels,
 so a fully ionised start would be a different workload from the one the
 metric is quoted on).
 
+The default config is the one BASELINE.json quotes the metric on
+(configs[1]: stromgren 256^3, 1e8 packets, H-only). --config selects the other
+single-GPU configs of the scope (configs[2], configs[3]).
+
 N > 1 is the replicated-grid mode of the reference's MPI path: every rank
 holds the whole grid and shoots `--packets` packets of its own (weak scaling),
-the [16][ncell] accumulator block is sum-reduced with one RCCL all-reduce.
+the [16 x ncell] accumulator block is sum-reduced with one RCCL all-reduce.
 """
 import argparse
 import json
@@ -28,39 +33,83 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-# algorithmic HBM bytes per DDA step, H-only fp64: 16 B cell
-# record read {n x_H, n x_He} + 8 B read + 8 B write of the J_H accumulator
-BYTES_PER_STEP_H_ONLY = 32.
+PC = 3.086e16
+LEXINGTON_ABUNDANCES = [0.1, 2.2e-4, 4.e-5, 3.3e-4, 5.e-5, 9.e-6]
+
+# algorithmic HBM bytes per DDA step: one 16 B
+# cell record {n x_H, n x_He} read + 8 B read + 8 B write per accumulator
+CONFIGS = {
+    "stromgren": dict(
+        name="stromgren.param", bytes_per_step=16. + 16. * 1, diffuse=False,
+        lexington=False, converge_iterations=12,
+        kernel="shoot_kernel<H-only, fast marcher>"),
+    "stromgren_diffuse": dict(
+        name="stromgren_diffuse.param", bytes_per_step=16. + 16. * 1,
+        diffuse=True, lexington=False, converge_iterations=12,
+        kernel="shoot_kernel<H-only, re-emission passes>"),
+    "lexington": dict(
+        name="lexingtonHII40.param", bytes_per_step=16. + 16. * 16,
+        diffuse=True, lexington=True, converge_iterations=8,
+        kernel="shoot_kernel<14 ions + heating, re-emission passes>"),
+}
 
 
-def setup_engine(backend, ncell):
+def setup_engine(backend, ncell, cfg):
     from cmacionize_amd import STROMGREN as S
     eng = backend.engine
-    eng.set_sources(S["source_position"], S["source_weight"], S["luminosity"])
-    eng.set_spectrum_monochromatic(S["frequency"])
-    sigma = np.zeros(14)
-    sigma[0] = S["sigma_H"]
-    alpha = np.zeros(14)
-    alpha[0] = S["alpha_H"]
-    eng.set_cross_sections_fixed(sigma)
-    eng.set_recombination_rates_fixed(alpha)
     n = ncell ** 3
     x = np.zeros((14, n))
-    x[0] = S["xH"]
-    x[1] = S["xHe"]
-    eng.upload_cells(np.full(n, S["density"]), np.full(n, S["temperature"]), x)
+    x[0] = 1.e-6
+    x[1] = 1.e-6
+    if not cfg["lexington"]:
+        eng.set_sources(S["source_position"], S["source_weight"],
+                        S["luminosity"])
+        eng.set_spectrum_monochromatic(S["frequency"])
+        sigma = np.zeros(14)
+        sigma[0] = S["sigma_H"]
+        alpha = np.zeros(14)
+        alpha[0] = S["alpha_H"]
+        eng.set_cross_sections_fixed(sigma)
+        eng.set_recombination_rates_fixed(alpha)
+        if cfg["diffuse"]:
+            eng.set_reemission(1)
+        eng.upload_cells(np.full(n, S["density"]),
+                         np.full(n, S["temperature"]), x)
+        return
+    # benchmarks/lexingtonHII40.param + .yml
+    eng.set_sources([[0., 0., 0.]], [1.], 4.26e49)
+    eng.set_spectrum_planck(40000.)
+    eng.set_cross_sections_verner()
+    eng.set_recombination_rates_verner()
+    eng.set_abundances(LEXINGTON_ABUNDANCES)
+    eng.set_reemission(1)
+    eng.set_temperature_params(do_temperature_calculation=1,
+                               pah_heating_factor=0.)
+    ax = -5. * PC + (np.arange(ncell) + 0.5) * (10. * PC / ncell)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    vacuum = (np.sqrt(X * X + Y * Y + Z * Z).ravel() <= 3.e16)
+    eng.upload_cells(np.where(vacuum, 0., 1.e8), np.where(vacuum, 0., 8000.),
+                     x)
 
 
-def cpu_baseline(ncell, xH, seconds=12.):
+def cpu_baseline(ncell, cfg, engine, seconds=12.):
     """The oracle's transport loop (OpenMP, all host cores) on a bounded
-    sample of the same workload: the converged x_H field of the GPU run."""
+    sample of the same workload: the converged state of the GPU run."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
+    from cmacionize_amd import engine as E
     oracle_lib.build()
-    sim = oracle_lib.stromgren_simulation(ncell, compact=True)
-    sim.x[0][:] = xH
+    if cfg["lexington"]:
+        sim = oracle_lib.lexington_simulation(ncell)
+        for ion in range(14):
+            sim.x[ion][:] = engine.download_field(E.FIELD_IONIC_FRACTION + ion)
+        sim.temperature[:] = engine.download_field(E.FIELD_TEMPERATURE)
+    else:
+        sim = oracle_lib.stromgren_simulation(ncell, diffuse=cfg["diffuse"],
+                                              compact=True)
+        sim.x[0][:] = engine.download_field(E.FIELD_IONIC_FRACTION)
     cores = oracle_lib.num_threads()
-    n = 20000 * cores
+    n = 10000 * cores
     t0 = time.perf_counter()
     sim.shoot(42, 1000, 0, n)
     dt = time.perf_counter() - t0
@@ -72,9 +121,9 @@ def cpu_baseline(ncell, xH, seconds=12.):
     dt = time.perf_counter() - t0
     return {"value": n2 / dt, "unit": "packets/s", "cores": cores,
             "kind": "port",
-            "sample": "%d packets on the converged %d^3 stromgren field, "
-                      "transport only, OpenMP C oracle, %.1f s" %
-                      (n2, ncell, dt)}
+            "sample": "%d packets on the converged %d^3 %s state, transport "
+                      "only, OpenMP C oracle, %.1f s" %
+                      (n2, ncell, cfg["name"], dt)}
 
 
 def main():
@@ -82,13 +131,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="stromgren", choices=sorted(CONFIGS))
     ap.add_argument("--ncell", type=int, default=256)
-    ap.add_argument("--packets", type=float, default=1e8,
-                    help="packets per rank per step")
-    ap.add_argument("--converge-iterations", type=int, default=12)
+    ap.add_argument("--packets", type=float, default=None,
+                    help="packets per rank per step (default 1e8; 2e7 for "
+                         "lexington)")
+    ap.add_argument("--converge-iterations", type=int, default=None)
     ap.add_argument("--converge-packets", type=float, default=1e7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.packets is None:
+        args.packets = 2e7 if cfg["lexington"] else 1e8
+    if args.converge_iterations is None:
+        args.converge_iterations = cfg["converge_iterations"]
 
     import torch
     from cmacionize_amd.simulation import GpuBackend, ReplicaIterationDriver
@@ -112,8 +168,8 @@ def main():
     ncell = args.ncell
     npk = int(args.packets)
     backend = GpuBackend((ncell,) * 3, S["anchor"], S["sides"], S["periodic"],
-                         device=local_rank, track_heating=False)
-    setup_engine(backend, ncell)
+                         device=local_rank, track_heating=cfg["lexington"])
+    setup_engine(backend, ncell, cfg)
     driver = ReplicaIterationDriver(backend, rank, world, dist)
 
     def barrier():
@@ -152,12 +208,23 @@ def main():
         total_packets = float(npk) * world * args.steps
         value = total_packets / elapsed
         shoot_s = timing["shoot_ms"] * 1e-3
-        launches = max(timing["shoot_launches"], 1)
+        # the transport kernel alone (HIP events around each launch on the
+        # engine's stream); shoot_ms also holds the packet ordering kernels
+        kernel_s = timing["kernel_ms"] * 1e-3
+        launches = max(timing["kernel_launches"], 1)
         # DDA steps executed by THIS rank's launches (nsteps is the global sum)
         steps_per_launch = nsteps_total / world / launches
-        achieved = (steps_per_launch * BYTES_PER_STEP_H_ONLY /
-                    (shoot_s / launches)) / 1e9
+        achieved = (steps_per_launch * cfg["bytes_per_step"] /
+                    (kernel_s / launches)) / 1e9
         xH = backend.engine.download_field(E.FIELD_IONIC_FRACTION)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath)).get(args.config)
+            if tj and tj.get("ncell") == ncell:
+                # bytes per DDA step measured with rocprofv3 --pmc (separate
+                # passes, profiles/README.md), scaled to this launch
+                traffic = (tj["hbm_bytes_per_dda_step"] * steps_per_launch)
         out = {
             "metric": "photon packets/sec, 256^3 stromgren",
             "value": value,
@@ -172,10 +239,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "stromgren.param %d^3 grid, %.0e packets per GPU "
-                            "per iteration, H-only, converged ionization "
-                            "state; step = reset + shoot + reduce + cell "
-                            "update" % (ncell, npk),
+                "workload": "%s %d^3 grid, %.0e packets per GPU per "
+                            "iteration, converged ionization state; step = "
+                            "reset + shoot + reduce + cell update" %
+                            (cfg["name"], ncell, npk),
                 "parallelism": "replica x%d (sum all-reduce of accumulators)"
                                % world,
             },
@@ -190,15 +257,18 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "shoot_kernel<H-only>",
-                "kernel_avg_ms": 1e3 * shoot_s / launches,
-                "bytes_per_dda_step": BYTES_PER_STEP_H_ONLY,
+                "traffic": traffic,
+                "kernel": cfg["kernel"],
+                "kernel_avg_ms": 1e3 * kernel_s / launches,
+                "kernel_launches": launches,
+                "bytes_per_dda_step": cfg["bytes_per_step"],
                 "dda_steps_per_launch": steps_per_launch,
             },
         }
+        if args.config != "stromgren":
+            out["metric"] = "photon packets/sec, 256^3 " + args.config
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ncell, xH)
+            out["cpu_baseline"] = cpu_baseline(ncell, cfg, backend.engine)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

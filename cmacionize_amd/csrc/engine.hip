@@ -103,7 +103,7 @@ struct cmi_gpu_engine {
     int reemit_max_passes = 12;
   } tune;
 
-  std::vector<EventPair> shoot_events, update_events;
+  std::vector<EventPair> shoot_events, update_events, kernel_events;
 };
 
 namespace {
@@ -1076,8 +1076,14 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       blocks = need;
     if (blocks < 1)
       blocks = 1;
+    EventPair kev;
+    HIP_TRY(hipEventCreate(&kev.start));
+    HIP_TRY(hipEventCreate(&kev.stop));
+    HIP_TRY(hipEventRecord(kev.start, e->stream));
     kernel<<<(unsigned)blocks, CMI_BLOCK, 0, e->stream>>>(a);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(kev.stop, e->stream));
+    e->kernel_events.push_back(kev);
     /* later generations: the re-emitted packets of the previous pass. Their
      * flights start all over the grid in random directions, so these passes
      * refill eagerly instead of keeping ray bundles together. */
@@ -1108,8 +1114,14 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         nb = nneed;
       if (nb < 1)
         nb = 1;
+      EventPair gev;
+      HIP_TRY(hipEventCreate(&gev.start));
+      HIP_TRY(hipEventCreate(&gev.stop));
+      HIP_TRY(hipEventRecord(gev.start, e->stream));
       kernel<<<(unsigned)nb, CMI_BLOCK, 0, e->stream>>>(b);
       HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(gev.stop, e->stream));
+      e->kernel_events.push_back(gev);
       if (last)
         break;
     }
@@ -1431,9 +1443,33 @@ int cmi_gpu_get_timing(cmi_gpu_engine *e, int32_t reset, double *shoot_ms,
       (void)hipEventDestroy(p.start);
       (void)hipEventDestroy(p.stop);
     }
+    for (auto &p : e->kernel_events) {
+      (void)hipEventDestroy(p.start);
+      (void)hipEventDestroy(p.stop);
+    }
     e->shoot_events.clear();
     e->update_events.clear();
+    e->kernel_events.clear();
   }
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_get_kernel_timing(cmi_gpu_engine *e, double *kernel_ms,
+                              uint64_t *kernel_launches) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  double k = 0.;
+  for (auto &p : e->kernel_events) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p.start, p.stop));
+    k += ms;
+  }
+  if (kernel_ms)
+    *kernel_ms = k;
+  if (kernel_launches)
+    *kernel_launches = e->kernel_events.size();
   return CMI_GPU_OK;
 }
 

@@ -66,6 +66,7 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_trace_packets", "cmi_gpu_get_timing", "cmi_gpu_set_tuning",
     "cmi_gpu_get_atomic_count", "cmi_gpu_sample_spectrum",
     "cmi_gpu_thermal_probe", "cmi_gpu_accumulator_layout",
+    "cmi_gpu_get_kernel_timing",
 ]
 
 _lib = None
@@ -120,6 +121,7 @@ def load_library():
         _dp]
     L.cmi_gpu_get_timing.argtypes = [vp, C.c_int32, _dp, C.POINTER(C.c_uint64),
                                      _dp, C.POINTER(C.c_uint64)]
+    L.cmi_gpu_get_kernel_timing.argtypes = [vp, _dp, C.POINTER(C.c_uint64)]
     L.cmi_gpu_set_tuning.argtypes = [vp, C.c_char_p, C.c_int64]
     L.cmi_gpu_get_atomic_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.cmi_gpu_sample_spectrum.argtypes = [vp, C.c_int32, C.c_double,
@@ -343,10 +345,15 @@ class GpuEngine:
     def get_timing(self, reset=True):
         s = C.c_double()
         u = C.c_double()
+        k = C.c_double()
         ns = C.c_uint64()
         nu = C.c_uint64()
+        nk = C.c_uint64()
+        self._check(self._lib.cmi_gpu_get_kernel_timing(
+            self._h, C.byref(k), C.byref(nk)))
         self._check(self._lib.cmi_gpu_get_timing(
             self._h, int(reset), C.byref(s), C.byref(ns), C.byref(u),
             C.byref(nu)))
         return {"shoot_ms": s.value, "shoot_launches": ns.value,
-                "update_ms": u.value, "update_launches": nu.value}
+                "update_ms": u.value, "update_launches": nu.value,
+                "kernel_ms": k.value, "kernel_launches": nk.value}

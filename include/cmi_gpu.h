@@ -203,7 +203,10 @@ int cmi_gpu_reset_grid(cmi_gpu_engine *engine);
  * numbers from Philox4x32-10(counter = {p, draw block}, key = {seed,
  * iteration}), so any partition of the packet range over calls / devices
  * gives the same packets. Accumulates into the mean-intensity (+heating)
- * fields and the counters. Asynchronous. */
+ * fields and the counters. Asynchronous on the engine's stream without
+ * re-emission; with re-emission passes (tuning reemit_passes = 1, the
+ * default) the host reads the size of each generation's queue of re-emitted
+ * packets back, so the call returns when the last generation is queued. */
 int cmi_gpu_shoot(cmi_gpu_engine *engine, uint32_t seed, uint32_t iteration,
                   uint64_t first_packet, uint64_t n_packets);
 
@@ -304,11 +307,19 @@ int cmi_gpu_thermal_probe(cmi_gpu_engine *engine, int64_t n, int32_t solve,
                           const double *number_density, double *out_fractions,
                           double *out_temperature, double *out_pair);
 
-/* Device time (HIP events on the engine's stream) spent in the transport and
- * cell-update kernels since the last call with reset != 0. Synchronous. */
+/* Device time (HIP events on the engine's stream) spent in cmi_gpu_shoot
+ * (packet ordering + every transport launch of a batch; shoot_launches counts
+ * batches) and in the cell-update kernels since the last call with
+ * reset != 0. Synchronous. */
 int cmi_gpu_get_timing(cmi_gpu_engine *engine, int32_t reset,
                        double *shoot_ms, uint64_t *shoot_launches,
                        double *update_ms, uint64_t *update_launches);
+
+/* Device time of the transport kernel alone (HIP events around each
+ * shoot_kernel launch, one per re-emission generation) since the last
+ * cmi_gpu_get_timing(reset != 0). Synchronous. */
+int cmi_gpu_get_kernel_timing(cmi_gpu_engine *engine, double *kernel_ms,
+                              uint64_t *kernel_launches);
 
 #ifdef __cplusplus
 }

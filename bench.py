@@ -41,15 +41,15 @@ LEXINGTON_ABUNDANCES = [0.1, 2.2e-4, 4.e-5, 3.3e-4, 5.e-5, 9.e-6]
 CONFIGS = {
     "stromgren": dict(
         name="stromgren.param", bytes_per_step=16. + 16. * 1, diffuse=False,
-        lexington=False, converge_iterations=12,
+        lexington=False, converge_iterations=20,
         kernel="shoot_kernel<H-only, fast marcher>"),
     "stromgren_diffuse": dict(
         name="stromgren_diffuse.param", bytes_per_step=16. + 16. * 1,
-        diffuse=True, lexington=False, converge_iterations=12,
+        diffuse=True, lexington=False, converge_iterations=20,
         kernel="shoot_kernel<H-only, re-emission passes>"),
     "lexington": dict(
         name="lexingtonHII40.param", bytes_per_step=16. + 16. * 16,
-        diffuse=True, lexington=True, converge_iterations=8,
+        diffuse=True, lexington=True, converge_iterations=12,
         kernel="shoot_kernel<14 ions + heating, re-emission passes>"),
 }
 
@@ -178,11 +178,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # bring the grid to the converged state (untimed)
+    # bring the grid to the converged state (untimed); rank 0 follows the
+    # ionized volume fraction for the iterations-to-converge figure
+    # (first iteration after which V(x_H < 0.5) / V_box changes
+    # by less than 1 % between consecutive iterations)
     loop = 0
+    volume = []
     for _ in range(args.converge_iterations):
         driver.iteration(loop, int(args.converge_packets) * world, 42)
         loop += 1
+        if rank == 0:
+            xH = backend.engine.download_field(E.FIELD_IONIC_FRACTION)
+            volume.append(float((xH < 0.5).mean()))
+    converged_at = None
+    for k in range(1, len(volume)):
+        if volume[k] > 0. and \
+                abs(volume[k] - volume[k - 1]) < 0.01 * volume[k]:
+            converged_at = k + 1  # 1-based count of iterations run
+            break
     # in the timed region every rank shoots npk packets: global = npk * world
     for _ in range(args.warmup):
         driver.iteration(loop, npk * world, 42)
@@ -251,6 +264,14 @@ def main():
             "cell_update_ms_per_step": timing["update_ms"] /
             max(timing["update_launches"], 1),
             "ionized_volume_fraction": float((xH < 0.5).mean()),
+            "iterations_to_converge": {
+                "value": converged_at,
+                "criterion": "first iteration whose ionized volume fraction "
+                             "V(x_H<0.5)/V_box is within 1 % of the previous "
+                             "iteration's",
+                "packets_per_iteration": args.converge_packets * world,
+                "ionized_volume_fraction_by_iteration": volume,
+            },
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,

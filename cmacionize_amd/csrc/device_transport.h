@@ -45,9 +45,12 @@ template <bool FULL> struct Packet {
   /* FAST marcher */
   double t;         /* path parameter reached so far */
   double tmax[3];   /* parameter of the next wall crossing per axis */
-  double tdelta[3]; /* parameter distance between walls per axis */
+  double tdelta[3]; /* parameter distance between walls (0 if dir == 0) */
   int32_t cell;     /* long index of the current cell */
-  int32_t inside;
+  int32_t cstep[3]; /* change of the long index when the axis advances */
+  int32_t rem[3];   /* cells left before the box face in the travel direction;
+                     * negative = the packet has left through that face */
+  /* EXACT marcher */
   int32_t index[3];
   int32_t type;
 };
@@ -138,8 +141,11 @@ __device__ __forceinline__ void start_flight(const GridDev &g,
                                              Packet<FULL> &p) {
   locate_cell(g, p);
   if (!EXACT) {
-    p.inside = is_inside(g, p) ? 1 : 0;
+    /* a start outside a non-periodic box ends the flight at once
+     * (is_inside(), :187-227); periodic axes wrap the start position */
+    const bool inside = is_inside(g, p);
     p.t = 0.;
+    const int32_t stride[3] = {g.ncell[1] * g.ncell[2], g.ncell[2], 1};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double lo = g.anchor[a] + g.cellside[a] * p.index[a];
@@ -148,8 +154,13 @@ __device__ __forceinline__ void start_flight(const GridDev &g,
           (p.dir[a] > 0.)
               ? (hi - p.pos[a]) * p.inv_dir[a]
               : ((p.dir[a] < 0.) ? (lo - p.pos[a]) * p.inv_dir[a] : DBL_MAX);
-      p.tdelta[a] = g.cellside[a] * fabs(p.inv_dir[a]);
+      /* an axis the packet does not move along never ties the minimum */
+      p.tdelta[a] = (p.dir[a] != 0.) ? g.cellside[a] * fabs(p.inv_dir[a]) : 0.;
+      p.cstep[a] = (p.dir[a] > 0.) ? stride[a] : -stride[a];
+      p.rem[a] = (p.dir[a] > 0.) ? g.ncell[a] - 1 - p.index[a] : p.index[a];
     }
+    if (!inside)
+      p.rem[0] = -1;
     p.cell = (p.index[0] * g.ncell[1] + p.index[1]) * g.ncell[2] + p.index[2];
   }
 }
@@ -234,51 +245,78 @@ __device__ __forceinline__ double dda_step(const GridDev &g,
   return ds;
 }
 
-/* FAST: the same loop iteration in incremental form. Precondition: p.inside
- * and tau > 0. On absorption (tau < 0 on return) p.t is the parameter of the
- * absorption point; call end_flight() to get the position. */
+/* FAST marcher: has the packet left the box? */
 template <bool FULL>
-__device__ __forceinline__ double fast_step(const GridDev &g,
-                                            const double2 *__restrict__ opacity,
-                                            Packet<FULL> &p, int64_t &cell,
+__device__ __forceinline__ bool fast_outside(const Packet<FULL> &p) {
+  return (p.rem[0] | p.rem[1] | p.rem[2]) < 0;
+}
+
+/* v_min_f64 without the canonicalisation the compiler wraps around fmin() in
+ * IEEE mode (the operands are never NaN here) */
+__device__ __forceinline__ double min_f64(double x, double y) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ double max_f64(double x, double y) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+
+/* FAST: the same loop iteration in incremental form, written without
+ * branches on the common path. Precondition: not outside and tau > 0. Returns
+ * the path length in `cell`. Afterwards tau < 0 means absorbed in `cell` at
+ * parameter p.t (the marcher state has still advanced to the wall - it is not
+ * read again, end_flight() / a new start_flight() follow); otherwise the
+ * packet is on the wall, in p.cell, or outside (fast_outside()). Periodic
+ * wrapping is left to fast_wrap(), which the caller runs when any axis of the
+ * grid is periodic. */
+template <bool FULL>
+__device__ __forceinline__ double fast_step(const double2 *__restrict__ opacity,
+                                            Packet<FULL> &p, int32_t &cell,
                                             double2 &kappa) {
   cell = p.cell;
-  kappa = opacity[p.cell];
-  const double tmin = fmin(p.tmax[0], fmin(p.tmax[1], p.tmax[2]));
+  kappa = *reinterpret_cast<const double2 *>(
+      reinterpret_cast<const char *>(opacity) + ((uint32_t)p.cell << 4));
+  const double tmin = min_f64(p.tmax[0], min_f64(p.tmax[1], p.tmax[2]));
   double ds = tmin - p.t;
-  const double kH = fmax(kappa.x, 0.);
-  const double tau_cell = ds * (p.sigma_H * kH + p.sigma_He_corr * kappa.y);
+  /* kappa = {n x_H, n x_He}; a negative .x marks vacuum */
+  const double kH = max_f64(kappa.x, 0.);
+  const double tau_cell =
+      FULL ? ds * (p.sigma_H * kH + p.sigma_He_corr * kappa.y)
+           : ds * (p.sigma_H * kH);
   p.tau -= tau_cell;
+  const double t_old = p.t;
+  p.t = tmin;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const bool hit = (p.tmax[a] == tmin); /* every tied axis advances */
+    /* tmax + 1.0 * tdelta and tmax + 0.0 * tdelta, both exact */
+    p.tmax[a] = __fma_rn(hit ? 1. : 0., p.tdelta[a], p.tmax[a]);
+    p.cell += hit ? p.cstep[a] : 0;
+    p.rem[a] -= hit ? 1 : 0;
+  }
   if (p.tau < 0.) {
     ds += ds * p.tau / tau_cell; /* Scorr */
-    p.t += ds;
-  } else {
-    p.t = tmin;
-    bool inside = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (p.tmax[a] == tmin) { /* every tied axis advances */
-        const int32_t s = (p.dir[a] > 0.) ? 1 : -1;
-        int32_t i = p.index[a] + s;
-        p.tmax[a] += p.tdelta[a];
-        if (i < 0 || i >= g.ncell[a]) {
-          if (g.periodic[a]) {
-            /* is_inside(): wrap the index and shift the position by a box
-             * side - here the flight origin, so that origin + t * dir stays
-             * the wrapped position */
-            i -= s * g.ncell[a];
-            p.pos[a] -= s * g.box_sides[a];
-          } else {
-            inside = false;
-          }
-        }
-        p.index[a] = i;
-      }
-    }
-    p.inside = inside ? 1 : 0;
-    p.cell = (p.index[0] * g.ncell[1] + p.index[1]) * g.ncell[2] + p.index[2];
+    p.t = t_old + ds;
   }
   return ds;
+}
+
+/* FAST: is_inside() for periodic axes - wrap the cell index and shift the
+ * flight's origin by a box side, so that origin + t * dir stays the wrapped
+ * position (src/CartesianDensityGrid.cpp:187-227) */
+template <bool FULL>
+__device__ __forceinline__ void fast_wrap(const GridDev &g, Packet<FULL> &p) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (g.periodic[a] && p.rem[a] < 0) {
+      p.cell -= p.cstep[a] * g.ncell[a];
+      p.rem[a] = g.ncell[a] - 1;
+      p.pos[a] -= (p.cstep[a] > 0 ? 1. : -1.) * g.box_sides[a];
+    }
+  }
 }
 
 /* FAST: materialise the current position (end of a flight) */

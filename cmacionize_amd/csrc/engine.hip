@@ -90,9 +90,10 @@ struct cmi_gpu_engine {
 
   struct Tuning {
     bool sort_packets = true;
-    bool aggregate = true;
+    int aggregate = CMI_AGG_BLOCK;      /* first generation (sorted bundles) */
+    int aggregate_reemit = CMI_AGG_RUNS; /* later generations (random flights) */
     int refill_threshold = CMI_REFILL_THRESHOLD;
-    uint32_t chunk = 256;
+    uint32_t chunk = 64;
     int max_blocks_per_cu = 8;
     uint64_t max_packets_per_launch = 1ull << 27;
     bool exp_no_atomics = false;
@@ -865,7 +866,9 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
   if (k == "sort_packets")
     e->tune.sort_packets = value != 0;
   else if (k == "aggregate")
-    e->tune.aggregate = value != 0;
+    e->tune.aggregate = (int)(value < 0 ? 0 : (value > 3 ? 3 : value));
+  else if (k == "aggregate_reemit")
+    e->tune.aggregate_reemit = (int)(value < 0 ? 0 : (value > 3 ? 3 : value));
   else if (k == "refill_threshold")
     e->tune.refill_threshold = (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
   else if (k == "chunk")
@@ -966,7 +969,8 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   /* cross-lane aggregation keys and the fast marcher use 32-bit cell
    * indices */
   const bool small_grid = e->ncell < (1ll << 31);
-  const bool agg = e->tune.aggregate && small_grid;
+  const int agg = small_grid ? e->tune.aggregate : CMI_AGG_NONE;
+  const int agg_reemit = small_grid ? e->tune.aggregate_reemit : CMI_AGG_NONE;
   const bool exact = e->tune.exact_dda || !small_grid;
   void (*kernel)(const ShootArgs) = nullptr;
 #define PICK(F, H, R, X)                                                       \
@@ -1037,7 +1041,7 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     a.iteration = iteration;
     a.refill_threshold = e->tune.refill_threshold;
     a.exp_no_atomics = e->tune.exp_no_atomics ? 1 : 0;
-    a.aggregate = agg ? 1 : 0;
+    a.aggregate = agg;
     a.qin = no_queue;
     a.qout = no_queue;
     if (passes) {
@@ -1101,6 +1105,7 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       b.order = nullptr;
       b.n_packets = count;
       b.refill_threshold = e->tune.refill_threshold_reemit;
+      b.aggregate = agg_reemit;
       b.qin = e->queue[gen & 1];
       b.qout = last ? no_queue : e->queue[(gen + 1) & 1];
       if (!last)

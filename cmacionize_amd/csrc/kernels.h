@@ -12,6 +12,15 @@
 /* slots of a wave's write-combining cache for accumulator updates */
 #define CMI_CACHE_BITS 8
 #define CMI_CACHE_SLOTS (1 << CMI_CACHE_BITS)
+/* slots of a block's combining table (aggregate mode 3) */
+#define CMI_TABLE_BITS 11
+#define CMI_TABLE_SLOTS (1 << CMI_TABLE_BITS)
+#define CMI_TABLE_PROBES 4
+/* a.aggregate: what happens to a step's contributions before HBM sees them */
+#define CMI_AGG_NONE 0  /* one atomic per lane and step */
+#define CMI_AGG_RUNS 1  /* cross-lane run sums, one atomic per run */
+#define CMI_AGG_WAVE 2  /* + per-wave write-combining cache in LDS */
+#define CMI_AGG_BLOCK 3 /* + per-block combining table in LDS */
 /* idle lanes of a wave are refilled with new packets once this many of them
  * are waiting (or when the whole wave is idle). 64 = a wave always carries one
  * group of 64 direction-sorted packets: its lanes stay in the same cells, so
@@ -49,7 +58,7 @@ struct ShootArgs {
   uint32_t iteration;
   int32_t refill_threshold;
   int32_t exp_no_atomics; /* experiment: skip the accumulation */
-  int32_t aggregate;      /* cross-lane run sums before the atomics */
+  int32_t aggregate;      /* CMI_AGG_* */
   /* re-emission in passes: qin.id != NULL: this launch continues the packets
    * of qin instead of emitting new ones; qout.id != NULL: packets that are
    * re-emitted are parked in qout instead of being followed in place */
@@ -72,15 +81,19 @@ __device__ __forceinline__ void update_integrals_H(const ShootArgs &a,
 }
 
 /* DPP lane moves (gfx9 family): no LDS round trip, VALU latency only.
- * Lanes without a source lane keep their own value (bound_ctrl = 0). */
+ * dpp_keep: lanes without a source lane keep `old`; dpp_zero: they read 0. */
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_i32(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+__device__ __forceinline__ int dpp_keep(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
 }
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = dpp_i32<CTRL, ROW_MASK>(__double2loint(v));
-  const int hi = dpp_i32<CTRL, ROW_MASK>(__double2hiint(v));
+__device__ __forceinline__ int dpp_zero(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_zero_f64(double v) {
+  const int lo = dpp_zero<CTRL, ROW_MASK>(__double2loint(v));
+  const int hi = dpp_zero<CTRL, ROW_MASK>(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
 #define CMI_DPP_ROW_SHR(n) (0x110 + (n))
@@ -92,37 +105,34 @@ __device__ __forceinline__ double dpp_f64(double v) {
 /* Sum `v` over runs of consecutive lanes that hold the same `key`: segmented
  * inclusive scan in the 6 DPP rounds of a wave64 scan (row_shr 1, 2, 4, 8
  * inside each row of 16 lanes, then row_bcast15 into rows 1 and 3 and
- * row_bcast31 into rows 2 and 3). The flag of a lane says "a run starts inside
- * the prefix I have summed so far"; a lane adds the incoming partial sum only
- * while its flag is clear. On return the LAST lane of every run holds the
- * run's total and is flagged in `tail`. Must be called by all 64 lanes. */
+ * row_bcast31 into rows 2 and 3). `stop` of a lane says "a run starts inside
+ * the window I have summed so far"; a lane adds the incoming partial sum only
+ * while it is clear - as v = fma(stop ? 0 : 1, incoming, v), which is the
+ * exactly rounded sum or v itself. Lanes a round has no source for read
+ * zeros, which change neither v nor stop. On return the LAST lane of every run
+ * holds the run's total and is flagged in `tail`. Must be called by all 64
+ * lanes. */
 template <int N>
 __device__ __forceinline__ void run_sums(int32_t key, double (&v)[N],
                                          bool &tail) {
-  const int lane = threadIdx.x & 63;
-  const int32_t prev = dpp_i32<CMI_DPP_WAVE_SHR1, 0xf>(key);
-  const int32_t next = dpp_i32<CMI_DPP_WAVE_SHL1, 0xf>(key);
-  int flag = (lane == 0) || (key != prev); /* run starts here */
-  tail = (lane == 63) || (key != next);
-#define CMI_SCAN_ROUND(CTRL, ROW_MASK, COND)                                   \
+  /* lane 0 / lane 63 have no neighbour: they keep ~key, which differs */
+  const int32_t prev = dpp_keep<CMI_DPP_WAVE_SHR1, 0xf>(~key, key);
+  const int32_t next = dpp_keep<CMI_DPP_WAVE_SHL1, 0xf>(~key, key);
+  int stop = (key != prev) ? 1 : 0; /* run starts here */
+  tail = (key != next);
+#define CMI_SCAN_ROUND(CTRL, ROW_MASK)                                         \
   {                                                                            \
-    double up[N];                                                              \
-    _Pragma("unroll") for (int k = 0; k < N; ++k) up[k] =                      \
-        dpp_f64<CTRL, ROW_MASK>(v[k]);                                         \
-    const int flag_up = dpp_i32<CTRL, ROW_MASK>(flag);                         \
-    if (COND) {                                                                \
-      _Pragma("unroll") for (int k = 0; k < N; ++k) v[k] +=                    \
-          flag ? 0. : up[k];                                                   \
-      flag |= flag_up;                                                         \
-    }                                                                          \
+    const double take = stop ? 0. : 1.;                                        \
+    _Pragma("unroll") for (int k = 0; k < N; ++k) v[k] =                       \
+        __fma_rn(take, dpp_zero_f64<CTRL, ROW_MASK>(v[k]), v[k]);              \
+    stop |= dpp_zero<CTRL, ROW_MASK>(stop);                                    \
   }
-  const int in_row = lane & 15;
-  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(1), 0xf, in_row >= 1)
-  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(2), 0xf, in_row >= 2)
-  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(4), 0xf, in_row >= 4)
-  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(8), 0xf, in_row >= 8)
-  CMI_SCAN_ROUND(CMI_DPP_ROW_BCAST15, 0xa, (lane & 16) != 0)
-  CMI_SCAN_ROUND(CMI_DPP_ROW_BCAST31, 0xc, lane >= 32)
+  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(1), 0xf)
+  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(2), 0xf)
+  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(4), 0xf)
+  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(8), 0xf)
+  CMI_SCAN_ROUND(CMI_DPP_ROW_BCAST15, 0xa)
+  CMI_SCAN_ROUND(CMI_DPP_ROW_BCAST31, 0xc)
 #undef CMI_SCAN_ROUND
 }
 
@@ -152,8 +162,8 @@ accumulate_full(const ShootArgs &a, FullStage &st, bool aggregate,
                 unsigned int &natomics) {
   const int lane = threadIdx.x & 63;
   const int32_t key = accumulate ? cell : ~lane;
-  const int32_t prev = dpp_i32<CMI_DPP_WAVE_SHR1, 0xf>(key);
-  const bool head = (lane == 0) || (key != prev) || !aggregate;
+  const int32_t prev = dpp_keep<CMI_DPP_WAVE_SHR1, 0xf>(~key, key);
+  const bool head = (key != prev) || !aggregate;
   const unsigned long long heads = __ballot(head);
   const int run = __popcll(heads & ((2ull << lane) - 1ull)) - 1;
   const int nruns = __popcll(heads);
@@ -201,7 +211,7 @@ accumulate_full(const ShootArgs &a, FullStage &st, bool aggregate,
  * rounding). EXACT selects the marcher (device_transport.h).
  */
 template <bool FULL, bool HEAT, bool REEMIT, bool EXACT>
-__global__ void __launch_bounds__(CMI_BLOCK)
+__global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 4)
     shoot_kernel(const ShootArgs a) {
   const int lane = threadIdx.x & 63;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
@@ -222,10 +232,13 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   PacketRng rng;
   uint32_t packet_id = 0;
   bool active = false;
-  int64_t last_cell = -1;
+  int32_t last_cell = -1; /* EXACT marcher on grids >= 2^31 cells: see below */
+  int64_t last_cell_wide = -1;
 
   double tw = 0., tc0 = 0., tc1 = 0., tc2 = 0., tc3 = 0.;
   unsigned int nsteps = 0, natomics = 0; /* per lane and launch: < 2^32 */
+  const bool any_periodic =
+      (a.grid.periodic[0] | a.grid.periodic[1] | a.grid.periodic[2]) != 0;
 
   /* H-only: per-wave write-combining cache in LDS. Scattered fp64 atomics
    * execute at the memory side at a chip-wide rate of a few 1e10 per second
@@ -237,24 +250,77 @@ __global__ void __launch_bounds__(CMI_BLOCK)
    * bundle of neighbouring rays, so consecutive steps (and the next bundle of
    * the wave's chunk) keep hitting the same few cells. The table is private to
    * the wave: no barriers, LDS operations of a wave execute in order. */
-  constexpr int cache_slots = FULL ? 64 : CMI_CACHE_SLOTS; /* unused if FULL */
-  __shared__ volatile int32_t cache_tag[CMI_BLOCK / 64][cache_slots];
-  __shared__ volatile int32_t cache_owner[CMI_BLOCK / 64][cache_slots];
-  __shared__ double cache_val[CMI_BLOCK / 64][(HEAT ? 2 : 1) * cache_slots];
+  /* CMI_AGG_BLOCK: per-block combining table. The 4 waves of a block follow
+   * neighbouring ray bundles (consecutive positions of the sorted order), which
+   * cross the same cells within a few steps of each other - too far apart in
+   * time for the small wave cache, and a cache shared between waves cannot
+   * evict safely without locks. So the table is insert-only: a run total
+   * claims a slot for its cell with an LDS compare-and-swap (linear probing,
+   * CMI_TABLE_PROBES tries, then it falls back to a global atomic) and adds
+   * with ds_add_f64; between two bundles the block meets at a barrier and
+   * flushes every used slot with ONE global atomic per cell. */
+  constexpr int lds_slots = FULL ? 64 : CMI_TABLE_SLOTS; /* unused if FULL */
+  __shared__ int32_t lds_tag[lds_slots];
+  __shared__ double lds_val[(HEAT ? 2 : 1) * lds_slots];
+  __shared__ int32_t block_has_work[CMI_BLOCK / 64];
   const int wib = threadIdx.x >> 6;
+  /* the wave cache (CMI_AGG_WAVE) lives in the same memory */
+  volatile int32_t *const cache_tag = lds_tag + wib * CMI_CACHE_SLOTS;
+  volatile int32_t *const cache_owner =
+      lds_tag + (CMI_BLOCK / 64 + wib) * CMI_CACHE_SLOTS;
+  double *const cache_val = lds_val + wib * (HEAT ? 2 : 1) * CMI_CACHE_SLOTS;
+  static_assert(FULL || 2 * (CMI_BLOCK / 64) * CMI_CACHE_SLOTS <= lds_slots,
+                "wave caches must fit the table's memory");
   /* FULL: per-wave accumulation weights and per-step scratch in LDS */
   __shared__ FullStage full_stage[FULL ? CMI_BLOCK / 64 : 1];
   FullStage &stage = full_stage[FULL ? wib : 0];
   double weights[CMI_NACC];
-#define CMI_TAG(k) cache_tag[wib][k]
-#define CMI_OWNER(k) cache_owner[wib][k]
-#define CMI_VAL(k) cache_val[wib][k]
+  const bool use_wave_cache = !FULL && a.aggregate == CMI_AGG_WAVE;
+  const bool use_table = !FULL && a.aggregate == CMI_AGG_BLOCK;
+#define CMI_TAG(k) cache_tag[k]
+#define CMI_OWNER(k) cache_owner[k]
+#define CMI_VAL(k) cache_val[k]
 /* compiler barrier: LDS values written by other lanes must be re-read */
 #define CMI_LDS_FENCE() asm volatile("" ::: "memory")
-  if (!FULL) {
+  if (use_wave_cache) {
     for (int k = lane; k < CMI_CACHE_SLOTS; k += 64)
       CMI_TAG(k) = -1;
   }
+  if (use_table) {
+    for (int k = threadIdx.x; k < CMI_TABLE_SLOTS; k += CMI_BLOCK) {
+      lds_tag[k] = -1;
+      lds_val[k] = 0.;
+      if (HEAT)
+        lds_val[CMI_TABLE_SLOTS + k] = 0.;
+    }
+    __syncthreads();
+  }
+  /* add (v0[, v1]) to `cell` through the block table; called by all 64 lanes */
+  auto table_add = [&](bool add, int32_t cell, double v0, double v1) {
+    uint32_t slot = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_TABLE_BITS);
+    bool pending = add;
+    for (int probe = 0; probe < CMI_TABLE_PROBES; ++probe) {
+      if (pending) {
+        const int32_t prev = atomicCAS(&lds_tag[slot], -1, cell);
+        if (prev == -1 || prev == cell) {
+          atomicAdd(&lds_val[slot], v0); /* ds_add_f64 */
+          if (HEAT)
+            atomicAdd(&lds_val[CMI_TABLE_SLOTS + slot], v1);
+          pending = false;
+        } else {
+          slot = (slot + 1) & (CMI_TABLE_SLOTS - 1);
+        }
+      }
+      if (__ballot(pending) == 0ull)
+        break;
+    }
+    if (pending) {
+      atomic_add_f64(acc_at(a.cells, ION_H_n, cell), v0);
+      if (HEAT)
+        atomic_add_f64(acc_at(a.cells, CMI_NION, cell), v1);
+      natomics += HEAT ? 2 : 1;
+    }
+  };
   /* add (v0[, v1]) to `cell` through the cache; called by all 64 lanes, lanes
    * with add == false only take part in the wave-uniform control flow */
   auto cache_add = [&](bool add, int32_t cell, double v0, double v1) {
@@ -311,8 +377,37 @@ __global__ void __launch_bounds__(CMI_BLOCK)
                                                   : a.n_packets;
     }
     const uint64_t avail = pos_end - pos;
-    if (active_mask == 0ull && avail == 0)
+    if (use_table) {
+      /* between two bundles: every wave of the block arrives here, the table
+       * is written back, and the block leaves together once no wave has work
+       * left (a wave never exits while others may still wait at a barrier) */
+      if (lane == 0)
+        block_has_work[wib] = (active_mask != 0ull || avail != 0) ? 1 : 0;
+      __syncthreads();
+      for (int k = threadIdx.x; k < CMI_TABLE_SLOTS; k += CMI_BLOCK) {
+        const int32_t t = lds_tag[k];
+        if (t >= 0) {
+          atomic_add_f64(acc_at(a.cells, ION_H_n, t), lds_val[k]);
+          lds_val[k] = 0.;
+          if (HEAT) {
+            atomic_add_f64(acc_at(a.cells, CMI_NION, t),
+                           lds_val[CMI_TABLE_SLOTS + k]);
+            lds_val[CMI_TABLE_SLOTS + k] = 0.;
+          }
+          lds_tag[k] = -1;
+          natomics += HEAT ? 2 : 1;
+        }
+      }
+      int any_work = 0;
+#pragma unroll
+      for (int w = 0; w < CMI_BLOCK / 64; ++w)
+        any_work |= block_has_work[w];
+      __syncthreads();
+      if (!any_work)
+        break;
+    } else if (active_mask == 0ull && avail == 0) {
       break;
+    }
     if (avail != 0 && idle_mask != 0ull &&
         (active_mask == 0ull || __popcll(idle_mask) >= a.refill_threshold)) {
       const uint64_t rank = __popcll(idle_mask & lane_lt);
@@ -343,6 +438,7 @@ __global__ void __launch_bounds__(CMI_BLOCK)
         }
         active = true;
         last_cell = -1;
+        last_cell_wide = -1;
       }
       const uint64_t taken = __popcll(idle_mask);
       pos += taken < avail ? taken : avail;
@@ -351,59 +447,86 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     const uint64_t avail_after =
         (pos_end - pos) + (chunk_begin + nwaves * chunk < a.n_packets ? 1 : 0);
 
-    /* ---- hot loop: march until the wave is due for a refill (or done) ---- */
-    unsigned long long still_active;
-    do {
-      /* ---- one DDA step for every lane that can take one ---- */
-      const bool inside =
-          active && (EXACT ? is_inside(a.grid, p) : (p.inside != 0));
-      const bool stepping = inside && p.tau > 0.;
+    /* ---- hot loop: only the march and the accumulation. It runs until so
+     * few lanes are still in flight that the wave is due for a refill (or
+     * none is); what happens to a packet at the end of its flight is decided
+     * after the loop, for all finished lanes together. ---- */
+    for (;;) {
+      bool stepping = active && p.tau > 0.;
+      if (EXACT)
+        stepping = stepping && is_inside(a.grid, p);
+      else
+        stepping = stepping && !fast_outside(p);
+      const unsigned long long flying = __ballot(stepping);
+      if (flying == 0ull ||
+          (avail_after != 0 && __popcll(~flying) >= a.refill_threshold))
+        break;
       double ds = 0.;
       bool accumulate = false;
       if (stepping) {
         double2 kappa;
-        ds = EXACT ? dda_step(a.grid, a.cells.opacity, p, last_cell, kappa)
-                   : fast_step(a.grid, a.cells.opacity, p, last_cell, kappa);
+        if (EXACT) {
+          ds = dda_step(a.grid, a.cells.opacity, p, last_cell_wide, kappa);
+          last_cell = (int32_t)last_cell_wide;
+        } else {
+          ds = fast_step(a.cells.opacity, p, last_cell, kappa);
+        }
         ++nsteps;
         accumulate = (kappa.x >= 0.); /* number density > 0 */
       }
-      if (!a.exp_no_atomics) {
-        if (FULL) {
-          accumulate_full<HEAT>(a, stage, a.aggregate != 0, accumulate,
-                                (int32_t)last_cell, ds * p.weight, natomics);
-        } else if (a.aggregate) {
-          /* lanes in the same cell: one atomic for the whole run */
-          const int32_t key = accumulate ? (int32_t)last_cell : ~lane;
-          {
-            const double dsw = accumulate ? ds * p.weight : 0.;
-            bool tail;
-            if (HEAT) {
-              double v[2] = {dsw * p.sigma_H,
-                             dsw * p.sigma_H * (p.nu - a.model.nu_H)};
-              run_sums<2>(key, v, tail);
-              cache_add(tail && accumulate, (int32_t)last_cell, v[0], v[1]);
-            } else {
-              double v[1] = {dsw * p.sigma_H};
-              run_sums<1>(key, v, tail);
-              cache_add(tail && accumulate, (int32_t)last_cell, v[0], 0.);
-            }
-          }
-        } else if (accumulate) {
-          update_integrals_H<HEAT>(a, p.sigma_H, p.nu, p.weight, last_cell, ds);
+      if (!EXACT && any_periodic && stepping && p.tau >= 0.)
+        fast_wrap(a.grid, p);
+      if (a.exp_no_atomics)
+        continue;
+      if (FULL) {
+        accumulate_full<HEAT>(a, stage, a.aggregate != CMI_AGG_NONE, accumulate,
+                              last_cell, ds * p.weight, natomics);
+      } else if (a.aggregate != CMI_AGG_NONE) {
+        /* lanes in the same cell: one add for the whole run */
+        const int32_t key = accumulate ? last_cell : ~lane;
+        const double dsw = accumulate ? ds * p.weight : 0.;
+        bool tail;
+        double v[2] = {dsw * p.sigma_H,
+                       HEAT ? dsw * p.sigma_H * (p.nu - a.model.nu_H) : 0.};
+        if (HEAT)
+          run_sums<2>(key, v, tail);
+        else
+          run_sums<1>(key, reinterpret_cast<double(&)[1]>(v), tail);
+        const bool add = tail && accumulate;
+        if (use_table) {
+          table_add(add, last_cell, v[0], v[1]);
+        } else if (use_wave_cache) {
+          cache_add(add, last_cell, v[0], v[1]);
+        } else if (add) {
+          atomic_add_f64(acc_at(a.cells, ION_H_n, last_cell), v[0]);
+          if (HEAT)
+            atomic_add_f64(acc_at(a.cells, CMI_NION, last_cell), v[1]);
           natomics += HEAT ? 2 : 1;
         }
+      } else if (accumulate) {
+        const int64_t c = EXACT ? last_cell_wide : (int64_t)last_cell;
+        update_integrals_H<HEAT>(a, p.sigma_H, p.nu, p.weight, c, ds);
+        natomics += HEAT ? 2 : 1;
       }
+    }
 
-      if (active) {
+    /* ---- end of flight for every lane that cannot step any more ---- */
+    if (active) {
+      bool inside_now;
+      if (EXACT)
+        inside_now = is_inside(a.grid, p);
+      else
+        inside_now = (p.tau < 0.) || !fast_outside(p);
+      const int64_t cell_now = EXACT ? last_cell_wide : (int64_t)last_cell;
+      if (!(inside_now && p.tau > 0.)) {
         bool absorbed = false, done = false;
-        if (stepping) {
-          /* tau < 0: absorbed inside last_cell (the index was not advanced, so
-           * the packet is still inside the box) */
-          absorbed = (p.tau < 0.);
-        } else if (inside) {
+        if (p.tau < 0.) {
+          /* absorbed inside last_cell (the packet is still inside the box) */
+          absorbed = true;
+        } else if (inside_now) {
           /* tau hit 0 exactly on a wall, packet still inside: interact()
            * returns the last traversed cell */
-          absorbed = (last_cell >= 0);
+          absorbed = (cell_now >= 0);
           done = !absorbed;
         } else {
           done = true; /* left the box: DensityGrid::end() */
@@ -412,11 +535,12 @@ __global__ void __launch_bounds__(CMI_BLOCK)
         if (absorbed) {
           /* PhotonSource::reemit, src/PhotonSource.cpp:272-308 */
           if (REEMIT)
-            new_frequency = reemit_decide<FULL, EXACT>(a.model, a.cells,
-                                                       last_cell, rng, p);
+            new_frequency =
+                reemit_decide<FULL, EXACT>(a.model, a.cells, cell_now, rng, p);
           else
             p.type = TYPE_ABSORBED;
           last_cell = -1;
+          last_cell_wide = -1;
           done = (new_frequency == 0.);
         }
         if (REEMIT) {
@@ -461,13 +585,9 @@ __global__ void __launch_bounds__(CMI_BLOCK)
           active = false;
         }
       }
-
-      still_active = __ballot(active);
-    } while (still_active != 0ull &&
-             (avail_after == 0 ||
-              __popcll(~still_active) < a.refill_threshold));
+    }
   }
-  if (!FULL) {
+  if (use_wave_cache) {
     /* write the wave's resident partial sums back */
     for (int k = lane; k < CMI_CACHE_SLOTS; k += 64) {
       const int32_t t = CMI_TAG(k);
@@ -740,7 +860,7 @@ __global__ void trace_probe_kernel(const GridDev grid, const double2 *opacity,
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n)
     return;
-  Packet<false> p;
+  Packet<true> p; /* carries the helium term of the optical depth */
   for (int a = 0; a < 3; ++a) {
     p.pos[a] = position[3 * i + a];
     p.dir[a] = direction[3 * i + a];
@@ -750,14 +870,22 @@ __global__ void trace_probe_kernel(const GridDev grid, const double2 *opacity,
   p.sigma_H = sigma_H[i];
   p.sigma_He_corr = sigma_He_corr[i];
   p.weight = 1.;
-  start_flight<false, EXACT>(grid, p);
+  start_flight<true, EXACT>(grid, p);
   int32_t steps = 0;
   int64_t last = -1;
-  while ((EXACT ? is_inside(grid, p) : (p.inside != 0)) && p.tau > 0.) {
+  while ((EXACT ? is_inside(grid, p) : !fast_outside(p)) && p.tau > 0.) {
     int64_t cell;
     double2 kappa;
-    const double ds = EXACT ? dda_step(grid, opacity, p, cell, kappa)
-                            : fast_step(grid, opacity, p, cell, kappa);
+    double ds;
+    if (EXACT) {
+      ds = dda_step(grid, opacity, p, cell, kappa);
+    } else {
+      int32_t c;
+      ds = fast_step(opacity, p, c, kappa);
+      cell = c;
+      if (p.tau >= 0.)
+        fast_wrap(grid, p);
+    }
     last = cell;
     if (steps < max_steps) {
       out_cell[(uint64_t)max_steps * i + steps] = cell;
@@ -765,7 +893,7 @@ __global__ void trace_probe_kernel(const GridDev grid, const double2 *opacity,
     }
     ++steps;
   }
-  if (!(EXACT ? is_inside(grid, p) : (p.inside != 0)))
+  if (!(EXACT ? is_inside(grid, p) : (p.tau < 0. || !fast_outside(p))))
     last = -1;
   if (!EXACT)
     end_flight(p);

@@ -51,6 +51,8 @@ class GpuBackend:
         self.torch = torch
         torch.cuda.set_device(device)
         n = int(np.prod(ncell))
+        self.ncell = n
+        self.track_heating = bool(track_heating)
         self.accumulators = torch.zeros(NACC * n, dtype=torch.float64,
                                         device="cuda:%d" % device)
         stream = torch.cuda.current_stream().cuda_stream
@@ -58,6 +60,21 @@ class GpuBackend:
             ncell, anchor, sides, periodic, device=device,
             track_heating=track_heating, stream=stream,
             external_accumulators=self.accumulators.data_ptr())
+
+    def active_accumulators(self):
+        """The parts of the accumulator block a transport step can have
+        written: with hydrogen-only transport (SoA block [16][ncell]) that is
+        J_H and, if tracked, the two heating terms; the other 13 fields stay
+        zero on every rank and need no reduction. With all ions transported
+        (AoS [ncell][16]) it is the whole block."""
+        _, cell_stride = self.engine.accumulator_layout()
+        n = self.ncell
+        if cell_stride != 1:
+            return [self.accumulators]
+        views = [self.accumulators[:n]]
+        if self.track_heating:
+            views.append(self.accumulators[14 * n:16 * n])
+        return views
 
     def reset_grid(self):
         self.engine.reset_grid()
@@ -99,8 +116,11 @@ class ReplicaIterationDriver:
             d = self.dist
             # MPI_Allreduce(SUM) of each accumulator field
             # (src/IonizationSimulation.cpp:459-528): one collective over the
-            # contiguous [16][ncell] block instead of 16 chunked ones
-            d.all_reduce(b.accumulators, op=d.ReduceOp.SUM)
+            # contiguous block of fields that can be non-zero instead of 16
+            # chunked ones
+            active = getattr(b, "active_accumulators", None)
+            for view in (active() if active else [b.accumulators]):
+                d.all_reduce(view, op=d.ReduceOp.SUM)
             # totweight + typecount (src/IonizationSimulation.cpp:410-414)
             small = torch.tensor([tw, tc[0], tc[1], tc[2], tc[3], float(ns)],
                                  dtype=torch.float64,

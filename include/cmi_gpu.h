@@ -235,10 +235,17 @@ int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
  *   "sort_packets" (1)      process the packets of a launch in emission-
  *                           direction order, so that the lanes of a wave cross
  *                           the same cells
- *   "aggregate" (1)         sum the contributions of lanes in the same cell
- *                           across the wave before the atomic
+ *   "aggregate" (3)         what happens to a step's contributions before
+ *                           HBM sees an atomic: 0 = one atomic per lane and
+ *                           step; 1 = lanes of a wave in the same cell are
+ *                           summed first; 2 = + per-wave write-combining cache
+ *                           in LDS; 3 = + per-block combining table in LDS,
+ *                           written back between ray bundles (hydrogen-only
+ *                           transport; multi-ion transport uses its own
+ *                           cooperative scheme for any value > 0)
+ *   "aggregate_reemit" (1)  the same for the later re-emission passes
  *   "refill_threshold" (64) idle lanes of a wave that trigger a refill
- *   "chunk" (256)           consecutive packets a wave takes at a time
+ *   "chunk" (64)            consecutive packets a wave takes at a time
  *   "max_blocks_per_cu" (8), "max_packets_per_launch" (2^27)
  *   "reemit_passes" (1)     with diffuse re-emission: park re-emitted packets
  *                           in a queue and follow them in later passes of the

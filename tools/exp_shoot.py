@@ -57,7 +57,7 @@ def main():
     for cfg in configs:
         kw = dict((k, int(v)) for k, v in
                   (item.split("=") for item in cfg.split(",")))
-        base = dict(sort_packets=1, aggregate=1, refill_threshold=64,
+        base = dict(sort_packets=1, aggregate=3, refill_threshold=64,
                     chunk=256, max_blocks_per_cu=8, exp_no_atomics=0,
                     exact_dda=0)
         base.update(kw)

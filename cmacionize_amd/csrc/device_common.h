@@ -195,6 +195,7 @@ struct CountersDev {
   double typecount[4];
   unsigned long long nsteps;
   unsigned long long natomics; /* atomic adds issued to the accumulators */
+  unsigned long long nwavesteps; /* hot-loop iterations summed over waves */
 };
 
 #endif

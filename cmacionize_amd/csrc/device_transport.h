@@ -273,12 +273,18 @@ __device__ __forceinline__ double max_f64(double x, double y) {
  * wrapping is left to fast_wrap(), which the caller runs when any axis of the
  * grid is periodic. */
 template <bool FULL>
-__device__ __forceinline__ double fast_step(const double2 *__restrict__ opacity,
-                                            Packet<FULL> &p, int32_t &cell,
-                                            double2 &kappa) {
-  cell = p.cell;
-  kappa = *reinterpret_cast<const double2 *>(
+__device__ __forceinline__ double2
+fast_load_record(const double2 *__restrict__ opacity, const Packet<FULL> &p) {
+  return *reinterpret_cast<const double2 *>(
       reinterpret_cast<const char *>(opacity) + ((uint32_t)p.cell << 4));
+}
+
+/* `kappa` is the transport record of p.cell, loaded by the caller
+ * (fast_load_record) - early, so that the load overlaps other work. */
+template <bool FULL>
+__device__ __forceinline__ double fast_step(Packet<FULL> &p, int32_t &cell,
+                                            const double2 kappa) {
+  cell = p.cell;
   const double tmin = min_f64(p.tmax[0], min_f64(p.tmax[1], p.tmax[2]));
   double ds = tmin - p.t;
   /* kappa = {n x_H, n x_He}; a negative .x marks vacuum */

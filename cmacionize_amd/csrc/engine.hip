@@ -90,6 +90,7 @@ struct cmi_gpu_engine {
 
   struct Tuning {
     bool sort_packets = true;
+    int sort_tau_bits = -1;  /* tau classes per direction bin; -1 = auto */
     int aggregate = CMI_AGG_BLOCK;      /* first generation (sorted bundles) */
     int aggregate_reemit = CMI_AGG_RUNS; /* later generations (random flights) */
     int refill_threshold = CMI_REFILL_THRESHOLD;
@@ -865,10 +866,12 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
   const std::string k(key);
   if (k == "sort_packets")
     e->tune.sort_packets = value != 0;
+  else if (k == "sort_tau_bits")
+    e->tune.sort_tau_bits = (int)(value < 0 ? -1 : (value > 3 ? 3 : value));
   else if (k == "aggregate")
-    e->tune.aggregate = (int)(value < 0 ? 0 : (value > 3 ? 3 : value));
+    e->tune.aggregate = (int)(value < 0 ? 0 : (value > 2 ? 2 : value));
   else if (k == "aggregate_reemit")
-    e->tune.aggregate_reemit = (int)(value < 0 ? 0 : (value > 3 ? 3 : value));
+    e->tune.aggregate_reemit = (int)(value < 0 ? 0 : (value > 2 ? 2 : value));
   else if (k == "refill_threshold")
     e->tune.refill_threshold = (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
   else if (k == "chunk")
@@ -1018,12 +1021,29 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   }
   const QueueDev no_queue = {{nullptr, nullptr, nullptr}, nullptr, nullptr,
                              nullptr, nullptr};
-  /* bits of the sort key in use: 22 direction bits + the source index */
-  int key_bits = 22;
+  /* sort key: 22 direction bits, the tau class and the source index. The
+   * tau classes only help when a packet's range follows from its optical
+   * depth alone (one cross section for all packets). */
+  uint32_t tau_bits = 0;
+  if (!e->full_ions) {
+    if (e->tune.sort_tau_bits >= 0) {
+      tau_bits = (uint32_t)e->tune.sort_tau_bits;
+    } else {
+      /* measured on 256^3: the classes pay off once a direction bin of
+       * 64 x 2^bits packets is still narrower than a few cells */
+      const uint64_t per_source =
+          (n_packets < max_launch ? n_packets : max_launch) /
+          (uint64_t)(e->model.nsource > 0 ? e->model.nsource : 1);
+      tau_bits = per_source >= (1ull << 24) ? 3u
+                                            : (per_source >= (1ull << 22) ? 2u : 0u);
+    }
+  }
+  uint32_t source_bits = 0;
   for (int s = e->model.nsource - 1; s > 0; s >>= 1)
-    ++key_bits;
-  if (key_bits > 32)
-    key_bits = 32;
+    ++source_bits;
+  if (source_bits > 10u - tau_bits)
+    source_bits = 10u - tau_bits;
+  const int key_bits = (int)(22u + tau_bits + source_bits);
 
   for (uint64_t done = 0; done < n_packets; done += max_launch) {
     const uint64_t n = n_packets - done < max_launch ? n_packets - done
@@ -1061,6 +1081,18 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       k.n_packets = n;
       k.seed = seed;
       k.iteration = iteration;
+      k.tau_bits = tau_bits;
+      k.source_mask = (1u << source_bits) - 1u;
+      /* coarse direction bins of ~64 x 2^tau_bits packets per source */
+      k.dir_hi_bits = 0;
+      if (tau_bits != 0) {
+        const uint64_t per_bin = 64ull << tau_bits;
+        const uint64_t per_source =
+            n / (uint64_t)(e->model.nsource > 0 ? e->model.nsource : 1);
+        while (k.dir_hi_bits < 22u &&
+               (per_source >> (k.dir_hi_bits + 1u)) >= per_bin)
+          ++k.dir_hi_bits;
+      }
       k.keys = e->sort_keys[0];
       k.ids = e->sort_ids[0];
       direction_key_kernel<<<grid_blocks(e, (int64_t)n, 8), CMI_BLOCK, 0,
@@ -1164,6 +1196,18 @@ int cmi_gpu_get_atomic_count(cmi_gpu_engine *e, uint64_t *natomics) {
                          hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   *natomics = host.natomics;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_get_wave_steps(cmi_gpu_engine *e, uint64_t *nwavesteps) {
+  if (!e || !nwavesteps)
+    return fail(CMI_GPU_EINVAL, "get_wave_steps: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  CountersDev host;
+  HIP_TRY(hipMemcpyAsync(&host, e->counters, sizeof host,
+                         hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *nwavesteps = host.nwavesteps;
   return CMI_GPU_OK;
 }
 

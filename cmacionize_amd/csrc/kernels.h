@@ -9,18 +9,18 @@
 #include "device_thermal.h"
 
 #define CMI_BLOCK 256
-/* slots of a wave's write-combining cache for accumulator updates */
-#define CMI_CACHE_BITS 8
-#define CMI_CACHE_SLOTS (1 << CMI_CACHE_BITS)
 /* slots of a block's combining table (aggregate mode 3) */
-#define CMI_TABLE_BITS 11
+#define CMI_TABLE_BITS 10
 #define CMI_TABLE_SLOTS (1 << CMI_TABLE_BITS)
 #define CMI_TABLE_PROBES 4
+/* run sums in front of the table cover groups of 2^this lanes */
+#ifndef CMI_TABLE_SCAN_ROUNDS
+#define CMI_TABLE_SCAN_ROUNDS 2
+#endif
 /* a.aggregate: what happens to a step's contributions before HBM sees them */
 #define CMI_AGG_NONE 0  /* one atomic per lane and step */
 #define CMI_AGG_RUNS 1  /* cross-lane run sums, one atomic per run */
-#define CMI_AGG_WAVE 2  /* + per-wave write-combining cache in LDS */
-#define CMI_AGG_BLOCK 3 /* + per-block combining table in LDS */
+#define CMI_AGG_BLOCK 2 /* + per-block combining table in LDS */
 /* idle lanes of a wave are refilled with new packets once this many of them
  * are waiting (or when the whole wave is idle). 64 = a wave always carries one
  * group of 64 direction-sorted packets: its lanes stay in the same cells, so
@@ -112,14 +112,19 @@ __device__ __forceinline__ double dpp_zero_f64(double v) {
  * zeros, which change neither v nor stop. On return the LAST lane of every run
  * holds the run's total and is flagged in `tail`. Must be called by all 64
  * lanes. */
-template <int N>
+template <int N, int ROUNDS>
 __device__ __forceinline__ void run_sums(int32_t key, double (&v)[N],
                                          bool &tail) {
+  constexpr int rounds = ROUNDS;
   /* lane 0 / lane 63 have no neighbour: they keep ~key, which differs */
   const int32_t prev = dpp_keep<CMI_DPP_WAVE_SHR1, 0xf>(~key, key);
   const int32_t next = dpp_keep<CMI_DPP_WAVE_SHL1, 0xf>(~key, key);
-  int stop = (key != prev) ? 1 : 0; /* run starts here */
-  tail = (key != next);
+  const int lane = threadIdx.x & 63;
+  /* with fewer than 6 rounds the sums stop at groups of 2^rounds lanes: a run
+   * that crosses a group boundary ends in one tail per group it touches */
+  const int group_mask = (1 << rounds) - 1;
+  int stop = ((key != prev) || (lane & group_mask) == 0) ? 1 : 0;
+  tail = (key != next) || (lane & group_mask) == group_mask;
 #define CMI_SCAN_ROUND(CTRL, ROW_MASK)                                         \
   {                                                                            \
     const double take = stop ? 0. : 1.;                                        \
@@ -128,11 +133,16 @@ __device__ __forceinline__ void run_sums(int32_t key, double (&v)[N],
     stop |= dpp_zero<CTRL, ROW_MASK>(stop);                                    \
   }
   CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(1), 0xf)
-  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(2), 0xf)
-  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(4), 0xf)
-  CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(8), 0xf)
-  CMI_SCAN_ROUND(CMI_DPP_ROW_BCAST15, 0xa)
-  CMI_SCAN_ROUND(CMI_DPP_ROW_BCAST31, 0xc)
+  if (rounds > 1)
+    CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(2), 0xf)
+  if (rounds > 2)
+    CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(4), 0xf)
+  if (rounds > 3)
+    CMI_SCAN_ROUND(CMI_DPP_ROW_SHR(8), 0xf)
+  if (rounds > 4)
+    CMI_SCAN_ROUND(CMI_DPP_ROW_BCAST15, 0xa)
+  if (rounds > 5)
+    CMI_SCAN_ROUND(CMI_DPP_ROW_BCAST31, 0xc)
 #undef CMI_SCAN_ROUND
 }
 
@@ -211,7 +221,7 @@ accumulate_full(const ShootArgs &a, FullStage &st, bool aggregate,
  * rounding). EXACT selects the marcher (device_transport.h).
  */
 template <bool FULL, bool HEAT, bool REEMIT, bool EXACT>
-__global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 4)
+__global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 8)
     shoot_kernel(const ShootArgs a) {
   const int lane = threadIdx.x & 63;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
@@ -237,6 +247,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 4)
 
   double tw = 0., tc0 = 0., tc1 = 0., tc2 = 0., tc3 = 0.;
   unsigned int nsteps = 0, natomics = 0; /* per lane and launch: < 2^32 */
+  unsigned int nwavesteps = 0;
   const bool any_periodic =
       (a.grid.periodic[0] | a.grid.periodic[1] | a.grid.periodic[2]) != 0;
 
@@ -264,28 +275,11 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 4)
   __shared__ double lds_val[(HEAT ? 2 : 1) * lds_slots];
   __shared__ int32_t block_has_work[CMI_BLOCK / 64];
   const int wib = threadIdx.x >> 6;
-  /* the wave cache (CMI_AGG_WAVE) lives in the same memory */
-  volatile int32_t *const cache_tag = lds_tag + wib * CMI_CACHE_SLOTS;
-  volatile int32_t *const cache_owner =
-      lds_tag + (CMI_BLOCK / 64 + wib) * CMI_CACHE_SLOTS;
-  double *const cache_val = lds_val + wib * (HEAT ? 2 : 1) * CMI_CACHE_SLOTS;
-  static_assert(FULL || 2 * (CMI_BLOCK / 64) * CMI_CACHE_SLOTS <= lds_slots,
-                "wave caches must fit the table's memory");
   /* FULL: per-wave accumulation weights and per-step scratch in LDS */
   __shared__ FullStage full_stage[FULL ? CMI_BLOCK / 64 : 1];
   FullStage &stage = full_stage[FULL ? wib : 0];
   double weights[CMI_NACC];
-  const bool use_wave_cache = !FULL && a.aggregate == CMI_AGG_WAVE;
   const bool use_table = !FULL && a.aggregate == CMI_AGG_BLOCK;
-#define CMI_TAG(k) cache_tag[k]
-#define CMI_OWNER(k) cache_owner[k]
-#define CMI_VAL(k) cache_val[k]
-/* compiler barrier: LDS values written by other lanes must be re-read */
-#define CMI_LDS_FENCE() asm volatile("" ::: "memory")
-  if (use_wave_cache) {
-    for (int k = lane; k < CMI_CACHE_SLOTS; k += 64)
-      CMI_TAG(k) = -1;
-  }
   if (use_table) {
     for (int k = threadIdx.x; k < CMI_TABLE_SLOTS; k += CMI_BLOCK) {
       lds_tag[k] = -1;
@@ -321,51 +315,6 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 4)
       natomics += HEAT ? 2 : 1;
     }
   };
-  /* add (v0[, v1]) to `cell` through the cache; called by all 64 lanes, lanes
-   * with add == false only take part in the wave-uniform control flow */
-  auto cache_add = [&](bool add, int32_t cell, double v0, double v1) {
-    const uint32_t slot =
-        ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_CACHE_BITS);
-    const int32_t t = add ? CMI_TAG(slot) : -2;
-    const bool hit = add && (t == cell);
-    if (hit) {
-      atomicAdd(&CMI_VAL(slot), v0); /* ds_add_f64 */
-      if (HEAT)
-        atomicAdd(&CMI_VAL(CMI_CACHE_SLOTS + slot), v1);
-    }
-    const bool miss = add && !hit;
-    if (__ballot(miss) != 0ull) {
-      /* several missing lanes can map to one slot: the last writer owns it */
-      if (miss)
-        CMI_OWNER(slot) = lane;
-      const bool winner = miss && (CMI_OWNER(slot) == lane);
-      if (winner) {
-        if (t >= 0) {
-          /* evict the resident cell: this is where HBM sees an atomic */
-          CMI_LDS_FENCE();
-          const double old0 = CMI_VAL(slot);
-          atomic_add_f64(acc_at(a.cells, ION_H_n, t), old0);
-          if (HEAT) {
-            const double old1 = CMI_VAL(CMI_CACHE_SLOTS + slot);
-            atomic_add_f64(acc_at(a.cells, CMI_NION, t), old1);
-          }
-          natomics += HEAT ? 2 : 1;
-        }
-        CMI_VAL(slot) = v0;
-        if (HEAT)
-          CMI_VAL(CMI_CACHE_SLOTS + slot) = v1;
-        CMI_TAG(slot) = cell;
-        CMI_LDS_FENCE();
-      } else if (miss) {
-        /* lost the slot to another lane in the same step: add directly */
-        atomic_add_f64(acc_at(a.cells, ION_H_n, cell), v0);
-        if (HEAT)
-          atomic_add_f64(acc_at(a.cells, CMI_NION, cell), v1);
-        natomics += HEAT ? 2 : 1;
-      }
-    }
-  };
-
   for (;;) {
     const unsigned long long active_mask = __ballot(active);
     const unsigned long long idle_mask = ~active_mask;
@@ -451,6 +400,11 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 4)
      * few lanes are still in flight that the wave is due for a refill (or
      * none is); what happens to a packet at the end of its flight is decided
      * after the loop, for all finished lanes together. ---- */
+    /* FAST: the record of the cell a lane is about to cross is loaded one
+     * iteration ahead, so that the load overlaps the accumulation */
+    double2 kappa_next = make_double2(0., 0.);
+    if (!EXACT && active && p.tau > 0. && !fast_outside(p))
+      kappa_next = fast_load_record(a.cells.opacity, p);
     for (;;) {
       bool stepping = active && p.tau > 0.;
       if (EXACT)
@@ -461,6 +415,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 4)
       if (flying == 0ull ||
           (avail_after != 0 && __popcll(~flying) >= a.refill_threshold))
         break;
+      ++nwavesteps;
       double ds = 0.;
       bool accumulate = false;
       if (stepping) {
@@ -469,13 +424,16 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 4)
           ds = dda_step(a.grid, a.cells.opacity, p, last_cell_wide, kappa);
           last_cell = (int32_t)last_cell_wide;
         } else {
-          ds = fast_step(a.cells.opacity, p, last_cell, kappa);
+          kappa = kappa_next;
+          ds = fast_step(p, last_cell, kappa);
         }
         ++nsteps;
         accumulate = (kappa.x >= 0.); /* number density > 0 */
       }
       if (!EXACT && any_periodic && stepping && p.tau >= 0.)
         fast_wrap(a.grid, p);
+      if (!EXACT && stepping && p.tau > 0. && !fast_outside(p))
+        kappa_next = fast_load_record(a.cells.opacity, p);
       if (a.exp_no_atomics)
         continue;
       if (FULL) {
@@ -488,16 +446,23 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 4)
         bool tail;
         double v[2] = {dsw * p.sigma_H,
                        HEAT ? dsw * p.sigma_H * (p.nu - a.model.nu_H) : 0.};
-        if (HEAT)
-          run_sums<2>(key, v, tail);
-        else
-          run_sums<1>(key, reinterpret_cast<double(&)[1]>(v), tail);
-        const bool add = tail && accumulate;
         if (use_table) {
-          table_add(add, last_cell, v[0], v[1]);
-        } else if (use_wave_cache) {
-          cache_add(add, last_cell, v[0], v[1]);
-        } else if (add) {
+          /* the table merges equal cells anyway: sums over groups of 2^ROUNDS
+           * lanes are enough to keep the LDS atomics few */
+          if (HEAT)
+            run_sums<2, CMI_TABLE_SCAN_ROUNDS>(key, v, tail);
+          else
+            run_sums<1, CMI_TABLE_SCAN_ROUNDS>(
+                key, reinterpret_cast<double(&)[1]>(v), tail);
+          table_add(tail && accumulate, last_cell, v[0], v[1]);
+          continue;
+        }
+        if (HEAT)
+          run_sums<2, 6>(key, v, tail);
+        else
+          run_sums<1, 6>(key, reinterpret_cast<double(&)[1]>(v), tail);
+        const bool add = tail && accumulate;
+        if (add) {
           atomic_add_f64(acc_at(a.cells, ION_H_n, last_cell), v[0]);
           if (HEAT)
             atomic_add_f64(acc_at(a.cells, CMI_NION, last_cell), v[1]);
@@ -587,25 +552,6 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 4)
       }
     }
   }
-  if (use_wave_cache) {
-    /* write the wave's resident partial sums back */
-    for (int k = lane; k < CMI_CACHE_SLOTS; k += 64) {
-      const int32_t t = CMI_TAG(k);
-      CMI_LDS_FENCE();
-      if (t >= 0) {
-        atomic_add_f64(acc_at(a.cells, ION_H_n, t), CMI_VAL(k));
-        if (HEAT)
-          atomic_add_f64(acc_at(a.cells, CMI_NION, t),
-                         CMI_VAL(CMI_CACHE_SLOTS + k));
-        natomics += HEAT ? 2 : 1;
-      }
-    }
-  }
-
-#undef CMI_TAG
-#undef CMI_OWNER
-#undef CMI_VAL
-#undef CMI_LDS_FENCE
   /* IonizationPhotonShootJobMarket::update_counters */
   tw = wave_sum(tw);
   tc0 = wave_sum(tc0);
@@ -622,18 +568,34 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 4)
     atomic_add_f64(&a.counters->typecount[3], tc3);
     atomicAdd(&a.counters->nsteps, (unsigned long long)ns);
     atomicAdd(&a.counters->natomics, (unsigned long long)na);
+    atomicAdd(&a.counters->nwavesteps, (unsigned long long)nwavesteps);
   }
 }
 
-/* Sort key of a packet: its emission direction, binned on an equal-area
- * (cos theta, phi) lattice and Morton-interleaved, below the index of the
- * source it starts from. Reproduces the first draws of emit_packet. */
+/* Sort key of a packet. Reproduces the first draws of emit_packet: the source,
+ * the emission direction - binned on an equal-area 2048 x 2048 (cos theta,
+ * phi) lattice and Morton-interleaved, 22 bits - and the first optical depth.
+ *
+ *   key = [source | direction, top dir_hi_bits | tau class | direction, rest]
+ *
+ * Packets of one coarse direction bin follow the same ray, so how far they get
+ * is a monotonic function of their optical depth tau = -ln u: the tau class
+ * (the top tau_bits of u) splits the bin's packets into groups that end their
+ * flights at about the same step. With bins of ~64 x 2^tau_bits packets each
+ * wave gets one group: its lanes stay busy until the bundle ends together,
+ * instead of idling behind the longest flight, while the waves of a block
+ * still share the bin's cells for the combining table. Inside a group the
+ * packets keep their fine direction order, so neighbouring lanes are
+ * neighbouring rays. tau_bits = 0 gives the plain direction order. */
 struct KeyArgs {
   ModelDev model;
   uint64_t first_packet;
   uint64_t n_packets;
   uint32_t seed;
   uint32_t iteration;
+  uint32_t dir_hi_bits; /* 0..22 */
+  uint32_t tau_bits;    /* 0..3 */
+  uint32_t source_mask;
   uint32_t *keys;
   uint32_t *ids;
 };
@@ -651,6 +613,7 @@ __device__ __forceinline__ uint32_t spread_bits_11(uint32_t x) {
 __global__ void __launch_bounds__(CMI_BLOCK)
     direction_key_kernel(const KeyArgs a) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint32_t lo_bits = 22u - a.dir_hi_bits;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
        i < a.n_packets; i += stride) {
     PacketRng rng;
@@ -665,7 +628,16 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     const uint32_t ic = (uint32_t)(u_cost * 2048.);
     const uint32_t ip = (uint32_t)(u_phi * 2048.);
     const uint32_t morton = spread_bits_11(ic) | (spread_bits_11(ip) << 1);
-    a.keys[i] = ((src & 0x3ffu) << 22) | morton;
+    uint32_t tau_class = 0;
+    if (a.tau_bits != 0) {
+      (void)sample_source_spectrum(a.model, rng); /* the frequency's draws */
+      const double u_tau = rng.next();            /* tau = -ln u */
+      tau_class = (uint32_t)(u_tau * (double)(1u << a.tau_bits));
+    }
+    const uint32_t hi = morton >> lo_bits;
+    const uint32_t lo = morton & ((1u << lo_bits) - 1u);
+    a.keys[i] = ((src & a.source_mask) << (22u + a.tau_bits)) |
+                (hi << (a.tau_bits + lo_bits)) | (tau_class << lo_bits) | lo;
     a.ids[i] = (uint32_t)i;
   }
 }
@@ -881,7 +853,8 @@ __global__ void trace_probe_kernel(const GridDev grid, const double2 *opacity,
       ds = dda_step(grid, opacity, p, cell, kappa);
     } else {
       int32_t c;
-      ds = fast_step(opacity, p, c, kappa);
+      kappa = fast_load_record(opacity, p);
+      ds = fast_step(p, c, kappa);
       cell = c;
       if (p.tau >= 0.)
         fast_wrap(grid, p);

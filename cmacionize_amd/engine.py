@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcmi_gpu.so")
+# CMI_GPU_LIBRARY: load another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("CMI_GPU_LIBRARY",
+                          os.path.join(_HERE, "libcmi_gpu.so"))
 
 NION = 14
 NACC = 16
@@ -66,7 +68,7 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_trace_packets", "cmi_gpu_get_timing", "cmi_gpu_set_tuning",
     "cmi_gpu_get_atomic_count", "cmi_gpu_sample_spectrum",
     "cmi_gpu_thermal_probe", "cmi_gpu_accumulator_layout",
-    "cmi_gpu_get_kernel_timing",
+    "cmi_gpu_get_kernel_timing", "cmi_gpu_get_wave_steps",
 ]
 
 _lib = None
@@ -124,6 +126,7 @@ def load_library():
     L.cmi_gpu_get_kernel_timing.argtypes = [vp, _dp, C.POINTER(C.c_uint64)]
     L.cmi_gpu_set_tuning.argtypes = [vp, C.c_char_p, C.c_int64]
     L.cmi_gpu_get_atomic_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.cmi_gpu_get_wave_steps.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.cmi_gpu_sample_spectrum.argtypes = [vp, C.c_int32, C.c_double,
                                           C.c_uint32, C.c_uint64, _dp]
     L.cmi_gpu_accumulator_layout.argtypes = [vp, C.POINTER(C.c_int64),
@@ -277,6 +280,11 @@ class GpuEngine:
     def get_atomic_count(self):
         n = C.c_uint64()
         self._check(self._lib.cmi_gpu_get_atomic_count(self._h, C.byref(n)))
+        return n.value
+
+    def get_wave_steps(self):
+        n = C.c_uint64()
+        self._check(self._lib.cmi_gpu_get_wave_steps(self._h, C.byref(n)))
         return n.value
 
     def update_cells(self, loop, totweight):

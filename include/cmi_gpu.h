@@ -221,6 +221,11 @@ int cmi_gpu_get_counters(cmi_gpu_engine *engine, double *totweight,
  * fields since the last reset (diagnostic of the cross-lane aggregation) */
 int cmi_gpu_get_atomic_count(cmi_gpu_engine *engine, uint64_t *natomics);
 
+/* iterations of the transport kernel's march loop summed over all wavefronts
+ * since the last reset: DDA steps / (64 x this) is the fraction of lanes that
+ * did a step in an average iteration (diagnostic of the packet ordering) */
+int cmi_gpu_get_wave_steps(cmi_gpu_engine *engine, uint64_t *nwavesteps);
+
 /* replaces: TemperatureCalculator::calculate_temperature(loop, totweight,
  * grid, block) (src/TemperatureCalculator.cpp:944-970), i.e. per cell either
  * IonizationStateCalculator::calculate_ionization_state
@@ -235,12 +240,17 @@ int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
  *   "sort_packets" (1)      process the packets of a launch in emission-
  *                           direction order, so that the lanes of a wave cross
  *                           the same cells
- *   "aggregate" (3)         what happens to a step's contributions before
+ *   "sort_tau_bits" (-1)    hydrogen-only transport: split every coarse
+ *                           direction bin into 2^bits classes of the first
+ *                           optical depth, so that the packets of a wave end
+ *                           their flights at about the same step (0 = plain
+ *                           direction order, -1 = chosen from the number of
+ *                           packets per launch)
+ *   "aggregate" (2)         what happens to a step's contributions before
  *                           HBM sees an atomic: 0 = one atomic per lane and
  *                           step; 1 = lanes of a wave in the same cell are
- *                           summed first; 2 = + per-wave write-combining cache
- *                           in LDS; 3 = + per-block combining table in LDS,
- *                           written back between ray bundles (hydrogen-only
+ *                           summed first; 2 = + per-block combining table in
+ *                           LDS, written back between ray bundles (hydrogen-only
  *                           transport; multi-ion transport uses its own
  *                           cooperative scheme for any value > 0)
  *   "aggregate_reemit" (1)  the same for the later re-emission passes

@@ -293,21 +293,21 @@ def test_tuning_does_not_change_results():
     eng = make_engine(32, track_heating=True)
     results = []
     for kw in (dict(sort_packets=0, aggregate=0, refill_threshold=16),
-               dict(sort_packets=1, aggregate=3, refill_threshold=64),
+               dict(sort_packets=1, aggregate=2, refill_threshold=64),
                dict(sort_packets=1, aggregate=1, refill_threshold=20,
                     chunk=64, max_packets_per_launch=30000),
                dict(sort_packets=0, aggregate=1, refill_threshold=1,
                     chunk=1000, max_blocks_per_cu=1),
-               dict(sort_packets=1, aggregate=2),
+               dict(sort_packets=1, aggregate=1, sort_tau_bits=0),
                dict(sort_packets=1, aggregate=2, refill_threshold=24,
-                    chunk=64),
-               dict(sort_packets=1, aggregate=3, chunk=64),
-               dict(sort_packets=0, aggregate=3, refill_threshold=7,
+                    chunk=256, sort_tau_bits=3),
+               dict(sort_packets=1, aggregate=2, chunk=64, sort_tau_bits=1),
+               dict(sort_packets=0, aggregate=2, refill_threshold=7,
                     chunk=100, max_blocks_per_cu=2,
                     max_packets_per_launch=33333),
                dict(exact_dda=1)):
-        base = dict(sort_packets=1, aggregate=3, refill_threshold=64,
-                    chunk=256, max_blocks_per_cu=8, exact_dda=0,
+        base = dict(sort_packets=1, aggregate=2, refill_threshold=64,
+                    sort_tau_bits=2, chunk=64, max_blocks_per_cu=8, exact_dda=0,
                     max_packets_per_launch=1 << 27)
         base.update(kw)
         eng.set_tuning(**base)

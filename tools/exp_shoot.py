@@ -57,8 +57,8 @@ def main():
     for cfg in configs:
         kw = dict((k, int(v)) for k, v in
                   (item.split("=") for item in cfg.split(",")))
-        base = dict(sort_packets=1, aggregate=3, refill_threshold=64,
-                    chunk=256, max_blocks_per_cu=8, exp_no_atomics=0,
+        base = dict(sort_packets=1, aggregate=2, refill_threshold=64,
+                    chunk=64, sort_tau_bits=2, max_blocks_per_cu=8, exp_no_atomics=0,
                     exact_dda=0)
         base.update(kw)
         eng.set_tuning(**base)
@@ -81,10 +81,11 @@ def main():
                     np.max(np.abs(J - ref)) / ref.max())
         ms = min(times)
         na = eng.get_atomic_count()
+        nw = eng.get_wave_steps()
         print("%-60s %8.1f ms  %7.1f Mpk/s  %6.2f Gstep/s  steps/pk %.1f "
-              "atomics/step %.3f %s" %
+              "atomics/step %.3f lanes busy %.3f %s" %
               (cfg, ms, npk / ms / 1e3, ns / ms / 1e6, ns / npk, na / max(ns, 1),
-               ok),
+               ns / max(64. * nw, 1.), ok),
               flush=True)
     eng.close()
 

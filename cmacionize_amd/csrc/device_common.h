@@ -177,17 +177,33 @@ __host__ __device__ __forceinline__ double *acc_at(const CellsDev &cells,
          cell * cells.acc_cell_stride;
 }
 
-/* Queue of re-emitted packets between two transport passes (SoA). An entry is
- * a packet right after the re-emission decision: where it is, its new
- * frequency and type, and how far its random stream has been consumed. */
+/* Packet queues between kernels (SoA). Two kinds of entry share the struct:
+ *
+ *  ended flights  (transport -> interaction kernel): a packet that was absorbed;
+ *                 pos = where, cell = in which cell, nu = its frequency;
+ *  ready flights  (interaction -> transport kernel, or imported from another
+ *                 process): a packet about to fly; pos, dir, tau = the
+ *                 optical depth left, nu.
+ *
+ * id is the packet's index relative to the launch's first packet; meta says
+ * how far its random stream has been consumed and carries its type. */
 struct QueueDev {
   double *pos[3];
+  double *dir[3]; /* ready flights only */
+  double *tau;    /* ready flights only */
   double *nu;
-  uint32_t *id;   /* packet id relative to the launch's first packet */
+  int32_t *cell;  /* ended flights only */
+  uint32_t *id;
   uint32_t *meta; /* bits 0-23 rng blocks consumed, bit 24 rng cache valid,
                      bits 28-31 photon type */
   unsigned int *count;
 };
+
+__host__ __device__ inline uint32_t cmi_pack_meta(uint32_t rng_block,
+                                                  uint32_t rng_have,
+                                                  uint32_t type) {
+  return (rng_block & 0xffffffu) | ((rng_have & 1u) << 24) | (type << 28);
+}
 
 /* packet counters accumulated by the transport kernel */
 struct CountersDev {

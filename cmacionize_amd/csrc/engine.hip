@@ -41,6 +41,7 @@ int fail(int code, const char *fmt, ...) {
 
 struct EventPair {
   hipEvent_t start, stop;
+  uint64_t packets = 0; /* flights started by the launch */
 };
 
 } // namespace
@@ -85,14 +86,14 @@ struct cmi_gpu_engine {
   /* re-emission queues (ping-pong) */
   double *queue_block = nullptr;
   uint64_t queue_capacity = 0;
-  QueueDev queue[2];
-  unsigned int *queue_counts = nullptr; /* [2] */
+  QueueDev ended_queue, ready_queue;
+  unsigned int *queue_counts = nullptr; /* [2]: ended, ready */
 
   struct Tuning {
     bool sort_packets = true;
     int sort_tau_bits = -1;  /* tau classes per direction bin; -1 = auto */
     int aggregate = CMI_AGG_BLOCK;      /* first generation (sorted bundles) */
-    int aggregate_reemit = CMI_AGG_RUNS; /* later generations (random flights) */
+    int aggregate_reemit = CMI_AGG_NONE; /* later generations (random flights) */
     int refill_threshold = CMI_REFILL_THRESHOLD;
     uint32_t chunk = 64;
     int max_blocks_per_cu = 8;
@@ -100,7 +101,7 @@ struct cmi_gpu_engine {
     bool exp_no_atomics = false;
     bool exact_dda = false;
     bool reemit_passes = true;
-    int refill_threshold_reemit = 16;
+    int refill_threshold_reemit = 32;
     uint64_t reemit_inline_below = 4096;
     int reemit_max_passes = 12;
   } tune;
@@ -931,20 +932,39 @@ static int reserve_queues(cmi_gpu_engine *e, uint64_t n) {
   (void)hipFree(e->queue_block);
   e->queue_block = nullptr;
   e->queue_capacity = 0;
-  /* per queue: 4 double arrays + 2 uint32 arrays = 5 doubles per packet */
-  HIP_TRY(hipMalloc(&e->queue_block, sizeof(double) * 10 * n));
+  /* ended flights: pos[3], nu + cell, id, meta = 5.5 doubles per packet;
+   * ready flights: pos[3], dir[3], tau, nu + id, meta = 9 doubles per packet;
+   * every packet of a launch can be in either */
+  const size_t ended_doubles = 6, ready_doubles = 9;
+  HIP_TRY(hipMalloc(&e->queue_block,
+                    sizeof(double) * (ended_doubles + ready_doubles) * n));
   if (!e->queue_counts) {
     HIP_TRY(hipMalloc(&e->queue_counts, 2 * sizeof(unsigned int)));
   }
-  for (int q = 0; q < 2; ++q) {
-    double *base = e->queue_block + (size_t)q * 5 * n;
-    for (int a = 0; a < 3; ++a)
-      e->queue[q].pos[a] = base + (size_t)a * n;
-    e->queue[q].nu = base + (size_t)3 * n;
-    e->queue[q].id = (uint32_t *)(base + (size_t)4 * n);
-    e->queue[q].meta = e->queue[q].id + n;
-    e->queue[q].count = e->queue_counts + q;
+  QueueDev &q = e->ended_queue;
+  double *base = e->queue_block;
+  for (int a = 0; a < 3; ++a) {
+    q.pos[a] = base + (size_t)a * n;
+    q.dir[a] = nullptr;
   }
+  q.tau = nullptr;
+  q.nu = base + (size_t)3 * n;
+  q.cell = (int32_t *)(base + (size_t)4 * n);
+  q.id = (uint32_t *)q.cell + n;
+  q.meta = q.id + n;
+  q.count = e->queue_counts;
+  QueueDev &r = e->ready_queue;
+  base = e->queue_block + ended_doubles * n;
+  for (int a = 0; a < 3; ++a) {
+    r.pos[a] = base + (size_t)a * n;
+    r.dir[a] = base + (size_t)(3 + a) * n;
+  }
+  r.tau = base + (size_t)6 * n;
+  r.nu = base + (size_t)7 * n;
+  r.cell = nullptr;
+  r.id = (uint32_t *)(base + (size_t)8 * n);
+  r.meta = r.id + n;
+  r.count = e->queue_counts + 1;
   e->queue_capacity = n;
   return CMI_GPU_OK;
 }
@@ -975,35 +995,48 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   const int agg = small_grid ? e->tune.aggregate : CMI_AGG_NONE;
   const int agg_reemit = small_grid ? e->tune.aggregate_reemit : CMI_AGG_NONE;
   const bool exact = e->tune.exact_dda || !small_grid;
+  /* with re-emission in passes the transport launches use the variant WITHOUT
+   * the re-emission code (absorbed packets go to the interaction kernel); the
+   * variant with it follows re-emissions in place */
+  const bool passes = reemit && e->tune.reemit_passes;
   void (*kernel)(const ShootArgs) = nullptr;
-#define PICK(F, H, R, X)                                                       \
-  if (e->full_ions == F && heat == H && reemit == R && exact == X)             \
-    kernel = shoot_kernel<F, H, R, X>;
-  PICK(false, false, false, false)
-  PICK(false, false, true, false)
-  PICK(false, true, false, false)
-  PICK(false, true, true, false)
-  PICK(true, false, false, false)
-  PICK(true, false, true, false)
-  PICK(true, true, false, false)
-  PICK(true, true, true, false)
-  PICK(false, false, false, true)
-  PICK(false, false, true, true)
-  PICK(false, true, false, true)
-  PICK(false, true, true, true)
-  PICK(true, false, false, true)
-  PICK(true, false, true, true)
-  PICK(true, true, false, true)
-  PICK(true, true, true, true)
+  void (*kernel_inline)(const ShootArgs) = nullptr;
+#define PICK(F, H, X)                                                          \
+  if (e->full_ions == F && heat == H && exact == X) {                          \
+    kernel = shoot_kernel<F, H, false, X>;                                     \
+    kernel_inline = shoot_kernel<F, H, true, X>;                               \
+  }
+  PICK(false, false, false)
+  PICK(false, true, false)
+  PICK(true, false, false)
+  PICK(true, true, false)
+  PICK(false, false, true)
+  PICK(false, true, true)
+  PICK(true, false, true)
+  PICK(true, true, true)
 #undef PICK
+  if (reemit && !passes)
+    kernel = kernel_inline;
 
-  int blocks_per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel,
-                                                       CMI_BLOCK, 0));
-  if (blocks_per_cu < 1)
-    blocks_per_cu = 1;
-  if (blocks_per_cu > e->tune.max_blocks_per_cu)
-    blocks_per_cu = e->tune.max_blocks_per_cu;
+  auto occupancy = [&](void (*k)(const ShootArgs), int &blocks_per_cu) -> int {
+    blocks_per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k,
+                                                         CMI_BLOCK, 0));
+    if (blocks_per_cu < 1)
+      blocks_per_cu = 1;
+    if (blocks_per_cu > e->tune.max_blocks_per_cu)
+      blocks_per_cu = e->tune.max_blocks_per_cu;
+    return CMI_GPU_OK;
+  };
+  int blocks_per_cu = 0, blocks_per_cu_inline = 0;
+  {
+    int rc = occupancy(kernel, blocks_per_cu);
+    if (rc)
+      return rc;
+    rc = occupancy(kernel_inline, blocks_per_cu_inline);
+    if (rc)
+      return rc;
+  }
 
   const bool sorted = e->tune.sort_packets;
   const uint64_t max_launch = e->tune.max_packets_per_launch;
@@ -1013,14 +1046,13 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     if (rc)
       return rc;
   }
-  const bool passes = reemit && e->tune.reemit_passes;
   if (passes) {
     int rc = reserve_queues(e, n_packets < max_launch ? n_packets : max_launch);
     if (rc)
       return rc;
   }
-  const QueueDev no_queue = {{nullptr, nullptr, nullptr}, nullptr, nullptr,
-                             nullptr, nullptr};
+  QueueDev no_queue;
+  memset(&no_queue, 0, sizeof no_queue);
   /* sort key: 22 direction bits, the tau class and the source index. The
    * tau classes only help when a packet's range follows from its optical
    * depth alone (one cross section for all packets). */
@@ -1067,7 +1099,7 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     if (passes) {
       HIP_TRY(hipMemsetAsync(e->queue_counts, 0, 2 * sizeof(unsigned int),
                              e->stream));
-      a.qout = e->queue[0];
+      a.qout = e->ended_queue;
     }
 
     EventPair ev;
@@ -1119,13 +1151,32 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     kernel<<<(unsigned)blocks, CMI_BLOCK, 0, e->stream>>>(a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(kev.stop, e->stream));
+    kev.packets = n;
     e->kernel_events.push_back(kev);
-    /* later generations: the re-emitted packets of the previous pass. Their
-     * flights start all over the grid in random directions, so these passes
-     * refill eagerly instead of keeping ray bundles together. */
+    /* later generations: the interaction kernel turns the ended flights of
+     * one transport launch into the ready flights of the next. Those start
+     * all over the grid in random directions, so these launches refill
+     * eagerly instead of keeping ray bundles together. */
     for (int gen = 0; passes; ++gen) {
+      InteractArgs ia;
+      ia.model = e->model;
+      ia.cells = e->cells;
+      ia.counters = e->counters;
+      ia.first_packet = a.first_packet;
+      ia.seed = seed;
+      ia.iteration = iteration;
+      ia.qin = e->ended_queue;
+      ia.qout = e->ready_queue;
+      HIP_TRY(hipMemsetAsync(e->ready_queue.count, 0, sizeof(unsigned int),
+                             e->stream));
+      const int iblocks = e->num_cu * 8;
+      if (e->full_ions)
+        interaction_kernel<true><<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);
+      else
+        interaction_kernel<false><<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);
+      HIP_TRY(hipGetLastError());
       unsigned int count = 0;
-      HIP_TRY(hipMemcpyAsync(&count, e->queue[gen & 1].count,
+      HIP_TRY(hipMemcpyAsync(&count, e->ready_queue.count,
                              sizeof(unsigned int), hipMemcpyDeviceToHost,
                              e->stream));
       HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1138,13 +1189,14 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       b.n_packets = count;
       b.refill_threshold = e->tune.refill_threshold_reemit;
       b.aggregate = agg_reemit;
-      b.qin = e->queue[gen & 1];
-      b.qout = last ? no_queue : e->queue[(gen + 1) & 1];
+      b.qin = e->ready_queue;
+      b.qout = last ? no_queue : e->ended_queue;
       if (!last)
-        HIP_TRY(hipMemsetAsync(e->queue[(gen + 1) & 1].count, 0,
-                               sizeof(unsigned int), e->stream));
+        HIP_TRY(hipMemsetAsync(e->ended_queue.count, 0, sizeof(unsigned int),
+                               e->stream));
       const uint64_t nch = ((uint64_t)count + b.chunk - 1) / b.chunk;
-      int64_t nb = (int64_t)e->num_cu * blocks_per_cu;
+      int64_t nb =
+          (int64_t)e->num_cu * (last ? blocks_per_cu_inline : blocks_per_cu);
       const int64_t nneed =
           (int64_t)((nch + (CMI_BLOCK / 64) - 1) / (CMI_BLOCK / 64));
       if (nb > nneed)
@@ -1155,9 +1207,12 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       HIP_TRY(hipEventCreate(&gev.start));
       HIP_TRY(hipEventCreate(&gev.stop));
       HIP_TRY(hipEventRecord(gev.start, e->stream));
-      kernel<<<(unsigned)nb, CMI_BLOCK, 0, e->stream>>>(b);
+      /* the last pass follows whatever is still re-emitted in place */
+      (last ? kernel_inline : kernel)<<<(unsigned)nb, CMI_BLOCK, 0,
+                                        e->stream>>>(b);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(gev.stop, e->stream));
+      gev.packets = count;
       e->kernel_events.push_back(gev);
       if (last)
         break;
@@ -1499,6 +1554,25 @@ int cmi_gpu_get_timing(cmi_gpu_engine *e, int32_t reset, double *shoot_ms,
     e->shoot_events.clear();
     e->update_events.clear();
     e->kernel_events.clear();
+  }
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_get_launch_times(cmi_gpu_engine *e, uint64_t capacity,
+                             double *ms, uint64_t *packets, uint64_t *count) {
+  if (!e || !count)
+    return fail(CMI_GPU_EINVAL, "get_launch_times: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *count = e->kernel_events.size();
+  for (uint64_t i = 0; i < e->kernel_events.size() && i < capacity; ++i) {
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, e->kernel_events[i].start,
+                                e->kernel_events[i].stop));
+    if (ms)
+      ms[i] = t;
+    if (packets)
+      packets[i] = e->kernel_events[i].packets;
   }
   return CMI_GPU_OK;
 }

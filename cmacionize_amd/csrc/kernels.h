@@ -59,9 +59,11 @@ struct ShootArgs {
   int32_t refill_threshold;
   int32_t exp_no_atomics; /* experiment: skip the accumulation */
   int32_t aggregate;      /* CMI_AGG_* */
-  /* re-emission in passes: qin.id != NULL: this launch continues the packets
-   * of qin instead of emitting new ones; qout.id != NULL: packets that are
-   * re-emitted are parked in qout instead of being followed in place */
+  /* qin.id != NULL: this launch flies the ready flights of qin instead of
+   * emitting new packets. qout.id != NULL: a packet that is absorbed is parked
+   * in qout (an "ended flight") for the interaction kernel to decide about
+   * its re-emission; otherwise it is re-emitted in place (REEMIT variants) or
+   * counted as absorbed. */
   QueueDev qin, qout;
 };
 
@@ -241,6 +243,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 8)
   Packet<FULL> p;
   PacketRng rng;
   uint32_t packet_id = 0;
+  uint32_t lane_meta = 0; /* rng position of the lane's packet (cmi_pack_meta) */
   bool active = false;
   int32_t last_cell = -1; /* EXACT marcher on grids >= 2^31 cells: see below */
   int64_t last_cell_wide = -1;
@@ -362,23 +365,31 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 8)
       const uint64_t rank = __popcll(idle_mask & lane_lt);
       if (!active && rank < avail) {
         const uint64_t i = pos + rank;
-        if (REEMIT && a.qin.id != nullptr) {
-          /* continue a re-emitted packet of the previous pass */
+        if (a.qin.id != nullptr) {
+          /* a ready flight: re-emitted by the interaction kernel, or handed
+           * over by another process */
           packet_id = a.qin.id[i];
-          const uint32_t meta = a.qin.meta[i];
-          rng.resume(a.seed, a.iteration, a.first_packet + packet_id,
-                     meta & 0xffffffu, (meta >> 24) & 1u);
+          lane_meta = a.qin.meta[i];
+          if (REEMIT)
+            rng.resume(a.seed, a.iteration, a.first_packet + packet_id,
+                       lane_meta & 0xffffffu, (lane_meta >> 24) & 1u);
 #pragma unroll
-          for (int ax = 0; ax < 3; ++ax)
+          for (int ax = 0; ax < 3; ++ax) {
             p.pos[ax] = a.qin.pos[ax][i];
-          p.type = (int32_t)(meta >> 28);
+            p.dir[ax] = a.qin.dir[ax][i];
+            p.inv_dir[ax] = 1. / p.dir[ax];
+          }
+          p.type = (int32_t)(lane_meta >> 28);
           p.weight = 1.;
-          reemit_launch<FULL, EXACT>(a.grid, a.model, a.qin.nu[i], rng, p,
-                                     weights);
+          p.nu = a.qin.nu[i];
+          p.tau = a.qin.tau[i];
+          set_cross_sections(a.model, p, weights);
+          start_flight<FULL, EXACT>(a.grid, p);
         } else {
           packet_id = a.order ? a.order[i] : (uint32_t)i;
           rng.init(a.seed, a.iteration, a.first_packet + packet_id);
           emit_packet<FULL, EXACT>(a.grid, a.model, rng, p, weights);
+          lane_meta = cmi_pack_meta(rng.block, rng.have, 0);
         }
         if (FULL) {
 #pragma unroll
@@ -496,9 +507,33 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 8)
         } else {
           done = true; /* left the box: DensityGrid::end() */
         }
-        double new_frequency = 0.;
-        if (absorbed) {
+        if (absorbed && a.qout.id != nullptr) {
+          /* park the packet for the interaction kernel (PhotonSource::reemit
+           * happens there): wave-level compaction into the queue */
+          if (!EXACT)
+            end_flight(p); /* position of the absorption */
+          const unsigned long long parked = __ballot(true);
+          unsigned int base = 0;
+          const int first = __ffsll((long long)parked) - 1;
+          if (lane == first)
+            base = atomicAdd(a.qout.count, (unsigned int)__popcll(parked));
+          base = __shfl(base, first, 64);
+          const unsigned int q = base + __popcll(parked & lane_lt);
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax)
+            a.qout.pos[ax][q] = p.pos[ax];
+          a.qout.nu[q] = p.nu;
+          a.qout.cell[q] = (int32_t)cell_now;
+          a.qout.id[q] = packet_id;
+          a.qout.meta[q] =
+              REEMIT ? cmi_pack_meta(rng.block, rng.have, (uint32_t)p.type)
+                     : ((lane_meta & 0x01ffffffu) | ((uint32_t)p.type << 28));
+          active = false; /* leaves this launch, not finished */
+          last_cell = -1;
+          last_cell_wide = -1;
+        } else if (absorbed) {
           /* PhotonSource::reemit, src/PhotonSource.cpp:272-308 */
+          double new_frequency = 0.;
           if (REEMIT)
             new_frequency =
                 reemit_decide<FULL, EXACT>(a.model, a.cells, cell_now, rng, p);
@@ -507,31 +542,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 8)
           last_cell = -1;
           last_cell_wide = -1;
           done = (new_frequency == 0.);
-        }
-        if (REEMIT) {
-          const bool again = absorbed && new_frequency != 0.;
-          if (a.qout.id != nullptr) {
-            /* park the re-emitted packets for the next pass: their flights
-             * share nothing with this wave's ray bundle */
-            const unsigned long long parked = __ballot(again);
-            if (parked != 0ull) {
-              unsigned int base = 0;
-              if (lane == __ffsll((long long)parked) - 1)
-                base = atomicAdd(a.qout.count, (unsigned int)__popcll(parked));
-              base = __shfl(base, __ffsll((long long)parked) - 1, 64);
-              if (again) {
-                const unsigned int q = base + __popcll(parked & lane_lt);
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax)
-                  a.qout.pos[ax][q] = p.pos[ax];
-                a.qout.nu[q] = new_frequency;
-                a.qout.id[q] = packet_id;
-                a.qout.meta[q] = (rng.block & 0xffffffu) | (rng.have << 24) |
-                                 ((uint32_t)p.type << 28);
-                active = false; /* leaves this launch, not finished */
-              }
-            }
-          } else if (again) {
+          if (REEMIT && !done) {
             reemit_launch<FULL, EXACT>(a.grid, a.model, new_frequency, rng, p,
                                        weights);
             if (FULL) {
@@ -569,6 +580,113 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 8)
     atomicAdd(&a.counters->nsteps, (unsigned long long)ns);
     atomicAdd(&a.counters->natomics, (unsigned long long)na);
     atomicAdd(&a.counters->nwavesteps, (unsigned long long)nwavesteps);
+  }
+}
+
+/*
+ * Interaction kernel: PhotonSource::reemit (src/PhotonSource.cpp:272-308) for
+ * every ended flight of `qin` - the diffuse re-emission decision of the
+ * handler, and for the packets that go on: new isotropic direction and new
+ * optical depth (src/IonizationPhotonShootJob.hpp:139-141). Survivors are
+ * compacted into `qout` as ready flights for the next transport launch; the
+ * others are counted as absorbed. The packet's random stream continues where
+ * the transport kernel left it, so the draws are those of the reference's
+ * loop, in its order. One lane per packet; keeping this long, divergent code
+ * (spectrum sampling, pow, sincos, log) out of the transport kernel is what
+ * lets that one run at 8 waves per SIMD.
+ */
+struct InteractArgs {
+  ModelDev model;
+  CellsDev cells;
+  CountersDev *counters;
+  uint64_t first_packet;
+  uint32_t seed;
+  uint32_t iteration;
+  QueueDev qin;  /* ended flights */
+  QueueDev qout; /* ready flights */
+};
+
+template <bool FULL>
+__global__ void __launch_bounds__(CMI_BLOCK)
+    interaction_kernel(const InteractArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  const uint64_t count = *a.qin.count;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  double tw = 0., tc3 = 0.;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x +
+                       (threadIdx.x & ~63u);
+       base < count; base += stride) {
+    const uint64_t i = base + lane;
+    const bool valid = i < count;
+    double new_frequency = 0.;
+    int32_t type = TYPE_ABSORBED;
+    PacketRng rng;
+    uint32_t id = 0;
+    if (valid) {
+      id = a.qin.id[i];
+      const uint32_t meta = a.qin.meta[i];
+      rng.resume(a.seed, a.iteration, a.first_packet + id, meta & 0xffffffu,
+                 (meta >> 24) & 1u);
+      const double nu = a.qin.nu[i];
+      const int32_t cell = a.qin.cell[i];
+      if (a.model.reemit_type == 2) {
+        /* FixedValueDiffuseReemissionHandler::reemit,
+         * src/FixedValueDiffuseReemissionHandler.hpp:73-86 */
+        if (rng.next() < a.model.reemit_fixed_probability) {
+          type = TYPE_DIFFUSE_HI;
+          new_frequency = a.model.reemit_fixed_frequency;
+        }
+      } else {
+        double sigma_H, sigma_He;
+        if (FULL) {
+          double sigma[CMI_NACC];
+          cmi_cross_sections(a.model, nu, sigma);
+          sigma_H = sigma[ION_H_n];
+          sigma_He = sigma[ION_He_n];
+        } else {
+          sigma_H = a.model.xsec_fixed[ION_H_n];
+          sigma_He = a.model.xsec_fixed[ION_He_n];
+        }
+        new_frequency = physical_reemit(
+            a.model, sigma_H, sigma_He, a.cells.temperature[cell],
+            a.cells.x[ION_H_n][cell], a.cells.x[ION_He_n][cell], rng, type);
+      }
+    }
+    const bool again = valid && new_frequency != 0.;
+    const unsigned long long going = __ballot(again);
+    if (going != 0ull) {
+      unsigned int q0 = 0;
+      const int first = __ffsll((long long)going) - 1;
+      if (lane == first)
+        q0 = atomicAdd(a.qout.count, (unsigned int)__popcll(going));
+      q0 = __shfl(q0, first, 64);
+      if (again) {
+        const unsigned int q = q0 + __popcll(going & lane_lt);
+        Packet<false> p;
+        random_direction(p, rng);
+        const double tau = -log(rng.next());
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          a.qout.pos[ax][q] = a.qin.pos[ax][i];
+          a.qout.dir[ax][q] = p.dir[ax];
+        }
+        a.qout.tau[q] = tau;
+        a.qout.nu[q] = new_frequency;
+        a.qout.id[q] = id;
+        a.qout.meta[q] = cmi_pack_meta(rng.block, rng.have, (uint32_t)type);
+      }
+    }
+    if (valid && !again) {
+      tw += 1.;
+      tc3 += 1.;
+    }
+  }
+  tw = wave_sum(tw);
+  tc3 = wave_sum(tc3);
+  if (lane == 0 && tw != 0.) {
+    atomic_add_f64(&a.counters->totweight, tw);
+    atomic_add_f64(&a.counters->typecount[3], tc3);
   }
 }
 

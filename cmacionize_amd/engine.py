@@ -69,6 +69,7 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_get_atomic_count", "cmi_gpu_sample_spectrum",
     "cmi_gpu_thermal_probe", "cmi_gpu_accumulator_layout",
     "cmi_gpu_get_kernel_timing", "cmi_gpu_get_wave_steps",
+    "cmi_gpu_get_launch_times",
 ]
 
 _lib = None
@@ -127,6 +128,9 @@ def load_library():
     L.cmi_gpu_set_tuning.argtypes = [vp, C.c_char_p, C.c_int64]
     L.cmi_gpu_get_atomic_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.cmi_gpu_get_wave_steps.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.cmi_gpu_get_launch_times.argtypes = [vp, C.c_uint64, _dp,
+                                           C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_uint64)]
     L.cmi_gpu_sample_spectrum.argtypes = [vp, C.c_int32, C.c_double,
                                           C.c_uint32, C.c_uint64, _dp]
     L.cmi_gpu_accumulator_layout.argtypes = [vp, C.POINTER(C.c_int64),
@@ -281,6 +285,19 @@ class GpuEngine:
         n = C.c_uint64()
         self._check(self._lib.cmi_gpu_get_atomic_count(self._h, C.byref(n)))
         return n.value
+
+    def get_launch_times(self):
+        """[(ms, flights)] of the transport launches since the last
+        get_timing(reset=True)."""
+        n = C.c_uint64()
+        self._check(self._lib.cmi_gpu_get_launch_times(self._h, 0, None, None,
+                                                       C.byref(n)))
+        ms = np.zeros(max(n.value, 1))
+        pk = np.zeros(max(n.value, 1), dtype=np.uint64)
+        self._check(self._lib.cmi_gpu_get_launch_times(
+            self._h, n.value, _p(ms),
+            pk.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(n)))
+        return list(zip(ms[:n.value].tolist(), pk[:n.value].tolist()))
 
     def get_wave_steps(self):
         n = C.c_uint64()

@@ -253,15 +253,18 @@ int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
  *                           LDS, written back between ray bundles (hydrogen-only
  *                           transport; multi-ion transport uses its own
  *                           cooperative scheme for any value > 0)
- *   "aggregate_reemit" (1)  the same for the later re-emission passes
+ *   "aggregate_reemit" (0)  the same for the later re-emission passes
  *   "refill_threshold" (64) idle lanes of a wave that trigger a refill
  *   "chunk" (64)            consecutive packets a wave takes at a time
  *   "max_blocks_per_cu" (8), "max_packets_per_launch" (2^27)
- *   "reemit_passes" (1)     with diffuse re-emission: park re-emitted packets
- *                           in a queue and follow them in later passes of the
- *                           kernel (keeps the primary ray bundles together);
- *                           0 = follow them in place
- *   "refill_threshold_reemit" (16), "reemit_inline_below" (4096),
+ *   "reemit_passes" (1)     with diffuse re-emission: absorbed packets are
+ *                           parked in a queue, a separate interaction kernel
+ *                           decides about their re-emission and the survivors
+ *                           fly in the next launch of the transport kernel
+ *                           (keeps the primary ray bundles together and the
+ *                           transport kernel small); 0 = follow re-emissions
+ *                           in place
+ *   "refill_threshold_reemit" (32), "reemit_inline_below" (4096),
  *   "reemit_max_passes" (12)  refill threshold of the later passes; a pass
  *                           with fewer packets than this, or the last allowed
  *                           pass, follows re-emissions in place
@@ -337,6 +340,12 @@ int cmi_gpu_get_timing(cmi_gpu_engine *engine, int32_t reset,
  * cmi_gpu_get_timing(reset != 0). Synchronous. */
 int cmi_gpu_get_kernel_timing(cmi_gpu_engine *engine, double *kernel_ms,
                               uint64_t *kernel_launches);
+/* the same per launch, in launch order: duration and the number of flights
+ * the launch started (packets of the batch, then of each re-emission
+ * generation). *count receives the number of launches; at most `capacity`
+ * entries are written. Synchronous. */
+int cmi_gpu_get_launch_times(cmi_gpu_engine *engine, uint64_t capacity,
+                             double *ms, uint64_t *packets, uint64_t *count);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,7 @@ def main():
         eng.update_cells(loop, tw)
         eng.synchronize()
         t2 = time.perf_counter()
+        launches = eng.get_launch_times()
         tm = eng.get_timing(reset=True)
         na = eng.get_atomic_count()
         xH = eng.download_field(E.FIELD_IONIC_FRACTION)
@@ -97,6 +98,9 @@ def main():
                ns / tm["shoot_ms"] / 1e6, na / max(ns, 1), tm["update_ms"],
                tc[3] / tw, tc[1] / tw, tc[2] / tw, (xH < 0.5).mean(),
                T[xH < 0.5].mean() if (xH < 0.5).any() else 0.), flush=True)
+        if os.environ.get("CMI_SHOW_LAUNCHES"):
+            print("      launches: " + " ".join(
+                "%.1fms/%.2gpk" % (ms, pk) for ms, pk in launches), flush=True)
     eng.close()
 
 

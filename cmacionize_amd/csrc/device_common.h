@@ -45,9 +45,30 @@ struct GridDev {
   double box_sides[3];
   double cellside[3];
   double inv_cellside[3];
-  int32_t ncell[3];
+  int32_t ncell[3];    /* cells of THIS engine's (sub)grid */
   int32_t periodic[3];
   int64_t ncell_total;
+  /* domain decomposition (DensitySubGridCreator,
+   * src/DensitySubGridCreator.hpp:314-396): the engine holds the block of
+   * cells [offset, offset + ncell) of a grid of global_ncell cells. anchor,
+   * box_sides and cellside always describe the WHOLE grid, so that wall
+   * coordinates are the same numbers in every block. */
+  int32_t offset[3];
+  int32_t global_ncell[3];
+  int32_t decomposed;
+};
+
+/* A flight handed from one block of a decomposed grid to another: the FAST
+ * marcher's state at the wall, CMI_FLIGHT_DOUBLES doubles per flight:
+ *  [0-2] origin of the flight  [3-5] direction  [6] path parameter t
+ *  [7-9] next wall parameter per axis  [10] optical depth left  [11] frequency
+ *  [12] (int64) long index, in the WHOLE grid, of the cell being entered
+ *  [13] (2 x uint32) packet id, meta  [14-15] unused */
+#define CMI_FLIGHT_DOUBLES 16
+struct ExchangeDev {
+  double *rows;
+  unsigned int *count;
+  unsigned int capacity;
 };
 
 /* one (ion, shell) term of the Verner cross section, converted as in

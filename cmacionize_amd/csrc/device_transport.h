@@ -107,7 +107,8 @@ __device__ __forceinline__ void locate_cell(const GridDev &g,
                                             Packet<FULL> &p) {
 #pragma unroll
   for (int a = 0; a < 3; ++a)
-    p.index[a] = (int32_t)((p.pos[a] - g.anchor[a]) * g.inv_cellside[a]);
+    p.index[a] = (int32_t)((p.pos[a] - g.anchor[a]) * g.inv_cellside[a]) -
+                 g.offset[a];
 }
 
 /* CartesianDensityGrid::is_inside, src/CartesianDensityGrid.cpp:187-227 */
@@ -148,7 +149,8 @@ __device__ __forceinline__ void start_flight(const GridDev &g,
     const int32_t stride[3] = {g.ncell[1] * g.ncell[2], g.ncell[2], 1};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const double lo = g.anchor[a] + g.cellside[a] * p.index[a];
+      const double lo =
+          g.anchor[a] + g.cellside[a] * (p.index[a] + g.offset[a]);
       const double hi = lo + g.cellside[a];
       p.tmax[a] =
           (p.dir[a] > 0.)
@@ -209,7 +211,7 @@ __device__ __forceinline__ double dda_step(const GridDev &g,
   double d[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const double lo = g.anchor[a] + g.cellside[a] * p.index[a];
+    const double lo = g.anchor[a] + g.cellside[a] * (p.index[a] + g.offset[a]);
     const double hi = lo + g.cellside[a];
     d[a] = (p.dir[a] > 0.)
                ? (hi - p.pos[a]) * p.inv_dir[a]
@@ -323,6 +325,62 @@ __device__ __forceinline__ void fast_wrap(const GridDev &g, Packet<FULL> &p) {
       p.pos[a] -= (p.cstep[a] > 0 ? 1. : -1.) * g.box_sides[a];
     }
   }
+}
+
+/* FAST, decomposed grids: continue a flight that another block handed over.
+ * The marcher's parametric state (origin, direction, t, tmax) travels with the
+ * packet, so the arithmetic goes on exactly as if the grid were whole; only
+ * the block-local bookkeeping is rebuilt from the cell being entered. */
+template <bool FULL>
+__device__ __forceinline__ void resume_flight(const GridDev &g, Packet<FULL> &p,
+                                              int64_t cell_global) {
+  const int64_t gz = cell_global % g.global_ncell[2];
+  const int64_t gy = (cell_global / g.global_ncell[2]) % g.global_ncell[1];
+  const int64_t gx = cell_global / ((int64_t)g.global_ncell[2] *
+                                    g.global_ncell[1]);
+  p.index[0] = (int32_t)gx - g.offset[0];
+  p.index[1] = (int32_t)gy - g.offset[1];
+  p.index[2] = (int32_t)gz - g.offset[2];
+  bool inside = true;
+  const int32_t stride[3] = {g.ncell[1] * g.ncell[2], g.ncell[2], 1};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    inside &= (p.index[a] >= 0 && p.index[a] < g.ncell[a]);
+    p.tdelta[a] = (p.dir[a] != 0.) ? g.cellside[a] * fabs(p.inv_dir[a]) : 0.;
+    p.cstep[a] = (p.dir[a] > 0.) ? stride[a] : -stride[a];
+    p.rem[a] = (p.dir[a] > 0.) ? g.ncell[a] - 1 - p.index[a] : p.index[a];
+  }
+  if (!inside)
+    p.rem[0] = -1;
+  p.cell = (p.index[0] * g.ncell[1] + p.index[1]) * g.ncell[2] + p.index[2];
+}
+
+/* FAST, decomposed grids: the packet has stepped out of this block from
+ * `last_cell` into p.cell (a long index one past a face). Returns the long
+ * index of that cell in the WHOLE grid, or -1 if it lies outside the whole
+ * grid. Every tied axis advanced by one cell, so the difference of the two
+ * long indices decodes uniquely (blocks are at least 3 cells wide). */
+template <bool FULL>
+__device__ __forceinline__ int64_t
+exit_cell_global(const GridDev &g, const Packet<FULL> &p, int32_t last_cell) {
+  const int32_t ny = g.ncell[1], nz = g.ncell[2];
+  int32_t iz = last_cell % nz;
+  int32_t iy = (last_cell / nz) % ny;
+  int32_t ix = last_cell / (nz * ny);
+  int32_t d = p.cell - last_cell;
+  int32_t dz = ((d % nz) + nz) % nz; /* 0, 1 or nz - 1 */
+  dz = (dz == nz - 1) ? -1 : dz;
+  d = (d - dz) / nz;
+  int32_t dy = ((d % ny) + ny) % ny;
+  dy = (dy == ny - 1) ? -1 : dy;
+  const int32_t dx = (d - dy) / ny;
+  const int64_t gx = (int64_t)ix + dx + g.offset[0];
+  const int64_t gy = (int64_t)iy + dy + g.offset[1];
+  const int64_t gz = (int64_t)iz + dz + g.offset[2];
+  if (gx < 0 || gx >= g.global_ncell[0] || gy < 0 ||
+      gy >= g.global_ncell[1] || gz < 0 || gz >= g.global_ncell[2])
+    return -1;
+  return (gx * g.global_ncell[1] + gy) * g.global_ncell[2] + gz;
 }
 
 /* FAST: materialise the current position (end of a flight) */

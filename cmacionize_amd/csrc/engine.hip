@@ -87,6 +87,10 @@ struct cmi_gpu_engine {
   double *queue_block = nullptr;
   uint64_t queue_capacity = 0;
   QueueDev ended_queue, ready_queue;
+  /* decomposed grids: caller-owned buffer for the flights that leave */
+  double *export_rows = nullptr;
+  uint64_t export_capacity = 0;
+  unsigned int *export_count = nullptr;
   unsigned int *queue_counts = nullptr; /* [2]: ended, ready */
 
   struct Tuning {
@@ -468,6 +472,23 @@ int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
     if (!(config->sides[a] > 0.))
       return fail(CMI_GPU_EINVAL, "box sides must be positive");
   }
+  if (config->sub_ncell[0] > 0 || config->sub_ncell[1] > 0 ||
+      config->sub_ncell[2] > 0) {
+    for (int a = 0; a < 3; ++a) {
+      if (config->sub_ncell[a] < 3 || config->sub_offset[a] < 0 ||
+          config->sub_offset[a] + config->sub_ncell[a] > config->ncell[a])
+        return fail(CMI_GPU_EINVAL,
+                    "a block of a decomposed grid must lie inside the grid "
+                    "and be at least 3 cells wide");
+      if (config->periodic[a])
+        return fail(CMI_GPU_EINVAL,
+                    "decomposed grids with periodic boundaries are not "
+                    "supported");
+    }
+  }
+  if ((int64_t)config->ncell[0] * config->ncell[1] * config->ncell[2] >=
+      (1ll << 62))
+    return fail(CMI_GPU_EINVAL, "grid too large");
   int ndev = 0;
   hipError_t err = hipGetDeviceCount(&ndev);
   if (err != hipSuccess || ndev == 0)
@@ -493,16 +514,24 @@ int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
     e->own_stream = true;
   }
 
-  /* CartesianDensityGrid ctor, src/CartesianDensityGrid.cpp:72-79 */
+  /* CartesianDensityGrid ctor, src/CartesianDensityGrid.cpp:72-79; a block
+   * of a decomposed grid keeps the whole grid's anchor and cell size
+   * (DensitySubGridCreator::create_subgrid,
+   * src/DensitySubGridCreator.hpp:314-396) */
   GridDev &g = e->grid;
+  const bool decomposed = config->sub_ncell[0] > 0 || config->sub_ncell[1] > 0 ||
+                          config->sub_ncell[2] > 0;
   for (int a = 0; a < 3; ++a) {
     g.anchor[a] = config->anchor[a];
     g.box_sides[a] = config->sides[a];
-    g.ncell[a] = config->ncell[a];
+    g.global_ncell[a] = config->ncell[a];
+    g.ncell[a] = decomposed ? config->sub_ncell[a] : config->ncell[a];
+    g.offset[a] = decomposed ? config->sub_offset[a] : 0;
     g.periodic[a] = config->periodic[a] ? 1 : 0;
     g.cellside[a] = config->sides[a] / config->ncell[a];
     g.inv_cellside[a] = 1. / g.cellside[a];
   }
+  g.decomposed = decomposed ? 1 : 0;
   e->ncell = (int64_t)g.ncell[0] * g.ncell[1] * g.ncell[2];
   g.ncell_total = e->ncell;
 
@@ -593,6 +622,7 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->sort_temp);
   (void)hipFree(e->queue_block);
   (void)hipFree(e->queue_counts);
+  (void)hipFree(e->export_count);
   if (e->own_stream)
     (void)hipStreamDestroy(e->stream);
   delete e;
@@ -969,8 +999,12 @@ static int reserve_queues(cmi_gpu_engine *e, uint64_t n) {
   return CMI_GPU_OK;
 }
 
-int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
-                  uint64_t first_packet, uint64_t n_packets) {
+/* Transport of n_packets flights and of everything they re-emit: new packets
+ * (flights == NULL) or flights handed over by other blocks of a decomposed
+ * grid (device rows of CMI_FLIGHT_DOUBLES doubles). */
+static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
+                      uint64_t first_packet, uint64_t n_packets,
+                      const double *flights) {
   if (!e)
     return fail(CMI_GPU_EINVAL, "null engine");
   if (!e->have_sources || !e->have_spectrum || !e->have_xsec ||
@@ -980,6 +1014,14 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                 "data must be set first");
   if (n_packets == 0)
     return CMI_GPU_OK;
+  if (n_packets >= (1ull << 32))
+    return fail(CMI_GPU_EINVAL,
+                "cmi_gpu_shoot: at most 2^32 - 1 packets per call");
+  if (e->grid.decomposed && (e->tune.exact_dda || !e->export_rows))
+    return fail(CMI_GPU_ESTATE,
+                "cmi_gpu_shoot: a block of a decomposed grid needs an export "
+                "buffer (cmi_gpu_set_export_buffer) and the incremental "
+                "marcher");
   HIP_TRY(hipSetDevice(e->device));
   {
     int rc = ensure_spectra(e);
@@ -1038,7 +1080,7 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       return rc;
   }
 
-  const bool sorted = e->tune.sort_packets;
+  const bool sorted = e->tune.sort_packets && !flights;
   const uint64_t max_launch = e->tune.max_packets_per_launch;
   if (sorted) {
     int rc = reserve_sort_buffers(e, n_packets < max_launch ? n_packets
@@ -1085,15 +1127,22 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     a.model = e->model;
     a.cells = e->cells;
     a.counters = e->counters;
-    a.first_packet = first_packet + done;
+    a.first_packet = first_packet;
+    a.batch_offset = done;
     a.n_packets = n;
     a.order = nullptr;
+    a.xin = flights ? flights + (size_t)CMI_FLIGHT_DOUBLES * done : nullptr;
+    a.xout.rows = e->export_rows;
+    a.xout.count = e->export_count;
+    a.xout.capacity = (unsigned int)e->export_capacity;
     a.chunk = e->tune.chunk;
     a.seed = seed;
     a.iteration = iteration;
-    a.refill_threshold = e->tune.refill_threshold;
+    /* handed-over flights are no ray bundles worth keeping together */
+    a.refill_threshold = flights ? e->tune.refill_threshold_reemit
+                                 : e->tune.refill_threshold;
     a.exp_no_atomics = e->tune.exp_no_atomics ? 1 : 0;
-    a.aggregate = agg;
+    a.aggregate = flights ? agg_reemit : agg;
     a.qin = no_queue;
     a.qout = no_queue;
     if (passes) {
@@ -1109,7 +1158,7 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     if (sorted) {
       KeyArgs k;
       k.model = e->model;
-      k.first_packet = a.first_packet;
+      k.first_packet = first_packet + done;
       k.n_packets = n;
       k.seed = seed;
       k.iteration = iteration;
@@ -1186,6 +1235,7 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                         gen + 2 >= e->tune.reemit_max_passes;
       ShootArgs b = a;
       b.order = nullptr;
+      b.xin = nullptr;
       b.n_packets = count;
       b.refill_threshold = e->tune.refill_threshold_reemit;
       b.aggregate = agg_reemit;
@@ -1220,6 +1270,67 @@ int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     HIP_TRY(hipEventRecord(ev.stop, e->stream));
     e->shoot_events.push_back(ev);
   }
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_shoot(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
+                  uint64_t first_packet, uint64_t n_packets) {
+  return shoot_impl(e, seed, iteration, first_packet, n_packets, nullptr);
+}
+
+int cmi_gpu_shoot_flights(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
+                          uint64_t first_packet, const void *flights,
+                          uint64_t n_flights) {
+  if (!e || (!flights && n_flights))
+    return fail(CMI_GPU_EINVAL, "shoot_flights: bad argument");
+  if (!e->grid.decomposed)
+    return fail(CMI_GPU_ESTATE,
+                "shoot_flights: the engine is not a block of a decomposed "
+                "grid");
+  return shoot_impl(e, seed, iteration, first_packet, n_flights,
+                    (const double *)flights);
+}
+
+int cmi_gpu_set_export_buffer(cmi_gpu_engine *e, void *rows,
+                              uint64_t capacity) {
+  if (!e || (!rows && capacity) || capacity >= (1ull << 32))
+    return fail(CMI_GPU_EINVAL, "set_export_buffer: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->export_count)
+    HIP_TRY(hipMalloc(&e->export_count, sizeof(unsigned int)));
+  HIP_TRY(hipMemsetAsync(e->export_count, 0, sizeof(unsigned int), e->stream));
+  e->export_rows = (double *)rows;
+  e->export_capacity = capacity;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_get_export_count(cmi_gpu_engine *e, uint64_t *count) {
+  if (!e || !count)
+    return fail(CMI_GPU_EINVAL, "get_export_count: bad argument");
+  *count = 0;
+  if (!e->export_count)
+    return CMI_GPU_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  unsigned int n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, e->export_count, sizeof n, hipMemcpyDeviceToHost,
+                         e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (n > e->export_capacity)
+    return fail(CMI_GPU_ENOMEM,
+                "export buffer overflow: %u flights left the block, room for "
+                "%llu - flights were lost, the iteration is invalid",
+                n, (unsigned long long)e->export_capacity);
+  *count = n;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_reset_exports(cmi_gpu_engine *e) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  if (!e->export_count)
+    return CMI_GPU_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemsetAsync(e->export_count, 0, sizeof(unsigned int), e->stream));
   return CMI_GPU_OK;
 }
 

@@ -47,8 +47,12 @@ struct ShootArgs {
   ModelDev model;
   CellsDev cells;
   CountersDev *counters;
-  /* packets [first_packet, first_packet + n_packets) of this launch */
+  /* the launch handles positions [0, n_packets); position i is packet
+   * first_packet + batch_offset + order[i] of the iteration (emission), or
+   * entry i of qin / xin. Packet ids in queues and hand-over records are
+   * relative to first_packet. */
   uint64_t first_packet;
+  uint64_t batch_offset;
   uint64_t n_packets;
   /* processing order: position i of the launch handles packet
    * first_packet + order[i] (direction-sorted); NULL = identity */
@@ -65,6 +69,11 @@ struct ShootArgs {
    * its re-emission; otherwise it is re-emitted in place (REEMIT variants) or
    * counted as absorbed. */
   QueueDev qin, qout;
+  /* decomposed grids: xin != NULL: this launch continues the flights handed
+   * over by other blocks (CMI_FLIGHT_DOUBLES doubles each); packets that
+   * leave this block into another one are appended to xout */
+  const double *xin;
+  ExchangeDev xout;
 };
 
 /* update_integrals, src/DensityGrid.hpp:150-197, hydrogen-only form without
@@ -365,9 +374,35 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 8)
       const uint64_t rank = __popcll(idle_mask & lane_lt);
       if (!active && rank < avail) {
         const uint64_t i = pos + rank;
-        if (a.qin.id != nullptr) {
-          /* a ready flight: re-emitted by the interaction kernel, or handed
-           * over by another process */
+        bool mine = true;
+        if (a.xin != nullptr) {
+          /* a flight handed over by another block of the grid */
+          const double *r = a.xin + (size_t)CMI_FLIGHT_DOUBLES * i;
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            p.pos[ax] = r[ax];
+            p.dir[ax] = r[3 + ax];
+            p.inv_dir[ax] = 1. / p.dir[ax];
+            p.tmax[ax] = r[7 + ax];
+          }
+          p.t = r[6];
+          p.tau = r[10];
+          p.nu = r[11];
+          const int64_t cell_global = __double_as_longlong(r[12]);
+          const unsigned long long idmeta =
+              (unsigned long long)__double_as_longlong(r[13]);
+          packet_id = (uint32_t)idmeta;
+          lane_meta = (uint32_t)(idmeta >> 32);
+          if (REEMIT)
+            rng.resume(a.seed, a.iteration, a.first_packet + packet_id,
+                       lane_meta & 0xffffffu, (lane_meta >> 24) & 1u);
+          p.type = (int32_t)(lane_meta >> 28);
+          p.weight = 1.;
+          set_cross_sections(a.model, p, weights);
+          if (!EXACT)
+            resume_flight(a.grid, p, cell_global);
+        } else if (a.qin.id != nullptr) {
+          /* a ready flight: re-emitted by the interaction kernel */
           packet_id = a.qin.id[i];
           lane_meta = a.qin.meta[i];
           if (REEMIT)
@@ -386,17 +421,33 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 8)
           set_cross_sections(a.model, p, weights);
           start_flight<FULL, EXACT>(a.grid, p);
         } else {
-          packet_id = a.order ? a.order[i] : (uint32_t)i;
+          packet_id =
+              (uint32_t)a.batch_offset + (a.order ? a.order[i] : (uint32_t)i);
           rng.init(a.seed, a.iteration, a.first_packet + packet_id);
           emit_packet<FULL, EXACT>(a.grid, a.model, rng, p, weights);
           lane_meta = cmi_pack_meta(rng.block, rng.have, 0);
+          if (a.grid.decomposed) {
+            /* every block runs through all packets of the iteration but only
+             * flies those whose source lies in it; a source outside the whole
+             * grid is the business of the block at the grid's origin */
+            bool in_block = true, in_grid = true;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+              const int32_t gi = p.index[ax] + a.grid.offset[ax];
+              in_block &= (p.index[ax] >= 0 && p.index[ax] < a.grid.ncell[ax]);
+              in_grid &= (gi >= 0 && gi < a.grid.global_ncell[ax]);
+            }
+            const bool at_origin = (a.grid.offset[0] | a.grid.offset[1] |
+                                    a.grid.offset[2]) == 0;
+            mine = in_block || (!in_grid && at_origin);
+          }
         }
         if (FULL) {
 #pragma unroll
           for (int i = 0; i < CMI_NACC; ++i)
             stage.weight[lane][i] = weights[i];
         }
-        active = true;
+        active = mine;
         last_cell = -1;
         last_cell_wide = -1;
       }
@@ -506,6 +557,43 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 8)
           done = !absorbed;
         } else {
           done = true; /* left the box: DensityGrid::end() */
+          if (!EXACT && a.grid.decomposed && last_cell >= 0) {
+            /* ... or only this block of it: hand the flight over */
+            const int64_t cell_global = exit_cell_global(a.grid, p, last_cell);
+            if (cell_global >= 0) {
+              const unsigned long long leaving = __ballot(true);
+              unsigned int base = 0;
+              const int first = __ffsll((long long)leaving) - 1;
+              if (lane == first)
+                base = atomicAdd(a.xout.count,
+                                 (unsigned int)__popcll(leaving));
+              base = __shfl(base, first, 64);
+              const unsigned int q = base + __popcll(leaving & lane_lt);
+              if (q < a.xout.capacity) {
+                double *r = a.xout.rows + (size_t)CMI_FLIGHT_DOUBLES * q;
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                  r[ax] = p.pos[ax];
+                  r[3 + ax] = p.dir[ax];
+                  r[7 + ax] = p.tmax[ax];
+                }
+                r[6] = p.t;
+                r[10] = p.tau;
+                r[11] = p.nu;
+                r[12] = __longlong_as_double(cell_global);
+                const uint32_t meta =
+                    REEMIT
+                        ? cmi_pack_meta(rng.block, rng.have, (uint32_t)p.type)
+                        : ((lane_meta & 0x01ffffffu) | ((uint32_t)p.type << 28));
+                r[13] = __longlong_as_double((long long)(
+                    ((unsigned long long)meta << 32) | packet_id));
+                r[14] = 0.;
+                r[15] = 0.;
+              }
+              done = false;
+              active = false; /* continues in another block */
+            }
+          }
         }
         if (absorbed && a.qout.id != nullptr) {
           /* park the packet for the interaction kernel (PhotonSource::reemit
@@ -827,7 +915,8 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     heating[1] = (*acc_at(a.cells, CMI_NION + 1, c));
     /* z of the cell midpoint, src/CartesianDensityGrid.hpp:85-89 */
     const int64_t iz = c % a.grid.ncell[2];
-    const double zmid = (a.grid.anchor[2] + a.grid.cellside[2] * iz) +
+    const double zmid = (a.grid.anchor[2] +
+                         a.grid.cellside[2] * (iz + a.grid.offset[2])) +
                         0.5 * a.grid.cellside[2];
     temperature_cell(a.model, a.jfac, a.hfac, ntot, zmid, T, J, heating, x);
     a.cells.temperature[c] = T;

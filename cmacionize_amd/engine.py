@@ -34,7 +34,8 @@ class Config(C.Structure):
                 ("ncell", C.c_int32 * 3), ("periodic", C.c_int32 * 3),
                 ("device", C.c_int32), ("track_heating", C.c_int32),
                 ("stream", C.c_void_p),
-                ("external_accumulators", C.c_void_p)]
+                ("external_accumulators", C.c_void_p),
+                ("sub_offset", C.c_int32 * 3), ("sub_ncell", C.c_int32 * 3)]
 
 
 class TemperatureParams(C.Structure):
@@ -69,7 +70,9 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_get_atomic_count", "cmi_gpu_sample_spectrum",
     "cmi_gpu_thermal_probe", "cmi_gpu_accumulator_layout",
     "cmi_gpu_get_kernel_timing", "cmi_gpu_get_wave_steps",
-    "cmi_gpu_get_launch_times",
+    "cmi_gpu_get_launch_times", "cmi_gpu_set_export_buffer",
+    "cmi_gpu_get_export_count", "cmi_gpu_reset_exports",
+    "cmi_gpu_shoot_flights",
 ]
 
 _lib = None
@@ -86,6 +89,16 @@ def load_library():
             "`python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C cmacionize_amd/csrc`. There is no CPU fallback." %
             LIB_PATH)
+    # torch ships its own copy of the HIP runtime; if the engine's library
+    # pulls in the system one first, torch cannot initialise the GPU later in
+    # the same process. Let torch (the owner of streams and of the buffers it
+    # shares with the engine) come first when it is there.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.cmi_gpu_last_error.restype = C.c_char_p
@@ -128,6 +141,11 @@ def load_library():
     L.cmi_gpu_set_tuning.argtypes = [vp, C.c_char_p, C.c_int64]
     L.cmi_gpu_get_atomic_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.cmi_gpu_get_wave_steps.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.cmi_gpu_set_export_buffer.argtypes = [vp, vp, C.c_uint64]
+    L.cmi_gpu_get_export_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.cmi_gpu_reset_exports.argtypes = [vp]
+    L.cmi_gpu_shoot_flights.argtypes = [vp, C.c_uint32, C.c_uint32,
+                                        C.c_uint64, vp, C.c_uint64]
     L.cmi_gpu_get_launch_times.argtypes = [vp, C.c_uint64, _dp,
                                            C.POINTER(C.c_uint64),
                                            C.POINTER(C.c_uint64)]
@@ -153,9 +171,16 @@ class GpuEngine:
     """One engine handle = one grid on one GPU."""
 
     def __init__(self, ncell, anchor, sides, periodic=(0, 0, 0), device=0,
-                 track_heating=False, stream=None, external_accumulators=None):
+                 track_heating=False, stream=None, external_accumulators=None,
+                 sub_offset=None, sub_ncell=None):
+        """ncell/anchor/sides describe the whole grid; sub_offset/sub_ncell
+        make the engine hold one block of it (domain decomposition)."""
         self._lib = load_library()
         cfg = Config()
+        if sub_ncell is not None:
+            for a in range(3):
+                cfg.sub_offset[a] = int(sub_offset[a])
+                cfg.sub_ncell[a] = int(sub_ncell[a])
         for a in range(3):
             cfg.anchor[a] = anchor[a]
             cfg.sides[a] = sides[a]
@@ -167,7 +192,8 @@ class GpuEngine:
         cfg.external_accumulators = external_accumulators
         self._h = C.c_void_p()
         self._check(self._lib.cmi_gpu_create(C.byref(cfg), C.byref(self._h)))
-        self.ncell = tuple(int(n) for n in ncell)
+        self.ncell = tuple(int(n) for n in
+                           (sub_ncell if sub_ncell is not None else ncell))
         self.n = int(np.prod(self.ncell))
 
     def _check(self, rc):
@@ -298,6 +324,24 @@ class GpuEngine:
             self._h, n.value, _p(ms),
             pk.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(n)))
         return list(zip(ms[:n.value].tolist(), pk[:n.value].tolist()))
+
+    # decomposed grids ---------------------------------------------------------
+    def set_export_buffer(self, device_pointer, capacity):
+        self._check(self._lib.cmi_gpu_set_export_buffer(
+            self._h, device_pointer, int(capacity)))
+
+    def get_export_count(self):
+        n = C.c_uint64()
+        self._check(self._lib.cmi_gpu_get_export_count(self._h, C.byref(n)))
+        return n.value
+
+    def reset_exports(self):
+        self._check(self._lib.cmi_gpu_reset_exports(self._h))
+
+    def shoot_flights(self, seed, iteration, first_packet, device_pointer, n):
+        self._check(self._lib.cmi_gpu_shoot_flights(
+            self._h, seed, iteration, int(first_packet), device_pointer,
+            int(n)))
 
     def get_wave_steps(self):
         n = C.c_uint64()

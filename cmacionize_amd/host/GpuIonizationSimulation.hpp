@@ -355,7 +355,7 @@ public:
     _density_grid.reset(new DensityGrid(_simulation_box, _ncell));
 
     if (create_engine) {
-      cmi_gpu_config config;
+      cmi_gpu_config config = {};
       for (int a = 0; a < 3; ++a) {
         config.anchor[a] = _simulation_box.anchor[a];
         config.sides[a] = _simulation_box.sides[a];

@@ -131,3 +131,278 @@ class ReplicaIterationDriver:
         self.totweight, self.typecount, self.nsteps = tw, np.asarray(tc), ns
         b.update_cells(loop, tw)
         return tw
+
+
+# ---------------------------------------------------------------------------
+# Domain-decomposed mode: the grid is cut into blocks, one per process (the
+# reference's DensitySubGridCreator decomposition + the MPI photon-buffer
+# exchange of its task-based path, src/DensitySubGridCreator.hpp:314-396,
+# src/TaskBasedIonizationSimulation.cpp:643-1073). Every cell has one owner,
+# so there is no accumulator reduction; packets that leave a block travel to
+# the block that owns the cell they enter.
+# ---------------------------------------------------------------------------
+
+FLIGHT_DOUBLES = 16   # include/cmi_gpu.h: CMI_GPU_FLIGHT_DOUBLES
+FLIGHT_CELL = 12      # column holding the int64 long index of the entered cell
+
+
+def default_blocks(world):
+    """(bx, by, bz) with bx*by*bz == world, as cubic as possible, larger
+    factors first: 8 -> (2,2,2), 4 -> (2,2,1), 2 -> (2,1,1), 6 -> (3,2,1)."""
+    best = None
+    for bx in range(1, world + 1):
+        if world % bx:
+            continue
+        for by in range(1, world // bx + 1):
+            if (world // bx) % by:
+                continue
+            bz = world // bx // by
+            dims = tuple(sorted((bx, by, bz), reverse=True))
+            score = (dims[0] - dims[2], dims)
+            if best is None or score < best[0]:
+                best = (score, dims)
+    return best[1]
+
+
+class DomainDecomposition:
+    """Block decomposition of an (nx, ny, nz) grid over bx*by*bz ranks; rank
+    r owns block (r // (by*bz), (r // bz) % by, r % bz)."""
+
+    def __init__(self, ncell, blocks):
+        self.ncell = tuple(int(n) for n in ncell)
+        self.blocks = tuple(int(b) for b in blocks)
+        self.world = int(np.prod(self.blocks))
+        # first cell of every block per axis (+ the end): as even as possible
+        self.edges = []
+        for n, b in zip(self.ncell, self.blocks):
+            q, r = divmod(n, b)
+            e = [0]
+            for i in range(b):
+                e.append(e[-1] + q + (1 if i < r else 0))
+            self.edges.append(e)
+        self._edge_tensors = {}
+
+    def block(self, rank):
+        """(offset, sub_ncell) of rank's block."""
+        bx, by, bz = self.blocks
+        idx = (rank // (by * bz), (rank // bz) % by, rank % bz)
+        offset = tuple(self.edges[a][idx[a]] for a in range(3))
+        size = tuple(self.edges[a][idx[a] + 1] - self.edges[a][idx[a]]
+                     for a in range(3))
+        return offset, size
+
+    def rank_of_cell(self, cell):
+        """Owner of each long index (whole-grid, int64 torch tensor)."""
+        import torch
+        nx, ny, nz = self.ncell
+        key = (cell.device, cell.dtype)
+        if key not in self._edge_tensors:
+            self._edge_tensors[key] = [
+                torch.tensor(self.edges[a][1:-1], dtype=cell.dtype,
+                             device=cell.device) for a in range(3)]
+        ex, ey, ez = self._edge_tensors[key]
+        gz = cell % nz
+        gy = (cell // nz) % ny
+        gx = cell // (nz * ny)
+        ix = torch.bucketize(gx, ex, right=True)
+        iy = torch.bucketize(gy, ey, right=True)
+        iz = torch.bucketize(gz, ez, right=True)
+        return (ix * self.blocks[1] + iy) * self.blocks[2] + iz
+
+
+class DomainGpuBackend:
+    """One block of the grid on one GPU: the HIP engine with a torch-owned
+    export buffer, enqueuing on torch's current stream."""
+
+    def __init__(self, decomposition, rank, anchor, sides, device=0,
+                 track_heating=False, export_capacity=1 << 22):
+        import torch
+        from .engine import GpuEngine
+        self.torch = torch
+        self.decomposition = decomposition
+        self.rank = rank
+        torch.cuda.set_device(device)
+        self.offset, self.sub_ncell = decomposition.block(rank)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.engine = GpuEngine(
+            decomposition.ncell, anchor, sides, (0, 0, 0), device=device,
+            track_heating=track_heating, stream=stream,
+            sub_offset=self.offset, sub_ncell=self.sub_ncell)
+        self.exports = torch.zeros((int(export_capacity), FLIGHT_DOUBLES),
+                                   dtype=torch.float64,
+                                   device="cuda:%d" % device)
+        self.engine.set_export_buffer(self.exports.data_ptr(),
+                                      int(export_capacity))
+
+    def reset_grid(self):
+        self.engine.reset_grid()
+        self.engine.reset_exports()
+
+    def shoot(self, seed, iteration, first, count):
+        self.engine.shoot(seed, iteration, first, count)
+
+    def take_exports(self):
+        """The flights that left the block since the last reset_exports():
+        a view of the export buffer, valid until the next transport call."""
+        return self.exports[:self.engine.get_export_count()]
+
+    def reset_exports(self):
+        self.engine.reset_exports()
+
+    def continue_flights(self, seed, iteration, first, rows):
+        if rows.shape[0]:
+            rows = rows.contiguous()
+            self.engine.shoot_flights(seed, iteration, first, rows.data_ptr(),
+                                      rows.shape[0])
+            # the rows must outlive the asynchronous launches that read them
+            self._inflight = rows
+
+    def get_counters(self):
+        return self.engine.get_counters()
+
+    def update_cells(self, loop, totweight):
+        self.engine.update_cells(loop, totweight)
+
+    def synchronize(self):
+        self.engine.synchronize()
+
+
+def route_flights(decomposition, rows):
+    """Sort exported flights by the rank that owns the cell they enter:
+    (rows sorted by destination, flights per destination rank [world])."""
+    import torch
+    if rows.shape[0] == 0:
+        return rows, torch.zeros(decomposition.world, dtype=torch.int64)
+    cell = rows.view(torch.int64)[:, FLIGHT_CELL]
+    dest = decomposition.rank_of_cell(cell)
+    order = torch.argsort(dest)
+    counts = torch.bincount(dest, minlength=decomposition.world)
+    return rows[order], counts.cpu()
+
+
+class DomainIterationDriver:
+    """One iteration of the domain-decomposed mode, one block per process:
+    reset -> every rank runs through the iteration's packets and flies those
+    emitted in its block -> rounds of {all-to-all of the flights that crossed a
+    block face, continue them} until no flight is left anywhere -> counters
+    reduce -> every rank updates its own cells."""
+
+    def __init__(self, backend, decomposition, rank=0, world=1, dist=None):
+        self.backend = backend
+        self.decomposition = decomposition
+        self.rank = rank
+        self.world = world
+        self.dist = dist
+        self.totweight = 0.
+        self.typecount = np.zeros(4)
+        self.nsteps = 0
+        self.rounds = 0
+        self.flights_exchanged = 0
+
+    def _exchange(self, rows, counts):
+        """all-to-all of the routed flights; returns the incoming rows."""
+        import torch
+        d = self.dist
+        send = counts.to(torch.int64)
+        recv = torch.empty_like(send)
+        dev = rows.device
+        # the split sizes travel first (on the payload's device: NCCL/RCCL
+        # moves device tensors, gloo host tensors)
+        send_dev, recv_dev = send.to(dev), recv.to(dev)
+        d.all_to_all_single(recv_dev, send_dev)
+        recv = recv_dev.cpu()
+        incoming = torch.empty((int(recv.sum()), FLIGHT_DOUBLES),
+                               dtype=rows.dtype, device=dev)
+        d.all_to_all_single(incoming, rows.contiguous(),
+                            output_split_sizes=recv.tolist(),
+                            input_split_sizes=send.tolist())
+        return incoming
+
+    def iteration(self, loop, n_packets, seed):
+        import torch
+        b = self.backend
+        b.reset_grid()
+        b.shoot(seed, loop, 0, n_packets)
+        self.rounds = 0
+        self.flights_exchanged = 0
+        while True:
+            rows, counts = route_flights(self.decomposition, b.take_exports())
+            if self.world > 1:
+                total = torch.tensor([float(rows.shape[0])],
+                                     dtype=torch.float64, device=rows.device)
+                self.dist.all_reduce(total, op=self.dist.ReduceOp.SUM)
+                total = int(total.item())
+                if total == 0:
+                    break
+                incoming = self._exchange(rows, counts)
+            else:
+                total = rows.shape[0]
+                if total == 0:
+                    break
+                incoming = rows.clone()
+            b.reset_exports()
+            b.continue_flights(seed, loop, 0, incoming)
+            self.rounds += 1
+            self.flights_exchanged += total
+        tw, tc, ns = b.get_counters()
+        if self.world > 1:
+            small = torch.tensor([tw, tc[0], tc[1], tc[2], tc[3], float(ns)],
+                                 dtype=torch.float64, device=rows.device)
+            self.dist.all_reduce(small, op=self.dist.ReduceOp.SUM)
+            small = small.cpu().numpy()
+            tw, tc, ns = small[0], small[1:5], int(small[5])
+        self.totweight, self.typecount, self.nsteps = tw, np.asarray(tc), ns
+        b.update_cells(loop, tw)
+        return tw
+
+
+class LocalDomainDriver:
+    """The same iteration with all blocks in ONE process (several engines on
+    one device): used to check the decomposed mode against the undivided grid
+    on a single GPU, and to run grids in blocks without a second process."""
+
+    def __init__(self, backends, decomposition):
+        self.backends = backends
+        self.decomposition = decomposition
+        self.totweight = 0.
+        self.typecount = np.zeros(4)
+        self.nsteps = 0
+        self.rounds = 0
+        self.flights_exchanged = 0
+
+    def iteration(self, loop, n_packets, seed, update=True):
+        import torch
+        for b in self.backends:
+            b.reset_grid()
+            b.shoot(seed, loop, 0, n_packets)
+        self.rounds = 0
+        self.flights_exchanged = 0
+        while True:
+            routed = [route_flights(self.decomposition, b.take_exports())
+                      for b in self.backends]
+            total = sum(r[0].shape[0] for r in routed)
+            if total == 0:
+                break
+            incoming = []
+            for dest in range(len(self.backends)):
+                parts = []
+                for rows, counts in routed:
+                    start = int(counts[:dest].sum())
+                    parts.append(rows[start:start + int(counts[dest])])
+                incoming.append(torch.cat(parts).clone())
+            for b, rows in zip(self.backends, incoming):
+                b.reset_exports()
+                b.continue_flights(seed, loop, 0, rows)
+            self.rounds += 1
+            self.flights_exchanged += total
+        tw, tc, ns = 0., np.zeros(4), 0
+        for b in self.backends:
+            t, c, n = b.get_counters()
+            tw += t
+            tc += np.asarray(c)
+            ns += n
+        self.totweight, self.typecount, self.nsteps = tw, tc, ns
+        if update:
+            for b in self.backends:
+                b.update_cells(loop, tw)
+        return tw

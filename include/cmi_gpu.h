@@ -87,6 +87,15 @@ typedef struct {
    * hand it to a collective, e.g. torch.distributed over RCCL); NULL = the
    * engine allocates it. */
   void *external_accumulators;
+  /* optional domain decomposition (replaces DensitySubGridCreator's block
+   * decomposition, src/DensitySubGridCreator.hpp:314-396): the engine holds
+   * only the block of sub_ncell cells starting at cell sub_offset of the grid
+   * described above; all zero = the whole grid. Every field, upload and
+   * download of the engine then refers to the block's cells (row-major inside
+   * the block). Packets that leave the block into another one are handed over
+   * through cmi_gpu_set_export_buffer / cmi_gpu_shoot_flights. */
+  int32_t sub_offset[3];
+  int32_t sub_ncell[3];
 } cmi_gpu_config;
 
 /* ------------------------------------------------------------ lifetime -- */
@@ -209,6 +218,35 @@ int cmi_gpu_reset_grid(cmi_gpu_engine *engine);
  * packets back, so the call returns when the last generation is queued. */
 int cmi_gpu_shoot(cmi_gpu_engine *engine, uint32_t seed, uint32_t iteration,
                   uint64_t first_packet, uint64_t n_packets);
+
+/* ---- decomposed grids: the photon-buffer exchange of the task-based path
+ * (PhotonTraversalTaskContext / MemorySpace / MPI photon buffers,
+ * src/PhotonTraversalTaskContext.hpp:100-278). A flight that leaves the
+ * engine's block into another block is appended to the export buffer as
+ * CMI_GPU_FLIGHT_DOUBLES doubles:
+ *   [0-2] origin, [3-5] direction, [6] path parameter, [7-9] next wall
+ *   parameters, [10] optical depth left, [11] frequency,
+ *   [12] int64: long index of the cell it enters, in the WHOLE grid,
+ *   [13] 2 x uint32: packet id (relative to first_packet), rng position/type.
+ * The caller moves the rows to the engine that owns that cell (any transport:
+ * RCCL all-to-all, peer copies) and continues them there with
+ * cmi_gpu_shoot_flights, which also follows their re-emissions and may export
+ * again. The marcher's own state travels, so a packet's path lengths are
+ * bit-identical to a run on the undivided grid. ---- */
+#define CMI_GPU_FLIGHT_DOUBLES 16
+/* device buffer [capacity][CMI_GPU_FLIGHT_DOUBLES] doubles, caller-owned;
+ * resets the export count */
+int cmi_gpu_set_export_buffer(cmi_gpu_engine *engine, void *device_rows,
+                              uint64_t capacity);
+/* flights exported since the last reset; fails with CMI_GPU_ENOMEM if more
+ * left the block than the buffer holds. Synchronous. */
+int cmi_gpu_get_export_count(cmi_gpu_engine *engine, uint64_t *count);
+int cmi_gpu_reset_exports(cmi_gpu_engine *engine);
+/* continue n_flights handed-over flights (device rows as above); seed,
+ * iteration and first_packet as in the cmi_gpu_shoot call that emitted them */
+int cmi_gpu_shoot_flights(cmi_gpu_engine *engine, uint32_t seed,
+                          uint32_t iteration, uint64_t first_packet,
+                          const void *device_rows, uint64_t n_flights);
 
 /* replaces: IonizationPhotonShootJobMarket::update_counters
  * (src/IonizationSimulation.cpp:406): totweight and typecount[4] summed over

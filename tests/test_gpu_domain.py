@@ -1,0 +1,202 @@
+"""GPU tests of the domain-decomposed mode (a block of the grid per engine,
+flights handed over between blocks): the decomposed run must reproduce the run
+on the undivided grid - the marcher's state travels with a packet, so every
+path length is bit-identical and only the order of the atomic sums differs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def configure(eng, model, n_local, density=None, temperature=None):
+    """benchmarks/stromgren*.param or lexingtonHII40.param on an engine."""
+    from cmacionize_amd import STROMGREN as S
+    x = np.zeros((14, n_local))
+    x[0] = 1.e-6
+    x[1] = 1.e-6
+    if model in ("stromgren", "diffuse"):
+        eng.set_sources(S["source_position"], S["source_weight"],
+                        S["luminosity"])
+        eng.set_spectrum_monochromatic(S["frequency"])
+        sigma = np.zeros(14)
+        sigma[0] = S["sigma_H"]
+        alpha = np.zeros(14)
+        alpha[0] = S["alpha_H"]
+        eng.set_cross_sections_fixed(sigma)
+        eng.set_recombination_rates_fixed(alpha)
+        if model == "diffuse":
+            eng.set_reemission(1)
+        eng.upload_cells(np.full(n_local, S["density"]),
+                         np.full(n_local, S["temperature"]), x)
+    else:
+        from test_oracle_physics import LEX
+        eng.set_sources([[0., 0., 0.]], [1.], 4.26e49)
+        eng.set_spectrum_planck(40000.)
+        eng.set_cross_sections_verner()
+        eng.set_recombination_rates_verner()
+        eng.set_abundances(LEX[1:])
+        eng.set_reemission(1)
+        eng.set_temperature_params(do_temperature_calculation=1,
+                                   pah_heating_factor=0.)
+        eng.upload_cells(density, temperature, x)
+
+
+def lexington_fields(ncell):
+    from cmacionize_amd.simulation import PC
+    ax = -5. * PC + (np.arange(ncell) + 0.5) * (10. * PC / ncell)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    vacuum = np.sqrt(X * X + Y * Y + Z * Z) <= 3.e16
+    return np.where(vacuum, 0., 1.e8), np.where(vacuum, 0., 8000.)
+
+
+def assemble(decomposition, backends, field):
+    out = np.zeros(decomposition.ncell)
+    for rank, b in enumerate(backends):
+        off, size = decomposition.block(rank)
+        out[off[0]:off[0] + size[0], off[1]:off[1] + size[1],
+            off[2]:off[2] + size[2]] = \
+            b.engine.download_field(field).reshape(size)
+    return out.ravel()
+
+
+def run_pair(model, ncell, blocks, npacket, iterations, tuning=None):
+    """Yield (whole-grid engine, decomposition, backends, driver) after each
+    iteration of both runs."""
+    from cmacionize_amd import GpuEngine, STROMGREN as S
+    from cmacionize_amd import engine as E
+    from cmacionize_amd.simulation import (DomainDecomposition,
+                                           DomainGpuBackend,
+                                           LocalDomainDriver)
+    heat = model == "lexington"
+    whole = GpuEngine((ncell,) * 3, S["anchor"], S["sides"], (0, 0, 0),
+                      device=0, track_heating=heat)
+    dens = temp = None
+    if model == "lexington":
+        dens, temp = lexington_fields(ncell)
+    configure(whole, model, ncell ** 3,
+              None if dens is None else dens.ravel(),
+              None if temp is None else temp.ravel())
+    if tuning:
+        whole.set_tuning(**tuning)
+    dec = DomainDecomposition((ncell,) * 3, blocks)
+    backends = []
+    for rank in range(dec.world):
+        b = DomainGpuBackend(dec, rank, S["anchor"], S["sides"], device=0,
+                             track_heating=heat, export_capacity=npacket)
+        off, size = dec.block(rank)
+        sl = tuple(slice(off[a], off[a] + size[a]) for a in range(3))
+        configure(b.engine, model, int(np.prod(size)),
+                  None if dens is None else dens[sl].ravel(),
+                  None if temp is None else temp[sl].ravel())
+        if tuning:
+            b.engine.set_tuning(**tuning)
+        backends.append(b)
+    driver = LocalDomainDriver(backends, dec)
+    nfield = 16 if model == "lexington" else 1
+    for loop in range(iterations):
+        whole.reset_grid()
+        whole.shoot(42, loop, 0, npacket)
+        tw, tc, ns = whole.get_counters()
+        driver.iteration(loop, npacket, 42, update=False)
+        # the integrals of this iteration, before the cell update
+        J = [assemble(dec, backends, E.FIELD_MEAN_INTENSITY + k)
+             for k in range(nfield)]
+        Jref = [whole.download_field(E.FIELD_MEAN_INTENSITY + k)
+                for k in range(nfield)]
+        whole.update_cells(loop, tw)
+        for b in backends:
+            b.update_cells(loop, driver.totweight)
+        yield loop, whole, (tw, tc, ns), dec, backends, driver, J, Jref
+        # the closed forms of the balance amplify the 1e-15 differences of the
+        # sums (1 - sqrt(1 + small)): start the next iteration from one state
+        dens_w = whole.download_field(E.FIELD_NUMBER_DENSITY).reshape(
+            (ncell,) * 3)
+        temp_w = whole.download_field(E.FIELD_TEMPERATURE).reshape(
+            (ncell,) * 3)
+        x_w = [whole.download_field(E.FIELD_IONIC_FRACTION + k).reshape(
+            (ncell,) * 3) for k in range(14)]
+        for rank, b in enumerate(backends):
+            off, size = dec.block(rank)
+            sl = tuple(slice(off[a], off[a] + size[a]) for a in range(3))
+            b.engine.upload_cells(dens_w[sl].ravel(), temp_w[sl].ravel(),
+                                  np.array([x[sl].ravel() for x in x_w]))
+    whole.close()
+    for b in backends:
+        b.engine.close()
+
+
+def check_integrals(J, Jref):
+    for k, (a, b) in enumerate(zip(J, Jref)):
+        # identical path lengths; only the order of the additions differs
+        assert np.allclose(a, b, rtol=1e-11, atol=1e-13 * np.abs(b).max()), k
+        assert np.abs(b).max() > 0. or k >= 14
+
+
+@pytest.mark.parametrize("blocks", [(2, 2, 2), (3, 1, 1), (1, 2, 3)])
+def test_decomposed_stromgren_equals_whole_grid(blocks):
+    from cmacionize_amd import engine as E
+    for loop, whole, (tw, tc, ns), dec, backends, driver, J, Jref in run_pair(
+            "stromgren", 24, blocks, 50000, 3):
+        assert driver.totweight == tw == 50000
+        assert np.array_equal(driver.typecount, tc)
+        assert driver.nsteps == ns  # same cells crossed, packet by packet
+        assert driver.rounds >= 1 and driver.flights_exchanged > 0
+        check_integrals(J, Jref)
+        x = assemble(dec, backends, E.FIELD_IONIC_FRACTION)
+        ref = whole.download_field(E.FIELD_IONIC_FRACTION)
+        assert np.allclose(x, ref, rtol=1e-6, atol=0.)
+    assert (ref < 0.5).any() and (ref > 0.5).any()
+
+
+def test_decomposed_diffuse_equals_whole_grid():
+    """Re-emission happens in the block where a packet is absorbed; the
+    re-emitted flight may cross blocks again."""
+    from cmacionize_amd import engine as E
+    for loop, whole, (tw, tc, ns), dec, backends, driver, J, Jref in run_pair(
+            "diffuse", 24, (2, 2, 2), 40000, 3,
+            tuning=dict(reemit_inline_below=64)):
+        assert driver.totweight == tw == 40000
+        assert np.array_equal(driver.typecount, tc)
+        assert driver.nsteps == ns
+        assert tc[1] > 0
+        check_integrals(J, Jref)
+        x = assemble(dec, backends, E.FIELD_IONIC_FRACTION)
+        ref = whole.download_field(E.FIELD_IONIC_FRACTION)
+        assert np.allclose(x, ref, rtol=1e-6, atol=0.)
+
+
+def test_decomposed_lexington_equals_whole_grid():
+    """All ions, heating terms and the temperature solve, block by block."""
+    from cmacionize_amd import engine as E
+    for loop, whole, (tw, tc, ns), dec, backends, driver, J, Jref in run_pair(
+            "lexington", 24, (2, 2, 2), 30000, 5):
+        assert driver.totweight == tw == 30000
+        assert np.array_equal(driver.typecount, tc)
+        assert driver.nsteps == ns
+        check_integrals(J, Jref)
+        T = assemble(dec, backends, E.FIELD_TEMPERATURE)
+        Tref = whole.download_field(E.FIELD_TEMPERATURE)
+        assert np.allclose(T, Tref, rtol=1e-6, atol=0.)
+        for ion in (0, 1, 5, 8):
+            x = assemble(dec, backends, E.FIELD_IONIC_FRACTION + ion)
+            ref = whole.download_field(E.FIELD_IONIC_FRACTION + ion)
+            ok = np.isclose(x, ref, rtol=1e-5, atol=1e-300) | \
+                (np.isnan(x) & np.isnan(ref))
+            assert ok.all(), (loop, ion)
+    assert Tref.max() > 6000.
+
+
+def test_export_buffer_overflow_is_an_error():
+    from cmacionize_amd import STROMGREN as S
+    from cmacionize_amd.engine import EngineError
+    from cmacionize_amd.simulation import (DomainDecomposition,
+                                           DomainGpuBackend)
+    dec = DomainDecomposition((16, 16, 16), (2, 1, 1))
+    b = DomainGpuBackend(dec, 1, S["anchor"], S["sides"], device=0,
+                         export_capacity=16)
+    configure(b.engine, "stromgren", 8 * 16 * 16)
+    b.reset_grid()
+    b.shoot(1, 0, 0, 10000)  # the source is in block 1; half the packets leave
+    with pytest.raises(EngineError):
+        b.take_exports()
+    b.engine.close()

@@ -54,10 +54,12 @@ CONFIGS = {
 }
 
 
-def setup_engine(backend, ncell, cfg):
+def setup_engine(backend, ncell, cfg, block=None):
+    """block = (offset, size): the engine holds only that part of the grid."""
     from cmacionize_amd import STROMGREN as S
     eng = backend.engine
-    n = ncell ** 3
+    offset, size = block if block else ((0, 0, 0), (ncell,) * 3)
+    n = int(np.prod(size))
     x = np.zeros((14, n))
     x[0] = 1.e-6
     x[1] = 1.e-6
@@ -85,8 +87,9 @@ def setup_engine(backend, ncell, cfg):
     eng.set_reemission(1)
     eng.set_temperature_params(do_temperature_calculation=1,
                                pah_heating_factor=0.)
-    ax = -5. * PC + (np.arange(ncell) + 0.5) * (10. * PC / ncell)
-    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    ax = [-5. * PC + (np.arange(offset[a], offset[a] + size[a]) + 0.5) *
+          (10. * PC / ncell) for a in range(3)]
+    X, Y, Z = np.meshgrid(ax[0], ax[1], ax[2], indexing="ij")
     vacuum = (np.sqrt(X * X + Y * Y + Z * Z).ravel() <= 3.e16)
     eng.upload_cells(np.where(vacuum, 0., 1.e8), np.where(vacuum, 0., 8000.),
                      x)
@@ -139,6 +142,12 @@ def main():
     ap.add_argument("--converge-iterations", type=int, default=None)
     ap.add_argument("--converge-packets", type=float, default=1e7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decomposition", default="replica",
+                    choices=["replica", "domain"],
+                    help="N > 1: every rank holds the whole grid and the "
+                         "accumulators are all-reduced (replica), or every "
+                         "rank holds one block and flights are exchanged "
+                         "(domain)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.packets is None:
@@ -167,16 +176,44 @@ def main():
 
     ncell = args.ncell
     npk = int(args.packets)
-    backend = GpuBackend((ncell,) * 3, S["anchor"], S["sides"], S["periodic"],
-                         device=local_rank, track_heating=cfg["lexington"])
-    setup_engine(backend, ncell, cfg)
-    driver = ReplicaIterationDriver(backend, rank, world, dist)
+    domain = args.decomposition == "domain"
+    if domain:
+        from cmacionize_amd.simulation import (DomainDecomposition,
+                                               DomainGpuBackend,
+                                               DomainIterationDriver,
+                                               default_blocks)
+        dec = DomainDecomposition((ncell,) * 3, default_blocks(world))
+        # the block with the source exports 7/8 of the packets in round one
+        backend = DomainGpuBackend(dec, rank, S["anchor"], S["sides"],
+                                   device=local_rank,
+                                   track_heating=cfg["lexington"],
+                                   export_capacity=npk * world + 1024)
+        setup_engine(backend, ncell, cfg, dec.block(rank))
+        driver = DomainIterationDriver(backend, dec, rank, world, dist)
+    else:
+        backend = GpuBackend((ncell,) * 3, S["anchor"], S["sides"],
+                             S["periodic"], device=local_rank,
+                             track_heating=cfg["lexington"])
+        setup_engine(backend, ncell, cfg)
+        driver = ReplicaIterationDriver(backend, rank, world, dist)
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def ionized_fraction():
+        """V(x_H < 0.5) / V_box; in domain mode every rank counts its block."""
+        if not domain and rank != 0:
+            return 0.
+        xH = backend.engine.download_field(E.FIELD_IONIC_FRACTION)
+        count = float((xH < 0.5).sum())
+        if domain and world > 1:
+            t = torch.tensor([count], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t)
+            count = float(t.item())
+        return count / float(ncell) ** 3
 
     # bring the grid to the converged state (untimed); rank 0 follows the
     # ionized volume fraction for the iterations-to-converge figure
@@ -187,9 +224,7 @@ def main():
     for _ in range(args.converge_iterations):
         driver.iteration(loop, int(args.converge_packets) * world, 42)
         loop += 1
-        if rank == 0:
-            xH = backend.engine.download_field(E.FIELD_IONIC_FRACTION)
-            volume.append(float((xH < 0.5).mean()))
+        volume.append(ionized_fraction())
     converged_at = None
     for k in range(1, len(volume)):
         if volume[k] > 0. and \
@@ -217,6 +252,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    final_volume = ionized_fraction()
     if rank == 0:
         total_packets = float(npk) * world * args.steps
         value = total_packets / elapsed
@@ -229,7 +265,6 @@ def main():
         steps_per_launch = nsteps_total / world / launches
         achieved = (steps_per_launch * cfg["bytes_per_step"] /
                     (kernel_s / launches)) / 1e9
-        xH = backend.engine.download_field(E.FIELD_IONIC_FRACTION)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -256,14 +291,16 @@ def main():
                             "iteration, converged ionization state; step = "
                             "reset + shoot + reduce + cell update" %
                             (cfg["name"], ncell, npk),
-                "parallelism": "replica x%d (sum all-reduce of accumulators)"
+                "parallelism": ("domain x%d (one block per GPU, all-to-all "
+                                "of crossing flights)" if domain else
+                                "replica x%d (sum all-reduce of accumulators)")
                                % world,
             },
             "transport_only_packets_per_s": float(npk) * args.steps / shoot_s,
             "dda_steps_per_packet": nsteps_total / total_packets,
             "cell_update_ms_per_step": timing["update_ms"] /
             max(timing["update_launches"], 1),
-            "ionized_volume_fraction": float((xH < 0.5).mean()),
+            "ionized_volume_fraction": final_volume,
             "iterations_to_converge": {
                 "value": converged_at,
                 "criterion": "first iteration whose ionized volume fraction "
@@ -288,8 +325,12 @@ def main():
         }
         if args.config != "stromgren":
             out["metric"] = "photon packets/sec, 256^3 " + args.config
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not (domain and world > 1):
+            # (needs the whole grid's state on this rank)
             out["cpu_baseline"] = cpu_baseline(ncell, cfg, backend.engine)
+        if domain:
+            out["exchange_rounds_last_step"] = driver.rounds
+            out["flights_exchanged_last_step"] = driver.flights_exchanged
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -232,7 +232,7 @@ accumulate_full(const ShootArgs &a, FullStage &st, bool aggregate,
  * rounding). EXACT selects the marcher (device_transport.h).
  */
 template <bool FULL, bool HEAT, bool REEMIT, bool EXACT>
-__global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 8)
+__global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 6)
     shoot_kernel(const ShootArgs a) {
   const int lane = threadIdx.x & 63;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
@@ -257,7 +257,9 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 8)
   int32_t last_cell = -1; /* EXACT marcher on grids >= 2^31 cells: see below */
   int64_t last_cell_wide = -1;
 
-  double tw = 0., tc0 = 0., tc1 = 0., tc2 = 0., tc3 = 0.;
+  /* packets finished per type; every packet on this path has weight 1
+   * (discrete sources, src/PhotonSource.cpp:244), so totweight is their sum */
+  unsigned int tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
   unsigned int nsteps = 0, natomics = 0; /* per lane and launch: < 2^32 */
   unsigned int nwavesteps = 0;
   const bool any_periodic =
@@ -641,30 +643,28 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 8)
           }
         }
         if (done) {
-          tw += p.weight;
-          tc0 += (p.type == TYPE_PRIMARY) ? p.weight : 0.;
-          tc1 += (p.type == TYPE_DIFFUSE_HI) ? p.weight : 0.;
-          tc2 += (p.type == TYPE_DIFFUSE_HeI) ? p.weight : 0.;
-          tc3 += (p.type == TYPE_ABSORBED) ? p.weight : 0.;
+          tc0 += (p.type == TYPE_PRIMARY) ? 1u : 0u;
+          tc1 += (p.type == TYPE_DIFFUSE_HI) ? 1u : 0u;
+          tc2 += (p.type == TYPE_DIFFUSE_HeI) ? 1u : 0u;
+          tc3 += (p.type == TYPE_ABSORBED) ? 1u : 0u;
           active = false;
         }
       }
     }
   }
   /* IonizationPhotonShootJobMarket::update_counters */
-  tw = wave_sum(tw);
-  tc0 = wave_sum(tc0);
-  tc1 = wave_sum(tc1);
-  tc2 = wave_sum(tc2);
-  tc3 = wave_sum(tc3);
+  const double s0 = wave_sum((double)tc0);
+  const double s1 = wave_sum((double)tc1);
+  const double s2 = wave_sum((double)tc2);
+  const double s3 = wave_sum((double)tc3);
   double ns = wave_sum((double)nsteps);
   double na = wave_sum((double)natomics);
   if (lane == 0) {
-    atomic_add_f64(&a.counters->totweight, tw);
-    atomic_add_f64(&a.counters->typecount[0], tc0);
-    atomic_add_f64(&a.counters->typecount[1], tc1);
-    atomic_add_f64(&a.counters->typecount[2], tc2);
-    atomic_add_f64(&a.counters->typecount[3], tc3);
+    atomic_add_f64(&a.counters->totweight, (s0 + s1) + (s2 + s3));
+    atomic_add_f64(&a.counters->typecount[0], s0);
+    atomic_add_f64(&a.counters->typecount[1], s1);
+    atomic_add_f64(&a.counters->typecount[2], s2);
+    atomic_add_f64(&a.counters->typecount[3], s3);
     atomicAdd(&a.counters->nsteps, (unsigned long long)ns);
     atomicAdd(&a.counters->natomics, (unsigned long long)na);
     atomicAdd(&a.counters->nwavesteps, (unsigned long long)nwavesteps);

@@ -17,6 +17,13 @@
 #ifndef CMI_TABLE_SCAN_ROUNDS
 #define CMI_TABLE_SCAN_ROUNDS 2
 #endif
+/* multi-ion kernels: slots (of 16 doubles) of the block's combining table and
+ * march-loop iterations between two write-backs of it */
+#define CMI_FTABLE_BITS 7
+#define CMI_FTABLE_SLOTS (1 << CMI_FTABLE_BITS)
+#ifndef CMI_FTABLE_WINDOW
+#define CMI_FTABLE_WINDOW 16
+#endif
 /* a.aggregate: what happens to a step's contributions before HBM sees them */
 #define CMI_AGG_NONE 0  /* one atomic per lane and step */
 #define CMI_AGG_RUNS 1  /* cross-lane run sums, one atomic per run */
@@ -160,54 +167,81 @@ __device__ __forceinline__ void run_sums(int32_t key, double (&v)[N],
 /* FULL mode (all 14 ions + 2 heating terms per step): update_integrals as a
  * cooperative, transposed accumulation. A lane's 16 accumulation weights
  * (sigma_ion, sigma (nu - nu_0)) are constants of its packet and live in LDS,
- * [lane][16]; per step only ds * w changes. Runs of consecutive lanes in the
- * same cell are found with one neighbour compare; then 16 lanes per run - one
- * per accumulator - sum  ds_l w_l * weight[l][i]  over the run's lanes out of
- * LDS and issue the atomic. With the accumulators stored [cell][16] (AoS,
- * 128 B per cell) one wave instruction adds 4 cells x 16 values as four
- * contiguous 128-B segments = 8 memory-side 64-B requests instead of 64:
+ * [lane][16]; per step only ds * w changes. Every lane posts its ds * w and
+ * the destination of its cell (a slot of the block's combining table, or the
+ * cell itself) in LDS; then each quarter of the wave - 16 lanes, one per
+ * accumulator - walks its own 16 packets in a fixed, fully unrolled loop,
+ * sums  ds_l w_l * weight[l][i]  while the destination stays the same and adds
+ * the sum when it changes: one contiguous 128-B group of ds_add_f64 (table)
+ * or global atomics per run. With the accumulators stored [cell][16] (AoS,
+ * 128 B per cell) a group of global atomics is two memory-side 64-B requests:
  * float atomics execute at the memory side in 64-B requests and their count,
- * not the bytes, bounds this kernel. (A 16-value segmented scan costs ~10x
- * the instructions of this form.) */
+ * not the bytes, bounds the kernel without the table. The fixed trip count is
+ * the point: the LDS reads of all 16 rounds are in flight together instead of
+ * one LDS latency per packet of a run. */
 struct FullStage {
   double weight[64][CMI_NACC];
   double dsw[64];
-  int32_t start[65];
-  int32_t cell[64];
+  int32_t dest[64]; /* >= 0: table slot; <= -2: cell -(dest + 2); -1: none */
 };
 
 template <bool HEAT>
 __device__ __forceinline__ void
-accumulate_full(const ShootArgs &a, FullStage &st, bool aggregate,
-                bool accumulate, int32_t cell, double dsw,
-                unsigned int &natomics) {
+accumulate_full(const ShootArgs &a, FullStage &st, bool accumulate,
+                int32_t cell, double dsw, unsigned int &natomics,
+                int32_t *table_tag, double *table_val) {
   const int lane = threadIdx.x & 63;
-  const int32_t key = accumulate ? cell : ~lane;
-  const int32_t prev = dpp_keep<CMI_DPP_WAVE_SHR1, 0xf>(~key, key);
-  const bool head = (key != prev) || !aggregate;
-  const unsigned long long heads = __ballot(head);
-  const int run = __popcll(heads & ((2ull << lane) - 1ull)) - 1;
-  const int nruns = __popcll(heads);
-  st.dsw[lane] = accumulate ? dsw : 0.;
-  if (head) {
-    st.start[run] = lane;
-    st.cell[run] = accumulate ? cell : -1;
+  int32_t dest = -1;
+  if (accumulate) {
+    dest = -(cell + 2);
+    if (table_tag != nullptr) {
+      /* claim the cell's slot, as in the hydrogen-only table */
+      uint32_t s = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_FTABLE_BITS);
+      for (int probe = 0; probe < CMI_TABLE_PROBES; ++probe) {
+        const int32_t was = atomicCAS(&table_tag[s], -1, cell);
+        if (was == -1 || was == cell) {
+          dest = (int32_t)s;
+          break;
+        }
+        s = (s + 1) & (CMI_FTABLE_SLOTS - 1);
+      }
+    }
   }
-  if (lane == 0)
-    st.start[nruns] = 64;
+  st.dsw[lane] = accumulate ? dsw : 0.;
+  st.dest[lane] = dest;
   asm volatile("" ::: "memory"); /* written by other lanes: re-read */
   const int i = lane & 15;
-  for (int e0 = 0; e0 < nruns; e0 += 4) {
-    const int e = e0 + (lane >> 4);
-    if (e < nruns) {
-      const int32_t c = st.cell[e];
-      if (c >= 0 && (HEAT || i < CMI_NION)) {
-        const int l1 = st.start[e + 1];
-        double sum = 0.;
-        for (int l = st.start[e]; l < l1; ++l)
-          sum += st.dsw[l] * st.weight[l][i];
-        atomic_add_f64(acc_at(a.cells, i, c), sum);
-        ++natomics;
+  const int first = lane & 48;
+  const bool mine = HEAT || i < CMI_NION;
+  /* accumulator i of cell c: AoS rows of CMI_NACC doubles */
+  double *const acc_i = a.cells.acc_base + i;
+  double *const table_i = table_val + i;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    /* all LDS reads of 8 packets first ... */
+    int32_t d[9];
+    double sum[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int l = first + 8 * half + r;
+      d[r] = st.dest[l];
+      sum[r] = st.dsw[l] * st.weight[l][i];
+    }
+    d[8] = -1; /* a run that goes on in the other half is added in two parts */
+    /* ... then running sums along each run, in registers ... */
+#pragma unroll
+    for (int r = 1; r < 8; ++r)
+      sum[r] = __fma_rn((d[r] == d[r - 1]) ? 1. : 0., sum[r - 1], sum[r]);
+    /* ... and one add where a run ends */
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (d[r] != d[r + 1] && d[r] != -1 && mine) {
+        if (d[r] >= 0) {
+          atomicAdd(table_i + d[r] * CMI_NACC, sum[r]); /* ds_add_f64 */
+        } else {
+          atomic_add_f64(acc_i + ((int64_t)(-(d[r] + 2)) << 4), sum[r]);
+          ++natomics;
+        }
       }
     }
   }
@@ -232,7 +266,7 @@ accumulate_full(const ShootArgs &a, FullStage &st, bool aggregate,
  * rounding). EXACT selects the marcher (device_transport.h).
  */
 template <bool FULL, bool HEAT, bool REEMIT, bool EXACT>
-__global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 6)
+__global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
     shoot_kernel(const ShootArgs a) {
   const int lane = threadIdx.x & 63;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
@@ -284,25 +318,76 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 6)
    * CMI_TABLE_PROBES tries, then it falls back to a global atomic) and adds
    * with ds_add_f64; between two bundles the block meets at a barrier and
    * flushes every used slot with ONE global atomic per cell. */
-  constexpr int lds_slots = FULL ? 64 : CMI_TABLE_SLOTS; /* unused if FULL */
+  constexpr int lds_slots = FULL ? CMI_FTABLE_SLOTS : CMI_TABLE_SLOTS;
+  constexpr int lds_values = FULL ? CMI_NACC : (HEAT ? 2 : 1);
   __shared__ int32_t lds_tag[lds_slots];
-  __shared__ double lds_val[(HEAT ? 2 : 1) * lds_slots];
+  __shared__ double lds_val[lds_values * lds_slots];
   __shared__ int32_t block_has_work[CMI_BLOCK / 64];
   const int wib = threadIdx.x >> 6;
   /* FULL: per-wave accumulation weights and per-step scratch in LDS */
   __shared__ FullStage full_stage[FULL ? CMI_BLOCK / 64 : 1];
   FullStage &stage = full_stage[FULL ? wib : 0];
   double weights[CMI_NACC];
-  const bool use_table = !FULL && a.aggregate == CMI_AGG_BLOCK;
+  /* Multi-ion kernels use the same kind of table with 16 values per slot
+   * (one accumulator row). 128 B per slot leave room for 256 slots only, so
+   * the block writes it back every CMI_FTABLE_WINDOW iterations of the march
+   * loop as well - the waves of a block advance together, one Manhattan shell
+   * per iteration, so a cell's contributions arrive within a few iterations
+   * of each other. */
+  const bool use_table = a.aggregate == CMI_AGG_BLOCK;
   if (use_table) {
-    for (int k = threadIdx.x; k < CMI_TABLE_SLOTS; k += CMI_BLOCK) {
+    for (int k = threadIdx.x; k < lds_slots; k += CMI_BLOCK)
       lds_tag[k] = -1;
+    for (int k = threadIdx.x; k < lds_values * lds_slots; k += CMI_BLOCK)
       lds_val[k] = 0.;
-      if (HEAT)
-        lds_val[CMI_TABLE_SLOTS + k] = 0.;
-    }
     __syncthreads();
   }
+  /* A flush point: every wave of the block arrives, the table is written
+   * back with one global atomic per value, and all learn whether any wave has
+   * work left. Waves may arrive from different places in the code - the
+   * points are interchangeable - but every wave must keep arriving until the
+   * block is done: a wave never exits while others may wait at a barrier. */
+  auto flush_point = [&](bool has_work) -> bool {
+    if (lane == 0)
+      block_has_work[wib] = has_work ? 1 : 0;
+    __syncthreads();
+    if (FULL) {
+      const int i = threadIdx.x & 15;
+      for (int k = threadIdx.x >> 4; k < lds_slots; k += CMI_BLOCK / 16) {
+        const int32_t t = lds_tag[k];
+        if (t >= 0) {
+          if (HEAT || i < CMI_NION) {
+            atomic_add_f64(acc_at(a.cells, i, t), lds_val[k * CMI_NACC + i]);
+            lds_val[k * CMI_NACC + i] = 0.;
+            ++natomics;
+          }
+          if (i == 0)
+            lds_tag[k] = -1; /* after the 16 lanes of the wave have read it */
+        }
+      }
+    } else {
+      for (int k = threadIdx.x; k < lds_slots; k += CMI_BLOCK) {
+        const int32_t t = lds_tag[k];
+        if (t >= 0) {
+          atomic_add_f64(acc_at(a.cells, ION_H_n, t), lds_val[k]);
+          lds_val[k] = 0.;
+          if (HEAT) {
+            atomic_add_f64(acc_at(a.cells, CMI_NION, t),
+                           lds_val[lds_slots + k]);
+            lds_val[lds_slots + k] = 0.;
+          }
+          lds_tag[k] = -1;
+          natomics += HEAT ? 2 : 1;
+        }
+      }
+    }
+    int any_work = 0;
+#pragma unroll
+    for (int w = 0; w < CMI_BLOCK / 64; ++w)
+      any_work |= block_has_work[w];
+    __syncthreads();
+    return any_work != 0;
+  };
   /* add (v0[, v1]) to `cell` through the block table; called by all 64 lanes */
   auto table_add = [&](bool add, int32_t cell, double v0, double v1) {
     uint32_t slot = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_TABLE_BITS);
@@ -341,32 +426,8 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 6)
     }
     const uint64_t avail = pos_end - pos;
     if (use_table) {
-      /* between two bundles: every wave of the block arrives here, the table
-       * is written back, and the block leaves together once no wave has work
-       * left (a wave never exits while others may still wait at a barrier) */
-      if (lane == 0)
-        block_has_work[wib] = (active_mask != 0ull || avail != 0) ? 1 : 0;
-      __syncthreads();
-      for (int k = threadIdx.x; k < CMI_TABLE_SLOTS; k += CMI_BLOCK) {
-        const int32_t t = lds_tag[k];
-        if (t >= 0) {
-          atomic_add_f64(acc_at(a.cells, ION_H_n, t), lds_val[k]);
-          lds_val[k] = 0.;
-          if (HEAT) {
-            atomic_add_f64(acc_at(a.cells, CMI_NION, t),
-                           lds_val[CMI_TABLE_SLOTS + k]);
-            lds_val[CMI_TABLE_SLOTS + k] = 0.;
-          }
-          lds_tag[k] = -1;
-          natomics += HEAT ? 2 : 1;
-        }
-      }
-      int any_work = 0;
-#pragma unroll
-      for (int w = 0; w < CMI_BLOCK / 64; ++w)
-        any_work |= block_has_work[w];
-      __syncthreads();
-      if (!any_work)
+      /* between two bundles */
+      if (!flush_point(active_mask != 0ull || avail != 0))
         break;
     } else if (active_mask == 0ull && avail == 0) {
       break;
@@ -466,6 +527,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 6)
      * after the loop, for all finished lanes together. ---- */
     /* FAST: the record of the cell a lane is about to cross is loaded one
      * iteration ahead, so that the load overlaps the accumulation */
+    int window = 0;
     double2 kappa_next = make_double2(0., 0.);
     if (!EXACT && active && p.tau > 0. && !fast_outside(p))
       kappa_next = fast_load_record(a.cells.opacity, p);
@@ -501,8 +563,13 @@ __global__ void __launch_bounds__(CMI_BLOCK, (FULL || REEMIT) ? 1 : 6)
       if (a.exp_no_atomics)
         continue;
       if (FULL) {
-        accumulate_full<HEAT>(a, stage, a.aggregate != CMI_AGG_NONE, accumulate,
-                              last_cell, ds * p.weight, natomics);
+        accumulate_full<HEAT>(a, stage, accumulate, last_cell, ds * p.weight,
+                              natomics, use_table ? lds_tag : nullptr,
+                              lds_val);
+        if (use_table && ++window == CMI_FTABLE_WINDOW) {
+          window = 0;
+          (void)flush_point(true);
+        }
       } else if (a.aggregate != CMI_AGG_NONE) {
         /* lanes in the same cell: one add for the whole run */
         const int32_t key = accumulate ? last_cell : ~lane;

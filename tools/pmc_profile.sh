@@ -1,17 +1,22 @@
 #!/bin/bash
 # GPU box: collect PMC counters for the transport kernel (separate passes, as
 # the MI355X guide prescribes; --pmc never combined with trace domains other
-# than --kernel-trace).  usage: tools/pmc_profile.sh OUTDIR -- <python args>
+# than --kernel-trace).
+#   usage (from the repo root): tools/pmc_profile.sh OUTDIR -- SCRIPT.py [args]
 set -u
-OUT=$1; shift; shift
+REPO=$(pwd)
+OUT=$REPO/$1; shift; shift
+SCRIPT=$REPO/$1; shift
 export TMPDIR=/tmp
 mkdir -p "$OUT"
 cd /tmp
 i=0
 for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAIT_INST_ANY" \
-           "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_WAVE32_INSTS" \
-           "FETCH_SIZE" "WRITE_SIZE TCC_EA0_ATOMIC_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "GRBM_GUI_ACTIVE"; do
+           "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_WAIT_INST_LDS" \
+           "FETCH_SIZE" "WRITE_SIZE TCC_EA0_ATOMIC_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$OUT/pass$i" -- python3 "$@" > "$OUT/pass$i.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$OUT/pass$i" -- python3 "$SCRIPT" "$@" > "$OUT/pass$i.log" 2>&1
   echo "pass $i rc=$? ($PMC)"
 done
+cd "$OUT"
+find . -name "*kernel_trace.csv" -size +8M -delete

@@ -137,8 +137,8 @@ def main():
     ap.add_argument("--config", default="stromgren", choices=sorted(CONFIGS))
     ap.add_argument("--ncell", type=int, default=256)
     ap.add_argument("--packets", type=float, default=None,
-                    help="packets per rank per step (default 1e8; 2e7 for "
-                         "lexington)")
+                    help="packets per rank per step (default 1e8, the "
+                         "number of photons of all three .param files)")
     ap.add_argument("--converge-iterations", type=int, default=None)
     ap.add_argument("--converge-packets", type=float, default=1e7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,7 +151,7 @@ def main():
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.packets is None:
-        args.packets = 2e7 if cfg["lexington"] else 1e8
+        args.packets = 1e8
     if args.converge_iterations is None:
         args.converge_iterations = cfg["converge_iterations"]
 

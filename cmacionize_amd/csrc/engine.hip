@@ -91,6 +91,9 @@ struct cmi_gpu_engine {
   double *export_rows = nullptr;
   uint64_t export_capacity = 0;
   unsigned int *export_count = nullptr;
+  bool own_export_rows = false;
+  double *import_rows = nullptr; /* staging for flights given in host memory */
+  uint64_t import_capacity = 0;
   unsigned int *queue_counts = nullptr; /* [2]: ended, ready */
 
   struct Tuning {
@@ -623,6 +626,9 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->queue_block);
   (void)hipFree(e->queue_counts);
   (void)hipFree(e->export_count);
+  if (e->own_export_rows)
+    (void)hipFree(e->export_rows);
+  (void)hipFree(e->import_rows);
   if (e->own_stream)
     (void)hipStreamDestroy(e->stream);
   delete e;
@@ -1293,13 +1299,24 @@ int cmi_gpu_shoot_flights(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
 
 int cmi_gpu_set_export_buffer(cmi_gpu_engine *e, void *rows,
                               uint64_t capacity) {
-  if (!e || (!rows && capacity) || capacity >= (1ull << 32))
+  if (!e || capacity >= (1ull << 32))
     return fail(CMI_GPU_EINVAL, "set_export_buffer: bad argument");
   HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
   if (!e->export_count)
     HIP_TRY(hipMalloc(&e->export_count, sizeof(unsigned int)));
   HIP_TRY(hipMemsetAsync(e->export_count, 0, sizeof(unsigned int), e->stream));
+  if (e->own_export_rows) {
+    (void)hipFree(e->export_rows);
+    e->own_export_rows = false;
+  }
   e->export_rows = (double *)rows;
+  if (!rows && capacity) {
+    /* engine-owned buffer, for hosts that exchange through host memory */
+    HIP_TRY(hipMalloc(&e->export_rows,
+                      sizeof(double) * CMI_FLIGHT_DOUBLES * capacity));
+    e->own_export_rows = true;
+  }
   e->export_capacity = capacity;
   return CMI_GPU_OK;
 }
@@ -1322,6 +1339,54 @@ int cmi_gpu_get_export_count(cmi_gpu_engine *e, uint64_t *count) {
                 n, (unsigned long long)e->export_capacity);
   *count = n;
   return CMI_GPU_OK;
+}
+
+int cmi_gpu_download_exports(cmi_gpu_engine *e, double *host_rows,
+                             uint64_t capacity, uint64_t *count) {
+  if (!e || !count || (!host_rows && capacity))
+    return fail(CMI_GPU_EINVAL, "download_exports: bad argument");
+  uint64_t n = 0;
+  int rc = cmi_gpu_get_export_count(e, &n);
+  if (rc)
+    return rc;
+  *count = n;
+  if (n > capacity)
+    return fail(CMI_GPU_ENOMEM,
+                "download_exports: %llu flights, room for %llu",
+                (unsigned long long)n, (unsigned long long)capacity);
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(host_rows, e->export_rows,
+                           sizeof(double) * CMI_FLIGHT_DOUBLES * n,
+                           hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_shoot_flights_host(cmi_gpu_engine *e, uint32_t seed,
+                               uint32_t iteration, uint64_t first_packet,
+                               const double *host_rows, uint64_t n_flights) {
+  if (!e || (!host_rows && n_flights))
+    return fail(CMI_GPU_EINVAL, "shoot_flights_host: bad argument");
+  if (n_flights == 0)
+    return CMI_GPU_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  if (e->import_capacity < n_flights) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    (void)hipFree(e->import_rows);
+    e->import_rows = nullptr;
+    e->import_capacity = 0;
+    HIP_TRY(hipMalloc(&e->import_rows,
+                      sizeof(double) * CMI_FLIGHT_DOUBLES * n_flights));
+    e->import_capacity = n_flights;
+  }
+  /* launches of an earlier call may still read the staging buffer */
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpyAsync(e->import_rows, host_rows,
+                         sizeof(double) * CMI_FLIGHT_DOUBLES * n_flights,
+                         hipMemcpyHostToDevice, e->stream));
+  return cmi_gpu_shoot_flights(e, seed, iteration, first_packet, e->import_rows,
+                               n_flights);
 }
 
 int cmi_gpu_reset_exports(cmi_gpu_engine *e) {

@@ -72,7 +72,8 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_get_kernel_timing", "cmi_gpu_get_wave_steps",
     "cmi_gpu_get_launch_times", "cmi_gpu_set_export_buffer",
     "cmi_gpu_get_export_count", "cmi_gpu_reset_exports",
-    "cmi_gpu_shoot_flights",
+    "cmi_gpu_shoot_flights", "cmi_gpu_download_exports",
+    "cmi_gpu_shoot_flights_host",
 ]
 
 _lib = None
@@ -144,6 +145,10 @@ def load_library():
     L.cmi_gpu_set_export_buffer.argtypes = [vp, vp, C.c_uint64]
     L.cmi_gpu_get_export_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.cmi_gpu_reset_exports.argtypes = [vp]
+    L.cmi_gpu_download_exports.argtypes = [vp, _dp, C.c_uint64,
+                                           C.POINTER(C.c_uint64)]
+    L.cmi_gpu_shoot_flights_host.argtypes = [vp, C.c_uint32, C.c_uint32,
+                                             C.c_uint64, _dp, C.c_uint64]
     L.cmi_gpu_shoot_flights.argtypes = [vp, C.c_uint32, C.c_uint32,
                                         C.c_uint64, vp, C.c_uint64]
     L.cmi_gpu_get_launch_times.argtypes = [vp, C.c_uint64, _dp,

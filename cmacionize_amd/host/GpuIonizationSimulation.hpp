@@ -12,7 +12,9 @@
 
 #include "Plugins.hpp"
 
+#include <array>
 #include <chrono>
+#include <cstring>
 #include <cstdio>
 #include <iomanip>
 #include <iostream>
@@ -238,6 +240,19 @@ class GpuIonizationSimulation {
   std::unique_ptr<DensityGrid> _density_grid;
 
   cmi_gpu_engine *_engine = nullptr;
+  /* domain decomposition (DensitySubGridCreator,
+   * src/DensitySubGridCreator.hpp:314-396): one engine per block of the grid,
+   * possibly on different devices; _engine is then unused */
+  struct Block {
+    cmi_gpu_engine *engine = nullptr;
+    int32_t offset[3], size[3];
+    int device = 0;
+    int64_t ncell() const { return (int64_t)size[0] * size[1] * size[2]; }
+  };
+  std::vector<Block> _blocks;
+  std::array<int, 3> _nblock = {1, 1, 1};
+  std::array<std::vector<int32_t>, 3> _block_edges;
+  uint64_t _exchange_rounds = 0, _flights_exchanged = 0;
   double _shoot_seconds = 0., _update_seconds = 0.;
   double _last_totweight = 0.;
   double _last_typecount[4] = {0., 0., 0., 0.};
@@ -250,8 +265,137 @@ class GpuIonizationSimulation {
     if (_verbose)
       std::cout << message << std::endl;
   }
+  bool decomposed() const { return !_blocks.empty(); }
+
+  void lower_model(cmi_gpu_engine *engine) {
+    if (_photon_source_distribution)
+      check(_photon_source_distribution->lower(engine), "sources");
+    check(_photon_source_spectrum->lower(engine), "spectrum");
+    check(_cross_sections->lower(engine), "cross sections");
+    check(_recombination_rates->lower(engine), "recombination rates");
+    check(_abundances.lower(engine), "abundances");
+    check(_reemission.lower(engine), "reemission");
+    check(cmi_gpu_set_temperature_params(engine, &_temperature_params),
+          "temperature parameters");
+  }
+
+  /* gather / scatter one field between the whole grid (host) and a block */
+  void block_slice(const Block &b, const std::vector<double> &whole,
+                   std::vector<double> &part) const {
+    part.resize((size_t)b.ncell());
+    size_t k = 0;
+    for (int32_t ix = 0; ix < b.size[0]; ++ix)
+      for (int32_t iy = 0; iy < b.size[1]; ++iy)
+        for (int32_t iz = 0; iz < b.size[2]; ++iz)
+          part[k++] = whole[(size_t)(((ix + b.offset[0]) * _ncell[1] + iy +
+                                      b.offset[1]) *
+                                         _ncell[2] +
+                                     iz + b.offset[2])];
+  }
+  void block_unslice(const Block &b, const std::vector<double> &part,
+                     std::vector<double> &whole) const {
+    size_t k = 0;
+    for (int32_t ix = 0; ix < b.size[0]; ++ix)
+      for (int32_t iy = 0; iy < b.size[1]; ++iy)
+        for (int32_t iz = 0; iz < b.size[2]; ++iz)
+          whole[(size_t)(((ix + b.offset[0]) * _ncell[1] + iy + b.offset[1]) *
+                             _ncell[2] +
+                         iz + b.offset[2])] = part[k++];
+  }
+  /* the block that owns a cell of the whole grid (long index) */
+  size_t owner_of_cell(int64_t cell) const {
+    const int64_t c[3] = {cell / (_ncell[1] * _ncell[2]),
+                          (cell / _ncell[2]) % _ncell[1], cell % _ncell[2]};
+    size_t idx[3];
+    for (int a = 0; a < 3; ++a) {
+      size_t i = 0;
+      while (i + 1 < (size_t)_nblock[a] && c[a] >= _block_edges[a][i + 1])
+        ++i;
+      idx[a] = i;
+    }
+    return (idx[0] * _nblock[1] + idx[1]) * _nblock[2] + idx[2];
+  }
+
+  void download_field(int field, std::vector<double> &whole) {
+    if (!decomposed()) {
+      check(cmi_gpu_download_field(_engine, field, whole.data()), "download");
+      return;
+    }
+    std::vector<double> part;
+    for (Block &b : _blocks) {
+      part.resize((size_t)b.ncell());
+      check(cmi_gpu_download_field(b.engine, field, part.data()), "download");
+      block_unslice(b, part, whole);
+    }
+  }
+
+  /* One iteration's transport on a decomposed grid: every block runs through
+   * the packet ids and flies those emitted inside it; then rounds of {collect
+   * the flights that left each block, hand each to the block that owns the
+   * cell it enters (through host memory here - the reference's MPI photon
+   * buffers are host memory too), continue} until no flight is left. */
+  void shoot_decomposed(uint_fast32_t loop, uint_fast64_t numphoton,
+                        double &totweight, double typecount[4]) {
+    for (Block &b : _blocks) {
+      check(cmi_gpu_reset_grid(b.engine), "reset_grid");
+      check(cmi_gpu_reset_exports(b.engine), "reset_exports");
+      check(cmi_gpu_shoot(b.engine, (uint32_t)_random_seed, loop, 0, numphoton),
+            "shoot");
+    }
+    std::vector<std::vector<double>> inbox(_blocks.size());
+    std::vector<double> rows;
+    for (;;) {
+      uint64_t total = 0;
+      for (Block &b : _blocks) {
+        uint64_t n = 0;
+        check(cmi_gpu_get_export_count(b.engine, &n), "get_export_count");
+        rows.resize((size_t)n * CMI_GPU_FLIGHT_DOUBLES);
+        check(cmi_gpu_download_exports(b.engine, rows.data(), n, &n),
+              "download_exports");
+        check(cmi_gpu_reset_exports(b.engine), "reset_exports");
+        for (uint64_t i = 0; i < n; ++i) {
+          const double *row = rows.data() + i * CMI_GPU_FLIGHT_DOUBLES;
+          int64_t cell;
+          std::memcpy(&cell, row + 12, sizeof cell);
+          std::vector<double> &box = inbox[owner_of_cell(cell)];
+          box.insert(box.end(), row, row + CMI_GPU_FLIGHT_DOUBLES);
+        }
+        total += n;
+      }
+      if (total == 0)
+        break;
+      ++_exchange_rounds;
+      _flights_exchanged += total;
+      for (size_t k = 0; k < _blocks.size(); ++k) {
+        check(cmi_gpu_shoot_flights_host(
+                  _blocks[k].engine, (uint32_t)_random_seed, loop, 0,
+                  inbox[k].data(), inbox[k].size() / CMI_GPU_FLIGHT_DOUBLES),
+              "shoot_flights");
+        inbox[k].clear();
+      }
+    }
+    totweight = 0.;
+    for (int i = 0; i < 4; ++i)
+      typecount[i] = 0.;
+    for (Block &b : _blocks) {
+      double tw = 0., tc[4];
+      check(cmi_gpu_get_counters(b.engine, &tw, tc, nullptr), "get_counters");
+      totweight += tw;
+      for (int i = 0; i < 4; ++i)
+        typecount[i] += tc[i];
+    }
+  }
+
   void download_state() {
     DensityGrid &g = *_density_grid;
+    if (decomposed()) {
+      download_field(CMI_GPU_FIELD_NUMBER_DENSITY, g._number_density);
+      download_field(CMI_GPU_FIELD_TEMPERATURE, g._temperature);
+      for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+        download_field(CMI_GPU_FIELD_IONIC_FRACTION + ion,
+                       g._ionic_fraction[ion]);
+      return;
+    }
     check(cmi_gpu_download_field(_engine, CMI_GPU_FIELD_NUMBER_DENSITY,
                                  g._number_density.data()),
           "download");
@@ -274,7 +418,9 @@ public:
                           const int_fast32_t num_thread,
                           const std::string &parameterfile,
                           const int device = 0, const bool verbose = true,
-                          const bool create_engine = true)
+                          const bool create_engine = true,
+                          const std::array<int, 3> blocks = {1, 1, 1},
+                          const std::vector<int> &devices = {})
       : _every_iteration_output(every_iteration_output),
         _output_statistics(output_statistics), _verbose(verbose),
         _parameter_file(parameterfile),
@@ -366,23 +512,58 @@ public:
       config.track_heating = t.do_temperature_calculation;
       config.stream = nullptr;
       config.external_accumulators = nullptr;
-      check(cmi_gpu_create(&config, &_engine), "cmi_gpu_create");
-      if (_photon_source_distribution)
-        check(_photon_source_distribution->lower(_engine), "sources");
-      check(_photon_source_spectrum->lower(_engine), "spectrum");
-      check(_cross_sections->lower(_engine), "cross sections");
-      check(_recombination_rates->lower(_engine), "recombination rates");
-      check(_abundances.lower(_engine), "abundances");
-      check(_reemission.lower(_engine), "reemission");
-      check(cmi_gpu_set_temperature_params(_engine, &_temperature_params),
-            "temperature parameters");
+      _nblock = blocks;
+      if (blocks[0] * blocks[1] * blocks[2] == 1) {
+        check(cmi_gpu_create(&config, &_engine), "cmi_gpu_create");
+        lower_model(_engine);
+      } else {
+        /* blocks as even as possible; block k runs on devices[k % n] */
+        for (int a = 0; a < 3; ++a) {
+          const long long q = _ncell[a] / blocks[a], r = _ncell[a] % blocks[a];
+          _block_edges[a].push_back(0);
+          for (int i = 0; i < blocks[a]; ++i)
+            _block_edges[a].push_back(_block_edges[a].back() + (int32_t)q +
+                                      (i < r ? 1 : 0));
+        }
+        size_t k = 0;
+        for (int bx = 0; bx < blocks[0]; ++bx)
+          for (int by = 0; by < blocks[1]; ++by)
+            for (int bz = 0; bz < blocks[2]; ++bz, ++k) {
+              Block b;
+              const int idx[3] = {bx, by, bz};
+              for (int a = 0; a < 3; ++a) {
+                b.offset[a] = _block_edges[a][idx[a]];
+                b.size[a] = _block_edges[a][idx[a] + 1] - b.offset[a];
+                config.sub_offset[a] = b.offset[a];
+                config.sub_ncell[a] = b.size[a];
+              }
+              b.device = devices.empty() ? device
+                                         : devices[k % devices.size()];
+              config.device = b.device;
+              check(cmi_gpu_create(&config, &b.engine), "cmi_gpu_create");
+              _blocks.push_back(b);
+              lower_model(b.engine);
+              /* room for every packet of an iteration to leave the block */
+              check(cmi_gpu_set_export_buffer(
+                        b.engine, nullptr,
+                        std::max(_number_of_photons, _number_of_photons_init) +
+                            1024),
+                    "set_export_buffer");
+            }
+        status("Domain decomposition: " + std::to_string(_blocks.size()) +
+               " blocks.");
+      }
     }
   }
 
   ~GpuIonizationSimulation() {
     if (_engine)
       cmi_gpu_destroy(_engine);
+    for (Block &b : _blocks)
+      cmi_gpu_destroy(b.engine);
   }
+  uint64_t exchange_rounds() const { return _exchange_rounds; }
+  uint64_t flights_exchanged() const { return _flights_exchanged; }
 
   ParameterFile &parameter_file() { return _parameter_file; }
   DensityGrid &grid() { return *_density_grid; }
@@ -427,11 +608,23 @@ public:
       check(cmi_gpu_upload_cells(_engine, g._number_density.data(),
                                  g._temperature.data(), x.data()),
             "cmi_gpu_upload_cells");
+    for (Block &b : _blocks) {
+      std::vector<double> dens, temp, part, xb;
+      block_slice(b, g._number_density, dens);
+      block_slice(b, g._temperature, temp);
+      for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion) {
+        block_slice(b, g._ionic_fraction[ion], part);
+        xb.insert(xb.end(), part.begin(), part.end());
+      }
+      check(cmi_gpu_upload_cells(b.engine, dens.data(), temp.data(),
+                                 xb.data()),
+            "cmi_gpu_upload_cells");
+    }
   }
 
   /* IonizationSimulation::run, src/IonizationSimulation.cpp:334-680 */
   void run(DensityGridWriter *density_grid_writer = nullptr) {
-    if (!_engine)
+    if (!_engine && !decomposed())
       throw std::runtime_error("run() needs an engine (not a dry run)");
     if (_density_grid_writer)
       _density_grid_writer->write(*_density_grid, 0, _parameter_file);
@@ -443,15 +636,20 @@ public:
       if (loop == 0)
         lnumphoton = _number_of_photons_init;
 
-      check(cmi_gpu_reset_grid(_engine), "reset_grid");
       status("Start shooting " + std::to_string(lnumphoton) + " photons...");
       auto t0 = std::chrono::steady_clock::now();
-      check(cmi_gpu_shoot(_engine, (uint32_t)_random_seed, loop, 0, lnumphoton),
-            "shoot");
       double totweight = 0.;
       double typecount[4] = {0., 0., 0., 0.};
-      check(cmi_gpu_get_counters(_engine, &totweight, typecount, nullptr),
-            "get_counters");
+      if (decomposed()) {
+        shoot_decomposed(loop, lnumphoton, totweight, typecount);
+      } else {
+        check(cmi_gpu_reset_grid(_engine), "reset_grid");
+        check(cmi_gpu_shoot(_engine, (uint32_t)_random_seed, loop, 0,
+                            lnumphoton),
+              "shoot");
+        check(cmi_gpu_get_counters(_engine, &totweight, typecount, nullptr),
+              "get_counters");
+      }
       auto t1 = std::chrono::steady_clock::now();
       _shoot_seconds += std::chrono::duration<double>(t1 - t0).count();
       _last_totweight = totweight;
@@ -478,8 +676,16 @@ public:
       status("Calculating ionization state after shooting " +
              std::to_string(lnumphoton) + " photons...");
       t0 = std::chrono::steady_clock::now();
-      check(cmi_gpu_update_cells(_engine, loop, totweight), "update_cells");
-      check(cmi_gpu_synchronize(_engine), "synchronize");
+      if (decomposed()) {
+        for (Block &b : _blocks)
+          check(cmi_gpu_update_cells(b.engine, loop, totweight),
+                "update_cells");
+        for (Block &b : _blocks)
+          check(cmi_gpu_synchronize(b.engine), "synchronize");
+      } else {
+        check(cmi_gpu_update_cells(_engine, loop, totweight), "update_cells");
+        check(cmi_gpu_synchronize(_engine), "synchronize");
+      }
       t1 = std::chrono::steady_clock::now();
       _update_seconds += std::chrono::duration<double>(t1 - t0).count();
       status("Done calculating ionization state.");
@@ -507,6 +713,9 @@ public:
     std::ostringstream s;
     s << "Total photon shooting time: " << _shoot_seconds << " s.\n"
       << "Total cell update time: " << _update_seconds << " s.";
+    if (decomposed())
+      s << "\nFlights handed over between blocks: " << _flights_exchanged
+        << " in " << _exchange_rounds << " rounds.";
     status(s.str());
   }
 

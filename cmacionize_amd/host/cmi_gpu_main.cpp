@@ -8,7 +8,10 @@
  * --verbose/-v. Flags that select other code paths of the reference (--rhd,
  * --emission, --dusty-radiative-transfer, --task-based-rhd) are rejected.
  * New: --device N (HIP device ordinal), --describe (print the lowered plugin
- * descriptors as JSON; with --dry-run no GPU is needed).
+ * descriptors as JSON; with --dry-run no GPU is needed), --blocks BX,BY,BZ
+ * (domain decomposition: one engine per block of the grid, the counterpart of
+ * the reference's DensitySubGridCreator:number of subgrids) and
+ * --devices D0,D1,... (the blocks' devices, round-robin; default --device).
  */
 #include "GpuIonizationSimulation.hpp"
 
@@ -96,6 +99,16 @@ static void describe(GpuIonizationSimulation &sim) {
 int main(int argc, char **argv) {
   std::string params;
   int threads = 1, device = 0;
+  std::array<int, 3> blocks = {1, 1, 1};
+  std::vector<int> devices;
+  auto int_list = [](const std::string &text) {
+    std::vector<int> values;
+    std::stringstream stream(text);
+    std::string item;
+    while (std::getline(stream, item, ','))
+      values.push_back(std::atoi(item.c_str()));
+    return values;
+  };
   bool every_iteration = false, statistics = false, dry_run = false,
        verbose = false, do_describe = false;
   for (int i = 1; i < argc; ++i) {
@@ -113,6 +126,15 @@ int main(int argc, char **argv) {
       threads = std::atoi(need("--threads").c_str());
     else if (a == "--device")
       device = std::atoi(need("--device").c_str());
+    else if (a == "--blocks") {
+      const std::vector<int> b = int_list(need("--blocks"));
+      if (b.size() != 3 || b[0] < 1 || b[1] < 1 || b[2] < 1) {
+        std::cerr << "--blocks needs three positive integers BX,BY,BZ\n";
+        return 1;
+      }
+      blocks = {b[0], b[1], b[2]};
+    } else if (a == "--devices")
+      devices = int_list(need("--devices"));
     else if (a == "--every-iteration-output" || a == "-e")
       every_iteration = true;
     else if (a == "--output-statistics" || a == "-s")
@@ -129,6 +151,7 @@ int main(int argc, char **argv) {
     else {
       std::cerr << "Unknown or unsupported option: " << a << "\n"
                 << "usage: cmi-gpu --params FILE [--threads N] [--device N] "
+                   "[--blocks BX,BY,BZ] [--devices D0,D1,...] "
                    "[--every-iteration-output] [--output-statistics] "
                    "[--dry-run] [--describe] [--verbose]\n";
       return 1;
@@ -141,7 +164,8 @@ int main(int argc, char **argv) {
   try {
     GpuIonizationSimulation simulation(!dry_run, every_iteration, statistics,
                                        threads, params, device,
-                                       verbose || !do_describe, !dry_run);
+                                       verbose || !do_describe, !dry_run,
+                                       blocks, devices);
     if (do_describe)
       describe(simulation);
     if (dry_run) {

@@ -234,14 +234,24 @@ int cmi_gpu_shoot(cmi_gpu_engine *engine, uint32_t seed, uint32_t iteration,
  * again. The marcher's own state travels, so a packet's path lengths are
  * bit-identical to a run on the undivided grid. ---- */
 #define CMI_GPU_FLIGHT_DOUBLES 16
-/* device buffer [capacity][CMI_GPU_FLIGHT_DOUBLES] doubles, caller-owned;
- * resets the export count */
+/* device buffer [capacity][CMI_GPU_FLIGHT_DOUBLES] doubles, caller-owned
+ * (device_rows == NULL: the engine allocates one of that capacity, for hosts
+ * that exchange through host memory); resets the export count */
 int cmi_gpu_set_export_buffer(cmi_gpu_engine *engine, void *device_rows,
                               uint64_t capacity);
 /* flights exported since the last reset; fails with CMI_GPU_ENOMEM if more
  * left the block than the buffer holds. Synchronous. */
 int cmi_gpu_get_export_count(cmi_gpu_engine *engine, uint64_t *count);
 int cmi_gpu_reset_exports(cmi_gpu_engine *engine);
+/* the same through host memory, for a host without a GPU-aware transport (the
+ * reference's MPI photon buffers are host memory): copy the exported rows to
+ * host_rows [capacity][CMI_GPU_FLIGHT_DOUBLES] (*count = their number) and
+ * continue flights given in host memory. Synchronous copies. */
+int cmi_gpu_download_exports(cmi_gpu_engine *engine, double *host_rows,
+                             uint64_t capacity, uint64_t *count);
+int cmi_gpu_shoot_flights_host(cmi_gpu_engine *engine, uint32_t seed,
+                               uint32_t iteration, uint64_t first_packet,
+                               const double *host_rows, uint64_t n_flights);
 /* continue n_flights handed-over flights (device rows as above); seed,
  * iteration and first_packet as in the cmi_gpu_shoot call that emitted them */
 int cmi_gpu_shoot_flights(cmi_gpu_engine *engine, uint32_t seed,

@@ -194,3 +194,46 @@ def test_cmi_gpu_executable_end_to_end(exe, tmp_path, oracle):
     mid = (np.arange(16) + 0.5) * (d["sides"][0] / 16) + d["anchor"][0]
     assert np.allclose(last[:16, 2], mid, rtol=1e-5)
     assert np.allclose(last[:, 4], (d["sides"][0] / 16) ** 3, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bench,blocks", [("stromgren.param", "2,1,2"),
+                                          ("stromgren_diffuse.param", "2,2,2"),
+                                          ("lexingtonHII40.param", "1,3,1")])
+def test_cmi_gpu_executable_with_blocks(exe, tmp_path, bench, blocks):
+    """--blocks: the C++ host drives one engine per block of the grid and hands
+    the flights over between them (through host memory); the snapshots equal
+    those of the undivided run of the same parameter file."""
+    text = open(os.path.join(BENCH, bench)).read()
+    text = text.replace("[64, 64, 64]", "[18, 18, 18]")
+    for old in ("number of photons: 1e6", "number of photons: 1e8"):
+        text = text.replace(old, "number of photons: 20000")
+    text = text.replace("number of iterations: 20", "number of iterations: 5")
+    text = text.replace("type: Binary", "type: AsciiFile")
+    outputs = {}
+    for label, extra in (("whole", []), ("blocks", ["--blocks", blocks])):
+        d = tmp_path / label
+        d.mkdir()
+        if bench.startswith("lexington"):
+            import shutil
+            shutil.copy(os.path.join(BENCH, "lexingtonHII40.yml"), d)
+        p = d / "run.param"
+        p.write_text(text)
+        r = subprocess.run([exe, "--params", str(p), "--output-statistics"] +
+                           extra, capture_output=True, text=True, cwd=str(d))
+        assert r.returncode == 0, r.stderr
+        if extra:
+            assert "Flights handed over between blocks" in r.stdout
+        snapshots = sorted(f for f in os.listdir(d) if f.endswith("005.txt"))
+        assert len(snapshots) == 1, os.listdir(d)
+        outputs[label] = (np.loadtxt(d / snapshots[0]), r.stdout)
+    whole, blocks_out = outputs["whole"][0], outputs["blocks"][0]
+    assert whole.shape == blocks_out.shape == (18 ** 3, 6)
+    assert np.array_equal(whole[:, :5], blocks_out[:, :5])
+    # identical packets and path lengths; 6 printed digits, and the balance
+    # amplifies the 1e-15 differences of the sums from iteration to iteration
+    assert np.allclose(whole[:, 5], blocks_out[:, 5], rtol=1e-3, atol=1e-12)
+    # the reference's statistics lines agree to the printed precision
+    stats = [[l for l in out.splitlines() if "Escape fraction" in l][-1]
+             for _, out in outputs.values()]
+    assert stats[0] == stats[1]

@@ -105,7 +105,7 @@ struct cmi_gpu_engine {
     uint32_t chunk = 64;
     int max_blocks_per_cu = 8;
     uint64_t max_packets_per_launch = 1ull << 27;
-    bool exp_no_atomics = false;
+    int exp_no_atomics = 0;
     bool exact_dda = false;
     bool reemit_passes = true;
     int refill_threshold_reemit = 32;
@@ -489,9 +489,18 @@ int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
                     "supported");
     }
   }
-  if ((int64_t)config->ncell[0] * config->ncell[1] * config->ncell[2] >=
-      (1ll << 62))
-    return fail(CMI_GPU_EINVAL, "grid too large");
+  {
+    /* the kernels index the cells of an engine with 32 bits (2^31 cells of
+     * 272 B would not fit one device anyway); a larger grid has to be
+     * decomposed into blocks */
+    int64_t local = 1;
+    for (int a = 0; a < 3; ++a)
+      local *= config->sub_ncell[0] > 0 ? config->sub_ncell[a]
+                                        : config->ncell[a];
+    if (local >= (1ll << 31))
+      return fail(CMI_GPU_EINVAL,
+                  "more than 2^31 - 1 cells per engine are not supported");
+  }
   int ndev = 0;
   hipError_t err = hipGetDeviceCount(&ndev);
   if (err != hipSuccess || ndev == 0)
@@ -919,7 +928,7 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
     e->tune.max_packets_per_launch =
         (uint64_t)(value < 1024 ? 1024 : (value > (1ll << 30) ? (1ll << 30) : value));
   else if (k == "exp_no_atomics")
-    e->tune.exp_no_atomics = value != 0;
+    e->tune.exp_no_atomics = (int)value;
   else if (k == "exact_dda")
     e->tune.exact_dda = value != 0;
   else if (k == "reemit_passes")
@@ -1147,7 +1156,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     /* handed-over flights are no ray bundles worth keeping together */
     a.refill_threshold = flights ? e->tune.refill_threshold_reemit
                                  : e->tune.refill_threshold;
-    a.exp_no_atomics = e->tune.exp_no_atomics ? 1 : 0;
+    a.exp_no_atomics = e->tune.exp_no_atomics;
     a.aggregate = flights ? agg_reemit : agg;
     a.qin = no_queue;
     a.qout = no_queue;

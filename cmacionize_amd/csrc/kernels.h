@@ -179,10 +179,12 @@ __device__ __forceinline__ void run_sums(int32_t key, double (&v)[N],
  * not the bytes, bounds the kernel without the table. The fixed trip count is
  * the point: the LDS reads of all 16 rounds are in flight together instead of
  * one LDS latency per packet of a run. */
+#define CMI_DEST_SAME INT32_MIN
 struct FullStage {
   double weight[64][CMI_NACC];
   double dsw[64];
-  int32_t dest[64]; /* >= 0: table slot; <= -2: cell -(dest + 2); -1: none */
+  int32_t dest[64]; /* >= 0: table slot; -1: none; CMI_DEST_SAME: as the
+                       packet before; other < -1: cell -(dest + 2) */
 };
 
 template <bool HEAT>
@@ -191,10 +193,17 @@ accumulate_full(const ShootArgs &a, FullStage &st, bool accumulate,
                 int32_t cell, double dsw, unsigned int &natomics,
                 int32_t *table_tag, double *table_val) {
   const int lane = threadIdx.x & 63;
+  /* only the first lane of a run of equal cells (and of each quarter) looks
+   * the destination up; the others post "same as the packet before me" */
+  const int32_t key = accumulate ? cell : ~lane;
+  const int32_t prev = dpp_keep<CMI_DPP_WAVE_SHR1, 0xf>(~key, key);
+  const bool head = (key != prev) || (lane & 15) == 0;
   int32_t dest = -1;
   if (accumulate) {
     dest = -(cell + 2);
-    if (table_tag != nullptr) {
+    if (!head) {
+      dest = CMI_DEST_SAME;
+    } else if (table_tag != nullptr && a.exp_no_atomics != 4) {
       /* claim the cell's slot, as in the hydrogen-only table */
       uint32_t s = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_FTABLE_BITS);
       for (int probe = 0; probe < CMI_TABLE_PROBES; ++probe) {
@@ -210,12 +219,15 @@ accumulate_full(const ShootArgs &a, FullStage &st, bool accumulate,
   st.dsw[lane] = accumulate ? dsw : 0.;
   st.dest[lane] = dest;
   asm volatile("" ::: "memory"); /* written by other lanes: re-read */
+  if (a.exp_no_atomics == 2 || a.exp_no_atomics >= 4) /* experiment: no walk */
+    return;
   const int i = lane & 15;
   const int first = lane & 48;
   const bool mine = HEAT || i < CMI_NION;
   /* accumulator i of cell c: AoS rows of CMI_NACC doubles */
   double *const acc_i = a.cells.acc_base + i;
   double *const table_i = table_val + i;
+  int32_t carry = -1; /* destination of the last packet of the first half */
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     /* all LDS reads of 8 packets first ... */
@@ -227,6 +239,12 @@ accumulate_full(const ShootArgs &a, FullStage &st, bool accumulate,
       d[r] = st.dest[l];
       sum[r] = st.dsw[l] * st.weight[l][i];
     }
+    if (d[0] == CMI_DEST_SAME)
+      d[0] = carry;
+#pragma unroll
+    for (int r = 1; r < 8; ++r)
+      d[r] = (d[r] == CMI_DEST_SAME) ? d[r - 1] : d[r];
+    carry = d[7];
     d[8] = -1; /* a run that goes on in the other half is added in two parts */
     /* ... then running sums along each run, in registers ... */
 #pragma unroll
@@ -235,7 +253,8 @@ accumulate_full(const ShootArgs &a, FullStage &st, bool accumulate,
     /* ... and one add where a run ends */
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      if (d[r] != d[r + 1] && d[r] != -1 && mine) {
+      if (d[r] != d[r + 1] && d[r] != -1 && mine &&
+          a.exp_no_atomics != 3) { /* 3 = experiment: walk without the adds */
         if (d[r] >= 0) {
           atomicAdd(table_i + d[r] * CMI_NACC, sum[r]); /* ds_add_f64 */
         } else {
@@ -560,13 +579,14 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
         fast_wrap(a.grid, p);
       if (!EXACT && stepping && p.tau > 0. && !fast_outside(p))
         kappa_next = fast_load_record(a.cells.opacity, p);
-      if (a.exp_no_atomics)
+      if (a.exp_no_atomics == 1)
         continue;
       if (FULL) {
         accumulate_full<HEAT>(a, stage, accumulate, last_cell, ds * p.weight,
                               natomics, use_table ? lds_tag : nullptr,
                               lds_val);
-        if (use_table && ++window == CMI_FTABLE_WINDOW) {
+        if (use_table && a.exp_no_atomics != 5 &&
+            ++window == CMI_FTABLE_WINDOW) {
           window = 0;
           (void)flush_point(true);
         }

@@ -319,7 +319,11 @@ int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
  *   "exact_dda" (0)         march with the reference's per-step arithmetic
  *                           (bit-identical path lengths) instead of the
  *                           incremental marcher (equal up to rounding)
- *   "exp_no_atomics" (0)    EXPERIMENT ONLY: skip the accumulation */
+ *   "exp_no_atomics" (0)    EXPERIMENT ONLY (results are wrong): 1 = skip the
+ *                           accumulation; multi-ion kernels: 2 = post
+ *                           destinations but skip the walk, 3 = walk without
+ *                           the adds, 4 = as 2 without the table look-up,
+ *                           5 = as 2 without the periodic write-backs */
 int cmi_gpu_set_tuning(cmi_gpu_engine *engine, const char *key, int64_t value);
 
 /* --------------------------------------------------- test / measurement -- */

@@ -343,3 +343,34 @@ def test_stromgren_converges_to_analytic_radius():
     frac = (xH < 0.5).mean()
     assert abs(frac - 0.3617) < 0.01, frac
     eng.close()
+
+
+def test_converged_neutral_fractions_within_one_percent_of_oracle(oracle):
+    """north_star's end-to-end bar: run the whole simulation independently on
+    the engine and on the CPU oracle (same seeds, each feeding its own state
+    back through 10 iterations) and compare the converged neutral fractions -
+    as shell averages, the quantity benchmarks/stromgren.py plots - within
+    1 %. (They agree far better: both follow the same packets.)"""
+    from cmacionize_amd import engine as E
+    ncell, npacket, iterations = 32, 100000, 10
+    eng = make_engine(ncell, track_heating=False)
+    sim = oracle.stromgren_simulation(ncell)
+    for loop in range(iterations):
+        eng.reset_grid()
+        eng.shoot(42, loop, 0, npacket)
+        tw, _, _ = eng.get_counters()
+        eng.update_cells(loop, tw)
+    sim.run(npacket, iterations, seed=42)
+    xg = eng.download_field(E.FIELD_IONIC_FRACTION).reshape((ncell,) * 3)
+    xo = np.asarray(sim.x[0]).reshape((ncell,) * 3)
+    ax = (np.arange(ncell) + 0.5) / ncell - 0.5
+    r = np.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 +
+                ax[None, None, :] ** 2)
+    shells = np.minimum((r / 0.5 * 16).astype(int), 27)
+    for s in range(shells.max() + 1):
+        m = shells == s
+        assert m.any()
+        assert abs(xg[m].mean() - xo[m].mean()) <= 0.01 * xo[m].mean(), s
+    # and cell by cell, away from the ionization front's single-packet noise
+    assert np.median(np.abs(xg - xo) / xo) < 1e-6
+    eng.close()

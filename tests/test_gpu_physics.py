@@ -226,3 +226,37 @@ def test_lexington_iteration_matches_oracle(oracle):
                          np.array([np.asarray(x) for x in sim.x]))
     assert sim.temperature.max() > 6000. and sim.temperature.min() == 500.
     eng.close()
+
+
+def test_lexington_converged_state_within_one_percent_of_oracle(oracle):
+    """The same bar for the multi-ion benchmark: engine and oracle run 8
+    iterations of lexingtonHII40 on their own (ionization balance, then the
+    temperature solve from iteration 4) and must agree on shell averages of
+    the temperature and of the H, He, O+ and N+ fractions within 1 %."""
+    from cmacionize_amd import engine as E
+    ncell, npacket, iterations = 24, 40000, 8
+    sim = oracle.lexington_simulation(ncell)
+    eng = lexington_engine(ncell, sim)
+    for loop in range(iterations):
+        eng.reset_grid()
+        eng.shoot(42, loop, 0, npacket)
+        tw, _, _ = eng.get_counters()
+        eng.update_cells(loop, tw)
+    sim.run(npacket, iterations, seed=42)
+    ax = (np.arange(ncell) + 0.5) / ncell - 0.5
+    r = np.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 +
+                ax[None, None, :] ** 2).ravel()
+    shells = np.minimum((r / 0.5 * 10).astype(int), 12)
+    fields = [(E.FIELD_TEMPERATURE, sim.temperature)]
+    for ion in (0, 1, 5, 8):
+        fields.append((E.FIELD_IONIC_FRACTION + ion, np.asarray(sim.x[ion])))
+    for field, ref in fields:
+        got = eng.download_field(field)
+        for s in range(shells.max() + 1):
+            m = (shells == s) & np.isfinite(ref)
+            if not m.any():
+                continue
+            a, b = got[m].mean(), ref[m].mean()
+            assert abs(a - b) <= 0.01 * abs(b) + 1e-300, (field, s, a, b)
+    assert np.asarray(sim.temperature).max() > 6000.
+    eng.close()

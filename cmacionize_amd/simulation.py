@@ -42,7 +42,11 @@ def distribute_packets(n_packets, rank, world):
 
 class GpuBackend:
     """The HIP engine with torch-owned accumulators (so that torch.distributed
-    can reduce them in place) enqueuing on torch's current stream."""
+    can reduce them in place). The engine enqueues on torch's current stream,
+    or on a stream of its own when that is the default stream; the drivers
+    below put a host synchronisation between engine work and torch work
+    (get_counters / get_export_count wait for the engine, .cpu() / .item() /
+    torch.cuda.synchronize() for torch and RCCL)."""
 
     def __init__(self, ncell, anchor, sides, periodic=(0, 0, 0), device=0,
                  track_heating=False):
@@ -212,7 +216,7 @@ class DomainDecomposition:
 
 class DomainGpuBackend:
     """One block of the grid on one GPU: the HIP engine with a torch-owned
-    export buffer, enqueuing on torch's current stream."""
+    export buffer (stream handling as in GpuBackend)."""
 
     def __init__(self, decomposition, rank, anchor, sides, device=0,
                  track_heating=False, export_capacity=1 << 22):
@@ -252,6 +256,10 @@ class DomainGpuBackend:
     def continue_flights(self, seed, iteration, first, rows):
         if rows.shape[0]:
             rows = rows.contiguous()
+            # the rows come out of torch work (sort, copies, the all-to-all on
+            # RCCL's stream); the engine may enqueue on another stream than
+            # torch's current one, so wait for them on the host
+            self.torch.cuda.synchronize()
             self.engine.shoot_flights(seed, iteration, first, rows.data_ptr(),
                                       rows.shape[0])
             # the rows must outlive the asynchronous launches that read them

@@ -153,6 +153,28 @@ __host__ __device__ inline void cmi_cross_sections(const ModelDev &m, double nu,
   }
 }
 
+/* the cross sections of H0 and He0 alone (the re-emission decision needs no
+ * others): same terms, same order of summation as cmi_cross_sections */
+__device__ inline void cmi_cross_sections_H_He(const ModelDev &m, double nu,
+                                               double &sigma_H,
+                                               double &sigma_He) {
+  if (!m.xsec_verner) {
+    sigma_H = m.xsec_fixed[ION_H_n];
+    sigma_He = m.xsec_fixed[ION_He_n];
+    return;
+  }
+  sigma_H = 0.;
+  sigma_He = 0.;
+  const VernerTermDev *terms = m.tables->verner;
+  for (int k = 0; k < CMI_VERNER_NTERM_DEV; ++k) {
+    const int ion = terms[k].ion; /* wave-uniform: the table is */
+    if (ion == ION_H_n)
+      sigma_H += verner_term_sigma(terms[k], nu);
+    else if (ion == ION_He_n)
+      sigma_He += verner_term_sigma(terms[k], nu);
+  }
+}
+
 /* -------------------------------------------------- recombination rates -- */
 
 /* src/VernerRecombinationRates.cpp:104-130 */

@@ -815,10 +815,7 @@ __global__ void __launch_bounds__(CMI_BLOCK)
       } else {
         double sigma_H, sigma_He;
         if (FULL) {
-          double sigma[CMI_NACC];
-          cmi_cross_sections(a.model, nu, sigma);
-          sigma_H = sigma[ION_H_n];
-          sigma_He = sigma[ION_He_n];
+          cmi_cross_sections_H_He(a.model, nu, sigma_H, sigma_He);
         } else {
           sigma_H = a.model.xsec_fixed[ION_H_n];
           sigma_He = a.model.xsec_fixed[ION_He_n];

@@ -180,6 +180,10 @@ __device__ __forceinline__ void run_sums(int32_t key, double (&v)[N],
  * the point: the LDS reads of all 16 rounds are in flight together instead of
  * one LDS latency per packet of a run. */
 #define CMI_DEST_SAME INT32_MIN
+/* packets per batch of LDS reads in the walk (divides 16) */
+#ifndef CMI_WALK_PART
+#define CMI_WALK_PART 8
+#endif
 struct FullStage {
   double weight[64][CMI_NACC];
   double dsw[64];
@@ -227,32 +231,33 @@ accumulate_full(const ShootArgs &a, FullStage &st, bool accumulate,
   /* accumulator i of cell c: AoS rows of CMI_NACC doubles */
   double *const acc_i = a.cells.acc_base + i;
   double *const table_i = table_val + i;
-  int32_t carry = -1; /* destination of the last packet of the first half */
+  int32_t carry = -1; /* destination of the last packet of the part before */
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    /* all LDS reads of 8 packets first ... */
-    int32_t d[9];
-    double sum[8];
+  for (int part = 0; part < 16 / CMI_WALK_PART; ++part) {
+    /* all LDS reads of a part's packets first ... */
+    int32_t d[CMI_WALK_PART + 1];
+    double sum[CMI_WALK_PART];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int l = first + 8 * half + r;
+    for (int r = 0; r < CMI_WALK_PART; ++r) {
+      const int l = first + CMI_WALK_PART * part + r;
       d[r] = st.dest[l];
       sum[r] = st.dsw[l] * st.weight[l][i];
     }
     if (d[0] == CMI_DEST_SAME)
       d[0] = carry;
 #pragma unroll
-    for (int r = 1; r < 8; ++r)
+    for (int r = 1; r < CMI_WALK_PART; ++r)
       d[r] = (d[r] == CMI_DEST_SAME) ? d[r - 1] : d[r];
-    carry = d[7];
-    d[8] = -1; /* a run that goes on in the other half is added in two parts */
+    carry = d[CMI_WALK_PART - 1];
+    /* a run that goes on in the next part is added in two pieces */
+    d[CMI_WALK_PART] = -1;
     /* ... then running sums along each run, in registers ... */
 #pragma unroll
-    for (int r = 1; r < 8; ++r)
+    for (int r = 1; r < CMI_WALK_PART; ++r)
       sum[r] = __fma_rn((d[r] == d[r - 1]) ? 1. : 0., sum[r - 1], sum[r]);
     /* ... and one add where a run ends */
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < CMI_WALK_PART; ++r) {
       if (d[r] != d[r + 1] && d[r] != -1 && mine &&
           a.exp_no_atomics != 3) { /* 3 = experiment: walk without the adds */
         if (d[r] >= 0) {

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""After `make -C cmacionize_amd/csrc asm`: for every shoot_kernel variant,
+find the march loop (the innermost loop that holds the combining table's
+ds_cmpst) in engine.s and report its size and - the point - whether the
+register allocator left scratch (spill) accesses inside it. The kernels are
+built with a forced occupancy; the cold code (emission, end of flight) is
+allowed to spill, the march loop is not.
+
+    python tools/check_hot_loops.py [cmacionize_amd/csrc/engine.s]
+exit code 1 if a default-path variant has scratch accesses in its march loop.
+"""
+import re
+import sys
+
+path = sys.argv[1] if len(sys.argv) > 1 else "cmacionize_amd/csrc/engine.s"
+text = open(path).read().split("\n")
+starts = [i for i, l in enumerate(text)
+          if re.match(r"^_Z12shoot_kernelILb[01]ELb[01]ELb[01]ELb[01]EEv9ShootArgs:", l)]
+bad = 0
+print("%-22s %6s %6s %6s %6s %8s" % ("variant <F,H,R,X>", "lines", "valu",
+                                     "salu", "lds", "scratch"))
+for s in starts:
+    e = next(i for i in range(s, len(text)) if "s_endpgm" in text[i])
+    body = text[s:e]
+    flags = re.findall(r"Lb([01])E", text[s])[:4]
+    cas = [i for i, l in enumerate(body) if "ds_cmpst" in l]
+    if not cas:
+        continue
+    headers = [i for i, l in enumerate(body)
+               if "Loop Header: Depth=2" in l and i < cas[0]]
+    if not headers:
+        continue
+    h = headers[-1]
+    label = None
+    for j in range(h, max(h - 6, 0), -1):
+        m = re.match(r"^(\.LBB\d+_\d+):", body[j])
+        if m:
+            label = m.group(1)
+            break
+    ends = [i for i, l in enumerate(body)
+            if label and re.search(r"s_cbranch\w*\s+" + re.escape(label) + r"\b", l)]
+    end = ends[-1] if ends else h
+    loop = body[h:end + 1]
+    count = lambda p: sum(1 for l in loop if l.strip().startswith(p))
+    scratch = sum(1 for l in loop if "scratch_" in l)
+    name = "<%s>" % ",".join(flags)
+    print("%-22s %6d %6d %6d %6d %8d" % (name, len(loop), count("v_"),
+                                         count("s_"), count("ds_"), scratch))
+    # the variants the default settings launch: no inline re-emission (R = 0),
+    # incremental marcher (X = 0)
+    if flags[2] == "0" and flags[3] == "0" and scratch:
+        bad = 1
+sys.exit(bad)

@@ -166,39 +166,118 @@ __device__ __forceinline__ void run_sums(int32_t key, double (&v)[N],
 
 /* FULL mode (all 14 ions + 2 heating terms per step): update_integrals as a
  * cooperative, transposed accumulation. A lane's 16 accumulation weights
- * (sigma_ion, sigma (nu - nu_0)) are constants of its packet and live in LDS,
- * [lane][16]; per step only ds * w changes. Every lane posts its ds * w and
- * the destination of its cell (a slot of the block's combining table, or the
- * cell itself) in LDS; then each quarter of the wave - 16 lanes, one per
- * accumulator - walks its own 16 packets in a fixed, fully unrolled loop,
- * sums  ds_l w_l * weight[l][i]  while the destination stays the same and adds
- * the sum when it changes: one contiguous 128-B group of ds_add_f64 (table)
- * or global atomics per run. With the accumulators stored [cell][16] (AoS,
- * 128 B per cell) a group of global atomics is two memory-side 64-B requests:
- * float atomics execute at the memory side in 64-B requests and their count,
- * not the bytes, bounds the kernel without the table. The fixed trip count is
- * the point: the LDS reads of all 16 rounds are in flight together instead of
- * one LDS latency per packet of a run. */
+ * (sigma_ion, sigma (nu - nu_0)) are constants of its packet; they are written
+ * to LDS once per flight, [lane][16], and every lane then keeps the TRANSPOSED
+ * weights of its quarter of the wave in registers: lane (q, i) holds
+ * weight[16 q + r][i], r = 0..15 - accumulator i of the 16 packets of quarter
+ * q. Per step only ds * w and the destination change, and those travel by DPP
+ * row broadcasts (row_newbcast: lane r of each row of 16 to the whole row):
+ * each quarter - 16 lanes, one per accumulator - walks its own 16 packets in a
+ * fixed, fully unrolled loop, keeps running sums along runs of equal
+ * destinations and issues one contiguous 128-B group of adds where a run ends:
+ * ds_add_f64 into the block's combining table or global atomics into the AoS
+ * accumulator row of the cell (two memory-side 64-B requests - float atomics
+ * execute at the memory side in 64-B requests and their count, not the bytes,
+ * bounds the kernel without the table). No LDS traffic in the walk at all. */
 #define CMI_DEST_SAME INT32_MIN
-/* packets per batch of LDS reads in the walk (divides 16) */
+/* packets per batch of the walk (divides 16) */
 #ifndef CMI_WALK_PART
 #define CMI_WALK_PART 8
 #endif
 struct FullStage {
   double weight[64][CMI_NACC];
-  double dsw[64];
-  int32_t dest[64]; /* >= 0: table slot; -1: none; CMI_DEST_SAME: as the
-                       packet before; other < -1: cell -(dest + 2) */
 };
+
+#define CMI_DPP_ROW_NEWBCAST(n) (0x150 + (n))
+template <int R> __device__ __forceinline__ int row_bcast_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CMI_DPP_ROW_NEWBCAST(R), 0xf, 0xf,
+                                     false);
+}
+template <int R> __device__ __forceinline__ double row_bcast_f64(double v) {
+  const int lo = row_bcast_i32<R>(__double2loint(v));
+  const int hi = row_bcast_i32<R>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+/* the transposed weights of the lane's quarter, after (re)launches */
+__device__ __forceinline__ void load_quarter_weights(const FullStage &st,
+                                                     double (&wq)[CMI_NACC]) {
+  const int lane = threadIdx.x & 63;
+  asm volatile("" ::: "memory"); /* written by other lanes: re-read */
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    wq[r] = st.weight[(lane & 48) + r][lane & 15];
+}
+
+template <bool HEAT, int PART>
+__device__ __forceinline__ void
+walk_part(const ShootArgs &a, const double (&wq)[CMI_NACC], int32_t dest,
+          double dsw, int32_t &carry, bool mine, double *acc_i, double *table_i,
+          unsigned int &natomics) {
+  constexpr int N = CMI_WALK_PART;
+  int32_t d[N + 1];
+  double sum[N];
+  /* destination and ds * w of the part's packets, from their lanes */
+#define CMI_WALK_FETCH(r)                                                      \
+  d[r] = row_bcast_i32<N * PART + (r)>(dest);                                  \
+  sum[r] = row_bcast_f64<N * PART + (r)>(dsw) * wq[N * PART + (r)];
+  CMI_WALK_FETCH(0)
+  CMI_WALK_FETCH(1)
+  CMI_WALK_FETCH(2)
+  CMI_WALK_FETCH(3)
+#if CMI_WALK_PART > 4
+  CMI_WALK_FETCH(4)
+  CMI_WALK_FETCH(5)
+  CMI_WALK_FETCH(6)
+  CMI_WALK_FETCH(7)
+#endif
+#if CMI_WALK_PART > 8
+  CMI_WALK_FETCH(8)
+  CMI_WALK_FETCH(9)
+  CMI_WALK_FETCH(10)
+  CMI_WALK_FETCH(11)
+  CMI_WALK_FETCH(12)
+  CMI_WALK_FETCH(13)
+  CMI_WALK_FETCH(14)
+  CMI_WALK_FETCH(15)
+#endif
+#undef CMI_WALK_FETCH
+  if (d[0] == CMI_DEST_SAME)
+    d[0] = carry;
+#pragma unroll
+  for (int r = 1; r < N; ++r)
+    d[r] = (d[r] == CMI_DEST_SAME) ? d[r - 1] : d[r];
+  carry = d[N - 1];
+  d[N] = -1; /* a run that goes on in the next part is added in two pieces */
+  /* running sums along each run, in registers ... */
+#pragma unroll
+  for (int r = 1; r < N; ++r)
+    sum[r] = __fma_rn((d[r] == d[r - 1]) ? 1. : 0., sum[r - 1], sum[r]);
+  /* ... and one add where a run ends */
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    if (d[r] != d[r + 1] && d[r] != -1 && mine &&
+        a.exp_no_atomics != 3) { /* 3 = experiment: walk without the adds */
+      if (d[r] >= 0) {
+        atomicAdd(table_i + d[r] * CMI_NACC, sum[r]); /* ds_add_f64 */
+      } else {
+        atomic_add_f64(acc_i + ((int64_t)(-(d[r] + 2)) << 4), sum[r]);
+        ++natomics;
+      }
+    }
+  }
+}
 
 template <bool HEAT>
 __device__ __forceinline__ void
-accumulate_full(const ShootArgs &a, FullStage &st, bool accumulate,
-                int32_t cell, double dsw, unsigned int &natomics,
-                int32_t *table_tag, double *table_val) {
+accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
+                bool accumulate, int32_t cell, double dsw,
+                unsigned int &natomics, int32_t *table_tag,
+                double *table_val) {
   const int lane = threadIdx.x & 63;
   /* only the first lane of a run of equal cells (and of each quarter) looks
-   * the destination up; the others post "same as the packet before me" */
+   * the destination up; the others post "same as the packet before me".
+   * dest >= 0: table slot; -1: nothing; other negatives: cell -(dest + 2) */
   const int32_t key = accumulate ? cell : ~lane;
   const int32_t prev = dpp_keep<CMI_DPP_WAVE_SHR1, 0xf>(~key, key);
   const bool head = (key != prev) || (lane & 15) == 0;
@@ -220,56 +299,23 @@ accumulate_full(const ShootArgs &a, FullStage &st, bool accumulate,
       }
     }
   }
-  st.dsw[lane] = accumulate ? dsw : 0.;
-  st.dest[lane] = dest;
-  asm volatile("" ::: "memory"); /* written by other lanes: re-read */
   if (a.exp_no_atomics == 2 || a.exp_no_atomics >= 4) /* experiment: no walk */
     return;
+  const double term = accumulate ? dsw : 0.;
   const int i = lane & 15;
-  const int first = lane & 48;
   const bool mine = HEAT || i < CMI_NION;
   /* accumulator i of cell c: AoS rows of CMI_NACC doubles */
   double *const acc_i = a.cells.acc_base + i;
   double *const table_i = table_val + i;
   int32_t carry = -1; /* destination of the last packet of the part before */
-#pragma unroll
-  for (int part = 0; part < 16 / CMI_WALK_PART; ++part) {
-    /* all LDS reads of a part's packets first ... */
-    int32_t d[CMI_WALK_PART + 1];
-    double sum[CMI_WALK_PART];
-#pragma unroll
-    for (int r = 0; r < CMI_WALK_PART; ++r) {
-      const int l = first + CMI_WALK_PART * part + r;
-      d[r] = st.dest[l];
-      sum[r] = st.dsw[l] * st.weight[l][i];
-    }
-    if (d[0] == CMI_DEST_SAME)
-      d[0] = carry;
-#pragma unroll
-    for (int r = 1; r < CMI_WALK_PART; ++r)
-      d[r] = (d[r] == CMI_DEST_SAME) ? d[r - 1] : d[r];
-    carry = d[CMI_WALK_PART - 1];
-    /* a run that goes on in the next part is added in two pieces */
-    d[CMI_WALK_PART] = -1;
-    /* ... then running sums along each run, in registers ... */
-#pragma unroll
-    for (int r = 1; r < CMI_WALK_PART; ++r)
-      sum[r] = __fma_rn((d[r] == d[r - 1]) ? 1. : 0., sum[r - 1], sum[r]);
-    /* ... and one add where a run ends */
-#pragma unroll
-    for (int r = 0; r < CMI_WALK_PART; ++r) {
-      if (d[r] != d[r + 1] && d[r] != -1 && mine &&
-          a.exp_no_atomics != 3) { /* 3 = experiment: walk without the adds */
-        if (d[r] >= 0) {
-          atomicAdd(table_i + d[r] * CMI_NACC, sum[r]); /* ds_add_f64 */
-        } else {
-          atomic_add_f64(acc_i + ((int64_t)(-(d[r] + 2)) << 4), sum[r]);
-          ++natomics;
-        }
-      }
-    }
-  }
-  asm volatile("" ::: "memory");
+  walk_part<HEAT, 0>(a, wq, dest, term, carry, mine, acc_i, table_i, natomics);
+#if CMI_WALK_PART < 16
+  walk_part<HEAT, 1>(a, wq, dest, term, carry, mine, acc_i, table_i, natomics);
+#endif
+#if CMI_WALK_PART < 8
+  walk_part<HEAT, 2>(a, wq, dest, term, carry, mine, acc_i, table_i, natomics);
+  walk_part<HEAT, 3>(a, wq, dest, term, carry, mine, acc_i, table_i, natomics);
+#endif
 }
 
 /*
@@ -352,6 +398,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
   __shared__ FullStage full_stage[FULL ? CMI_BLOCK / 64 : 1];
   FullStage &stage = full_stage[FULL ? wib : 0];
   double weights[CMI_NACC];
+  double wq[CMI_NACC]; /* FULL: transposed weights of the lane's quarter */
   /* Multi-ion kernels use the same kind of table with 16 values per slot
    * (one accumulator row). 128 B per slot leave room for 256 slots only, so
    * the block writes it back every CMI_FTABLE_WINDOW iterations of the march
@@ -552,6 +599,8 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
     /* FAST: the record of the cell a lane is about to cross is loaded one
      * iteration ahead, so that the load overlaps the accumulation */
     int window = 0;
+    if (FULL)
+      load_quarter_weights(stage, wq);
     double2 kappa_next = make_double2(0., 0.);
     if (!EXACT && active && p.tau > 0. && !fast_outside(p))
       kappa_next = fast_load_record(a.cells.opacity, p);
@@ -587,7 +636,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
       if (a.exp_no_atomics == 1)
         continue;
       if (FULL) {
-        accumulate_full<HEAT>(a, stage, accumulate, last_cell, ds * p.weight,
+        accumulate_full<HEAT>(a, wq, accumulate, last_cell, ds * p.weight,
                               natomics, use_table ? lds_tag : nullptr,
                               lds_val);
         if (use_table && a.exp_no_atomics != 5 &&

@@ -45,8 +45,10 @@ def main():
             if best is None or t["shoot_ms"] < best[0]:
                 best = (t["shoot_ms"], launches)
         tw, tc, ns = eng.get_counters()
-        print("%-40s shoot %7.1f ms  steps/pk %.1f  launches: %s" %
-              (cfg, best[0], ns / npk,
+        nw = eng.get_wave_steps()
+        print("%-40s shoot %7.1f ms  steps/pk %.1f  lanes busy %.3f  "
+              "launches: %s" %
+              (cfg, best[0], ns / npk, ns / max(64. * nw, 1.),
                " ".join("%.1f/%.2g" % (ms, pk) for ms, pk in best[1][:4])),
               flush=True)
     eng.close()

@@ -155,7 +155,7 @@ __host__ __device__ inline void cmi_cross_sections(const ModelDev &m, double nu,
 
 /* the cross sections of H0 and He0 alone (the re-emission decision needs no
  * others): same terms, same order of summation as cmi_cross_sections */
-__device__ inline void cmi_cross_sections_H_He(const ModelDev &m, double nu,
+__host__ __device__ inline void cmi_cross_sections_H_He(const ModelDev &m, double nu,
                                                double &sigma_H,
                                                double &sigma_He) {
   if (!m.xsec_verner) {

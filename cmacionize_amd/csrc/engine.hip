@@ -1114,18 +1114,25 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
    * tau classes only help when a packet's range follows from its optical
    * depth alone (one cross section for all packets). */
   uint32_t tau_bits = 0;
-  if (!e->full_ions) {
-    if (e->tune.sort_tau_bits >= 0) {
+  {
+    const uint64_t per_source =
+        (n_packets < max_launch ? n_packets : max_launch) /
+        (uint64_t)(e->model.nsource > 0 ? e->model.nsource : 1);
+    if (e->tune.sort_tau_bits >= 0)
       tau_bits = (uint32_t)e->tune.sort_tau_bits;
-    } else {
+    else
       /* measured on 256^3: the classes pay off once a direction bin of
        * 64 x 2^bits packets is still narrower than a few cells */
-      const uint64_t per_source =
-          (n_packets < max_launch ? n_packets : max_launch) /
-          (uint64_t)(e->model.nsource > 0 ? e->model.nsource : 1);
       tau_bits = per_source >= (1ull << 24) ? 3u
                                             : (per_source >= (1ull << 22) ? 2u : 0u);
-    }
+  }
+  double sigma_ref = 1.;
+  if (e->full_ions) {
+    double sigma_He;
+    ModelDev host_model = e->model;
+    host_model.tables = e->host_tables;
+    cmi_cross_sections_H_He(host_model, 1.0001 * e->model.nu_H, sigma_ref,
+                            sigma_He);
   }
   uint32_t source_bits = 0;
   for (int s = e->model.nsource - 1; s > 0; s >>= 1)
@@ -1178,6 +1185,8 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       k.seed = seed;
       k.iteration = iteration;
       k.tau_bits = tau_bits;
+      k.full_ions = e->full_ions ? 1 : 0;
+      k.sigma_ref = sigma_ref;
       k.source_mask = (1u << source_bits) - 1u;
       /* coarse direction bins of ~64 x 2^tau_bits packets per source */
       k.dir_hi_bits = 0;

@@ -939,6 +939,10 @@ struct KeyArgs {
   uint32_t iteration;
   uint32_t dir_hi_bits; /* 0..22 */
   uint32_t tau_bits;    /* 0..3 */
+  /* multi-ion transport: a packet's range also depends on its frequency; the
+   * class is then the octave of tau sigma_ref / (sigma_H + A_He sigma_He) */
+  int32_t full_ions;
+  double sigma_ref;
   uint32_t source_mask;
   uint32_t *keys;
   uint32_t *ids;
@@ -974,9 +978,21 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     const uint32_t morton = spread_bits_11(ic) | (spread_bits_11(ip) << 1);
     uint32_t tau_class = 0;
     if (a.tau_bits != 0) {
-      (void)sample_source_spectrum(a.model, rng); /* the frequency's draws */
-      const double u_tau = rng.next();            /* tau = -ln u */
-      tau_class = (uint32_t)(u_tau * (double)(1u << a.tau_bits));
+      if (!a.full_ions) {
+        (void)sample_source_spectrum(a.model, rng); /* the frequency's draws */
+        const double u_tau = rng.next();            /* tau = -ln u */
+        tau_class = (uint32_t)(u_tau * (double)(1u << a.tau_bits));
+      } else {
+        const double nu = sample_source_spectrum(a.model, rng);
+        const double tau = -log(rng.next());
+        double sigma_H, sigma_He;
+        cmi_cross_sections_H_He(a.model, nu, sigma_H, sigma_He);
+        const double range = tau * a.sigma_ref /
+                             (sigma_H + a.model.abundance[0] * sigma_He);
+        const int octave = (int)floor(log2(range)) + (1 << (a.tau_bits - 1));
+        const int top = (1 << a.tau_bits) - 1;
+        tau_class = (uint32_t)(octave < 0 ? 0 : (octave > top ? top : octave));
+      }
     }
     const uint32_t hi = morton >> lo_bits;
     const uint32_t lo = morton & ((1u << lo_bits) - 1u);

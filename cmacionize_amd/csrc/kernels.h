@@ -190,8 +190,10 @@ struct FullStage {
 
 #define CMI_DPP_ROW_NEWBCAST(n) (0x150 + (n))
 template <int R> __device__ __forceinline__ int row_bcast_i32(int v) {
+  /* every lane has a source lane: bound_ctrl lets the compiler drop the
+   * initialisation of the destination */
   return __builtin_amdgcn_update_dpp(0, v, CMI_DPP_ROW_NEWBCAST(R), 0xf, 0xf,
-                                     false);
+                                     true);
 }
 template <int R> __device__ __forceinline__ double row_bcast_f64(double v) {
   const int lo = row_bcast_i32<R>(__double2loint(v));
@@ -268,6 +270,21 @@ walk_part(const ShootArgs &a, const double (&wq)[CMI_NACC], int32_t dest,
   }
 }
 
+/* Table mode: every row adds its term to its slot straight away - 16
+ * ds_add_f64 per lane and step, no running sums, no branches: the LDS unit
+ * merges what the running sums would have merged. Lanes without a slot add
+ * (zero, or a term that is also added elsewhere - see below) to a dummy row
+ * after the table that is never written back. */
+template <int R>
+__device__ __forceinline__ void table_row(const double (&wq)[CMI_NACC],
+                                          int32_t dest, double dsw,
+                                          double *table_i) {
+  const int32_t d = row_bcast_i32<R>(dest);
+  const double term = row_bcast_f64<R>(dsw) * wq[R];
+  const int32_t slot = d >= 0 ? d : CMI_FTABLE_SLOTS;
+  atomicAdd(table_i + slot * CMI_NACC, term); /* ds_add_f64 */
+}
+
 template <bool HEAT>
 __device__ __forceinline__ void
 accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
@@ -275,38 +292,85 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
                 unsigned int &natomics, int32_t *table_tag,
                 double *table_val) {
   const int lane = threadIdx.x & 63;
-  /* only the first lane of a run of equal cells (and of each quarter) looks
-   * the destination up; the others post "same as the packet before me".
-   * dest >= 0: table slot; -1: nothing; other negatives: cell -(dest + 2) */
-  const int32_t key = accumulate ? cell : ~lane;
-  const int32_t prev = dpp_keep<CMI_DPP_WAVE_SHR1, 0xf>(~key, key);
-  const bool head = (key != prev) || (lane & 15) == 0;
-  int32_t dest = -1;
-  if (accumulate) {
-    dest = -(cell + 2);
-    if (!head) {
-      dest = CMI_DEST_SAME;
-    } else if (table_tag != nullptr && a.exp_no_atomics != 4) {
-      /* claim the cell's slot, as in the hydrogen-only table */
-      uint32_t s = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_FTABLE_BITS);
-      for (int probe = 0; probe < CMI_TABLE_PROBES; ++probe) {
-        const int32_t was = atomicCAS(&table_tag[s], -1, cell);
-        if (was == -1 || was == cell) {
-          dest = (int32_t)s;
-          break;
-        }
-        s = (s + 1) & (CMI_FTABLE_SLOTS - 1);
-      }
-    }
-  }
-  if (a.exp_no_atomics == 2 || a.exp_no_atomics >= 4) /* experiment: no walk */
-    return;
-  const double term = accumulate ? dsw : 0.;
   const int i = lane & 15;
   const bool mine = HEAT || i < CMI_NION;
   /* accumulator i of cell c: AoS rows of CMI_NACC doubles */
   double *const acc_i = a.cells.acc_base + i;
   double *const table_i = table_val + i;
+  const double term = accumulate ? dsw : 0.;
+
+  if (table_tag != nullptr) {
+    /* every lane claims (or finds) the slot of its cell, as in the
+     * hydrogen-only table. dest >= 0: slot; -1: nothing to add;
+     * other negatives: cell -(dest + 2), no slot was free */
+    int32_t dest = -1;
+    if (accumulate) {
+      dest = -(cell + 2);
+      if (a.exp_no_atomics != 4) {
+        uint32_t s = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_FTABLE_BITS);
+        for (int probe = 0; probe < CMI_TABLE_PROBES; ++probe) {
+          const int32_t was = atomicCAS(&table_tag[s], -1, cell);
+          if (was == -1 || was == cell) {
+            dest = (int32_t)s;
+            break;
+          }
+          s = (s + 1) & (CMI_FTABLE_SLOTS - 1);
+        }
+      }
+    }
+    if (a.exp_no_atomics == 2 || a.exp_no_atomics >= 4) /* exp.: no walk */
+      return;
+    table_row<0>(wq, dest, term, table_i);
+    table_row<1>(wq, dest, term, table_i);
+    table_row<2>(wq, dest, term, table_i);
+    table_row<3>(wq, dest, term, table_i);
+    if (a.exp_no_atomics == 6) /* experiment: a quarter of the adds */
+      return;
+    table_row<4>(wq, dest, term, table_i);
+    table_row<5>(wq, dest, term, table_i);
+    table_row<6>(wq, dest, term, table_i);
+    table_row<7>(wq, dest, term, table_i);
+    table_row<8>(wq, dest, term, table_i);
+    table_row<9>(wq, dest, term, table_i);
+    table_row<10>(wq, dest, term, table_i);
+    table_row<11>(wq, dest, term, table_i);
+    table_row<12>(wq, dest, term, table_i);
+    table_row<13>(wq, dest, term, table_i);
+    table_row<14>(wq, dest, term, table_i);
+    table_row<15>(wq, dest, term, table_i);
+    /* rare: packets that found no slot go the general way below, alone */
+    const bool direct = dest < -1;
+    if (__ballot(direct) == 0ull)
+      return;
+    int32_t carry = -1;
+    const int32_t only_direct = direct ? dest : -1;
+    const double only_term = direct ? term : 0.;
+    walk_part<HEAT, 0>(a, wq, only_direct, only_term, carry, mine, acc_i,
+                       table_i, natomics);
+#if CMI_WALK_PART < 16
+    walk_part<HEAT, 1>(a, wq, only_direct, only_term, carry, mine, acc_i,
+                       table_i, natomics);
+#endif
+#if CMI_WALK_PART < 8
+    walk_part<HEAT, 2>(a, wq, only_direct, only_term, carry, mine, acc_i,
+                       table_i, natomics);
+    walk_part<HEAT, 3>(a, wq, only_direct, only_term, carry, mine, acc_i,
+                       table_i, natomics);
+#endif
+    return;
+  }
+
+  /* no table: only the first lane of a run of equal cells (and of each
+   * quarter) names the destination, the others post "same as the packet
+   * before me", and the walk merges each run into one group of atomics */
+  const int32_t key = accumulate ? cell : ~lane;
+  const int32_t prev = dpp_keep<CMI_DPP_WAVE_SHR1, 0xf>(~key, key);
+  const bool head = (key != prev) || (lane & 15) == 0;
+  int32_t dest = -1;
+  if (accumulate)
+    dest = head ? -(cell + 2) : CMI_DEST_SAME;
+  if (a.exp_no_atomics == 2 || a.exp_no_atomics >= 4) /* experiment: no walk */
+    return;
   int32_t carry = -1; /* destination of the last packet of the part before */
   walk_part<HEAT, 0>(a, wq, dest, term, carry, mine, acc_i, table_i, natomics);
 #if CMI_WALK_PART < 16
@@ -391,7 +455,8 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
   constexpr int lds_slots = FULL ? CMI_FTABLE_SLOTS : CMI_TABLE_SLOTS;
   constexpr int lds_values = FULL ? CMI_NACC : (HEAT ? 2 : 1);
   __shared__ int32_t lds_tag[lds_slots];
-  __shared__ double lds_val[lds_values * lds_slots];
+  /* FULL: one more row, the sink of table_row() for lanes without a slot */
+  __shared__ double lds_val[lds_values * (lds_slots + (FULL ? 1 : 0))];
   __shared__ int32_t block_has_work[CMI_BLOCK / 64];
   const int wib = threadIdx.x >> 6;
   /* FULL: per-wave accumulation weights and per-step scratch in LDS */

@@ -323,7 +323,8 @@ int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
  *                           accumulation; multi-ion kernels: 2 = post
  *                           destinations but skip the walk, 3 = walk without
  *                           the adds, 4 = as 2 without the table look-up,
- *                           5 = as 2 without the periodic write-backs */
+ *                           5 = as 2 without the periodic write-backs,
+ *                           6 = a quarter of the table adds */
 int cmi_gpu_set_tuning(cmi_gpu_engine *engine, const char *key, int64_t value);
 
 /* --------------------------------------------------- test / measurement -- */

@@ -200,3 +200,43 @@ def test_export_buffer_overflow_is_an_error():
     with pytest.raises(EngineError):
         b.take_exports()
     b.engine.close()
+
+
+def test_decomposed_grid_with_sources_in_different_blocks():
+    """Every block runs through all packet ids and flies those whose source
+    lies inside it: three weighted sources in three different blocks."""
+    from cmacionize_amd import GpuEngine, STROMGREN as S
+    from cmacionize_amd import engine as E
+    from cmacionize_amd.simulation import (DomainDecomposition,
+                                           DomainGpuBackend,
+                                           LocalDomainDriver)
+    from test_gpu_transport import SOURCES
+    ncell, npacket = 24, 60000
+    whole = GpuEngine((ncell,) * 3, S["anchor"], S["sides"], (0, 0, 0),
+                      device=0, track_heating=False)
+    configure(whole, "stromgren", ncell ** 3)
+    whole.set_sources(SOURCES[0], SOURCES[1], S["luminosity"])
+    dec = DomainDecomposition((ncell,) * 3, (2, 2, 2))
+    backends = []
+    for rank in range(dec.world):
+        b = DomainGpuBackend(dec, rank, S["anchor"], S["sides"], device=0,
+                             export_capacity=npacket)
+        configure(b.engine, "stromgren", int(np.prod(dec.block(rank)[1])))
+        b.engine.set_sources(SOURCES[0], SOURCES[1], S["luminosity"])
+        backends.append(b)
+    driver = LocalDomainDriver(backends, dec)
+    whole.reset_grid()
+    whole.shoot(5, 0, 0, npacket)
+    tw, tc, ns = whole.get_counters()
+    driver.iteration(0, npacket, 5, update=False)
+    assert driver.totweight == tw == npacket
+    assert np.array_equal(driver.typecount, tc) and driver.nsteps == ns
+    J = assemble(dec, backends, E.FIELD_MEAN_INTENSITY)
+    Jref = whole.download_field(E.FIELD_MEAN_INTENSITY)
+    assert np.allclose(J, Jref, rtol=1e-11, atol=1e-13 * Jref.max())
+    # the three sources sit in three different blocks: each emitted its share
+    emitted = sorted((b.get_counters()[0] > 0) for b in backends)
+    assert sum(emitted) >= 3
+    whole.close()
+    for b in backends:
+        b.engine.close()

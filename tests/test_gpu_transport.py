@@ -374,3 +374,42 @@ def test_converged_neutral_fractions_within_one_percent_of_oracle(oracle):
     # and cell by cell, away from the ionization front's single-packet noise
     assert np.median(np.abs(xg - xo) / xo) < 1e-6
     eng.close()
+
+
+SOURCES = ([[0., 0., 0.], [-3.1e16, 2.2e16, 1.0e16], [4.4e16, -4.6e16, 3.9e16]],
+           [0.5, 0.3, 0.2])
+
+
+def test_multiple_weighted_sources_match_oracle(oracle):
+    """PhotonSource with several discrete sources and weights
+    (src/PhotonSource.cpp:74-93,222-227): the source is picked from the second
+    uniform, the sort key carries the source index."""
+    from cmacionize_amd import STROMGREN as S
+    from cmacionize_amd import engine as E
+    ncell, npacket = 24, 60000
+    eng = make_engine(ncell, track_heating=False)
+    eng.set_sources(SOURCES[0], SOURCES[1], S["luminosity"])
+    sim = oracle.stromgren_simulation(ncell)
+    sim.set_sources(SOURCES[0], SOURCES[1], S["luminosity"])
+    for loop in range(3):
+        eng.reset_grid()
+        eng.shoot(42, loop, 0, npacket)
+        tw, tc, ns = eng.get_counters()
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(42, loop, 0, npacket)
+        assert tw == sim.totweight == npacket
+        assert np.array_equal(tc, sim.typecount)
+        J = eng.download_field(E.FIELD_MEAN_INTENSITY)
+        assert np.allclose(J, sim.J[0], rtol=1e-9, atol=1e-12 * sim.J[0].max())
+        eng.upload_field(E.FIELD_MEAN_INTENSITY, sim.J[0])
+        eng.update_cells(loop, tw)
+        sim.update(loop, sim.totweight)
+        assert np.array_equal(eng.download_field(E.FIELD_IONIC_FRACTION),
+                              sim.x[0])
+    # three separate ionized regions
+    pos, _, _, _, _ = eng.emit_packets(42, 0, 0, 20000)
+    share = [np.all(pos == np.array(p), axis=1).mean() for p in SOURCES[0]]
+    assert np.allclose(share, SOURCES[1], atol=0.02)
+    eng.close()

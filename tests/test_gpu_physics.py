@@ -260,3 +260,40 @@ def test_lexington_converged_state_within_one_percent_of_oracle(oracle):
             assert abs(a - b) <= 0.01 * abs(b) + 1e-300, (field, s, a, b)
     assert np.asarray(sim.temperature).max() > 6000.
     eng.close()
+
+
+@pytest.mark.parametrize("passes", [1, 0])
+def test_fixed_value_reemission_matches_oracle(oracle, passes):
+    """FixedValueDiffuseReemissionHandler (src/FixedValueDiffuseReemission
+    Handler.hpp:73-86): re-emission with a fixed probability at a fixed
+    frequency - through the interaction kernel (passes) and in place."""
+    from cmacionize_amd import engine as E
+    from test_gpu_transport import make_engine
+    ncell, npacket = 24, 50000
+    eng = make_engine(ncell, track_heating=False)
+    nu = 1.01 * 3.288465385e15
+    eng.set_reemission(2, 0.42, nu)
+    eng.set_tuning(reemit_passes=passes, reemit_inline_below=64)
+    sim = oracle.stromgren_simulation(ncell)
+    sim.model.reemit_type = 2
+    sim.model.reemit_fixed_probability = 0.42
+    sim.model.reemit_fixed_frequency = nu
+    for loop in range(3):
+        eng.reset_grid()
+        eng.shoot(9, loop, 0, npacket)
+        tw, tc, ns = eng.get_counters()
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(9, loop, 0, npacket)
+        assert tw == sim.totweight == npacket
+        assert np.array_equal(tc, sim.typecount)
+        assert tc[1] > 0 and tc[3] > 0
+        J = eng.download_field(E.FIELD_MEAN_INTENSITY)
+        assert np.allclose(J, sim.J[0], rtol=1e-9, atol=1e-12 * sim.J[0].max())
+        eng.upload_field(E.FIELD_MEAN_INTENSITY, sim.J[0])
+        eng.update_cells(loop, tw)
+        sim.update(loop, sim.totweight)
+        assert np.array_equal(eng.download_field(E.FIELD_IONIC_FRACTION),
+                              sim.x[0])
+    eng.close()

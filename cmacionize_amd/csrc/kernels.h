@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
       break;
     }
     if (avail != 0 && idle_mask != 0ull &&
-        (active_mask == 0ull || __popcll(idle_mask) >= a.refill_threshold)) {
+        (active_mask == 0ull || (int)__popcll(idle_mask) >= a.refill_threshold)) {
       const uint64_t rank = __popcll(idle_mask & lane_lt);
       if (!active && rank < avail) {
         const uint64_t i = pos + rank;
@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
         stepping = stepping && !fast_outside(p);
       const unsigned long long flying = __ballot(stepping);
       if (flying == 0ull ||
-          (avail_after != 0 && __popcll(~flying) >= a.refill_threshold))
+          (avail_after != 0 && (int)__popcll(~flying) >= a.refill_threshold))
         break;
       ++nwavesteps;
       double ds = 0.;

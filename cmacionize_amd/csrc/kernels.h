@@ -1117,7 +1117,10 @@ __global__ void __launch_bounds__(CMI_BLOCK)
  * branch (src/TemperatureCalculator.cpp:944-964 -> :567-931): one cell per
  * lane. fp64-ALU / transcendental bound (up to 100 x 3 balance evaluations,
  * each with ten 5x5 level-population solves). */
-__global__ void __launch_bounds__(CMI_BLOCK)
+#ifndef CMI_TEMPERATURE_WAVES
+#define CMI_TEMPERATURE_WAVES 4
+#endif
+__global__ void __launch_bounds__(CMI_BLOCK, CMI_TEMPERATURE_WAVES)
     temperature_kernel(const UpdateArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

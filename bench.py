@@ -183,11 +183,14 @@ def main():
                                                DomainIterationDriver,
                                                default_blocks)
         dec = DomainDecomposition((ncell,) * 3, default_blocks(world))
-        # the block with the source exports 7/8 of the packets in round one
+        # domain mode is STRONG scaling: --packets is the iteration's total.
+        # (All packets start in the one block that holds the source, which
+        # hands 7/8 of them over in the first round: with N x packets that
+        # single hand-over would be N x 7/8 x packets x 128 B.)
         backend = DomainGpuBackend(dec, rank, S["anchor"], S["sides"],
                                    device=local_rank,
                                    track_heating=cfg["lexington"],
-                                   export_capacity=npk * world + 1024)
+                                   export_capacity=npk + 1024)
         setup_engine(backend, ncell, cfg, dec.block(rank))
         driver = DomainIterationDriver(backend, dec, rank, world, dist)
     else:
@@ -222,7 +225,8 @@ def main():
     loop = 0
     volume = []
     for _ in range(args.converge_iterations):
-        driver.iteration(loop, int(args.converge_packets) * world, 42)
+        driver.iteration(loop, int(args.converge_packets) *
+                         (1 if domain else world), 42)
         loop += 1
         volume.append(ionized_fraction())
     converged_at = None
@@ -231,16 +235,18 @@ def main():
                 abs(volume[k] - volume[k - 1]) < 0.01 * volume[k]:
             converged_at = k + 1  # 1-based count of iterations run
             break
-    # in the timed region every rank shoots npk packets: global = npk * world
+    # replica mode: every rank shoots npk packets, global = npk * world (weak
+    # scaling); domain mode: npk packets in total (strong scaling)
+    global_packets = npk if domain else npk * world
     for _ in range(args.warmup):
-        driver.iteration(loop, npk * world, 42)
+        driver.iteration(loop, global_packets, 42)
         loop += 1
     barrier()
     backend.engine.get_timing(reset=True)
     nsteps_total = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        driver.iteration(loop, npk * world, 42)
+        driver.iteration(loop, global_packets, 42)
         nsteps_total += driver.nsteps
         loop += 1
     barrier()
@@ -254,7 +260,7 @@ def main():
 
     final_volume = ionized_fraction()
     if rank == 0:
-        total_packets = float(npk) * world * args.steps
+        total_packets = float(global_packets) * args.steps
         value = total_packets / elapsed
         shoot_s = timing["shoot_ms"] * 1e-3
         # the transport kernel alone (HIP events around each launch on the
@@ -282,21 +288,24 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if domain else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s %d^3 grid, %.0e packets per GPU per "
-                            "iteration, converged ionization state; step = "
-                            "reset + shoot + reduce + cell update" %
-                            (cfg["name"], ncell, npk),
+                "workload": "%s %d^3 grid, %.0e packets per %s, "
+                            "converged ionization state; step = "
+                            "reset + shoot + %s + cell update" %
+                            (cfg["name"], ncell, npk,
+                             "iteration (all GPUs together)" if domain else "GPU per iteration",
+                             "flight hand-over" if domain else "reduce"),
                 "parallelism": ("domain x%d (one block per GPU, all-to-all "
                                 "of crossing flights)" if domain else
                                 "replica x%d (sum all-reduce of accumulators)")
                                % world,
             },
-            "transport_only_packets_per_s": float(npk) * args.steps / shoot_s,
+            "transport_only_packets_per_s": (float(npk) * args.steps /
+                                             shoot_s),
             "dda_steps_per_packet": nsteps_total / total_packets,
             "cell_update_ms_per_step": timing["update_ms"] /
             max(timing["update_launches"], 1),
@@ -306,7 +315,8 @@ def main():
                 "criterion": "first iteration whose ionized volume fraction "
                              "V(x_H<0.5)/V_box is within 1 % of the previous "
                              "iteration's",
-                "packets_per_iteration": args.converge_packets * world,
+                "packets_per_iteration": args.converge_packets *
+                (1 if domain else world),
                 "ionized_volume_fraction_by_iteration": volume,
             },
             "roofline": {

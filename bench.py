@@ -140,7 +140,10 @@ def main():
                     help="packets per rank per step (default 1e8, the "
                          "number of photons of all three .param files)")
     ap.add_argument("--converge-iterations", type=int, default=None)
-    ap.add_argument("--converge-packets", type=float, default=1e7)
+    ap.add_argument("--converge-packets", type=float, default=None,
+                    help="packets per rank of the untimed iterations that "
+                         "bring the grid to its converged state (default: "
+                         "--packets, the reference's run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decomposition", default="replica",
                     choices=["replica", "domain"],
@@ -154,6 +157,8 @@ def main():
         args.packets = 1e8
     if args.converge_iterations is None:
         args.converge_iterations = cfg["converge_iterations"]
+    if args.converge_packets is None:
+        args.converge_packets = args.packets
 
     import torch
     from cmacionize_amd.simulation import GpuBackend, ReplicaIterationDriver
@@ -221,7 +226,8 @@ def main():
     # bring the grid to the converged state (untimed); rank 0 follows the
     # ionized volume fraction for the iterations-to-converge figure
     # (first iteration after which V(x_H < 0.5) / V_box changes
-    # by less than 1 % between consecutive iterations)
+    # by less than 1 % between consecutive iterations), at the reference's
+    # packet count
     loop = 0
     volume = []
     for _ in range(args.converge_iterations):
@@ -229,12 +235,17 @@ def main():
                          (1 if domain else world), 42)
         loop += 1
         volume.append(ionized_fraction())
+    # (the first iterations of a fully ionized start change little too: what
+    # counts is the last change of 1 % or more)
     converged_at = None
-    for k in range(1, len(volume)):
-        if volume[k] > 0. and \
-                abs(volume[k] - volume[k - 1]) < 0.01 * volume[k]:
-            converged_at = k + 1  # 1-based count of iterations run
-            break
+    if len(volume) > 1:
+        last_big = 0
+        for k in range(1, len(volume)):
+            if volume[k] <= 0. or \
+                    abs(volume[k] - volume[k - 1]) >= 0.01 * volume[k]:
+                last_big = k
+        if last_big + 1 < len(volume):
+            converged_at = last_big + 2  # 1-based count of iterations run
     # replica mode: every rank shoots npk packets, global = npk * world (weak
     # scaling); domain mode: npk packets in total (strong scaling)
     global_packets = npk if domain else npk * world
@@ -312,9 +323,9 @@ def main():
             "ionized_volume_fraction": final_volume,
             "iterations_to_converge": {
                 "value": converged_at,
-                "criterion": "first iteration whose ionized volume fraction "
-                             "V(x_H<0.5)/V_box is within 1 % of the previous "
-                             "iteration's",
+                "criterion": "first iteration from which on the ionized "
+                             "volume fraction V(x_H<0.5)/V_box changes by "
+                             "less than 1 % per iteration",
                 "packets_per_iteration": args.converge_packets *
                 (1 if domain else world),
                 "ionized_volume_fraction_by_iteration": volume,

@@ -169,12 +169,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # (CMI_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a
+    # box with fewer GPUs than ranks - ranks then share devices)
+    collective = os.environ.get("CMI_BENCH_BACKEND", "nccl")
+    if collective != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if collective == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda",
+                                                           local_rank))
+        else:
+            dist.init_process_group(collective, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" %
               (args.gpus, world), file=sys.stderr)

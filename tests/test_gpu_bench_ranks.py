@@ -1,0 +1,62 @@
+"""GPU rehearsal of bench.py's multi-rank control flow: two ranks (sharing
+device 0, collectives over gloo - CMI_BENCH_BACKEND) in replica and in domain
+mode must run to the end, print one JSON line from rank 0 and reach the same
+converged state as the one-rank run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--steps", "2", "--warmup", "1", "--ncell", "64", "--packets", "4e5",
+          "--converge-iterations", "8", "--no-cpu-baseline"]
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_bench(ranks, extra):
+    env = dict(os.environ, CMI_BENCH_BACKEND="gloo")
+    if ranks == 1:
+        cmd = [sys.executable, "bench.py", "--gpus", "1"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), "bench.py", "--gpus",
+               str(ranks)]
+    r = subprocess.run(cmd + COMMON + extra, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 only
+    return json.loads(lines[0])
+
+
+def test_two_ranks_replica_and_domain_reach_the_one_rank_state():
+    one = run_bench(1, [])
+    assert one["n_gpus"] == 1 and one["scaling"] == "weak"
+    for key in ("roofline", "config", "iterations_to_converge"):
+        assert key in one
+    replica = run_bench(2, [])
+    assert replica["n_gpus"] == 2 and replica["scaling"] == "weak"
+    assert "replica x2" in replica["config"]["parallelism"]
+    domain = run_bench(2, ["--decomposition", "domain"])
+    assert domain["n_gpus"] == 2 and domain["scaling"] == "strong"
+    assert domain["flights_exchanged_last_step"] > 0
+    # replica: twice the packets per iteration - the same physical state up to
+    # Monte Carlo noise; domain: the same packets as the one-rank run
+    ref = one["ionized_volume_fraction"]
+    # (at 4e5 packets on 64^3 the noise of the estimator biases the volume)
+    assert abs(replica["ionized_volume_fraction"] - ref) < 0.05 * ref
+    assert abs(domain["ionized_volume_fraction"] - ref) < 1e-4 * ref
+    assert abs(domain["dda_steps_per_packet"] -
+               one["dda_steps_per_packet"]) < 1e-6 * one["dda_steps_per_packet"]
+    assert replica["value"] > 0. and domain["value"] > 0.

@@ -626,9 +626,38 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
           emit_packet<FULL, EXACT>(a.grid, a.model, rng, p, weights);
           lane_meta = cmi_pack_meta(rng.block, rng.have, 0);
           if (a.grid.decomposed) {
-            /* every block runs through all packets of the iteration but only
-             * flies those whose source lies in it; a source outside the whole
-             * grid is the business of the block at the grid's origin */
+            /* Every block runs through all packets of the iteration but only
+             * flies those that start in it; a source outside the whole grid
+             * is the business of the block at the grid's origin. A source ON
+             * a cell wall - the benchmarks' star sits on the corner shared by
+             * the 8 octants - sends most of its packets through a first step
+             * of length zero into a neighbouring cell: such steps are pure
+             * geometry (no opacity, no optical depth), so every block takes
+             * them here, identically, before asking whose packet it is.
+             * Otherwise the block with the source cell would emit everything
+             * and hand 7/8 of it over. */
+            int skipped = 0;
+            if (!EXACT) {
+              /* (one such step at most: afterwards every tmax is positive) */
+              const double tmin =
+                  min_f64(p.tmax[0], min_f64(p.tmax[1], p.tmax[2]));
+              bool start_in_grid = true;
+#pragma unroll
+              for (int ax = 0; ax < 3; ++ax) {
+                const int32_t gi = p.index[ax] + a.grid.offset[ax];
+                start_in_grid &= (gi >= 0 && gi < a.grid.global_ncell[ax]);
+              }
+              if (start_in_grid && tmin == p.t) {
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                  if (p.tmax[ax] == tmin) { /* exactly fast_step's advance */
+                    p.tmax[ax] = __fma_rn(1., p.tdelta[ax], p.tmax[ax]);
+                    p.index[ax] += (p.dir[ax] > 0.) ? 1 : -1;
+                  }
+                }
+                skipped = 1;
+              }
+            }
             bool in_block = true, in_grid = true;
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
@@ -639,6 +668,19 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
             const bool at_origin = (a.grid.offset[0] | a.grid.offset[1] |
                                     a.grid.offset[2]) == 0;
             mine = in_block || (!in_grid && at_origin);
+            if (skipped != 0 && mine) {
+              nsteps += skipped; /* they are DDA steps of the undivided run */
+#pragma unroll
+              for (int ax = 0; ax < 3; ++ax)
+                p.rem[ax] = (p.dir[ax] > 0.)
+                                ? a.grid.ncell[ax] - 1 - p.index[ax]
+                                : p.index[ax];
+              if (!in_block)
+                p.rem[0] = -1;
+              p.cell = (p.index[0] * a.grid.ncell[1] + p.index[1]) *
+                           a.grid.ncell[2] +
+                       p.index[2];
+            }
           }
         }
         if (FULL) {

@@ -170,10 +170,12 @@ __device__ __forceinline__ void start_flight(const GridDev &g,
 /* PhotonSource::get_random_photon (discrete branch) + the first optical depth
  * of IonizationPhotonShootJob::execute
  * (src/PhotonSource.cpp:208-249, src/IonizationPhotonShootJob.hpp:119-135) */
+/* ... in two parts, so that a block of a decomposed grid can drop a packet
+ * that starts elsewhere before paying for its frequency and cross sections:
+ * where and in which direction (draws 1-4) ... */
 template <bool FULL, bool EXACT>
-__device__ inline void emit_packet(const GridDev &g, const ModelDev &m,
-                                   PacketRng &rng, Packet<FULL> &p,
-                                   double (&weights)[CMI_NACC]) {
+__device__ inline void emit_geometry(const GridDev &g, const ModelDev &m,
+                                     PacketRng &rng, Packet<FULL> &p) {
   /* first uniform: continuous vs discrete source; no continuous source on
    * this path, so it is drawn and ignored */
   double x = rng.next();
@@ -185,12 +187,27 @@ __device__ inline void emit_packet(const GridDev &g, const ModelDev &m,
   for (int a = 0; a < 3; ++a)
     p.pos[a] = m.source_position[3 * i + a];
   random_direction(p, rng);
-  p.nu = sample_source_spectrum(m, rng);
   p.type = TYPE_PRIMARY;
-  set_cross_sections(m, p, weights);
   p.weight = 1.;
-  p.tau = -log(rng.next());
   start_flight<FULL, EXACT>(g, p);
+}
+
+/* ... and what it is: frequency, cross sections, first optical depth */
+template <bool FULL>
+__device__ inline void emit_physics(const ModelDev &m, PacketRng &rng,
+                                    Packet<FULL> &p,
+                                    double (&weights)[CMI_NACC]) {
+  p.nu = sample_source_spectrum(m, rng);
+  set_cross_sections(m, p, weights);
+  p.tau = -log(rng.next());
+}
+
+template <bool FULL, bool EXACT>
+__device__ inline void emit_packet(const GridDev &g, const ModelDev &m,
+                                   PacketRng &rng, Packet<FULL> &p,
+                                   double (&weights)[CMI_NACC]) {
+  emit_geometry<FULL, EXACT>(g, m, rng, p);
+  emit_physics<FULL>(m, rng, p, weights);
 }
 
 /* EXACT: one iteration of the loop of CartesianDensityGrid::interact

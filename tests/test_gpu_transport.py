@@ -413,3 +413,34 @@ def test_multiple_weighted_sources_match_oracle(oracle):
     share = [np.all(pos == np.array(p), axis=1).mean() for p in SOURCES[0]]
     assert np.allclose(share, SOURCES[1], atol=0.02)
     eng.close()
+
+
+@pytest.mark.parametrize("npacket", [1, 63, 65, 1000])
+def test_ragged_packet_counts_match_oracle(oracle, npacket):
+    """Launches that do not fill a wave: the lanes without a packet take part
+    in the cross-lane sums and must contribute exact zeros."""
+    from cmacionize_amd import engine as E
+    ncell = 16
+    eng = make_engine(ncell)
+    sim = oracle.stromgren_simulation(ncell)
+    for loop, tuning in enumerate((dict(), dict(aggregate=1),
+                                   dict(max_packets_per_launch=17))):
+        base = dict(aggregate=2, max_packets_per_launch=1 << 27)
+        base.update(tuning)
+        eng.set_tuning(**base)
+        eng.reset_grid()
+        eng.shoot(3, loop, 7, npacket)
+        tw, tc, ns = eng.get_counters()
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(3, loop, 7, npacket)
+        assert tw == sim.totweight == npacket
+        assert np.array_equal(tc, sim.typecount)
+        for field, ref in ((E.FIELD_MEAN_INTENSITY, sim.J[0]),
+                           (E.FIELD_HEATING, sim.heating[0])):
+            got = eng.download_field(field)
+            assert np.isfinite(got).all()
+            assert np.allclose(got, ref, rtol=1e-9,
+                               atol=1e-12 * max(np.abs(ref).max(), 1e-300))
+    eng.close()

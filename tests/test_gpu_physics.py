@@ -297,3 +297,34 @@ def test_fixed_value_reemission_matches_oracle(oracle, passes):
         assert np.array_equal(eng.download_field(E.FIELD_IONIC_FRACTION),
                               sim.x[0])
     eng.close()
+
+
+@pytest.mark.parametrize("npacket", [1, 65, 700])
+def test_lexington_ragged_packet_counts(oracle, npacket):
+    """Multi-ion launches that do not fill a wave or a quarter of one: the
+    walk's idle rows must contribute exact zeros to all 16 accumulators."""
+    from cmacionize_amd import engine as E
+    ncell = 12
+    sim = oracle.lexington_simulation(ncell)
+    eng = lexington_engine(ncell, sim)
+    for loop, tuning in enumerate((dict(aggregate=2), dict(aggregate=0))):
+        eng.set_tuning(**tuning)
+        eng.reset_grid()
+        eng.shoot(5, loop, 3, npacket)
+        tw, tc, ns = eng.get_counters()
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(5, loop, 3, npacket)
+        assert tw == sim.totweight == npacket
+        assert np.abs(tc - sim.typecount).max() <= 1
+        for ion in range(14):
+            J = eng.download_field(E.FIELD_MEAN_INTENSITY + ion)
+            ref = np.asarray(sim.J[ion])
+            assert np.isfinite(J).all()
+            assert np.allclose(J, ref, rtol=1e-6,
+                               atol=1e-6 * max(ref.max(), 1e-300)), ion
+        for k in range(2):
+            h = eng.download_field(E.FIELD_HEATING + k)
+            assert np.isfinite(h).all()
+    eng.close()

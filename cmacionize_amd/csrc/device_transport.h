@@ -291,6 +291,11 @@ __device__ __forceinline__ double max_f64(double x, double y) {
  * packet is on the wall, in p.cell, or outside (fast_outside()). Periodic
  * wrapping is left to fast_wrap(), which the caller runs when any axis of the
  * grid is periodic. */
+/* (the byte offset is kept in 32 bits so that the load can use the scalar
+ * base + 32-bit vector offset addressing form: the FAST marcher therefore
+ * serves engines of fewer than CMI_FAST_MARCHER_MAX_CELLS cells; the host
+ * selects the EXACT marcher above that) */
+#define CMI_FAST_MARCHER_MAX_CELLS (1ll << 28)
 template <bool FULL>
 __device__ __forceinline__ double2
 fast_load_record(const double2 *__restrict__ opacity, const Packet<FULL> &p) {

@@ -1032,11 +1032,13 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   if (n_packets >= (1ull << 32))
     return fail(CMI_GPU_EINVAL,
                 "cmi_gpu_shoot: at most 2^32 - 1 packets per call");
-  if (e->grid.decomposed && (e->tune.exact_dda || !e->export_rows))
+  if (e->grid.decomposed &&
+      (e->tune.exact_dda || !e->export_rows ||
+       e->ncell >= CMI_FAST_MARCHER_MAX_CELLS))
     return fail(CMI_GPU_ESTATE,
                 "cmi_gpu_shoot: a block of a decomposed grid needs an export "
                 "buffer (cmi_gpu_set_export_buffer) and the incremental "
-                "marcher");
+                "marcher (fewer than 2^28 cells per block)");
   HIP_TRY(hipSetDevice(e->device));
   {
     int rc = ensure_spectra(e);
@@ -1047,8 +1049,10 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   const bool heat = e->config.track_heating != 0;
   const bool reemit = e->model.reemit_type != CMI_GPU_REEMIT_NONE;
   /* cross-lane aggregation keys and the fast marcher use 32-bit cell
-   * indices */
-  const bool small_grid = e->ncell < (1ll << 31);
+   * indices, and the marcher a 32-bit BYTE offset into the 16-B transport
+   * records (fast_load_record): 2^28 cells. Larger engines (768^3 and up;
+   * 2^28 cells are 73 GB of state) march with the exact marcher. */
+  const bool small_grid = e->ncell < CMI_FAST_MARCHER_MAX_CELLS;
   const int agg = small_grid ? e->tune.aggregate : CMI_AGG_NONE;
   const int agg_reemit = small_grid ? e->tune.aggregate_reemit : CMI_AGG_NONE;
   const bool exact = e->tune.exact_dda || !small_grid;
@@ -1595,7 +1599,7 @@ int cmi_gpu_trace_packets(cmi_gpu_engine *e, uint64_t n,
   if (err == hipSuccess)
     err = hipMemsetAsync(dds, 0, ds_bytes, e->stream);
   if (err == hipSuccess) {
-    if (e->tune.exact_dda || e->ncell >= (1ll << 31))
+    if (e->tune.exact_dda || e->ncell >= CMI_FAST_MARCHER_MAX_CELLS)
       trace_probe_kernel<true><<<(unsigned)((n + 63) / 64), 64, 0, e->stream>>>(
           e->grid, e->opacity, n, dpos, ddir, dtau, dsh, dshe, max_steps,
           dcell, dds, dnsteps, dlast, dfinal);
@@ -1700,6 +1704,38 @@ int cmi_gpu_thermal_probe(cmi_gpu_engine *e, int64_t n, int32_t solve,
                     hipMemcpyDeviceToHost);
   if (err == hipSuccess)
     err = hipMemcpy(out_pair, dp, sizeof(double) * 2 * n,
+                    hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(err);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_physics_probe(cmi_gpu_engine *e, int32_t kind, int64_t n,
+                          const double *in, double *out) {
+  static const int in_width[5] = {1, 1, 15, 1, 1};
+  static const int out_width[5] = {CMI_NION, CMI_NION, 1, 5, 3 * CMI_NION};
+  if (!e || n <= 0 || !in || !out || kind < 0 || kind > 4)
+    return fail(CMI_GPU_EINVAL, "physics_probe: bad argument");
+  if (kind == 0 && !e->have_xsec)
+    return fail(CMI_GPU_ESTATE, "physics_probe: cross sections not set");
+  if (kind == 1 && !e->have_recomb)
+    return fail(CMI_GPU_ESTATE, "physics_probe: recombination rates not set");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t nin = (size_t)n * in_width[kind];
+  const size_t nout = (size_t)n * out_width[kind];
+  double *d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(double) * (nin + nout)));
+  hipError_t err =
+      hipMemcpy(d, in, sizeof(double) * nin, hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    physics_probe_kernel<<<(unsigned)((n + 63) / 64), 64, 0, e->stream>>>(
+        e->model, kind, n, d, in_width[kind], d + nin, out_width[kind]);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess)
+    err = hipStreamSynchronize(e->stream);
+  if (err == hipSuccess)
+    err = hipMemcpy(out, d + nin, sizeof(double) * nout,
                     hipMemcpyDeviceToHost);
   (void)hipFree(d);
   HIP_TRY(err);

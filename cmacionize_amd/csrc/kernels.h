@@ -1249,6 +1249,52 @@ __global__ void thermal_probe_kernel(const ModelDev model, int64_t n,
     x_out[CMI_NION * i + k] = x[k];
 }
 
+/* probe of the atomic-data functions, one input row per lane (parity tests of
+ * the reference's fixtures on the device):
+ *  kind 0: in {nu}                 -> 14 cross sections (cmi_cross_sections)
+ *  kind 1: in {T}                  -> 14 recombination rates
+ *  kind 2: in {T, n_e, 13 abund.}  -> line cooling (line_cooling)
+ *  kind 3: in {T}                  -> 5 re-emission probabilities
+ *  kind 4: in {T4}                 -> 14 x {CT recombination with H,
+ *                                     CT ionization by H+, CT rec. with He} */
+__global__ void physics_probe_kernel(const ModelDev model, int32_t kind,
+                                     int64_t n, const double *in,
+                                     int32_t in_width, double *out,
+                                     int32_t out_width) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const double *r = in + (int64_t)in_width * i;
+  double *o = out + (int64_t)out_width * i;
+  if (kind == 0) {
+    double sigma[CMI_NION];
+    cmi_cross_sections(model, r[0], sigma);
+    for (int k = 0; k < CMI_NION; ++k)
+      o[k] = sigma[k];
+  } else if (kind == 1) {
+    for (int k = 0; k < CMI_NION; ++k)
+      o[k] = cmi_recombination_rate(model, k, r[0]);
+  } else if (kind == 2) {
+    double abund[13];
+    for (int k = 0; k < 13; ++k)
+      abund[k] = r[2 + k];
+    o[0] = line_cooling(model.tables->lc, r[0], r[1], abund);
+  } else if (kind == 3) {
+    double pH, pHe[4];
+    reemission_probabilities(r[0], pH, pHe);
+    o[0] = pH;
+    for (int k = 0; k < 4; ++k)
+      o[1 + k] = pHe[k];
+  } else {
+    const TablesDev *tb = model.tables;
+    for (int k = 0; k < CMI_NION; ++k) {
+      o[3 * k] = ct_eval(tb->ct_recomb_H[k], r[0]);
+      o[3 * k + 1] = ct_eval(tb->ct_ion_H[k], r[0]);
+      o[3 * k + 2] = ct_eval(tb->ct_recomb_He[k], r[0]);
+    }
+  }
+}
+
 /* probe: n samples of one of the sampled spectra */
 __global__ void spectrum_probe_kernel(const ModelDev model, int32_t kind,
                                       double temperature, uint32_t seed,

@@ -73,7 +73,7 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_get_launch_times", "cmi_gpu_set_export_buffer",
     "cmi_gpu_get_export_count", "cmi_gpu_reset_exports",
     "cmi_gpu_shoot_flights", "cmi_gpu_download_exports",
-    "cmi_gpu_shoot_flights_host",
+    "cmi_gpu_shoot_flights_host", "cmi_gpu_physics_probe",
 ]
 
 _lib = None
@@ -160,6 +160,7 @@ def load_library():
                                              C.POINTER(C.c_int64)]
     L.cmi_gpu_thermal_probe.argtypes = [vp, C.c_int64, C.c_int32, _dp, _dp,
                                         _dp, _dp, _dp, _dp, _dp]
+    L.cmi_gpu_physics_probe.argtypes = [vp, C.c_int32, C.c_int64, _dp, _dp]
     _lib = L
     return L
 
@@ -415,6 +416,19 @@ class GpuEngine:
             self._h, n, int(solve), _p(J), _p(heating), _p(T), _p(dens),
             _p(x), _p(Tout), _p(pair)))
         return x, Tout, pair
+
+    def physics_probe(self, kind, rows):
+        """Atomic-data functions on the device for the given input rows; kind
+        0 cross sections (nu), 1 recombination rates (T), 2 line cooling
+        ({T, n_e, 13 abundances}), 3 re-emission probabilities (T), 4 charge
+        transfer rates (T4)."""
+        width_in = (1, 1, 15, 1, 1)[kind]
+        width_out = (14, 14, 1, 5, 42)[kind]
+        rows = _f64(rows).reshape(-1, width_in)
+        out = np.zeros((rows.shape[0], width_out))
+        self._check(self._lib.cmi_gpu_physics_probe(
+            self._h, kind, rows.shape[0], _p(rows), _p(out)))
+        return out
 
     def get_timing(self, reset=True):
         s = C.c_double()

@@ -380,6 +380,27 @@ int cmi_gpu_thermal_probe(cmi_gpu_engine *engine, int64_t n, int32_t solve,
                           const double *number_density, double *out_fractions,
                           double *out_temperature, double *out_pair);
 
+/* Parity probe of the atomic-data functions for n input rows (host arrays),
+ * so that the reference's own fixtures can be checked on the device:
+ *  kind 0: in [n] frequency (Hz) -> out [n][14] CrossSections::
+ *          get_cross_section (src/VernerCrossSections.cpp:259-322 or
+ *          src/FixedValueCrossSections.hpp:151-154), m^2;
+ *  kind 1: in [n] T (K) -> out [n][14] RecombinationRates::
+ *          get_recombination_rate (src/VernerRecombinationRates.cpp:140-333),
+ *          m^3 s^-1;
+ *  kind 2: in [n][15] {T, n_e (m^-3), 13 abundances in the order of
+ *          src/LineCoolingData.hpp:38-80} -> out [n] LineCoolingData::
+ *          get_cooling (src/LineCoolingData.cpp:1767-1847);
+ *  kind 3: in [n] T -> out [n][5] PhysicalDiffuseReemissionHandler::
+ *          set_reemission_probabilities
+ *          (src/PhysicalDiffuseReemissionHandler.hpp:66-105);
+ *  kind 4: in [n] T / 1e4 K -> out [n][14][3] charge transfer: recombination
+ *          with H, ionization by H+, recombination with He
+ *          (src/ChargeTransferRates.cpp:44-157, :169-250, :262-395).
+ * Synchronous. */
+int cmi_gpu_physics_probe(cmi_gpu_engine *engine, int32_t kind, int64_t n,
+                          const double *in, double *out);
+
 /* Device time (HIP events on the engine's stream) spent in cmi_gpu_shoot
  * (packet ordering + every transport launch of a batch; shoot_launches counts
  * batches) and in the cell-update kernels since the last call with

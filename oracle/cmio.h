@@ -189,6 +189,18 @@ double cmio_he2pc_integral(void);
  * p[1..4] = cumulative He channel probabilities */
 void cmio_reemission_probabilities(double temperature, double p[5]);
 
+/* PhysicalDiffuseReemissionHandler::reemit
+ * (src/PhysicalDiffuseReemissionHandler.cpp:219-370) with the uniform random
+ * numbers GIVEN by the caller instead of drawn from the packet stream: draw d
+ * of the call is uniforms[d]. sigma_H / sigma_He are the packet's cross
+ * sections. Returns the new frequency (0 = absorbed for good); *type receives
+ * the photon type, *draws the number of uniforms consumed. For tests that
+ * walk every branch of the handler. */
+double cmio_reemit_scripted(const cmio_model *model, double sigma_H,
+                            double sigma_He, double AHe, double T, double xH,
+                            double xHe, const double *uniforms,
+                            int32_t *type, uint32_t *draws);
+
 /* A photon packet: src/Photon.hpp:36-69 */
 typedef struct {
   double position[3];

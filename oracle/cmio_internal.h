@@ -12,9 +12,15 @@ typedef struct {
   uint32_t iteration;
   uint64_t packet;
   uint32_t draw;
+  /* tests only (cmio_reemit_scripted): when set, draw d returns script[d]
+   * instead of the Philox stream, so that a test can steer a function
+   * through a chosen branch */
+  const double *script;
 } cmio_rng;
 
 static inline double cmio_rng_next(cmio_rng *rng) {
+  if (rng->script)
+    return rng->script[rng->draw++];
   return cmio_rng_uniform(rng->seed, rng->iteration, rng->packet,
                           rng->draw++);
 }

@@ -191,7 +191,7 @@ void cmio_sample_spectrum(const cmio_model *model, int kind,
                           double *out) {
   const cmio_tables *t = model->tables;
   for (uint64_t i = 0; i < n; ++i) {
-    cmio_rng rng = {seed, 0u, i, 0u};
+    cmio_rng rng = {seed, 0u, i, 0u, NULL};
     switch (kind) {
     case 0:
       out[i] = sample_planck(t, &rng);
@@ -308,4 +308,21 @@ double cmio_reemit_frequency(const cmio_model *model, const cmio_photon *photon,
     }
   }
   return new_frequency;
+}
+
+double cmio_reemit_scripted(const cmio_model *model, double sigma_H,
+                            double sigma_He, double AHe, double T, double xH,
+                            double xHe, const double *uniforms,
+                            int32_t *type, uint32_t *draws) {
+  cmio_photon photon;
+  for (int ion = 0; ion < CMIO_NION; ++ion)
+    photon.cross_section[ion] = 0.;
+  photon.cross_section[CMIO_ION_H_n] = sigma_H;
+  photon.cross_section[CMIO_ION_He_n] = sigma_He;
+  cmio_rng rng = {0u, 0u, 0u, 0u, uniforms};
+  const double nu =
+      cmio_reemit_frequency(model, &photon, AHe, T, xH, xHe, &rng, type);
+  if (draws)
+    *draws = rng.draw;
+  return nu;
 }

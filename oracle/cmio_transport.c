@@ -72,7 +72,7 @@ static void random_photon(const cmio_model *model, cmio_rng *rng,
 void cmio_emit(const cmio_model *model, uint32_t seed, uint32_t iteration,
                uint64_t packet, cmio_photon *photon, double *tau,
                uint32_t *draws) {
-  cmio_rng rng = {seed, iteration, packet, 0};
+  cmio_rng rng = {seed, iteration, packet, 0, NULL};
   random_photon(model, &rng, photon);
   *tau = -log(cmio_rng_next(&rng));
   if (draws)
@@ -263,7 +263,7 @@ void cmio_shoot(const cmio_grid *grid, const cmio_model *model,
   double tc0 = 0., tc1 = 0., tc2 = 0., tc3 = 0.;
 #pragma omp parallel for schedule(dynamic, 1024) reduction(+ : tw, tc0, tc1, tc2, tc3)
   for (uint64_t i = 0; i < n_packets; ++i) {
-    cmio_rng rng = {seed, iteration, first_packet + i, 0};
+    cmio_rng rng = {seed, iteration, first_packet + i, 0, NULL};
     cmio_photon photon;
     random_photon(model, &rng, &photon);
     double tau = -log(cmio_rng_next(&rng));

@@ -249,3 +249,152 @@ def test_decomposed_grid_with_sources_in_different_blocks():
     whole.close()
     for b in backends:
         b.engine.close()
+
+
+# ---------------------------------------------------------------------------
+# the decomposed path against the ORACLE (not against the engine's own
+# undivided run): the semantics of the reference's block decomposition
+# (DensitySubGridCreator + the photon-buffer traffic between DensitySubGrids,
+# src/DensitySubGrid.hpp:1137-1274, src/PhotonTraversalTaskContext.hpp:100-278)
+# are "the same packets deposit the same path lengths in the same cells as on
+# the undivided grid", which is what the oracle computes.
+# ---------------------------------------------------------------------------
+
+def decomposed_backends(model, ncell, blocks, npacket, sim=None):
+    from cmacionize_amd import STROMGREN as S
+    from cmacionize_amd.simulation import (DomainDecomposition,
+                                           DomainGpuBackend,
+                                           LocalDomainDriver)
+    heat = model == "lexington"
+    dec = DomainDecomposition((ncell,) * 3, blocks)
+    dens = temp = None
+    if model == "lexington":
+        dens = np.asarray(sim.number_density).reshape((ncell,) * 3)
+        temp = np.asarray(sim.temperature).reshape((ncell,) * 3)
+    backends = []
+    for rank in range(dec.world):
+        b = DomainGpuBackend(dec, rank, S["anchor"], S["sides"], device=0,
+                             track_heating=True if heat else False,
+                             export_capacity=npacket)
+        off, size = dec.block(rank)
+        sl = tuple(slice(off[a], off[a] + size[a]) for a in range(3))
+        configure(b.engine, model, int(np.prod(size)),
+                  None if dens is None else dens[sl].ravel(),
+                  None if temp is None else temp[sl].ravel())
+        backends.append(b)
+    return dec, backends, LocalDomainDriver(backends, dec)
+
+
+def upload_state(dec, backends, sim, ncell):
+    """the oracle's cell state into every block"""
+    shape = (ncell,) * 3
+    dens = np.asarray(sim.number_density).reshape(shape)
+    temp = np.asarray(sim.temperature).reshape(shape)
+    xs = [np.asarray(x).reshape(shape) for x in sim.x]
+    for rank, b in enumerate(backends):
+        off, size = dec.block(rank)
+        sl = tuple(slice(off[a], off[a] + size[a]) for a in range(3))
+        b.engine.upload_cells(dens[sl].ravel(), temp[sl].ravel(),
+                              np.array([x[sl].ravel() for x in xs]))
+
+
+@pytest.mark.parametrize("blocks", [(2, 2, 2), (3, 2, 1)])
+def test_decomposed_diffuse_matches_oracle(oracle, blocks):
+    """stromgren_diffuse.param on 24^3 in blocks, LocalDomainDriver, against
+    the oracle on the same seeds: identical packet counters, J_H at 1e-9, and
+    the bit-exact closed-form cell update per block."""
+    from cmacionize_amd import engine as E
+    ncell, npacket = 24, 50000
+    sim = oracle.stromgren_simulation(ncell, diffuse=True)
+    dec, backends, driver = decomposed_backends("diffuse", ncell, blocks,
+                                                npacket)
+    for b in backends:
+        b.engine.set_tuning(reemit_inline_below=64)
+    for loop in range(3):
+        driver.iteration(loop, npacket, 42, update=False)
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(42, loop, 0, npacket)
+        assert driver.totweight == sim.totweight == npacket
+        assert np.array_equal(driver.typecount, sim.typecount)
+        assert driver.typecount[1] > 0
+        J = assemble(dec, backends, E.FIELD_MEAN_INTENSITY)
+        assert np.allclose(J, sim.J[0], rtol=1e-9, atol=1e-12 * sim.J[0].max())
+        # the cell update, block by block, from the oracle's integrals
+        Jo = np.asarray(sim.J[0]).reshape((ncell,) * 3)
+        for rank, b in enumerate(backends):
+            off, size = dec.block(rank)
+            sl = tuple(slice(off[a], off[a] + size[a]) for a in range(3))
+            b.engine.upload_field(E.FIELD_MEAN_INTENSITY, Jo[sl].ravel())
+            b.update_cells(loop, driver.totweight)
+        sim.update(loop, sim.totweight)
+        x = assemble(dec, backends, E.FIELD_IONIC_FRACTION)
+        assert np.array_equal(x, sim.x[0])
+    assert (x < 0.5).any() and (x > 0.5).any()
+    for b in backends:
+        b.engine.close()
+
+
+def test_decomposed_lexington_matches_oracle(oracle):
+    """Config 5's physics and decomposition at test size: lexingtonHII40 on
+    24^3 as 2 x 2 x 2 blocks through LocalDomainDriver against the ORACLE:
+    packet counters, all 14 mean intensities and both heating terms at 1e-6
+    (the tolerance of the undivided multi-ion test: device pow/log10 ulps),
+    then the cell update (ionization balance, temperature solve from loop 4)
+    of every block from the oracle's integrals."""
+    from cmacionize_amd import engine as E
+    ncell, npacket = 24, 40000
+    sim = oracle.lexington_simulation(ncell)
+    dec, backends, driver = decomposed_backends("lexington", ncell, (2, 2, 2),
+                                                npacket, sim)
+    upload_state(dec, backends, sim, ncell)
+    shape = (ncell,) * 3
+    exchanged = 0
+    for loop in range(6):
+        driver.iteration(loop, npacket, 42, update=False)
+        exchanged += driver.flights_exchanged
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(42, loop, 0, npacket)
+        assert driver.totweight == sim.totweight == npacket
+        # (a frequency within an ulp of a threshold may fall on the other
+        # side on the device - as in the undivided test)
+        assert np.abs(driver.typecount - sim.typecount).max() <= 3
+        for ion in range(14):
+            J = assemble(dec, backends, E.FIELD_MEAN_INTENSITY + ion)
+            ref = np.asarray(sim.J[ion])
+            assert np.allclose(J, ref, rtol=1e-6, atol=1e-6 * ref.max()), ion
+            assert abs(J.sum() - ref.sum()) <= 1e-6 * ref.sum()
+        for k in range(2):
+            h = assemble(dec, backends, E.FIELD_HEATING + k)
+            ref = sim.heating[k]
+            assert np.allclose(h, ref, rtol=1e-6,
+                               atol=1e-6 * np.abs(ref).max())
+        for rank, b in enumerate(backends):
+            off, size = dec.block(rank)
+            sl = tuple(slice(off[a], off[a] + size[a]) for a in range(3))
+            for ion in range(14):
+                b.engine.upload_field(
+                    E.FIELD_MEAN_INTENSITY + ion,
+                    np.asarray(sim.J[ion]).reshape(shape)[sl].ravel())
+            for k in range(2):
+                b.engine.upload_field(
+                    E.FIELD_HEATING + k,
+                    np.asarray(sim.heating[k]).reshape(shape)[sl].ravel())
+            b.update_cells(loop, driver.totweight)
+        sim.update(loop, sim.totweight)
+        T = assemble(dec, backends, E.FIELD_TEMPERATURE)
+        assert np.allclose(T, sim.temperature, rtol=1e-6, atol=0.), loop
+        for ion in range(14):
+            x = assemble(dec, backends, E.FIELD_IONIC_FRACTION + ion)
+            ref = np.asarray(sim.x[ion])
+            ok = np.isclose(x, ref, rtol=1e-5, atol=1e-300) | \
+                (np.isnan(x) & np.isnan(ref))
+            assert ok.all(), (loop, ion)
+        upload_state(dec, backends, sim, ncell)
+    assert exchanged > 0  # re-emitted flights did cross block faces
+    assert sim.temperature.max() > 6000. and sim.temperature.min() == 500.
+    for b in backends:
+        b.engine.close()

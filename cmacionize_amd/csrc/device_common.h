@@ -71,6 +71,34 @@ struct ExchangeDev {
   unsigned int capacity;
 };
 
+/* Tile rounds (incoherent flights: re-emitted packets, flights handed over):
+ * the engine's grid is cut into tiles of T^3 cells (T = 2^log2_side), a
+ * flight is marched one tile at a time by a workgroup that keeps the tile's
+ * accumulators in LDS; between rounds the flights wait as rows of
+ * CMI_FLIGHT_DOUBLES doubles (the marcher's state, as in a hand-over between
+ * blocks) with these differences:
+ *  [12] (int64) long index of the cell being entered in THIS engine's grid
+ *  [14] (int64) the cell's coordinates inside its tile, packed x | y<<8 | z<<16
+ * plus, for multi-ion transport, the packet's 16 accumulation weights in a
+ * second array (weights[row][16]) so that no cross section is evaluated
+ * twice. keys[row] is the tile of the entered cell (sorted between rounds). */
+struct TileGridDev {
+  int32_t log2_side; /* tile side = 1 << log2_side cells */
+  int32_t ntile[3];  /* tiles per axis (the last one may be clipped) */
+  int32_t ntiles;
+};
+struct FlightRowsDev {
+  double *rows;     /* [capacity][CMI_FLIGHT_DOUBLES] */
+  double *weights;  /* [capacity][CMI_NACC], multi-ion transport only */
+  uint32_t *keys;   /* [capacity] tile of the cell being entered */
+  unsigned int *count;
+  unsigned int capacity;
+};
+/* one unit of work of the tile kernel: flights order[begin, end) of a tile */
+struct TileItemDev {
+  uint32_t tile, begin, end, pad;
+};
+
 /* one (ion, shell) term of the Verner cross section, converted as in
  * src/VernerCrossSections.cpp:36-154 */
 struct VernerTermDev {

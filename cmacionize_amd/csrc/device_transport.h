@@ -50,6 +50,10 @@ template <bool FULL> struct Packet {
   int32_t cstep[3]; /* change of the long index when the axis advances */
   int32_t rem[3];   /* cells left before the box face in the travel direction;
                      * negative = the packet has left through that face */
+  /* tile rounds: coordinates of the current cell inside its tile, and their
+   * change (+1 / -1) when the axis advances */
+  int32_t lc[3];
+  int32_t lsgn[3];
   /* EXACT marcher */
   int32_t index[3];
   int32_t type;
@@ -305,7 +309,7 @@ fast_load_record(const double2 *__restrict__ opacity, const Packet<FULL> &p) {
 
 /* `kappa` is the transport record of p.cell, loaded by the caller
  * (fast_load_record) - early, so that the load overlaps other work. */
-template <bool FULL>
+template <bool FULL, bool TILE = false>
 __device__ __forceinline__ double fast_step(Packet<FULL> &p, int32_t &cell,
                                             const double2 kappa) {
   cell = p.cell;
@@ -326,6 +330,8 @@ __device__ __forceinline__ double fast_step(Packet<FULL> &p, int32_t &cell,
     p.tmax[a] = __fma_rn(hit ? 1. : 0., p.tdelta[a], p.tmax[a]);
     p.cell += hit ? p.cstep[a] : 0;
     p.rem[a] -= hit ? 1 : 0;
+    if (TILE)
+      p.lc[a] += hit ? p.lsgn[a] : 0;
   }
   if (p.tau < 0.) {
     ds += ds * p.tau / tau_cell; /* Scorr */
@@ -375,6 +381,28 @@ __device__ __forceinline__ void resume_flight(const GridDev &g, Packet<FULL> &p,
   if (!inside)
     p.rem[0] = -1;
   p.cell = (p.index[0] * g.ncell[1] + p.index[1]) * g.ncell[2] + p.index[2];
+}
+
+/* FAST: the same for a flight that waited inside this engine (tile rounds):
+ * `cell` is the long index in THIS engine's grid */
+template <bool FULL>
+__device__ __forceinline__ void resume_flight_local(const GridDev &g,
+                                                    Packet<FULL> &p,
+                                                    int32_t cell) {
+  const int32_t iz = cell % g.ncell[2];
+  const int32_t iy = (cell / g.ncell[2]) % g.ncell[1];
+  const int32_t ix = cell / (g.ncell[2] * g.ncell[1]);
+  p.index[0] = ix;
+  p.index[1] = iy;
+  p.index[2] = iz;
+  const int32_t stride[3] = {g.ncell[1] * g.ncell[2], g.ncell[2], 1};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    p.tdelta[a] = (p.dir[a] != 0.) ? g.cellside[a] * fabs(p.inv_dir[a]) : 0.;
+    p.cstep[a] = (p.dir[a] > 0.) ? stride[a] : -stride[a];
+    p.rem[a] = (p.dir[a] > 0.) ? g.ncell[a] - 1 - p.index[a] : p.index[a];
+  }
+  p.cell = cell;
 }
 
 /* FAST, decomposed grids: the packet has stepped out of this block from

@@ -95,6 +95,15 @@ struct cmi_gpu_engine {
   double *import_rows = nullptr; /* staging for flights given in host memory */
   uint64_t import_capacity = 0;
   unsigned int *queue_counts = nullptr; /* [2]: ended, ready */
+  /* tile rounds: two sets of flight rows (in / out of a round), the plan */
+  char *tile_block = nullptr;
+  uint64_t tile_capacity = 0;
+  bool tile_has_weights = false;
+  FlightRowsDev tile_rows[2];
+  uint32_t *tile_iota = nullptr;
+  TileItemDev *tile_items = nullptr;
+  unsigned int *tile_counts = nullptr; /* [4]: rows A, rows B, nitems, next */
+  uint64_t tile_rounds_run = 0;
 
   struct Tuning {
     bool sort_packets = true;
@@ -111,6 +120,13 @@ struct cmi_gpu_engine {
     int refill_threshold_reemit = 32;
     uint64_t reemit_inline_below = 4096;
     int reemit_max_passes = 12;
+    /* later generations in tile rounds (tile_kernels.h) instead of passes of
+     * the transport kernel; below tile_min_flights flights the transport
+     * kernel finishes them with single atomics */
+    bool tile_rounds = true;
+    uint64_t tile_min_flights = 100000;
+    int tile_refill_threshold = 16;
+    int tile_max_rounds = 1000;
   } tune;
 
   std::vector<EventPair> shoot_events, update_events, kernel_events;
@@ -638,6 +654,8 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   if (e->own_export_rows)
     (void)hipFree(e->export_rows);
   (void)hipFree(e->import_rows);
+  (void)hipFree(e->tile_block);
+  (void)hipFree(e->tile_counts);
   if (e->own_stream)
     (void)hipStreamDestroy(e->stream);
   delete e;
@@ -940,6 +958,15 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
     e->tune.reemit_inline_below = (uint64_t)(value < 0 ? 0 : value);
   else if (k == "reemit_max_passes")
     e->tune.reemit_max_passes = (int)(value < 1 ? 1 : value);
+  else if (k == "tile_rounds")
+    e->tune.tile_rounds = value != 0;
+  else if (k == "tile_min_flights")
+    e->tune.tile_min_flights = (uint64_t)(value < 0 ? 0 : value);
+  else if (k == "tile_refill_threshold")
+    e->tune.tile_refill_threshold =
+        (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
+  else if (k == "tile_max_rounds")
+    e->tune.tile_max_rounds = (int)(value < 0 ? 0 : value);
   else
     return fail(CMI_GPU_EINVAL, "set_tuning: unknown key '%s'", key);
   return CMI_GPU_OK;
@@ -1011,6 +1038,70 @@ static int reserve_queues(cmi_gpu_engine *e, uint64_t n) {
   r.meta = r.id + n;
   r.count = e->queue_counts + 1;
   e->queue_capacity = n;
+  return CMI_GPU_OK;
+}
+
+__global__ void iota_kernel(uint32_t *out, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride)
+    out[i] = (uint32_t)i;
+}
+
+/* tiles of the engine's grid for the current transport flavour */
+static TileGridDev tile_grid(const cmi_gpu_engine *e) {
+  TileGridDev t;
+  t.log2_side = e->full_ions ? CMI_TILE_LOG2_FULL : CMI_TILE_LOG2_H;
+  const int side = 1 << t.log2_side;
+  int64_t total = 1;
+  for (int a = 0; a < 3; ++a) {
+    t.ntile[a] = (e->grid.ncell[a] + side - 1) / side;
+    total *= t.ntile[a];
+  }
+  t.ntiles = (int32_t)total;
+  return t;
+}
+
+/* make sure the flight rows of the tile rounds hold n flights each */
+static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
+  const bool weights = e->full_ions;
+  if (e->tile_capacity >= n && (e->tile_has_weights || !weights))
+    return CMI_GPU_OK;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(e->tile_block);
+  e->tile_block = nullptr;
+  e->tile_capacity = 0;
+  const TileGridDev t = tile_grid(e);
+  const size_t row_bytes = sizeof(double) * CMI_FLIGHT_DOUBLES * n;
+  const size_t weight_bytes = weights ? sizeof(double) * CMI_NACC * n : 0;
+  const size_t key_bytes = (sizeof(uint32_t) * n + 255) & ~(size_t)255;
+  const size_t nitems = (size_t)t.ntiles + n / CMI_TILE_ITEM_FLIGHTS + 2;
+  const size_t item_bytes = sizeof(TileItemDev) * nitems;
+  const size_t total =
+      2 * (row_bytes + weight_bytes + key_bytes) + key_bytes + item_bytes;
+  HIP_TRY(hipMalloc(&e->tile_block, total));
+  if (!e->tile_counts)
+    HIP_TRY(hipMalloc(&e->tile_counts, 4 * sizeof(unsigned int)));
+  char *at = e->tile_block;
+  for (int k = 0; k < 2; ++k) {
+    FlightRowsDev &r = e->tile_rows[k];
+    r.rows = (double *)at;
+    at += row_bytes;
+    r.weights = weights ? (double *)at : nullptr;
+    at += weight_bytes;
+    r.keys = (uint32_t *)at;
+    at += key_bytes;
+    r.count = e->tile_counts + k;
+    r.capacity = (unsigned int)n;
+  }
+  e->tile_iota = (uint32_t *)at;
+  at += key_bytes;
+  e->tile_items = (TileItemDev *)at;
+  iota_kernel<<<grid_blocks(e, (int64_t)n, 8), CMI_BLOCK, 0, e->stream>>>(
+      e->tile_iota, n);
+  HIP_TRY(hipGetLastError());
+  e->tile_capacity = n;
+  e->tile_has_weights = weights;
   return CMI_GPU_OK;
 }
 
@@ -1112,6 +1203,30 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     if (rc)
       return rc;
   }
+  /* later generations in tile rounds: needs the incremental marcher */
+  const bool tiles = passes && e->tune.tile_rounds && !exact;
+  void (*tkernel)(const TileArgs) = nullptr;
+  int tile_threads = 0, tile_blocks_per_cu = 0;
+  if (tiles) {
+    const uint64_t cap = n_packets < max_launch ? n_packets : max_launch;
+    int rc = reserve_tile_buffers(e, cap);
+    if (rc)
+      return rc;
+    rc = reserve_sort_buffers(e, cap);
+    if (rc)
+      return rc;
+    if (e->full_ions) {
+      tkernel = heat ? tile_kernel<true, true> : tile_kernel<true, false>;
+      tile_threads = CMI_TILE_THREADS_FULL;
+    } else {
+      tkernel = heat ? tile_kernel<false, true> : tile_kernel<false, false>;
+      tile_threads = CMI_TILE_THREADS_H;
+    }
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &tile_blocks_per_cu, tkernel, tile_threads, 0));
+    if (tile_blocks_per_cu < 1)
+      tile_blocks_per_cu = 1;
+  }
   QueueDev no_queue;
   memset(&no_queue, 0, sizeof no_queue);
   /* sort key: 22 direction bits, the tau class and the source index. The
@@ -1158,6 +1273,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     a.n_packets = n;
     a.order = nullptr;
     a.xin = flights ? flights + (size_t)CMI_FLIGHT_DOUBLES * done : nullptr;
+    a.xin_local = 0;
     a.xout.rows = e->export_rows;
     a.xout.count = e->export_count;
     a.xout.capacity = (unsigned int)e->export_capacity;
@@ -1230,11 +1346,179 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     HIP_TRY(hipEventRecord(kev.stop, e->stream));
     kev.packets = n;
     e->kernel_events.push_back(kev);
-    /* later generations: the interaction kernel turns the ended flights of
-     * one transport launch into the ready flights of the next. Those start
-     * all over the grid in random directions, so these launches refill
-     * eagerly instead of keeping ray bundles together. */
-    for (int gen = 0; passes; ++gen) {
+    /* later generations, in tile rounds (tile_kernels.h): the interaction
+     * kernel turns the ended flights into flight rows keyed by the tile they
+     * start in; every round sorts the rows by tile, flies each flight through
+     * ONE tile with the tile's accumulators in LDS, and collects the flights
+     * that go on (into another tile, or re-emitted) for the next round */
+    if (tiles) {
+      const TileGridDev tg = tile_grid(e);
+      int tile_bits = 1; /* keys: tiles and the "free slot" key ntiles */
+      while ((1ll << tile_bits) < (int64_t)tg.ntiles + 1)
+        ++tile_bits;
+      InteractArgs ia;
+      ia.model = e->model;
+      ia.cells = e->cells;
+      ia.counters = e->counters;
+      ia.first_packet = a.first_packet;
+      ia.seed = seed;
+      ia.iteration = iteration;
+      ia.qin = e->ended_queue;
+      ia.qout = no_queue;
+      ia.grid = e->grid;
+      ia.tiles = tg;
+      ia.nslots = 0;
+      unsigned int *const d_nrows = e->tile_counts;
+      unsigned int *const d_nlive = e->tile_counts + 1;
+      unsigned int *const d_nitems = e->tile_counts + 2;
+      unsigned int *const d_next = e->tile_counts + 3;
+      int cur = 0;
+      HIP_TRY(hipMemsetAsync(e->tile_counts, 0, 4 * sizeof(unsigned int),
+                             e->stream));
+      /* the absorbed packets of the first generation -> flights in slots */
+      ia.rows = e->tile_rows[cur];
+      ia.rows.count = d_nrows;
+      {
+        const int iblocks = e->num_cu * 8;
+        if (e->full_ions)
+          interaction_kernel<true, true>
+              <<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);
+        else
+          interaction_kernel<false, true>
+              <<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);
+        HIP_TRY(hipGetLastError());
+      }
+      unsigned int nslots = 0;
+      HIP_TRY(hipMemcpyAsync(&nslots, d_nrows, sizeof(unsigned int),
+                             hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipStreamSynchronize(e->stream));
+      if (nslots > e->tile_rows[cur].capacity)
+        return fail(CMI_GPU_ENOMEM,
+                    "tile rounds: %u flights, room for %u - flights were "
+                    "lost, the iteration is invalid",
+                    nslots, e->tile_rows[cur].capacity);
+      for (int round = 0; nslots != 0; ++round) {
+        /* sort the slots by tile (free slots last), cut the flights into
+         * units of work */
+        HIP_TRY(cmi_sort_pairs(e->sort_temp, e->sort_temp_bytes,
+                               e->tile_rows[cur].keys, e->sort_keys[1],
+                               e->tile_iota, e->sort_ids[1], nslots, tile_bits,
+                               e->stream));
+        TilePlanArgs pa;
+        pa.tiles = tg;
+        pa.sorted_keys = e->sort_keys[1];
+        pa.nslots = nslots;
+        pa.items = e->tile_items;
+        pa.nitems = d_nitems;
+        pa.next_item = d_next;
+        pa.nlive = d_nlive;
+        tile_plan_kernel<<<1, CMI_TILE_PLAN_THREADS, 0, e->stream>>>(pa);
+        HIP_TRY(hipGetLastError());
+        unsigned int nlive = 0;
+        HIP_TRY(hipMemcpyAsync(&nlive, d_nlive, sizeof(unsigned int),
+                               hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (nlive == 0)
+          break;
+        const bool finish = nlive < e->tune.tile_min_flights ||
+                            round >= e->tune.tile_max_rounds;
+        const uint32_t *order = e->sort_ids[1];
+        if (finish || 2ull * nlive < nslots) {
+          /* squeeze the free slots out (and put the flights in tile order) */
+          TileCompactArgs ca;
+          ca.from = e->tile_rows[cur];
+          ca.to = e->tile_rows[1 - cur];
+          ca.order = e->sort_ids[1];
+          ca.sorted_keys = e->sort_keys[1];
+          ca.nlive = d_nlive;
+          ca.with_weights = e->full_ions ? 1 : 0;
+          tile_compact_kernel<<<grid_blocks(e, 8ll * nlive, 8), CMI_BLOCK, 0,
+                                e->stream>>>(ca);
+          HIP_TRY(hipGetLastError());
+          cur = 1 - cur;
+          nslots = nlive;
+          order = nullptr;
+        }
+        if (finish) {
+          /* few flights left: the transport kernel follows them and their
+           * re-emissions to the end, with single atomics */
+          ShootArgs b = a;
+          b.order = nullptr;
+          b.xin = e->tile_rows[cur].rows;
+          b.xin_local = 1;
+          b.n_packets = nlive;
+          b.refill_threshold = e->tune.refill_threshold_reemit;
+          b.aggregate = agg_reemit;
+          b.qin = no_queue;
+          b.qout = no_queue;
+          const uint64_t nch = ((uint64_t)nlive + b.chunk - 1) / b.chunk;
+          int64_t nb = (int64_t)e->num_cu * blocks_per_cu_inline;
+          const int64_t nneed =
+              (int64_t)((nch + (CMI_BLOCK / 64) - 1) / (CMI_BLOCK / 64));
+          if (nb > nneed)
+            nb = nneed;
+          if (nb < 1)
+            nb = 1;
+          EventPair gev;
+          HIP_TRY(hipEventCreate(&gev.start));
+          HIP_TRY(hipEventCreate(&gev.stop));
+          HIP_TRY(hipEventRecord(gev.start, e->stream));
+          kernel_inline<<<(unsigned)nb, CMI_BLOCK, 0, e->stream>>>(b);
+          HIP_TRY(hipGetLastError());
+          HIP_TRY(hipEventRecord(gev.stop, e->stream));
+          gev.packets = nlive;
+          e->kernel_events.push_back(gev);
+          break;
+        }
+        TileArgs ta;
+        ta.grid = e->grid;
+        ta.model = e->model;
+        ta.cells = e->cells;
+        ta.counters = e->counters;
+        ta.tiles = tg;
+        ta.refill_threshold = e->tune.tile_refill_threshold;
+        ta.rows = e->tile_rows[cur];
+        ta.order = order;
+        ta.items = e->tile_items;
+        ta.nitems = d_nitems;
+        ta.next_item = d_next;
+        ta.xout = a.xout;
+        /* no more workgroups than units of work can exist */
+        int64_t tb = (int64_t)e->num_cu * tile_blocks_per_cu;
+        const int64_t most =
+            (int64_t)tg.ntiles + (int64_t)nlive / CMI_TILE_ITEM_FLIGHTS + 1;
+        if (tb > most)
+          tb = most;
+        EventPair tev;
+        HIP_TRY(hipEventCreate(&tev.start));
+        HIP_TRY(hipEventCreate(&tev.stop));
+        HIP_TRY(hipEventRecord(tev.start, e->stream));
+        tkernel<<<(unsigned)tb, tile_threads, 0, e->stream>>>(ta);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(tev.stop, e->stream));
+        tev.packets = nlive;
+        e->kernel_events.push_back(tev);
+        ++e->tile_rounds_run;
+        /* the packets absorbed in this round: re-emitted into their slots */
+        ia.rows = e->tile_rows[cur];
+        ia.nslots = nslots;
+        const int sblocks = grid_blocks(
+            e, ((int64_t)nslots + CMI_SLOTS_CHUNK - 1) / CMI_SLOTS_CHUNK *
+                   CMI_BLOCK, 8);
+        if (e->full_ions)
+          interaction_slots_kernel<true>
+              <<<sblocks, CMI_BLOCK, 0, e->stream>>>(ia);
+        else
+          interaction_slots_kernel<false>
+              <<<sblocks, CMI_BLOCK, 0, e->stream>>>(ia);
+        HIP_TRY(hipGetLastError());
+      }
+    }
+    /* ... or as passes of the transport kernel: the interaction kernel turns
+     * the ended flights of one launch into the ready flights of the next.
+     * Those start all over the grid in random directions, so these launches
+     * refill eagerly instead of keeping ray bundles together. */
+    for (int gen = 0; passes && !tiles; ++gen) {
       InteractArgs ia;
       ia.model = e->model;
       ia.cells = e->cells;
@@ -1247,10 +1531,16 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       HIP_TRY(hipMemsetAsync(e->ready_queue.count, 0, sizeof(unsigned int),
                              e->stream));
       const int iblocks = e->num_cu * 8;
+      memset(&ia.rows, 0, sizeof ia.rows);
+      ia.grid = e->grid;
+      memset(&ia.tiles, 0, sizeof ia.tiles);
+      ia.nslots = 0;
       if (e->full_ions)
-        interaction_kernel<true><<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);
+        interaction_kernel<true, false>
+            <<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);
       else
-        interaction_kernel<false><<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);
+        interaction_kernel<false, false>
+            <<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);
       HIP_TRY(hipGetLastError());
       unsigned int count = 0;
       HIP_TRY(hipMemcpyAsync(&count, e->ready_queue.count,

@@ -9,6 +9,14 @@
 #include "device_thermal.h"
 
 #define CMI_BLOCK 256
+/* the "exp_no_atomics" experiments (results are wrong by design) exist only in
+ * builds with -DCMI_EXPERIMENTS (make variant ...); the product kernels carry
+ * none of their branches */
+#ifdef CMI_EXPERIMENTS
+#define CMI_EXP(a) ((a).exp_no_atomics)
+#else
+#define CMI_EXP(a) 0
+#endif
 /* slots of a block's combining table (aggregate mode 3) */
 #define CMI_TABLE_BITS 10
 #define CMI_TABLE_SLOTS (1 << CMI_TABLE_BITS)
@@ -80,6 +88,9 @@ struct ShootArgs {
    * over by other blocks (CMI_FLIGHT_DOUBLES doubles each); packets that
    * leave this block into another one are appended to xout */
   const double *xin;
+  /* xin rows hold the long index of the entered cell in THIS engine's grid
+   * (flights left over by the tile rounds) instead of the whole grid's */
+  int32_t xin_local;
   ExchangeDev xout;
 };
 
@@ -259,7 +270,7 @@ walk_part(const ShootArgs &a, const double (&wq)[CMI_NACC], int32_t dest,
 #pragma unroll
   for (int r = 0; r < N; ++r) {
     if (d[r] != d[r + 1] && d[r] != -1 && mine &&
-        a.exp_no_atomics != 3) { /* 3 = experiment: walk without the adds */
+        CMI_EXP(a) != 3) { /* 3 = experiment: walk without the adds */
       if (d[r] >= 0) {
         atomicAdd(table_i + d[r] * CMI_NACC, sum[r]); /* ds_add_f64 */
       } else {
@@ -306,7 +317,7 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
     int32_t dest = -1;
     if (accumulate) {
       dest = -(cell + 2);
-      if (a.exp_no_atomics != 4) {
+      if (CMI_EXP(a) != 4) {
         uint32_t s = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_FTABLE_BITS);
         for (int probe = 0; probe < CMI_TABLE_PROBES; ++probe) {
           const int32_t was = atomicCAS(&table_tag[s], -1, cell);
@@ -318,13 +329,13 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
         }
       }
     }
-    if (a.exp_no_atomics == 2 || a.exp_no_atomics >= 4) /* exp.: no walk */
+    if (CMI_EXP(a) == 2 || CMI_EXP(a) >= 4) /* exp.: no walk */
       return;
     table_row<0>(wq, dest, term, table_i);
     table_row<1>(wq, dest, term, table_i);
     table_row<2>(wq, dest, term, table_i);
     table_row<3>(wq, dest, term, table_i);
-    if (a.exp_no_atomics == 6) /* experiment: a quarter of the adds */
+    if (CMI_EXP(a) == 6) /* experiment: a quarter of the adds */
       return;
     table_row<4>(wq, dest, term, table_i);
     table_row<5>(wq, dest, term, table_i);
@@ -369,7 +380,7 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
   int32_t dest = -1;
   if (accumulate)
     dest = head ? -(cell + 2) : CMI_DEST_SAME;
-  if (a.exp_no_atomics == 2 || a.exp_no_atomics >= 4) /* experiment: no walk */
+  if (CMI_EXP(a) == 2 || CMI_EXP(a) >= 4) /* experiment: no walk */
     return;
   int32_t carry = -1; /* destination of the last packet of the part before */
   walk_part<HEAT, 0>(a, wq, dest, term, carry, mine, acc_i, table_i, natomics);
@@ -614,8 +625,12 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
           p.type = (int32_t)(lane_meta >> 28);
           p.weight = 1.;
           set_cross_sections(a.model, p, weights);
-          if (!EXACT)
-            resume_flight(a.grid, p, cell_global);
+          if (!EXACT) {
+            if (a.xin_local)
+              resume_flight_local(a.grid, p, (int32_t)cell_global);
+            else
+              resume_flight(a.grid, p, cell_global);
+          }
         } else if (a.qin.id != nullptr) {
           /* a ready flight: re-emitted by the interaction kernel */
           packet_id = a.qin.id[i];
@@ -759,13 +774,13 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
         fast_wrap(a.grid, p);
       if (!EXACT && stepping && p.tau > 0. && !fast_outside(p))
         kappa_next = fast_load_record(a.cells.opacity, p);
-      if (a.exp_no_atomics == 1)
+      if (CMI_EXP(a) == 1)
         continue;
       if (FULL) {
         accumulate_full<HEAT>(a, wq, accumulate, last_cell, ds * p.weight,
                               natomics, use_table ? lds_tag : nullptr,
                               lds_val);
-        if (use_table && a.exp_no_atomics != 5 &&
+        if (use_table && CMI_EXP(a) != 5 &&
             ++window == CMI_FTABLE_WINDOW) {
           window = 0;
           (void)flush_point(true);
@@ -938,6 +953,8 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
   }
 }
 
+#include "tile_kernels.h"
+
 /*
  * Interaction kernel: PhotonSource::reemit (src/PhotonSource.cpp:272-308) for
  * every ended flight of `qin` - the diffuse re-emission decision of the
@@ -959,20 +976,112 @@ struct InteractArgs {
   uint32_t iteration;
   QueueDev qin;  /* ended flights */
   QueueDev qout; /* ready flights */
+  /* ROWS: the survivors become flight rows of the tile rounds instead - the
+   * new flight is set up here (cell, wall parameters, cross sections) and
+   * waits with the key of the tile it starts in */
+  GridDev grid;
+  TileGridDev tiles;
+  FlightRowsDev rows;
+  unsigned int nslots; /* interaction_slots_kernel: slots to look at */
 };
 
+/* the handler's decision for a packet of frequency nu absorbed in `cell`:
+ * new frequency (0 = absorbed for good) and photon type */
 template <bool FULL>
+__device__ __forceinline__ double
+interaction_decide(const InteractArgs &a, double nu, int32_t cell,
+                   PacketRng &rng, int32_t &type) {
+  type = TYPE_ABSORBED;
+  if (a.model.reemit_type == 2) {
+    /* FixedValueDiffuseReemissionHandler::reemit,
+     * src/FixedValueDiffuseReemissionHandler.hpp:73-86 */
+    if (rng.next() < a.model.reemit_fixed_probability) {
+      type = TYPE_DIFFUSE_HI;
+      return a.model.reemit_fixed_frequency;
+    }
+    return 0.;
+  }
+  double sigma_H, sigma_He;
+  if (FULL) {
+    cmi_cross_sections_H_He(a.model, nu, sigma_H, sigma_He);
+  } else {
+    sigma_H = a.model.xsec_fixed[ION_H_n];
+    sigma_He = a.model.xsec_fixed[ION_He_n];
+  }
+  return physical_reemit(a.model, sigma_H, sigma_He, a.cells.temperature[cell],
+                         a.cells.x[ION_H_n][cell], a.cells.x[ION_He_n][cell],
+                         rng, type);
+}
+
+/* PhotonSource::reemit + IonizationPhotonShootJob::execute
+ * (src/PhotonSource.cpp:296-303, src/IonizationPhotonShootJob.hpp:139-141),
+ * in the order of reemit_launch(): the re-emitted packet as a flight of the
+ * tile rounds, starting at p.pos. Returns false if the start lies outside the
+ * box: the flight ends at once (CartesianDensityGrid::is_inside, :187-227). */
+template <bool FULL>
+__device__ __forceinline__ bool
+interaction_new_flight(const InteractArgs &a, double new_frequency,
+                       int32_t type, PacketRng &rng, Packet<FULL> &p,
+                       double (&weights)[CMI_NACC], uint32_t &plc,
+                       uint32_t &key) {
+  constexpr int L = FULL ? CMI_TILE_LOG2_FULL : CMI_TILE_LOG2_H;
+  p.nu = new_frequency;
+  random_direction(p, rng);
+  set_cross_sections(a.model, p, weights);
+  p.tau = -log(rng.next());
+  p.type = type;
+  start_flight<FULL, false>(a.grid, p);
+  if (fast_outside(p))
+    return false;
+  plc = 0;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax)
+    plc |= (uint32_t)(p.index[ax] & ((1 << L) - 1)) << (8 * ax);
+  key = tile_index(a.tiles, p.index[0] >> L, p.index[1] >> L, p.index[2] >> L);
+  return true;
+}
+
+/* `mine` lanes of the workgroup each want one slot of a queue: ONE atomic on
+ * the queue's counter for the whole workgroup (a counter word takes ~90
+ * returning atomics per microsecond chip-wide; one per wave of 64 entries was
+ * the bound of this kernel at 1e8 entries). Must be called by every thread. */
+__device__ __forceinline__ unsigned int
+block_reserve(bool mine, unsigned int *counter, unsigned int *s_count,
+              unsigned int *s_base) {
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const unsigned long long want = __ballot(mine);
+  if (lane == 0)
+    s_count[wib] = (unsigned int)__popcll(want);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int total = 0;
+    for (int w = 0; w < CMI_BLOCK / 64; ++w)
+      total += s_count[w];
+    *s_base = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  unsigned int q = *s_base;
+  for (int w = 0; w < wib; ++w)
+    q += s_count[w];
+  q += (unsigned int)__popcll(want & ((1ull << lane) - 1ull));
+  __syncthreads(); /* s_count / s_base are reused by the next call */
+  return q;
+}
+
+template <bool FULL, bool ROWS>
 __global__ void __launch_bounds__(CMI_BLOCK)
     interaction_kernel(const InteractArgs a) {
+  __shared__ unsigned int s_count[CMI_BLOCK / 64], s_base;
   const int lane = threadIdx.x & 63;
-  const uint64_t lane_lt = (1ull << lane) - 1ull;
   const uint64_t count = *a.qin.count;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   double tw = 0., tc3 = 0.;
-  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x +
-                       (threadIdx.x & ~63u);
-       base < count; base += stride) {
-    const uint64_t i = base + lane;
+  double tc1 = 0., tc2 = 0.; /* ROWS: re-emitted outside the box (rounding) */
+  /* (the trip count is the same for every thread of a workgroup) */
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < count;
+       base += stride) {
+    const uint64_t i = base + threadIdx.x;
     const bool valid = i < count;
     double new_frequency = 0.;
     int32_t type = TYPE_ABSORBED;
@@ -983,38 +1092,35 @@ __global__ void __launch_bounds__(CMI_BLOCK)
       const uint32_t meta = a.qin.meta[i];
       rng.resume(a.seed, a.iteration, a.first_packet + id, meta & 0xffffffu,
                  (meta >> 24) & 1u);
-      const double nu = a.qin.nu[i];
-      const int32_t cell = a.qin.cell[i];
-      if (a.model.reemit_type == 2) {
-        /* FixedValueDiffuseReemissionHandler::reemit,
-         * src/FixedValueDiffuseReemissionHandler.hpp:73-86 */
-        if (rng.next() < a.model.reemit_fixed_probability) {
-          type = TYPE_DIFFUSE_HI;
-          new_frequency = a.model.reemit_fixed_frequency;
-        }
-      } else {
-        double sigma_H, sigma_He;
-        if (FULL) {
-          cmi_cross_sections_H_He(a.model, nu, sigma_H, sigma_He);
-        } else {
-          sigma_H = a.model.xsec_fixed[ION_H_n];
-          sigma_He = a.model.xsec_fixed[ION_He_n];
-        }
-        new_frequency = physical_reemit(
-            a.model, sigma_H, sigma_He, a.cells.temperature[cell],
-            a.cells.x[ION_H_n][cell], a.cells.x[ION_He_n][cell], rng, type);
-      }
+      new_frequency =
+          interaction_decide<FULL>(a, a.qin.nu[i], a.qin.cell[i], rng, type);
     }
     const bool again = valid && new_frequency != 0.;
-    const unsigned long long going = __ballot(again);
-    if (going != 0ull) {
-      unsigned int q0 = 0;
-      const int first = __ffsll((long long)going) - 1;
-      if (lane == first)
-        q0 = atomicAdd(a.qout.count, (unsigned int)__popcll(going));
-      q0 = __shfl(q0, first, 64);
+    if (ROWS) {
+      bool fly = false;
+      Packet<FULL> p;
+      double weights[CMI_NACC];
+      uint32_t plc = 0, key = 0;
       if (again) {
-        const unsigned int q = q0 + __popcll(going & lane_lt);
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+          p.pos[ax] = a.qin.pos[ax][i];
+        fly = interaction_new_flight<FULL>(a, new_frequency, type, rng, p,
+                                           weights, plc, key);
+        if (!fly) {
+          tw += 1.;
+          tc1 += (type == TYPE_DIFFUSE_HI) ? 1. : 0.;
+          tc2 += (type == TYPE_DIFFUSE_HeI) ? 1. : 0.;
+        }
+      }
+      const unsigned int q = block_reserve(fly, a.rows.count, s_count, &s_base);
+      if (fly && q < a.rows.capacity)
+        write_flight_row<FULL>(
+            a.rows, q, p, plc, key, id,
+            cmi_pack_meta(rng.block, rng.have, (uint32_t)type), weights);
+    } else {
+      const unsigned int q = block_reserve(again, a.qout.count, s_count, &s_base);
+      if (again) {
         Packet<false> p;
         random_direction(p, rng);
         const double tau = -log(rng.next());
@@ -1036,8 +1142,99 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   }
   tw = wave_sum(tw);
   tc3 = wave_sum(tc3);
+  if (ROWS) {
+    tc1 = wave_sum(tc1);
+    tc2 = wave_sum(tc2);
+  }
   if (lane == 0 && tw != 0.) {
     atomic_add_f64(&a.counters->totweight, tw);
+    atomic_add_f64(&a.counters->typecount[3], tc3);
+    if (ROWS && tc1 + tc2 != 0.) {
+      atomic_add_f64(&a.counters->typecount[1], tc1);
+      atomic_add_f64(&a.counters->typecount[2], tc2);
+    }
+  }
+}
+
+/* The same for the tile rounds, in place: every slot whose key says
+ * "absorbed" holds an absorption record (tile_kernel); it becomes the
+ * re-emitted flight, or a free slot. A workgroup looks at
+ * CMI_SLOTS_CHUNK slots at a time, collects the absorbed ones in LDS and
+ * then works through that list with all lanes busy (about one slot in seven
+ * is absorbed per round). */
+#define CMI_SLOTS_CHUNK 2048
+template <bool FULL>
+__global__ void __launch_bounds__(CMI_BLOCK)
+    interaction_slots_kernel(const InteractArgs a) {
+  __shared__ uint32_t s_list[CMI_SLOTS_CHUNK];
+  __shared__ unsigned int s_n;
+  const int lane = threadIdx.x & 63;
+  const uint32_t key_dead = CMI_TILE_KEY_DEAD(a.tiles);
+  const uint32_t key_absorbed = CMI_TILE_KEY_ABSORBED(a.tiles);
+  double tw = 0., tc1 = 0., tc2 = 0., tc3 = 0.;
+  for (uint64_t chunk = (uint64_t)blockIdx.x * CMI_SLOTS_CHUNK;
+       chunk < a.nslots; chunk += (uint64_t)gridDim.x * CMI_SLOTS_CHUNK) {
+    if (threadIdx.x == 0)
+      s_n = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < CMI_SLOTS_CHUNK; k += CMI_BLOCK) {
+      const uint64_t s = chunk + k;
+      if (s < a.nslots && a.rows.keys[s] == key_absorbed)
+        s_list[atomicAdd(&s_n, 1u)] = (uint32_t)s;
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    for (uint32_t k = threadIdx.x; k < n; k += CMI_BLOCK) {
+      const uint32_t slot = s_list[k];
+      double *r = a.rows.rows + (size_t)CMI_FLIGHT_DOUBLES * slot;
+      const double nu = r[11];
+      const int32_t cell = (int32_t)__double_as_longlong(r[12]);
+      const unsigned long long idmeta =
+          (unsigned long long)__double_as_longlong(r[13]);
+      const uint32_t id = (uint32_t)idmeta;
+      const uint32_t meta = (uint32_t)(idmeta >> 32);
+      PacketRng rng;
+      rng.resume(a.seed, a.iteration, a.first_packet + id, meta & 0xffffffu,
+                 (meta >> 24) & 1u);
+      int32_t type;
+      const double new_frequency =
+          interaction_decide<FULL>(a, nu, cell, rng, type);
+      uint32_t key = key_dead;
+      if (new_frequency != 0.) {
+        Packet<FULL> p;
+        double weights[CMI_NACC];
+        uint32_t plc = 0;
+        p.pos[0] = r[0];
+        p.pos[1] = r[1];
+        p.pos[2] = r[2];
+        if (interaction_new_flight<FULL>(a, new_frequency, type, rng, p,
+                                         weights, plc, key)) {
+          write_flight_row<FULL>(
+              a.rows, slot, p, plc, key, id,
+              cmi_pack_meta(rng.block, rng.have, (uint32_t)type), weights);
+        } else {
+          key = key_dead;
+          tw += 1.;
+          tc1 += (type == TYPE_DIFFUSE_HI) ? 1. : 0.;
+          tc2 += (type == TYPE_DIFFUSE_HeI) ? 1. : 0.;
+        }
+      } else {
+        tw += 1.;
+        tc3 += 1.;
+      }
+      if (key == key_dead)
+        a.rows.keys[slot] = key;
+    }
+    __syncthreads();
+  }
+  tw = wave_sum(tw);
+  tc1 = wave_sum(tc1);
+  tc2 = wave_sum(tc2);
+  tc3 = wave_sum(tc3);
+  if (lane == 0 && tw != 0.) {
+    atomic_add_f64(&a.counters->totweight, tw);
+    atomic_add_f64(&a.counters->typecount[1], tc1);
+    atomic_add_f64(&a.counters->typecount[2], tc2);
     atomic_add_f64(&a.counters->typecount[3], tc3);
   }
 }

@@ -298,8 +298,9 @@ def upload_state(dec, backends, sim, ncell):
                               np.array([x[sl].ravel() for x in xs]))
 
 
+@pytest.mark.parametrize("tiles", [0, 1])
 @pytest.mark.parametrize("blocks", [(2, 2, 2), (3, 2, 1)])
-def test_decomposed_diffuse_matches_oracle(oracle, blocks):
+def test_decomposed_diffuse_matches_oracle(oracle, blocks, tiles):
     """stromgren_diffuse.param on 24^3 in blocks, LocalDomainDriver, against
     the oracle on the same seeds: identical packet counters, J_H at 1e-9, and
     the bit-exact closed-form cell update per block."""
@@ -309,7 +310,10 @@ def test_decomposed_diffuse_matches_oracle(oracle, blocks):
     dec, backends, driver = decomposed_backends("diffuse", ncell, blocks,
                                                 npacket)
     for b in backends:
-        b.engine.set_tuning(reemit_inline_below=64)
+        # tiles: the later generations fly in tile rounds inside each block,
+        # flights that leave a block from a tile are handed over
+        b.engine.set_tuning(reemit_inline_below=64, tile_rounds=tiles,
+                            tile_min_flights=0)
     for loop in range(3):
         driver.iteration(loop, npacket, 42, update=False)
         sim.reset()
@@ -336,7 +340,8 @@ def test_decomposed_diffuse_matches_oracle(oracle, blocks):
         b.engine.close()
 
 
-def test_decomposed_lexington_matches_oracle(oracle):
+@pytest.mark.parametrize("tiles", [0, 1])
+def test_decomposed_lexington_matches_oracle(oracle, tiles):
     """Config 5's physics and decomposition at test size: lexingtonHII40 on
     24^3 as 2 x 2 x 2 blocks through LocalDomainDriver against the ORACLE:
     packet counters, all 14 mean intensities and both heating terms at 1e-6
@@ -349,6 +354,8 @@ def test_decomposed_lexington_matches_oracle(oracle):
     dec, backends, driver = decomposed_backends("lexington", ncell, (2, 2, 2),
                                                 npacket, sim)
     upload_state(dec, backends, sim, ncell)
+    for b in backends:
+        b.engine.set_tuning(tile_rounds=tiles, tile_min_flights=0)
     shape = (ncell,) * 3
     exchanged = 0
     for loop in range(6):

@@ -73,6 +73,8 @@ def test_fullsize_reemission_conservation_and_additivity(converged):
     # several re-emission generations flew, each smaller than the one before
     flights = [f for _, f in launches]
     assert len(flights) >= 5 and flights[0] == n
+    # (tile rounds: launch k flies whatever is in flight after k - 1 tile
+    # crossings - first the re-emissions of the whole first generation)
     assert all(b < a for a, b in zip(flights, flights[1:]))
     assert 0.25 * n < flights[1] < 0.6 * n
     assert 100. < ns / n < 400.
@@ -96,9 +98,12 @@ def test_fullsize_reemission_reordering_invariance(converged):
     default = dict(aggregate=2, aggregate_reemit=0, reemit_passes=1,
                    reemit_inline_below=4096, reemit_max_passes=12,
                    refill_threshold_reemit=32, sort_packets=1,
-                   max_packets_per_launch=1 << 27)
+                   max_packets_per_launch=1 << 27, tile_rounds=1,
+                   tile_min_flights=100000, tile_refill_threshold=16)
     results = []
     for kw in (dict(),
+               dict(tile_rounds=0),
+               dict(tile_min_flights=0, tile_refill_threshold=40),
                dict(aggregate=0, sort_packets=0),
                dict(reemit_passes=0),
                dict(aggregate_reemit=2, refill_threshold_reemit=8,

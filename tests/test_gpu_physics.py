@@ -137,6 +137,13 @@ def test_temperature_solve_fixture(oracle):
 @pytest.mark.parametrize("tuning", [
     dict(reemit_passes=1),
     dict(reemit_passes=0),
+    # later generations in tile rounds, down to the last flight / with a
+    # hand-over to the transport kernel / refilling lane by lane
+    dict(tile_rounds=1, tile_min_flights=0),
+    dict(tile_rounds=1, tile_min_flights=700),
+    dict(tile_rounds=1, tile_min_flights=0, tile_refill_threshold=1,
+         max_packets_per_launch=25000),
+    dict(tile_rounds=0),
     dict(reemit_passes=1, reemit_inline_below=0, reemit_max_passes=3,
          refill_threshold_reemit=1, max_packets_per_launch=25000),
     dict(reemit_passes=1, exact_dda=1, aggregate=0, sort_packets=0),
@@ -176,15 +183,24 @@ def test_diffuse_stromgren_shoot_matches_oracle(oracle, tuning):
     eng.close()
 
 
-def test_lexington_iteration_matches_oracle(oracle):
+@pytest.mark.parametrize("tuning", [
+    dict(),
+    dict(tile_rounds=1, tile_min_flights=0),
+    dict(tile_rounds=0),
+])
+def test_lexington_iteration_matches_oracle(oracle, tuning):
     """benchmarks/lexingtonHII40.param at 24^3: Planck source, Verner cross
     sections, 14 mean intensities + 2 heating terms, physical re-emission with
     He channels, then the cell update (ionization balance for loop <= 3,
-    temperature solve after)."""
+    temperature solve after). With the later generations as tile rounds (8^3
+    tiles, 16 accumulators per cell in LDS), as passes of the transport
+    kernel, and the default mix."""
     from cmacionize_amd import engine as E
     ncell, npacket = 24, 40000
     sim = oracle.lexington_simulation(ncell)
     eng = lexington_engine(ncell, sim)
+    if tuning:
+        eng.set_tuning(**tuning)
     for loop in range(6):
         eng.reset_grid()
         eng.shoot(42, loop, 0, npacket)
@@ -327,4 +343,69 @@ def test_lexington_ragged_packet_counts(oracle, npacket):
         for k in range(2):
             h = eng.download_field(E.FIELD_HEATING + k)
             assert np.isfinite(h).all()
+    eng.close()
+
+
+@pytest.mark.parametrize("tuning", [
+    dict(tile_rounds=0),
+    dict(tile_rounds=1, tile_min_flights=0),
+    dict(tile_rounds=1, tile_min_flights=0, exact_dda=1),
+])
+def test_periodic_diffuse_shoot_matches_oracle(oracle, tuning):
+    """A box that is periodic in x and y (CartesianDensityGrid::is_inside,
+    src/CartesianDensityGrid.cpp:187-227) with physical re-emission: packets
+    and their re-emissions wrap around the box, in the tile rounds across
+    clipped tiles (20 cells = one 16-cell tile + one 4-cell tile per axis).
+    Counters and J against the oracle on the same seeds."""
+    from cmacionize_amd import GpuEngine, STROMGREN as S
+    from cmacionize_amd import engine as E
+    ncell, npacket = 20, 30000
+    periodic = (1, 1, 0)
+    eng = GpuEngine((ncell,) * 3, S["anchor"], S["sides"], periodic, device=0,
+                    track_heating=True)
+    source = [[0.31 * S["sides"][0], -0.2 * S["sides"][0], 0.07 * S["sides"][0]]]
+    eng.set_sources(source, [1.], S["luminosity"])
+    eng.set_spectrum_monochromatic(S["frequency"])
+    sigma = np.zeros(14)
+    sigma[0] = S["sigma_H"]
+    alpha = np.zeros(14)
+    alpha[0] = S["alpha_H"]
+    eng.set_cross_sections_fixed(sigma)
+    eng.set_recombination_rates_fixed(alpha)
+    eng.set_reemission(1)
+    eng.set_tuning(**tuning)
+    n = ncell ** 3
+    sim = oracle.OracleSimulation((ncell,) * 3, S["anchor"], S["sides"],
+                                  periodic=periodic)
+    sim.set_sources(source, [1.], S["luminosity"])
+    # thin enough that most packets cross the box several times
+    sim.set_homogeneous(S["density"], S["temperature"], xH=2.e-5)
+    m = sim.model
+    m.spectrum_type = oracle.SPECTRUM_MONOCHROMATIC
+    m.mono_frequency = S["frequency"]
+    m.xsec_type = oracle.XSEC_FIXED
+    m.xsec_fixed[0] = S["sigma_H"]
+    m.recomb_type = oracle.RECOMB_FIXED
+    m.recomb_fixed[0] = S["alpha_H"]
+    m.reemit_type = oracle.REEMIT_PHYSICAL
+    eng.upload_cells(sim.number_density, sim.temperature,
+                     np.array([np.asarray(x) for x in sim.x]))
+    for loop in range(2):
+        eng.reset_grid()
+        eng.shoot(9, loop, 0, npacket)
+        tw, tc, ns = eng.get_counters()
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(9, loop, 0, npacket)
+        assert tw == sim.totweight == npacket
+        assert np.array_equal(tc, sim.typecount), (tc, sim.typecount)
+        assert tc[1] > 0 and tc[3] > 0
+        # the source sits 4 cells from the +x face: many paths wrap around
+        assert ns > 1.5 * ncell * npacket
+        J = eng.download_field(E.FIELD_MEAN_INTENSITY)
+        assert np.allclose(J, sim.J[0], rtol=1e-9, atol=1e-12 * sim.J[0].max())
+        h = eng.download_field(E.FIELD_HEATING)
+        assert np.allclose(h, sim.heating[0], rtol=1e-9,
+                           atol=1e-12 * np.abs(sim.heating[0]).max())
     eng.close()

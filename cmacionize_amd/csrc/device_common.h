@@ -76,12 +76,28 @@ struct ExchangeDev {
  * flight is marched one tile at a time by a workgroup that keeps the tile's
  * accumulators in LDS; between rounds the flights wait as rows of
  * CMI_FLIGHT_DOUBLES doubles (the marcher's state, as in a hand-over between
- * blocks) with these differences:
- *  [12] (int64) long index of the cell being entered in THIS engine's grid
- *  [14] (int64) the cell's coordinates inside its tile, packed x | y<<8 | z<<16
- * plus, for multi-ion transport, the packet's 16 accumulation weights in a
- * second array (weights[row][16]) so that no cross section is evaluated
- * twice. keys[row] is the tile of the entered cell (sorted between rounds). */
+ * blocks) in slots of their own layout (below) plus, for multi-ion
+ * transport, the packet's 16 accumulation weights in a second array
+ * (weights[slot][16]) so that no cross section is evaluated twice.
+ * keys[slot] is the tile of the entered cell (sorted between rounds). */
+/* Slot layout of the tile rounds (CMI_FLIGHT_DOUBLES doubles, two 64-B
+ * halves): what a tile visit never changes,
+ *   [0-2] origin of the flight  [3-5] direction  [6] frequency
+ *   [7] (2 x uint32) packet id, meta
+ * and what it does (ONE full line written per visit),
+ *   [8] path parameter t  [9-11] next wall parameter per axis
+ *   [12] optical depth left
+ *   [13] (2 x uint32) long index of the cell being entered, in this engine's
+ *        grid | its coordinates inside the tile, x | y<<8 | z<<16
+ * An absorbed packet leaves its absorption record in the same slot: position
+ * in [0-2], cell in [13]. */
+#define CMI_SLOT_NU 6
+#define CMI_SLOT_IDMETA 7
+#define CMI_SLOT_T 8
+#define CMI_SLOT_TMAX 9
+#define CMI_SLOT_TAU 12
+#define CMI_SLOT_CELL 13
+
 struct TileGridDev {
   int32_t log2_side; /* tile side = 1 << log2_side cells */
   int32_t ntile[3];  /* tiles per axis (the last one may be clipped) */

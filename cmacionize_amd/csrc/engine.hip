@@ -102,7 +102,12 @@ struct cmi_gpu_engine {
   FlightRowsDev tile_rows[2];
   uint32_t *tile_iota = nullptr;
   TileItemDev *tile_items = nullptr;
-  unsigned int *tile_counts = nullptr; /* [4]: rows A, rows B, nitems, next */
+  uint32_t *tile_begin = nullptr;      /* [ntiles + 2] */
+  uint32_t *tile_ended_slot = nullptr; /* slot of each absorption record */
+  unsigned int *tile_absorbed_count = nullptr; /* [units of work] */
+  unsigned int *tile_absorbed_before = nullptr; /* their running totals */
+  unsigned int *tile_counts = nullptr; /* [8]: rows, live, nitems, next item,
+                                          absorbed */
   uint64_t tile_rounds_run = 0;
 
   struct Tuning {
@@ -125,6 +130,7 @@ struct cmi_gpu_engine {
      * kernel finishes them with single atomics */
     bool tile_rounds = true;
     uint64_t tile_min_flights = 100000;
+    int tile_min_per_item = -1; /* flights per unit of work; -1 = auto */
     int tile_refill_threshold = 16;
     int tile_max_rounds = 1000;
   } tune;
@@ -962,6 +968,8 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
     e->tune.tile_rounds = value != 0;
   else if (k == "tile_min_flights")
     e->tune.tile_min_flights = (uint64_t)(value < 0 ? 0 : value);
+  else if (k == "tile_min_per_item")
+    e->tune.tile_min_per_item = (int)(value < 0 ? -1 : value);
   else if (k == "tile_refill_threshold")
     e->tune.tile_refill_threshold =
         (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
@@ -1075,13 +1083,19 @@ static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
   const size_t row_bytes = sizeof(double) * CMI_FLIGHT_DOUBLES * n;
   const size_t weight_bytes = weights ? sizeof(double) * CMI_NACC * n : 0;
   const size_t key_bytes = (sizeof(uint32_t) * n + 255) & ~(size_t)255;
-  const size_t nitems = (size_t)t.ntiles + n / CMI_TILE_ITEM_FLIGHTS + 2;
+  const size_t nitems =
+      (size_t)t.ntiles + n / CMI_TILE_ITEM_FLIGHTS_FULL + 4;
   const size_t item_bytes = sizeof(TileItemDev) * nitems;
-  const size_t total =
-      2 * (row_bytes + weight_bytes + key_bytes) + key_bytes + item_bytes;
+  const size_t begin_bytes =
+      (sizeof(uint32_t) * ((size_t)t.ntiles + 2) + 255) & ~(size_t)255;
+  const size_t count_bytes =
+      (sizeof(unsigned int) * nitems + 255) & ~(size_t)255;
+  const size_t total = 2 * (row_bytes + weight_bytes + key_bytes) +
+                       2 * key_bytes + begin_bytes + 2 * count_bytes +
+                       item_bytes;
   HIP_TRY(hipMalloc(&e->tile_block, total));
   if (!e->tile_counts)
-    HIP_TRY(hipMalloc(&e->tile_counts, 4 * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&e->tile_counts, 8 * sizeof(unsigned int)));
   char *at = e->tile_block;
   for (int k = 0; k < 2; ++k) {
     FlightRowsDev &r = e->tile_rows[k];
@@ -1096,6 +1110,14 @@ static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
   }
   e->tile_iota = (uint32_t *)at;
   at += key_bytes;
+  e->tile_ended_slot = (uint32_t *)at;
+  at += key_bytes;
+  e->tile_begin = (uint32_t *)at;
+  at += begin_bytes;
+  e->tile_absorbed_count = (unsigned int *)at;
+  at += count_bytes;
+  e->tile_absorbed_before = (unsigned int *)at;
+  at += count_bytes;
   e->tile_items = (TileItemDev *)at;
   iota_kernel<<<grid_blocks(e, (int64_t)n, 8), CMI_BLOCK, 0, e->stream>>>(
       e->tile_iota, n);
@@ -1215,13 +1237,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     rc = reserve_sort_buffers(e, cap);
     if (rc)
       return rc;
-    if (e->full_ions) {
+    if (e->full_ions)
       tkernel = heat ? tile_kernel<true, true> : tile_kernel<true, false>;
-      tile_threads = CMI_TILE_THREADS_FULL;
-    } else {
+    else
       tkernel = heat ? tile_kernel<false, true> : tile_kernel<false, false>;
-      tile_threads = CMI_TILE_THREADS_H;
-    }
+    tile_threads = CMI_TILE_THREADS;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &tile_blocks_per_cu, tkernel, tile_threads, 0));
     if (tile_blocks_per_cu < 1)
@@ -1351,6 +1371,8 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
      * start in; every round sorts the rows by tile, flies each flight through
      * ONE tile with the tile's accumulators in LDS, and collects the flights
      * that go on (into another tile, or re-emitted) for the next round */
+    const double *handover = nullptr; /* flights the tile rounds leave over */
+    unsigned int handover_count = 0;
     if (tiles) {
       const TileGridDev tg = tile_grid(e);
       int tile_bits = 1; /* keys: tiles and the "free slot" key ntiles */
@@ -1367,13 +1389,18 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       ia.qout = no_queue;
       ia.grid = e->grid;
       ia.tiles = tg;
-      ia.nslots = 0;
+      ia.items = e->tile_items;
+      ia.nitems = e->tile_counts + 2;
+      ia.absorbed_before = e->tile_absorbed_before;
+      ia.ended_slot = e->tile_ended_slot;
+      const uint32_t item_flights = e->full_ions ? CMI_TILE_ITEM_FLIGHTS_FULL
+                                                 : CMI_TILE_ITEM_FLIGHTS_H;
       unsigned int *const d_nrows = e->tile_counts;
       unsigned int *const d_nlive = e->tile_counts + 1;
       unsigned int *const d_nitems = e->tile_counts + 2;
       unsigned int *const d_next = e->tile_counts + 3;
       int cur = 0;
-      HIP_TRY(hipMemsetAsync(e->tile_counts, 0, 4 * sizeof(unsigned int),
+      HIP_TRY(hipMemsetAsync(e->tile_counts, 0, 8 * sizeof(unsigned int),
                              e->stream));
       /* the absorbed packets of the first generation -> flights in slots */
       ia.rows = e->tile_rows[cur];
@@ -1408,19 +1435,33 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         pa.tiles = tg;
         pa.sorted_keys = e->sort_keys[1];
         pa.nslots = nslots;
+        pa.tile_begin = e->tile_begin;
+        pa.item_flights = item_flights;
         pa.items = e->tile_items;
         pa.nitems = d_nitems;
         pa.next_item = d_next;
         pa.nlive = d_nlive;
+        tile_begin_kernel<<<grid_blocks(e, (int64_t)nslots + 1, 8), CMI_BLOCK,
+                            0, e->stream>>>(pa);
+        HIP_TRY(hipGetLastError());
         tile_plan_kernel<<<1, CMI_TILE_PLAN_THREADS, 0, e->stream>>>(pa);
         HIP_TRY(hipGetLastError());
-        unsigned int nlive = 0;
-        HIP_TRY(hipMemcpyAsync(&nlive, d_nlive, sizeof(unsigned int),
+        unsigned int plan[2] = {0, 0}; /* flights, units of work */
+        HIP_TRY(hipMemcpyAsync(plan, d_nlive, 2 * sizeof(unsigned int),
                                hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
+        const unsigned int nlive = plan[0];
         if (nlive == 0)
           break;
+        /* a unit of work costs a fixed ~20-40 us (tile records in, tile
+         * accumulators out); measured on MI355X the round beats single
+         * atomics while a unit has a few hundred flights to share that */
+        const uint64_t per_item =
+            e->tune.tile_min_per_item >= 0
+                ? (uint64_t)e->tune.tile_min_per_item
+                : (e->full_ions ? 200u : 400u);
         const bool finish = nlive < e->tune.tile_min_flights ||
+                            (uint64_t)nlive < per_item * plan[1] ||
                             round >= e->tune.tile_max_rounds;
         const uint32_t *order = e->sort_ids[1];
         if (finish || 2ull * nlive < nslots) {
@@ -1440,34 +1481,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
           order = nullptr;
         }
         if (finish) {
-          /* few flights left: the transport kernel follows them and their
-           * re-emissions to the end, with single atomics */
-          ShootArgs b = a;
-          b.order = nullptr;
-          b.xin = e->tile_rows[cur].rows;
-          b.xin_local = 1;
-          b.n_packets = nlive;
-          b.refill_threshold = e->tune.refill_threshold_reemit;
-          b.aggregate = agg_reemit;
-          b.qin = no_queue;
-          b.qout = no_queue;
-          const uint64_t nch = ((uint64_t)nlive + b.chunk - 1) / b.chunk;
-          int64_t nb = (int64_t)e->num_cu * blocks_per_cu_inline;
-          const int64_t nneed =
-              (int64_t)((nch + (CMI_BLOCK / 64) - 1) / (CMI_BLOCK / 64));
-          if (nb > nneed)
-            nb = nneed;
-          if (nb < 1)
-            nb = 1;
-          EventPair gev;
-          HIP_TRY(hipEventCreate(&gev.start));
-          HIP_TRY(hipEventCreate(&gev.stop));
-          HIP_TRY(hipEventRecord(gev.start, e->stream));
-          kernel_inline<<<(unsigned)nb, CMI_BLOCK, 0, e->stream>>>(b);
-          HIP_TRY(hipGetLastError());
-          HIP_TRY(hipEventRecord(gev.stop, e->stream));
-          gev.packets = nlive;
-          e->kernel_events.push_back(gev);
+          /* too few flights per tile for the LDS accumulators to pay: the
+           * rest goes on as passes of the transport kernel (below), the first
+           * of which resumes the flights from their slots */
+          handover = e->tile_rows[cur].rows;
+          handover_count = nlive;
           break;
         }
         TileArgs ta;
@@ -1482,11 +1500,14 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         ta.items = e->tile_items;
         ta.nitems = d_nitems;
         ta.next_item = d_next;
+        ta.ended = e->ended_queue;
+        ta.ended_slot = e->tile_ended_slot;
+        ta.absorbed_count = e->tile_absorbed_count;
         ta.xout = a.xout;
         /* no more workgroups than units of work can exist */
         int64_t tb = (int64_t)e->num_cu * tile_blocks_per_cu;
         const int64_t most =
-            (int64_t)tg.ntiles + (int64_t)nlive / CMI_TILE_ITEM_FLIGHTS + 1;
+            (int64_t)tg.ntiles + (int64_t)nlive / item_flights + 1;
         if (tb > most)
           tb = most;
         EventPair tev;
@@ -1501,10 +1522,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         ++e->tile_rounds_run;
         /* the packets absorbed in this round: re-emitted into their slots */
         ia.rows = e->tile_rows[cur];
-        ia.nslots = nslots;
-        const int sblocks = grid_blocks(
-            e, ((int64_t)nslots + CMI_SLOTS_CHUNK - 1) / CMI_SLOTS_CHUNK *
-                   CMI_BLOCK, 8);
+        absorbed_scan_kernel<<<1, CMI_TILE_PLAN_THREADS, 0, e->stream>>>(
+            d_nitems, e->tile_absorbed_count, e->tile_absorbed_before);
+        HIP_TRY(hipGetLastError());
+        /* (about a quarter of a round's flights are absorbed) */
+        const int sblocks = grid_blocks(e, (int64_t)nlive / 2 + 1, 8);
         if (e->full_ions)
           interaction_slots_kernel<true>
               <<<sblocks, CMI_BLOCK, 0, e->stream>>>(ia);
@@ -1518,7 +1540,45 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
      * the ended flights of one launch into the ready flights of the next.
      * Those start all over the grid in random directions, so these launches
      * refill eagerly instead of keeping ray bundles together. */
-    for (int gen = 0; passes && !tiles; ++gen) {
+    if (handover_count != 0) {
+      /* pass 0 of the tail: the flights resume from their slots, absorbed
+       * ones are parked for the interaction kernel as in every pass */
+      const bool last = handover_count < e->tune.reemit_inline_below;
+      ShootArgs b = a;
+      b.order = nullptr;
+      b.xin = handover;
+      b.xin_local = 1;
+      b.n_packets = handover_count;
+      b.refill_threshold = e->tune.refill_threshold_reemit;
+      b.aggregate = agg_reemit;
+      b.qin = no_queue;
+      b.qout = last ? no_queue : e->ended_queue;
+      if (!last)
+        HIP_TRY(hipMemsetAsync(e->ended_queue.count, 0, sizeof(unsigned int),
+                               e->stream));
+      const uint64_t nch = ((uint64_t)handover_count + b.chunk - 1) / b.chunk;
+      int64_t nb =
+          (int64_t)e->num_cu * (last ? blocks_per_cu_inline : blocks_per_cu);
+      const int64_t nneed =
+          (int64_t)((nch + (CMI_BLOCK / 64) - 1) / (CMI_BLOCK / 64));
+      if (nb > nneed)
+        nb = nneed;
+      if (nb < 1)
+        nb = 1;
+      EventPair gev;
+      HIP_TRY(hipEventCreate(&gev.start));
+      HIP_TRY(hipEventCreate(&gev.stop));
+      HIP_TRY(hipEventRecord(gev.start, e->stream));
+      (last ? kernel_inline : kernel)<<<(unsigned)nb, CMI_BLOCK, 0,
+                                        e->stream>>>(b);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(gev.stop, e->stream));
+      gev.packets = handover_count;
+      e->kernel_events.push_back(gev);
+      if (last)
+        handover_count = 0;
+    }
+    for (int gen = 0; passes && (!tiles || handover_count != 0); ++gen) {
       InteractArgs ia;
       ia.model = e->model;
       ia.cells = e->cells;
@@ -1534,7 +1594,10 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       memset(&ia.rows, 0, sizeof ia.rows);
       ia.grid = e->grid;
       memset(&ia.tiles, 0, sizeof ia.tiles);
-      ia.nslots = 0;
+      ia.items = nullptr;
+      ia.nitems = nullptr;
+      ia.absorbed_before = nullptr;
+      ia.ended_slot = nullptr;
       if (e->full_ions)
         interaction_kernel<true, false>
             <<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);

@@ -604,19 +604,38 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
         if (a.xin != nullptr) {
           /* a flight handed over by another block of the grid */
           const double *r = a.xin + (size_t)CMI_FLIGHT_DOUBLES * i;
+          int64_t cell_global;
+          unsigned long long idmeta;
+          if (a.xin_local) {
+            /* a slot of the tile rounds (tile_kernels.h) */
 #pragma unroll
-          for (int ax = 0; ax < 3; ++ax) {
-            p.pos[ax] = r[ax];
-            p.dir[ax] = r[3 + ax];
-            p.inv_dir[ax] = 1. / p.dir[ax];
-            p.tmax[ax] = r[7 + ax];
+            for (int ax = 0; ax < 3; ++ax) {
+              p.pos[ax] = r[ax];
+              p.dir[ax] = r[3 + ax];
+              p.inv_dir[ax] = 1. / p.dir[ax];
+              p.tmax[ax] = r[CMI_SLOT_TMAX + ax];
+            }
+            p.t = r[CMI_SLOT_T];
+            p.tau = r[CMI_SLOT_TAU];
+            p.nu = r[CMI_SLOT_NU];
+            cell_global = (int64_t)(uint32_t)__double_as_longlong(
+                r[CMI_SLOT_CELL]);
+            idmeta = (unsigned long long)__double_as_longlong(
+                r[CMI_SLOT_IDMETA]);
+          } else {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+              p.pos[ax] = r[ax];
+              p.dir[ax] = r[3 + ax];
+              p.inv_dir[ax] = 1. / p.dir[ax];
+              p.tmax[ax] = r[7 + ax];
+            }
+            p.t = r[6];
+            p.tau = r[10];
+            p.nu = r[11];
+            cell_global = __double_as_longlong(r[12]);
+            idmeta = (unsigned long long)__double_as_longlong(r[13]);
           }
-          p.t = r[6];
-          p.tau = r[10];
-          p.nu = r[11];
-          const int64_t cell_global = __double_as_longlong(r[12]);
-          const unsigned long long idmeta =
-              (unsigned long long)__double_as_longlong(r[13]);
           packet_id = (uint32_t)idmeta;
           lane_meta = (uint32_t)(idmeta >> 32);
           if (REEMIT)
@@ -982,7 +1001,11 @@ struct InteractArgs {
   GridDev grid;
   TileGridDev tiles;
   FlightRowsDev rows;
-  unsigned int nslots; /* interaction_slots_kernel: slots to look at */
+  /* interaction_slots_kernel: the absorption records of a tile round */
+  const TileItemDev *items;
+  const unsigned int *nitems;
+  const unsigned int *absorbed_before; /* running totals of the counts */
+  const uint32_t *ended_slot;
 };
 
 /* the handler's decision for a packet of frequency nu absorbed in `cell`:
@@ -1156,76 +1179,107 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   }
 }
 
-/* The same for the tile rounds, in place: every slot whose key says
- * "absorbed" holds an absorption record (tile_kernel); it becomes the
- * re-emitted flight, or a free slot. A workgroup looks at
- * CMI_SLOTS_CHUNK slots at a time, collects the absorbed ones in LDS and
- * then works through that list with all lanes busy (about one slot in seven
- * is absorbed per round). */
-#define CMI_SLOTS_CHUNK 2048
+/* The same for the tile rounds, in place: unit of work k of the tile kernel
+ * has left the absorption records of its packets at positions
+ * [items[k].begin, + absorbed_count[k]) of `qin`, with the slot each came
+ * from; the slot becomes the re-emitted flight, or a free slot. First the
+ * running totals of the counts (one workgroup) ... */
+__global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
+    absorbed_scan_kernel(const unsigned int *nitems,
+                         const unsigned int *absorbed_count,
+                         unsigned int *absorbed_before) {
+  __shared__ uint32_t partial[CMI_TILE_PLAN_THREADS];
+  const uint32_t n = *nitems;
+  const uint32_t per = (n + CMI_TILE_PLAN_THREADS - 1) / CMI_TILE_PLAN_THREADS;
+  const uint32_t k0 = threadIdx.x * per;
+  const uint32_t k1 = k0 + per < n ? k0 + per : n;
+  uint32_t mine = 0;
+  for (uint32_t k = k0; k < k1; ++k)
+    mine += absorbed_count[k];
+  partial[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 1; off < CMI_TILE_PLAN_THREADS; off <<= 1) {
+    const uint32_t v =
+        threadIdx.x >= (unsigned)off ? partial[threadIdx.x - off] : 0u;
+    __syncthreads();
+    partial[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t at = partial[threadIdx.x] - mine;
+  for (uint32_t k = k0; k < k1; ++k) {
+    absorbed_before[k] = at;
+    at += absorbed_count[k];
+  }
+  if (threadIdx.x == CMI_TILE_PLAN_THREADS - 1)
+    absorbed_before[n] = partial[threadIdx.x];
+}
+
+/* ... then one lane per record, whatever unit it belongs to (the decision is
+ * long and divergent - for multi-ion transport it ends with 14 Verner cross
+ * sections - so every lane should have one) */
 template <bool FULL>
 __global__ void __launch_bounds__(CMI_BLOCK)
     interaction_slots_kernel(const InteractArgs a) {
-  __shared__ uint32_t s_list[CMI_SLOTS_CHUNK];
-  __shared__ unsigned int s_n;
   const int lane = threadIdx.x & 63;
   const uint32_t key_dead = CMI_TILE_KEY_DEAD(a.tiles);
-  const uint32_t key_absorbed = CMI_TILE_KEY_ABSORBED(a.tiles);
+  const uint32_t nitems = *a.nitems;
+  const uint64_t total = a.absorbed_before[nitems];
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   double tw = 0., tc1 = 0., tc2 = 0., tc3 = 0.;
-  for (uint64_t chunk = (uint64_t)blockIdx.x * CMI_SLOTS_CHUNK;
-       chunk < a.nslots; chunk += (uint64_t)gridDim.x * CMI_SLOTS_CHUNK) {
-    if (threadIdx.x == 0)
-      s_n = 0;
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < CMI_SLOTS_CHUNK; k += CMI_BLOCK) {
-      const uint64_t s = chunk + k;
-      if (s < a.nslots && a.rows.keys[s] == key_absorbed)
-        s_list[atomicAdd(&s_n, 1u)] = (uint32_t)s;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < total;
+       base += stride) {
+    /* the unit of work the workgroup's first record belongs to: last k with
+     * before[k] <= base (a uniform search: scalar loads) ... */
+    uint32_t lo = 0, hi = nitems;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (a.absorbed_before[mid] <= (uint32_t)base)
+        lo = mid;
+      else
+        hi = mid;
     }
-    __syncthreads();
-    const uint32_t n = s_n;
-    for (uint32_t k = threadIdx.x; k < n; k += CMI_BLOCK) {
-      const uint32_t slot = s_list[k];
-      double *r = a.rows.rows + (size_t)CMI_FLIGHT_DOUBLES * slot;
-      const double nu = r[11];
-      const int32_t cell = (int32_t)__double_as_longlong(r[12]);
-      const unsigned long long idmeta =
-          (unsigned long long)__double_as_longlong(r[13]);
-      const uint32_t id = (uint32_t)idmeta;
-      const uint32_t meta = (uint32_t)(idmeta >> 32);
-      PacketRng rng;
-      rng.resume(a.seed, a.iteration, a.first_packet + id, meta & 0xffffffu,
-                 (meta >> 24) & 1u);
-      int32_t type;
-      const double new_frequency =
-          interaction_decide<FULL>(a, nu, cell, rng, type);
-      uint32_t key = key_dead;
-      if (new_frequency != 0.) {
-        Packet<FULL> p;
-        double weights[CMI_NACC];
-        uint32_t plc = 0;
-        p.pos[0] = r[0];
-        p.pos[1] = r[1];
-        p.pos[2] = r[2];
-        if (interaction_new_flight<FULL>(a, new_frequency, type, rng, p,
-                                         weights, plc, key)) {
-          write_flight_row<FULL>(
-              a.rows, slot, p, plc, key, id,
-              cmi_pack_meta(rng.block, rng.have, (uint32_t)type), weights);
-        } else {
-          key = key_dead;
-          tw += 1.;
-          tc1 += (type == TYPE_DIFFUSE_HI) ? 1. : 0.;
-          tc2 += (type == TYPE_DIFFUSE_HeI) ? 1. : 0.;
-        }
+    const uint64_t j = base + threadIdx.x;
+    if (j >= total)
+      continue;
+    /* ... and this lane's, a few units further at most */
+    while (a.absorbed_before[lo + 1] <= (uint32_t)j)
+      ++lo;
+    const unsigned int i =
+        a.items[lo].begin + ((uint32_t)j - a.absorbed_before[lo]);
+    const uint32_t slot = a.ended_slot[i];
+    const uint32_t id = a.qin.id[i];
+    const uint32_t meta = a.qin.meta[i];
+    PacketRng rng;
+    rng.resume(a.seed, a.iteration, a.first_packet + id, meta & 0xffffffu,
+               (meta >> 24) & 1u);
+    int32_t type;
+    const double new_frequency =
+        interaction_decide<FULL>(a, a.qin.nu[i], a.qin.cell[i], rng, type);
+    uint32_t key = key_dead;
+    if (new_frequency != 0.) {
+      Packet<FULL> p;
+      double weights[CMI_NACC];
+      uint32_t plc = 0;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax)
+        p.pos[ax] = a.qin.pos[ax][i];
+      if (interaction_new_flight<FULL>(a, new_frequency, type, rng, p, weights,
+                                       plc, key)) {
+        write_flight_row<FULL>(
+            a.rows, slot, p, plc, key, id,
+            cmi_pack_meta(rng.block, rng.have, (uint32_t)type), weights);
       } else {
+        key = key_dead;
         tw += 1.;
-        tc3 += 1.;
+        tc1 += (type == TYPE_DIFFUSE_HI) ? 1. : 0.;
+        tc2 += (type == TYPE_DIFFUSE_HeI) ? 1. : 0.;
       }
-      if (key == key_dead)
-        a.rows.keys[slot] = key;
+    } else {
+      tw += 1.;
+      tc3 += 1.;
     }
-    __syncthreads();
+    if (key == key_dead)
+      a.rows.keys[slot] = key;
   }
   tw = wave_sum(tw);
   tc1 = wave_sum(tc1);

@@ -46,20 +46,16 @@
 /* tile side (log2) and workgroup size per transport flavour */
 #define CMI_TILE_LOG2_H 4    /* hydrogen-only: 16^3 cells */
 #define CMI_TILE_LOG2_FULL 3 /* 14 ions + heating: 8^3 cells */
-#define CMI_TILE_THREADS_H 256
-#define CMI_TILE_THREADS_FULL 512
+#define CMI_TILE_THREADS 512
 /* flights per unit of work: a tile with more is shared by several workgroups
  * (each with its own LDS copy, all written back with atomics) */
-#ifndef CMI_TILE_ITEM_FLIGHTS
-#define CMI_TILE_ITEM_FLIGHTS 2048
-#endif
+#define CMI_TILE_ITEM_FLIGHTS_H 4096
+#define CMI_TILE_ITEM_FLIGHTS_FULL 2048
 #define CMI_TILE_PLAN_THREADS 1024
 
-/* keys of slots that hold no flight (tiles have keys < ntiles): a slot whose
- * packet is gone sorts behind every tile; an absorbed packet waits for the
- * interaction kernel of the same round (never seen by a sort) */
+/* key of a slot that holds no flight (tiles have keys < ntiles): sorts behind
+ * every tile */
 #define CMI_TILE_KEY_DEAD(tiles) ((uint32_t)(tiles).ntiles)
-#define CMI_TILE_KEY_ABSORBED(tiles) ((uint32_t)(tiles).ntiles + 1u)
 
 struct TileArgs {
   GridDev grid;
@@ -69,14 +65,21 @@ struct TileArgs {
   TileGridDev tiles;
   int32_t refill_threshold;
   /* the flights: every slot is updated IN PLACE (a flight that goes on into
-   * another tile gets its new marcher state and key, an absorbed packet its
-   * absorption record and CMI_TILE_KEY_ABSORBED, a finished one
-   * CMI_TILE_KEY_DEAD) - no output queue, no shared counter */
+   * another tile gets its new marcher state and key, a finished one
+   * CMI_TILE_KEY_DEAD; the slot of an absorbed packet is rewritten by the
+   * interaction kernel of the round) - no output queue, no shared counter */
   FlightRowsDev rows;
   const uint32_t *order; /* slots sorted by tile; NULL = identity */
   const TileItemDev *items;
   const unsigned int *nitems;
   unsigned int *next_item;
+  /* the packets absorbed in this round, for the interaction kernel: unit of
+   * work k leaves its absorption records (position, cell, frequency, id,
+   * meta - and the slot they came from) at positions [begin, begin + n_k) of
+   * these arrays and n_k in absorbed_count[k] */
+  QueueDev ended;
+  uint32_t *ended_slot;
+  unsigned int *absorbed_count;
   ExchangeDev xout; /* decomposed grids: flights that leave the block */
 };
 
@@ -86,50 +89,50 @@ __device__ __forceinline__ uint32_t tile_index(const TileGridDev &t, int32_t tx,
   return (uint32_t)((tx * t.ntile[1] + ty) * t.ntile[2] + tz);
 }
 
-/* Plan of a round: the sorted keys are cut into units of work of at most
- * CMI_TILE_ITEM_FLIGHTS flights of one tile. One workgroup. */
+/* Plan of a round, from the sorted keys: first the position where every
+ * tile's flights begin ... */
 struct TilePlanArgs {
   TileGridDev tiles;
   const uint32_t *sorted_keys;
   unsigned int nslots; /* slots sorted (flights + dead slots behind them) */
+  uint32_t *tile_begin; /* [ntiles + 2] */
+  uint32_t item_flights;
   TileItemDev *items;
   unsigned int *nitems;
   unsigned int *next_item;
   unsigned int *nlive; /* out: flights among the slots */
 };
 
-__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a,
-                                                    uint32_t n, uint32_t v) {
-  uint32_t lo = 0, hi = n;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (a[mid] < v)
-      lo = mid + 1;
-    else
-      hi = mid;
+__global__ void __launch_bounds__(CMI_BLOCK)
+    tile_begin_kernel(const TilePlanArgs a) {
+  const uint32_t n = a.nslots;
+  const uint32_t last = (uint32_t)a.tiles.ntiles + 1u; /* keys 0 .. ntiles */
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n;
+       i += stride) {
+    /* keys in (key[i-1], key[i]] begin at i; beyond the last key, at n */
+    const uint32_t lo = (i == 0) ? 0u : a.sorted_keys[i - 1] + 1u;
+    const uint32_t hi = (i == n) ? last : a.sorted_keys[i];
+    for (uint32_t k = lo; k <= hi && k <= last; ++k)
+      a.tile_begin[k] = (uint32_t)i;
   }
-  return lo;
 }
 
+/* ... then the units of work: at most item_flights flights of one tile each.
+ * One workgroup. */
 __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
     tile_plan_kernel(const TilePlanArgs a) {
   __shared__ uint32_t partial[CMI_TILE_PLAN_THREADS];
-  const uint32_t n = a.nslots;
   const uint32_t ntiles = (uint32_t)a.tiles.ntiles;
+  const uint32_t M = a.item_flights;
   /* thread k owns a contiguous range of tiles */
   const uint32_t per = (ntiles + CMI_TILE_PLAN_THREADS - 1) /
                        CMI_TILE_PLAN_THREADS;
   const uint32_t t0 = threadIdx.x * per;
   const uint32_t t1 = t0 + per < ntiles ? t0 + per : ntiles;
   uint32_t mine = 0;
-  if (t0 < ntiles) {
-    uint32_t begin = lower_bound_u32(a.sorted_keys, n, t0);
-    for (uint32_t t = t0; t < t1; ++t) {
-      const uint32_t end = lower_bound_u32(a.sorted_keys, n, t + 1);
-      mine += (end - begin + CMI_TILE_ITEM_FLIGHTS - 1) / CMI_TILE_ITEM_FLIGHTS;
-      begin = end;
-    }
-  }
+  for (uint32_t t = t0; t < t1; ++t)
+    mine += (a.tile_begin[t + 1] - a.tile_begin[t] + M - 1) / M;
   partial[threadIdx.x] = mine;
   __syncthreads();
   /* inclusive scan of the 1024 partial counts (Hillis-Steele in LDS) */
@@ -141,26 +144,21 @@ __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
     __syncthreads();
   }
   uint32_t at = partial[threadIdx.x] - mine;
-  if (t0 < ntiles) {
-    uint32_t begin = lower_bound_u32(a.sorted_keys, n, t0);
-    for (uint32_t t = t0; t < t1; ++t) {
-      const uint32_t end = lower_bound_u32(a.sorted_keys, n, t + 1);
-      for (uint32_t b = begin; b < end; b += CMI_TILE_ITEM_FLIGHTS) {
-        TileItemDev it;
-        it.tile = t;
-        it.begin = b;
-        it.end = b + CMI_TILE_ITEM_FLIGHTS < end ? b + CMI_TILE_ITEM_FLIGHTS
-                                                 : end;
-        it.pad = 0;
-        a.items[at++] = it;
-      }
-      begin = end;
+  for (uint32_t t = t0; t < t1; ++t) {
+    const uint32_t begin = a.tile_begin[t], end = a.tile_begin[t + 1];
+    for (uint32_t b = begin; b < end; b += M) {
+      TileItemDev it;
+      it.tile = t;
+      it.begin = b;
+      it.end = b + M < end ? b + M : end;
+      it.pad = 0;
+      a.items[at++] = it;
     }
   }
   if (threadIdx.x == CMI_TILE_PLAN_THREADS - 1) {
     *a.nitems = partial[threadIdx.x];
     *a.next_item = 0;
-    *a.nlive = lower_bound_u32(a.sorted_keys, n, ntiles);
+    *a.nlive = a.tile_begin[ntiles];
   }
 }
 
@@ -205,16 +203,19 @@ write_flight_row(const FlightRowsDev &out, unsigned int q,
                  const Packet<FULL> &p, uint32_t packed_lc, uint32_t key,
                  uint32_t packet_id, uint32_t meta,
                  const double (&weights)[CMI_NACC]) {
-  double *r = out.rows + (size_t)CMI_FLIGHT_DOUBLES * q;
-  double4 *r4 = reinterpret_cast<double4 *>(r);
+  double4 *r4 = reinterpret_cast<double4 *>(out.rows +
+                                            (size_t)CMI_FLIGHT_DOUBLES * q);
   r4[0] = make_double4(p.pos[0], p.pos[1], p.pos[2], p.dir[0]);
-  r4[1] = make_double4(p.dir[1], p.dir[2], p.t, p.tmax[0]);
-  r4[2] = make_double4(p.tmax[1], p.tmax[2], p.tau, p.nu);
-  r4[3] = make_double4(
-      __longlong_as_double((long long)p.cell),
+  r4[1] = make_double4(
+      p.dir[1], p.dir[2], p.nu,
       __longlong_as_double(
-          (long long)(((unsigned long long)meta << 32) | packet_id)),
-      __longlong_as_double((long long)packed_lc), 0.);
+          (long long)(((unsigned long long)meta << 32) | packet_id)));
+  r4[2] = make_double4(p.t, p.tmax[0], p.tmax[1], p.tmax[2]);
+  r4[3] = make_double4(
+      p.tau,
+      __longlong_as_double((long long)(((unsigned long long)packed_lc << 32) |
+                                       (uint32_t)p.cell)),
+      0., 0.);
   out.keys[q] = key;
   if (FULL) {
     double4 *w = reinterpret_cast<double4 *>(out.weights + (size_t)CMI_NACC * q);
@@ -229,44 +230,50 @@ write_flight_row(const FlightRowsDev &out, unsigned int q,
  * The tile kernel: PhotonTraversalTaskContext::execute
  * (src/PhotonTraversalTaskContext.hpp:100-278) for the flights of one tile,
  * with DensitySubGrid::interact (src/DensitySubGrid.hpp:1137-1274) as the
- * incremental marcher of device_transport.h and the tile's
- * update_integrals (src/DensityGrid.hpp:150-197) in LDS.
+ * incremental marcher of device_transport.h - here with tile-local
+ * bookkeeping only - and both the tile's transport records
+ * (get_optical_depth, src/DensityGrid.hpp:117-140) and its accumulators
+ * (update_integrals, :150-197) in LDS: the march loop touches no global
+ * memory.
  */
 template <bool FULL, bool HEAT>
-__global__ void __launch_bounds__(FULL ? CMI_TILE_THREADS_FULL
-                                       : CMI_TILE_THREADS_H,
-                                  FULL ? 4 : (HEAT ? 2 : 4))
+__global__ void __launch_bounds__(CMI_TILE_THREADS, (!FULL && HEAT) ? 2 : 4)
     tile_kernel(const TileArgs a) {
   constexpr int L = FULL ? CMI_TILE_LOG2_FULL : CMI_TILE_LOG2_H;
   constexpr int T = 1 << L;
   constexpr int TC = T * T * T;
   constexpr int NV = FULL ? CMI_NACC : (HEAT ? 2 : 1);
-  constexpr int NT = FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H;
+  constexpr int NT = CMI_TILE_THREADS;
   /* value v of tile cell k lives at acc[v * TC + k]: neighbouring cells in
    * neighbouring banks whatever the value */
   __shared__ double acc[NV * TC];
-  __shared__ unsigned int s_item, s_next;
+  /* transport records of the tile's cells: n x_H (< 0: vacuum), and n x_He
+   * for multi-ion transport */
+  __shared__ double opac[(FULL ? 2 : 1) * TC];
+  __shared__ unsigned int s_item, s_next, s_nabs;
 
   const int lane = threadIdx.x & 63;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
-  const bool any_periodic =
-      (a.grid.periodic[0] | a.grid.periodic[1] | a.grid.periodic[2]) != 0;
   const uint32_t key_dead = CMI_TILE_KEY_DEAD(a.tiles);
-  const uint32_t key_absorbed = CMI_TILE_KEY_ABSORBED(a.tiles);
 
-  Packet<FULL> p;
-  p.sigma_H = 0.;
-  p.sigma_He_corr = 0.;
-  p.nu = 0.;
-  p.weight = 1.;
+  /* marcher state of the lane's flight, tile-local */
+  double pos[3], dir[3], tmax[3], tdelta[3];
+  double t = 0., tau = 0., nu = 0., sigma_H = 0., sigma_He_corr = 0.;
   double weights[CMI_NACC];
+  int32_t lc[3] = {0, 0, 0}, lsgn[3] = {0, 0, 0};
+  int32_t type = 0;
   uint32_t packet_id = 0, lane_meta = 0, slot = 0;
   unsigned int tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
   unsigned int nsteps = 0, natomics = 0, nwavesteps = 0;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax)
+    pos[ax] = dir[ax] = tmax[ax] = tdelta[ax] = 0.;
 
   for (;;) {
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
       s_item = atomicAdd(a.next_item, 1u);
+      s_nabs = 0;
+    }
     for (int k = threadIdx.x; k < NV * TC; k += NT)
       acc[k] = 0.;
     __syncthreads();
@@ -276,17 +283,41 @@ __global__ void __launch_bounds__(FULL ? CMI_TILE_THREADS_FULL
     const TileItemDev it = a.items[item];
     if (threadIdx.x == 0)
       s_next = it.begin;
-    __syncthreads();
-    /* the tile: coordinates of its first cell */
+    /* the tile: coordinates of its first cell, its extent (the last tile of
+     * an axis may be clipped) */
     const int32_t tz = (int32_t)(it.tile % (uint32_t)a.tiles.ntile[2]);
     const int32_t ty = (int32_t)((it.tile / (uint32_t)a.tiles.ntile[2]) %
                                  (uint32_t)a.tiles.ntile[1]);
     const int32_t tx = (int32_t)(it.tile / ((uint32_t)a.tiles.ntile[2] *
                                             (uint32_t)a.tiles.ntile[1]));
     const int32_t o[3] = {tx << L, ty << L, tz << L};
+    int32_t td[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax)
+      td[ax] = a.grid.ncell[ax] - o[ax] < T ? a.grid.ncell[ax] - o[ax] : T;
+    const bool clipped = (td[0] | td[1] | td[2]) != T;
+    for (int k = threadIdx.x; k < TC; k += NT) {
+      const int32_t lx = k >> (2 * L), ly = (k >> L) & (T - 1),
+                    lz = k & (T - 1);
+      double2 rec = make_double2(-1., 0.);
+      if (lx < td[0] && ly < td[1] && lz < td[2])
+        rec = a.cells.opacity[((int64_t)(o[0] + lx) * a.grid.ncell[1] + o[1] +
+                               ly) * a.grid.ncell[2] + o[2] + lz];
+      opac[k] = rec.x;
+      if (FULL)
+        opac[TC + k] = rec.y;
+    }
+    __syncthreads();
 
     bool active = false;
-    int32_t last_cell = -1, last_lidx = 0;
+    int32_t last_lidx = 0;
+    bool stepped = false; /* the flight has crossed a cell in this tile */
+    auto in_tile = [&]() {
+      bool in = (((uint32_t)(lc[0] | lc[1] | lc[2])) >> L) == 0u;
+      if (clipped)
+        in = in && lc[0] < td[0] && lc[1] < td[1] && lc[2] < td[2];
+      return in;
+    };
     for (;;) {
       const unsigned long long active_mask = __ballot(active);
       const unsigned long long idle_mask = ~active_mask;
@@ -308,26 +339,25 @@ __global__ void __launch_bounds__(FULL ? CMI_TILE_THREADS_FULL
           const double4 *r = reinterpret_cast<const double4 *>(
               a.rows.rows + (size_t)CMI_FLIGHT_DOUBLES * slot);
           const double4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-          p.pos[0] = r0.x;
-          p.pos[1] = r0.y;
-          p.pos[2] = r0.z;
-          p.dir[0] = r0.w;
-          p.dir[1] = r1.x;
-          p.dir[2] = r1.y;
-          p.t = r1.z;
-          p.tmax[0] = r1.w;
-          p.tmax[1] = r2.x;
-          p.tmax[2] = r2.y;
-          p.tau = r2.z;
-          p.nu = r2.w;
-          p.cell = (int32_t)__double_as_longlong(r3.x);
+          pos[0] = r0.x;
+          pos[1] = r0.y;
+          pos[2] = r0.z;
+          dir[0] = r0.w;
+          dir[1] = r1.x;
+          dir[2] = r1.y;
+          nu = r1.z;
           const unsigned long long idmeta =
-              (unsigned long long)__double_as_longlong(r3.y);
+              (unsigned long long)__double_as_longlong(r1.w);
           packet_id = (uint32_t)idmeta;
           lane_meta = (uint32_t)(idmeta >> 32);
-          const uint32_t plc = (uint32_t)__double_as_longlong(r3.z);
-          p.type = (int32_t)(lane_meta >> 28);
-          p.weight = 1.;
+          t = r2.x;
+          tmax[0] = r2.y;
+          tmax[1] = r2.z;
+          tmax[2] = r2.w;
+          tau = r3.x;
+          const uint32_t plc =
+              (uint32_t)((unsigned long long)__double_as_longlong(r3.y) >> 32);
+          type = (int32_t)(lane_meta >> 28);
           if (FULL) {
             const double4 *w = reinterpret_cast<const double4 *>(
                 a.rows.weights + (size_t)CMI_NACC * slot);
@@ -339,239 +369,264 @@ __global__ void __launch_bounds__(FULL ? CMI_TILE_THREADS_FULL
               weights[k + 2] = w4.z;
               weights[k + 3] = w4.w;
             }
-            p.sigma_H = weights[ION_H_n];
-            p.sigma_He = weights[ION_He_n];
-            p.sigma_He_corr = a.model.abundance[0] * p.sigma_He;
+            sigma_H = weights[ION_H_n];
+            sigma_He_corr = a.model.abundance[0] * weights[ION_He_n];
           } else {
-            p.sigma_H = a.model.xsec_fixed[ION_H_n];
-            p.sigma_He = a.model.xsec_fixed[ION_He_n];
-            p.sigma_He_corr = a.model.abundance[0] * p.sigma_He;
-            weights[ION_H_n] = p.sigma_H;
-            weights[CMI_NION] = p.sigma_H * (p.nu - a.model.nu_H);
+            sigma_H = a.model.xsec_fixed[ION_H_n];
+            weights[ION_H_n] = sigma_H;
+            weights[CMI_NION] = sigma_H * (nu - a.model.nu_H);
           }
-          const int32_t stride[3] = {a.grid.ncell[1] * a.grid.ncell[2],
-                                     a.grid.ncell[2], 1};
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax) {
-            p.lc[ax] = (int32_t)((plc >> (8 * ax)) & 0xffu);
-            const bool fwd = p.dir[ax] > 0.;
+            lc[ax] = (int32_t)((plc >> (8 * ax)) & 0xffu);
             /* exactly start_flight()'s expression: the increments must be
              * the same numbers in every tile the flight crosses */
-            p.inv_dir[ax] = 1. / p.dir[ax];
-            p.tdelta[ax] = (p.dir[ax] != 0.)
-                               ? a.grid.cellside[ax] * fabs(p.inv_dir[ax])
-                               : 0.;
-            p.cstep[ax] = fwd ? stride[ax] : -stride[ax];
-            p.lsgn[ax] = fwd ? 1 : -1;
-            const int32_t g = o[ax] + p.lc[ax];
-            p.rem[ax] = fwd ? a.grid.ncell[ax] - 1 - g : g;
+            const double inv_dir = 1. / dir[ax];
+            tdelta[ax] =
+                (dir[ax] != 0.) ? a.grid.cellside[ax] * fabs(inv_dir) : 0.;
+            lsgn[ax] = (dir[ax] > 0.) ? 1 : -1;
           }
           active = true;
-          last_cell = -1;
+          stepped = false;
         }
       }
       const bool avail_after =
           __ballot(*(volatile unsigned int *)&s_next < it.end) != 0ull;
 
-      /* ---- hot loop: march + LDS accumulation ---- */
-      auto in_tile = [&]() {
-        return (((uint32_t)(p.lc[0] | p.lc[1] | p.lc[2])) >> L) == 0u;
-      };
-      double2 kappa_next = make_double2(0., 0.);
-      if (active && p.tau > 0. && !fast_outside(p) && in_tile())
-        kappa_next = fast_load_record(a.cells.opacity, p);
+      /* ---- hot loop: fast_step() of device_transport.h (the same
+       * floating-point operations in the same order) on tile-local
+       * coordinates, records and accumulators in LDS ---- */
+      int32_t lidx = (lc[0] << (2 * L)) | (lc[1] << L) | lc[2];
+      double kx = 0., ky = 0.;
+      if (active && tau > 0. && in_tile()) {
+        kx = opac[lidx];
+        if (FULL)
+          ky = opac[TC + lidx];
+      }
       for (;;) {
-        const bool stepping =
-            active && p.tau > 0. && !fast_outside(p) && in_tile();
+        const bool stepping = active && tau > 0. && in_tile();
         const unsigned long long flying = __ballot(stepping);
         if (flying == 0ull ||
             (avail_after && (int)__popcll(~flying) >= a.refill_threshold))
           break;
         ++nwavesteps;
         if (stepping) {
-          const double2 kappa = kappa_next;
-          last_lidx = (p.lc[0] << (2 * L)) | (p.lc[1] << L) | p.lc[2];
-          const double ds = fast_step<FULL, true>(p, last_cell, kappa);
-          ++nsteps;
-          if (any_periodic && p.tau >= 0.) {
-            /* fast_wrap(), and the flight has left this tile: the last tile
-             * of an axis may be clipped (fewer than T cells), so the tile
-             * coordinate alone would not say so */
+          last_lidx = lidx;
+          stepped = true;
+          const double tmin = min_f64(tmax[0], min_f64(tmax[1], tmax[2]));
+          double ds = tmin - t;
+          const double kH = max_f64(kx, 0.);
+          const double tau_cell = FULL
+                                      ? ds * (sigma_H * kH + sigma_He_corr * ky)
+                                      : ds * (sigma_H * kH);
+          const bool matter = kx >= 0.; /* number density > 0 */
+          tau -= tau_cell;
+          const double t_old = t;
+          t = tmin;
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-              if (a.grid.periodic[ax] && p.rem[ax] < 0) {
-                if (p.cstep[ax] > 0)
-                  p.lc[ax] = T;
-                p.cell -= p.cstep[ax] * a.grid.ncell[ax];
-                p.rem[ax] = a.grid.ncell[ax] - 1;
-                p.pos[ax] -=
-                    (p.cstep[ax] > 0 ? 1. : -1.) * a.grid.box_sides[ax];
-              }
-            }
+          for (int ax = 0; ax < 3; ++ax) {
+            const bool hit = (tmax[ax] == tmin); /* every tied axis advances */
+            tmax[ax] = __fma_rn(hit ? 1. : 0., tdelta[ax], tmax[ax]);
+            lc[ax] += hit ? lsgn[ax] : 0;
           }
-          if (p.tau > 0. && !fast_outside(p) && in_tile())
-            kappa_next = fast_load_record(a.cells.opacity, p);
-          if (kappa.x >= 0.) { /* number density > 0 */
-            const double dsw = ds * p.weight;
+          if (tau < 0.) {
+            ds += ds * tau / tau_cell; /* Scorr */
+            t = t_old + ds;
+          }
+          ++nsteps;
+          lidx = (lc[0] << (2 * L)) | (lc[1] << L) | lc[2];
+          if (tau > 0. && in_tile()) {
+            kx = opac[lidx];
+            if (FULL)
+              ky = opac[TC + lidx];
+          }
+          if (matter) {
             if (FULL) {
 #pragma unroll
               for (int i = 0; i < CMI_NACC; ++i)
                 if (HEAT || i < CMI_NION)
-                  atomicAdd(&acc[i * TC + last_lidx], dsw * weights[i]);
+                  atomicAdd(&acc[i * TC + last_lidx], ds * weights[i]);
             } else {
-              atomicAdd(&acc[last_lidx], dsw * weights[ION_H_n]);
+              atomicAdd(&acc[last_lidx], ds * weights[ION_H_n]);
               if (HEAT)
-                atomicAdd(&acc[TC + last_lidx], dsw * weights[CMI_NION]);
+                atomicAdd(&acc[TC + last_lidx], ds * weights[CMI_NION]);
             }
           }
         }
       }
 
       /* ---- end of the tile visit for every lane that cannot step ---- */
-      if (active) {
-        const bool outside_grid = fast_outside(p);
-        const bool stay = p.tau > 0. && !outside_grid && in_tile();
-        if (!stay) {
-          bool absorbed = false, done = false, moved = false;
-          if (p.tau < 0.) {
-            absorbed = true;
-          } else if (!outside_grid && !(p.tau > 0.)) {
-            /* tau hit 0 exactly on a wall, packet still inside the grid:
-             * interact() returns the last traversed cell */
-            absorbed = last_cell >= 0;
-            done = !absorbed;
-          } else if (outside_grid) {
-            done = true; /* left the grid: DensityGrid::end() ... */
-            if (a.grid.decomposed && last_cell >= 0) {
-              /* ... or only this block of it: hand the flight over */
-              const int64_t cell_global =
-                  exit_cell_global(a.grid, p, last_cell);
-              if (cell_global >= 0) {
-                const unsigned long long leaving = __ballot(true);
-                unsigned int base = 0;
-                const int first = __ffsll((long long)leaving) - 1;
-                if (lane == first)
-                  base = atomicAdd(a.xout.count,
-                                   (unsigned int)__popcll(leaving));
-                base = __shfl(base, first, 64);
-                const unsigned int q = base + __popcll(leaving & lane_lt);
-                if (q < a.xout.capacity) {
-                  double *r = a.xout.rows + (size_t)CMI_FLIGHT_DOUBLES * q;
+      if (active && !(tau > 0. && in_tile())) {
+        /* where the flight is now: coordinates in the engine's grid (one past
+         * a face if it has left it); a periodic axis wraps, and the origin of
+         * the flight shifts by a box side (fast_wrap()) */
+        int32_t g[3];
+        bool outside_grid = false, wrapped = false;
 #pragma unroll
-                  for (int ax = 0; ax < 3; ++ax) {
-                    r[ax] = p.pos[ax];
-                    r[3 + ax] = p.dir[ax];
-                    r[7 + ax] = p.tmax[ax];
-                  }
-                  r[6] = p.t;
-                  r[10] = p.tau;
-                  r[11] = p.nu;
-                  r[12] = __longlong_as_double(cell_global);
-                  r[13] = __longlong_as_double((long long)(
-                      ((unsigned long long)lane_meta << 32) | packet_id));
-                  r[14] = 0.;
-                  r[15] = 0.;
-                }
-                done = false; /* goes on elsewhere: this slot is free */
-              }
+        for (int ax = 0; ax < 3; ++ax) {
+          g[ax] = o[ax] + lc[ax];
+          if (tau >= 0. && (g[ax] < 0 || g[ax] >= a.grid.ncell[ax])) {
+            if (a.grid.periodic[ax]) {
+              pos[ax] -= (g[ax] < 0 ? -1. : 1.) * a.grid.box_sides[ax];
+              g[ax] = g[ax] < 0 ? a.grid.ncell[ax] - 1 : 0;
+              wrapped = true;
+            } else {
+              outside_grid = true;
             }
-          } else {
-            moved = true; /* into another tile of this grid */
           }
-          double *r = a.rows.rows + (size_t)CMI_FLIGHT_DOUBLES * slot;
-          uint32_t key = key_dead;
-          if (moved) {
-            /* the marcher's state at the wall, into the same slot; the
-             * coordinates of the cell being entered (a periodic axis has
-             * already wrapped the long index; the coordinate follows) */
-            int32_t g[3];
-            uint32_t plc = 0;
+        }
+        bool absorbed = false, done = false, moved = false;
+        if (tau < 0.) {
+          absorbed = true;
+        } else if (!outside_grid && !(tau > 0.)) {
+          /* tau hit 0 exactly on a wall, packet still inside the grid:
+           * interact() returns the last traversed cell */
+          absorbed = stepped;
+          done = !absorbed;
+        } else if (outside_grid) {
+          done = true; /* left the grid: DensityGrid::end() ... */
+          if (a.grid.decomposed && stepped) {
+            /* ... or only this block of it: hand the flight over if the cell
+             * it enters exists in the whole grid */
+            bool in_whole = true;
+            int64_t gg[3];
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
-              g[ax] = o[ax] + p.lc[ax];
-              if (g[ax] < 0)
-                g[ax] = a.grid.ncell[ax] - 1;
-              else if (g[ax] >= a.grid.ncell[ax])
-                g[ax] = 0;
-              plc |= (uint32_t)(g[ax] & (T - 1)) << (8 * ax);
+              gg[ax] = (int64_t)g[ax] + a.grid.offset[ax];
+              in_whole &= gg[ax] >= 0 && gg[ax] < a.grid.global_ncell[ax];
             }
-            key = tile_index(a.tiles, g[0] >> L, g[1] >> L, g[2] >> L);
-            if (any_periodic) { /* a wrap shifts the origin of the flight */
-              r[0] = p.pos[0];
-              r[1] = p.pos[1];
-              r[2] = p.pos[2];
+            if (in_whole) {
+              const int64_t cell_global =
+                  (gg[0] * a.grid.global_ncell[1] + gg[1]) *
+                      a.grid.global_ncell[2] +
+                  gg[2];
+              const unsigned long long leaving = __ballot(true);
+              unsigned int base = 0;
+              const int first = __ffsll((long long)leaving) - 1;
+              if (lane == first)
+                base = atomicAdd(a.xout.count, (unsigned int)__popcll(leaving));
+              base = __shfl(base, first, 64);
+              const unsigned int q = base + __popcll(leaving & lane_lt);
+              if (q < a.xout.capacity) {
+                double *r = a.xout.rows + (size_t)CMI_FLIGHT_DOUBLES * q;
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                  r[ax] = pos[ax];
+                  r[3 + ax] = dir[ax];
+                  r[7 + ax] = tmax[ax];
+                }
+                r[6] = t;
+                r[10] = tau;
+                r[11] = nu;
+                r[12] = __longlong_as_double(cell_global);
+                r[13] = __longlong_as_double((long long)(
+                    ((unsigned long long)lane_meta << 32) | packet_id));
+                r[14] = 0.;
+                r[15] = 0.;
+              }
+              done = false; /* goes on elsewhere: this slot is free */
             }
-            r[6] = p.t;
-            r[7] = p.tmax[0];
-            r[8] = p.tmax[1];
-            r[9] = p.tmax[2];
-            r[10] = p.tau;
-            r[12] = __longlong_as_double((long long)p.cell);
-            r[14] = __longlong_as_double((long long)plc);
-          } else if (absorbed) {
-            /* the absorption record, for the interaction kernel of this
-             * round: where, in which cell (frequency, id and random stream
-             * position are in the slot already) */
-            end_flight(p);
-            r[0] = p.pos[0];
-            r[1] = p.pos[1];
-            r[2] = p.pos[2];
-            r[12] = __longlong_as_double((long long)last_cell);
-            key = key_absorbed;
           }
-          a.rows.keys[slot] = key;
-          if (done) {
-            tc0 += (p.type == TYPE_PRIMARY) ? 1u : 0u;
-            tc1 += (p.type == TYPE_DIFFUSE_HI) ? 1u : 0u;
-            tc2 += (p.type == TYPE_DIFFUSE_HeI) ? 1u : 0u;
-            tc3 += (p.type == TYPE_ABSORBED) ? 1u : 0u;
-          }
-          active = false;
+        } else {
+          moved = true; /* into another tile of this grid */
         }
+        double *r = a.rows.rows + (size_t)CMI_FLIGHT_DOUBLES * slot;
+        uint32_t key = key_dead;
+        if (moved) {
+          /* the marcher's state at the wall, into the same slot */
+          uint32_t plc = 0;
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax)
+            plc |= (uint32_t)(g[ax] & (T - 1)) << (8 * ax);
+          key = tile_index(a.tiles, g[0] >> L, g[1] >> L, g[2] >> L);
+          const uint32_t cell =
+              (uint32_t)((g[0] * a.grid.ncell[1] + g[1]) * a.grid.ncell[2] +
+                         g[2]);
+          if (wrapped) {
+            r[0] = pos[0];
+            r[1] = pos[1];
+            r[2] = pos[2];
+          }
+          double4 *r4 = reinterpret_cast<double4 *>(r);
+          r4[2] = make_double4(t, tmax[0], tmax[1], tmax[2]);
+          r4[3] = make_double4(
+              tau,
+              __longlong_as_double(
+                  (long long)(((unsigned long long)plc << 32) | cell)),
+              0., 0.);
+        } else if (absorbed) {
+          /* the absorption record, for the interaction kernel of this round:
+           * where (end_flight()), in which cell, which packet - densely, in
+           * this unit's stretch of the record arrays; the slot keeps its key
+           * until that kernel has decided */
+          const int32_t lx = last_lidx >> (2 * L),
+                        ly = (last_lidx >> L) & (T - 1),
+                        lz = last_lidx & (T - 1);
+          const int32_t cell =
+              ((o[0] + lx) * a.grid.ncell[1] + o[1] + ly) * a.grid.ncell[2] +
+              o[2] + lz;
+          const unsigned int q = it.begin + atomicAdd(&s_nabs, 1u);
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax)
+            a.ended.pos[ax][q] = pos[ax] + t * dir[ax];
+          a.ended.nu[q] = nu;
+          a.ended.cell[q] = cell;
+          a.ended.id[q] = packet_id;
+          a.ended.meta[q] = lane_meta;
+          a.ended_slot[q] = slot;
+        }
+        if (!absorbed)
+          a.rows.keys[slot] = key;
+        if (done) {
+          tc0 += (type == TYPE_PRIMARY) ? 1u : 0u;
+          tc1 += (type == TYPE_DIFFUSE_HI) ? 1u : 0u;
+          tc2 += (type == TYPE_DIFFUSE_HeI) ? 1u : 0u;
+          tc3 += (type == TYPE_ABSORBED) ? 1u : 0u;
+        }
+        active = false;
       }
     }
 
-    /* ---- write the tile back: one full-line atomic per 8 values ---- */
+    /* ---- write the tile back: one full-line atomic per 8 values; hand the
+     * absorbed slots to the interaction kernel ---- */
     __syncthreads();
+    if (threadIdx.x == 0)
+      a.absorbed_count[item] = s_nabs;
     if (FULL) {
       const int i = threadIdx.x & 15;
       if (HEAT || i < CMI_NION) {
         for (int k = threadIdx.x >> 4; k < TC; k += NT / 16) {
-          const int32_t lx = k >> (2 * L), ly = (k >> L) & (T - 1),
-                        lz = k & (T - 1);
-          const int32_t gx = o[0] + lx, gy = o[1] + ly, gz = o[2] + lz;
-          if (gx < a.grid.ncell[0] && gy < a.grid.ncell[1] &&
-              gz < a.grid.ncell[2]) {
-            const double v = acc[i * TC + k];
-            if (v != 0.) {
-              const int64_t cell =
-                  ((int64_t)gx * a.grid.ncell[1] + gy) * a.grid.ncell[2] + gz;
-              atomic_add_f64(acc_at(a.cells, i, cell), v);
-              ++natomics;
-            }
+          const double v = acc[i * TC + k];
+          if (v != 0.) {
+            const int32_t lx = k >> (2 * L), ly = (k >> L) & (T - 1),
+                          lz = k & (T - 1);
+            const int64_t cell =
+                ((int64_t)(o[0] + lx) * a.grid.ncell[1] + o[1] + ly) *
+                    a.grid.ncell[2] +
+                o[2] + lz;
+            atomic_add_f64(acc_at(a.cells, i, cell), v);
+            ++natomics;
           }
         }
       }
     } else {
       for (int k = threadIdx.x; k < TC; k += NT) {
-        const int32_t lx = k >> (2 * L), ly = (k >> L) & (T - 1),
-                      lz = k & (T - 1);
-        const int32_t gx = o[0] + lx, gy = o[1] + ly, gz = o[2] + lz;
-        if (gx < a.grid.ncell[0] && gy < a.grid.ncell[1] &&
-            gz < a.grid.ncell[2]) {
+        const double v = acc[k];
+        const double h = HEAT ? acc[TC + k] : 0.;
+        if (v != 0. || h != 0.) {
+          const int32_t lx = k >> (2 * L), ly = (k >> L) & (T - 1),
+                        lz = k & (T - 1);
           const int64_t cell =
-              ((int64_t)gx * a.grid.ncell[1] + gy) * a.grid.ncell[2] + gz;
-          const double v = acc[k];
+              ((int64_t)(o[0] + lx) * a.grid.ncell[1] + o[1] + ly) *
+                  a.grid.ncell[2] +
+              o[2] + lz;
           if (v != 0.) {
             atomic_add_f64(acc_at(a.cells, ION_H_n, cell), v);
             ++natomics;
           }
-          if (HEAT) {
-            const double h = acc[TC + k];
-            if (h != 0.) {
-              atomic_add_f64(acc_at(a.cells, CMI_NION, cell), h);
-              ++natomics;
-            }
+          if (HEAT && h != 0.) {
+            atomic_add_f64(acc_at(a.cells, CMI_NION, cell), h);
+            ++natomics;
           }
         }
       }

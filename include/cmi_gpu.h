@@ -316,10 +316,27 @@ int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
  *   "reemit_max_passes" (12)  refill threshold of the later passes; a pass
  *                           with fewer packets than this, or the last allowed
  *                           pass, follows re-emissions in place
+ *   "tile_rounds" (1)       with re-emission in passes: the later generations
+ *                           fly in tile rounds - flights wait in slots keyed by
+ *                           the tile (16^3 cells; 8^3 for multi-ion transport)
+ *                           they are about to enter; every round sorts the
+ *                           slots and marches each flight through ONE tile
+ *                           with the tile's transport records and accumulators
+ *                           in LDS (written back with full-line atomics)
+ *                           instead of one memory-side atomic per DDA step
+ *   "tile_min_flights" (100000), "tile_min_per_item" (-1 = auto: 400, or 200
+ *                           for multi-ion transport), "tile_max_rounds" (1000)
+ *                           the rounds end - and passes of the transport
+ *                           kernel take over - once fewer flights than this,
+ *                           or fewer than this per unit of work (<= 4096
+ *                           flights of one tile), are left
+ *   "tile_refill_threshold" (16)  idle lanes of a wave that trigger a refill
+ *                           in the tile kernel
  *   "exact_dda" (0)         march with the reference's per-step arithmetic
  *                           (bit-identical path lengths) instead of the
  *                           incremental marcher (equal up to rounding)
- *   "exp_no_atomics" (0)    EXPERIMENT ONLY (results are wrong): 1 = skip the
+ *   "exp_no_atomics" (0)    EXPERIMENT ONLY, builds with -DCMI_EXPERIMENTS
+ *                           (results are wrong): 1 = skip the
  *                           accumulation; multi-ion kernels: 2 = post
  *                           destinations but skip the walk, 3 = walk without
  *                           the adds, 4 = as 2 without the table look-up,

@@ -313,7 +313,7 @@ def test_decomposed_diffuse_matches_oracle(oracle, blocks, tiles):
         # tiles: the later generations fly in tile rounds inside each block,
         # flights that leave a block from a tile are handed over
         b.engine.set_tuning(reemit_inline_below=64, tile_rounds=tiles,
-                            tile_min_flights=0)
+                            tile_min_flights=0, tile_min_per_item=0)
     for loop in range(3):
         driver.iteration(loop, npacket, 42, update=False)
         sim.reset()
@@ -355,7 +355,7 @@ def test_decomposed_lexington_matches_oracle(oracle, tiles):
                                                 npacket, sim)
     upload_state(dec, backends, sim, ncell)
     for b in backends:
-        b.engine.set_tuning(tile_rounds=tiles, tile_min_flights=0)
+        b.engine.set_tuning(tile_rounds=tiles, tile_min_flights=0, tile_min_per_item=0)
     shape = (ncell,) * 3
     exchanged = 0
     for loop in range(6):

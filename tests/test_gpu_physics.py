@@ -139,9 +139,11 @@ def test_temperature_solve_fixture(oracle):
     dict(reemit_passes=0),
     # later generations in tile rounds, down to the last flight / with a
     # hand-over to the transport kernel / refilling lane by lane
-    dict(tile_rounds=1, tile_min_flights=0),
-    dict(tile_rounds=1, tile_min_flights=700),
-    dict(tile_rounds=1, tile_min_flights=0, tile_refill_threshold=1,
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0),
+    dict(tile_rounds=1, tile_min_flights=700, tile_min_per_item=0),
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=3,
+         reemit_inline_below=0),
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0, tile_refill_threshold=1,
          max_packets_per_launch=25000),
     dict(tile_rounds=0),
     dict(reemit_passes=1, reemit_inline_below=0, reemit_max_passes=3,
@@ -185,7 +187,7 @@ def test_diffuse_stromgren_shoot_matches_oracle(oracle, tuning):
 
 @pytest.mark.parametrize("tuning", [
     dict(),
-    dict(tile_rounds=1, tile_min_flights=0),
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0),
     dict(tile_rounds=0),
 ])
 def test_lexington_iteration_matches_oracle(oracle, tuning):
@@ -348,8 +350,8 @@ def test_lexington_ragged_packet_counts(oracle, npacket):
 
 @pytest.mark.parametrize("tuning", [
     dict(tile_rounds=0),
-    dict(tile_rounds=1, tile_min_flights=0),
-    dict(tile_rounds=1, tile_min_flights=0, exact_dda=1),
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0),
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0, exact_dda=1),
 ])
 def test_periodic_diffuse_shoot_matches_oracle(oracle, tuning):
     """A box that is periodic in x and y (CartesianDensityGrid::is_inside,

@@ -8,18 +8,24 @@ One "step" is one full iteration of the reference's loop
 (src/IonizationSimulation.cpp:359-643) on every rank:
     reset_grid -> shoot `--packets` packets -> [sum all-reduce of the
     accumulators over ranks] -> cell update.
-The grid is first brought to its converged ionization state with untimed
-low-statistics iterations (the cost of a packet depends on how far it travels,
-so a fully ionised start would be a different workload from the one the
-metric is quoted on).
+The grid is first brought to its converged ionization state with the
+reference's own run - 20 iterations from the fully ionised start of
+HomogeneousDensityFunction - which is also what the `whole_run_packets_per_s`
+figure times (N_iter x N_p / sum of the shooting times); the
+headline `value` is the steady-state iteration rate on the converged state
+(the cost of a packet depends on how far it travels).
 
 The default config is the one BASELINE.json quotes the metric on
 (configs[1]: stromgren 256^3, 1e8 packets, H-only). --config selects the other
-single-GPU configs of the scope (configs[2], configs[3]).
+single-GPU configs of the scope (configs[2], configs[3]). The packet count is
+BASELINE.json's (1e8 per iteration; the reference's stromgren*.param files
+themselves say 1e6).
 
 N > 1 is the replicated-grid mode of the reference's MPI path: every rank
-holds the whole grid and shoots `--packets` packets of its own (weak scaling),
-the [16 x ncell] accumulator block is sum-reduced with one RCCL all-reduce.
+holds the whole grid, the accumulators are sum-reduced with one RCCL
+all-reduce. The timed steps are WEAK scaling (every rank shoots `--packets`
+packets, `value` counts all of them); the same line carries a
+`strong_scaling` object: the iteration with `--packets` packets IN TOTAL.
 """
 import argparse
 import json
@@ -32,7 +38,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.        # HBM3E peak 8.0 TB/s (spec)
+N_SIMD = 256 * 4            # 256 CUs x 4 SIMDs
+N_CU = 256
+MAX_CLOCK_GHZ = 2.4
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the 157.3 TFLOP/s fp32 vector rate
 PC = 3.086e16
 LEXINGTON_ABUNDANCES = [0.1, 2.2e-4, 4.e-5, 3.3e-4, 5.e-5, 9.e-6]
 
@@ -46,11 +57,24 @@ CONFIGS = {
     "stromgren_diffuse": dict(
         name="stromgren_diffuse.param", bytes_per_step=16. + 16. * 1,
         diffuse=True, lexington=False, converge_iterations=20,
-        kernel="shoot_kernel<H-only, re-emission passes>"),
+        kernel="shoot_kernel<H-only, fast marcher> (first generation)"),
     "lexington": dict(
         name="lexingtonHII40.param", bytes_per_step=16. + 16. * 16,
-        diffuse=True, lexington=True, converge_iterations=12,
-        kernel="shoot_kernel<14 ions + heating, re-emission passes>"),
+        diffuse=True, lexington=True, converge_iterations=20,
+        kernel="shoot_kernel<14 ions + heating> (first generation)"),
+}
+
+# The CPU baseline (oracle/cmio_transport_fast.c) against the REFERENCE on the
+# same cores: 8-thread Xeon 2.1 GHz of the build container, 64^3, the whole
+# 20-iteration run of each .param file (tools/
+# calibrate_cpu_baseline.py reproduces the port's side).
+CALIBRATION = {
+    "stromgren": dict(port=1.50e6, reference_classic=1.24e6,
+                      reference_task_based=2.79e6),
+    "stromgren_diffuse": dict(port=1.17e6, reference_classic=0.98e6,
+                              reference_task_based=1.84e6),
+    "lexington": dict(port=1.10e6, reference_classic=1.04e6,
+                      reference_task_based=1.52e6),
 }
 
 
@@ -95,9 +119,11 @@ def setup_engine(backend, ncell, cfg, block=None):
                      x)
 
 
-def cpu_baseline(ncell, cfg, engine, seconds=12.):
-    """The oracle's transport loop (OpenMP, all host cores) on a bounded
-    sample of the same workload: the converged state of the GPU run."""
+def cpu_baseline(ncell, config, cfg, engine, seconds=12.):
+    """The CPU form of the transport loop (oracle/cmio_transport_fast.c:
+    the reference's classic organisation - cells as structures, one lock per
+    cell - OpenMP over all host cores) on a bounded sample of the same
+    workload: the converged state of the GPU run."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from cmacionize_amd import engine as E
@@ -111,40 +137,122 @@ def cpu_baseline(ncell, cfg, engine, seconds=12.):
         sim = oracle_lib.stromgren_simulation(ncell, diffuse=cfg["diffuse"],
                                               compact=True)
         sim.x[0][:] = engine.download_field(E.FIELD_IONIC_FRACTION)
-    cores = oracle_lib.num_threads()
-    n = 10000 * cores
-    t0 = time.perf_counter()
-    sim.shoot(42, 1000, 0, n)
-    dt = time.perf_counter() - t0
-    rate = n / dt
-    n2 = int(max(n, min(rate * seconds, 5e7)))
+    # every packet starts in the 8 cells around the star: with many threads
+    # the first steps contend for their cache lines (the reference's classic
+    # path has the same hot spot; its task-based path replicates the source
+    # subgrid instead). Take the thread count that serves the CPU best.
+    all_cores = oracle_lib.num_threads()
+    best = None
+    for threads in sorted(set([all_cores, max(all_cores // 2, 1),
+                               max(all_cores // 4, 1)]), reverse=True):
+        oracle_lib.set_num_threads(threads)
+        n = 10000 * threads
+        sim.reset()
+        t0 = time.perf_counter()
+        sim.shoot_fast(42, 1000, 0, n)
+        rate = n / (time.perf_counter() - t0)
+        if best is None or rate > best[0]:
+            best = (rate, threads)
+    rate, cores = best
+    oracle_lib.set_num_threads(cores)
+    n2 = int(max(20000 * cores, min(rate * seconds, 2e8)))
     sim.reset()
     t0 = time.perf_counter()
-    sim.shoot(42, 1001, 0, n2)
+    sim.shoot_fast(42, 1001, 0, n2)
     dt = time.perf_counter() - t0
+    oracle_lib.set_num_threads(all_cores)
+    cal = CALIBRATION[config]
     return {"value": n2 / dt, "unit": "packets/s", "cores": cores,
             "kind": "port",
+            "host_threads_available": all_cores,
             "sample": "%d packets on the converged %d^3 %s state, transport "
-                      "only, OpenMP C oracle, %.1f s" %
-                      (n2, ncell, cfg["name"], dt)}
+                      "only, %.1f s, at the best of {all, 1/2, 1/4} of the "
+                      "host's threads; the reference's classic loop restated "
+                      "in C (cells as structures, one lock per cell, OpenMP). "
+                      "Calibration against the reference itself, 8 threads, "
+                      "64^3, whole 20-iteration run: this port %.3g, reference "
+                      "classic %.3g, reference task-based %.3g packets/s "
+                      "(port / classic = %.2f)" %
+                      (n2, ncell, cfg["name"], dt, cal["port"],
+                       cal["reference_classic"], cal["reference_task_based"],
+                       cal["port"] / cal["reference_classic"]),
+            "calibration": cal}
+
+
+def roofline(config, ncell, cfg, steps_per_launch, kernel_s, launches,
+             first_generation_ms):
+    """What bounds the dominant kernel, from this run's clocks and the PMC
+    counters of the same kernels (profiles/r02/counters.json, made by
+    tools/pmc_rooflines.py from separate rocprofv3 --pmc passes of this very
+    command; instruction counts per launch are deterministic - same packets)."""
+    out = {
+        "kernel": cfg["kernel"],
+        "bound": None, "achieved": None, "peak": None, "unit": None,
+        "frac": None, "traffic": None,
+        "kernel_avg_ms": first_generation_ms,
+        "dda_steps_per_launch": steps_per_launch,
+    }
+    path = os.path.join(ROOT, "profiles", "r02", "counters.json")
+    if not os.path.exists(path):
+        return out
+    c = json.load(open(path)).get(config)
+    if not c or c.get("ncell") != ncell:
+        return out
+    k = c["dominant"]
+    t = first_generation_ms * 1e-3
+    # candidates: fraction of the unit's capacity the kernel uses
+    cand = {
+        # VALU issue: busy SIMD cycles / (1024 SIMDs x cycles at max clock)
+        "valu-issue": (k["valu_busy_cycles"] / t / 1e9,
+                       N_SIMD * MAX_CLOCK_GHZ, "G SIMD-cycles/s"),
+        # LDS: busy LDS cycles / (256 CUs x cycles)
+        "lds": (k["lds_busy_cycles"] / t / 1e9, N_CU * MAX_CLOCK_GHZ,
+                "G LDS-cycles/s"),
+        # memory-side atomic requests (64-B) against the measured chip rate
+        "atomic-requests": (k["atomic_requests"] / t / 1e9, 23.5,
+                            "G requests/s"),
+        # fabric traffic against HBM peak
+        "hbm": (k["hbm_bytes"] / t / 1e9, HBM_PEAK_GBS, "GB/s"),
+    }
+    bound = max(cand, key=lambda n: cand[n][0] / cand[n][1])
+    achieved, peak, unit = cand[bound]
+    out.update({
+        "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+        "frac": achieved / peak, "traffic": k["hbm_bytes"],
+        "utilization": dict((n, v[0] / v[1]) for n, v in cand.items()),
+        "profiled_kernel_ms": k["kernel_ms"],
+        "profile": "profiles/r02/counters.json",
+        # the algorithmic-byte model of SURVEY 8d, for reference: it exceeds
+        # what the fabric moves because the on-chip aggregation works
+        "algorithmic_GBps": (steps_per_launch * cfg["bytes_per_step"] / t /
+                             1e9),
+        "bytes_per_dda_step_algorithmic": cfg["bytes_per_step"],
+        "bytes_per_dda_step_measured": k["hbm_bytes"] /
+        max(steps_per_launch, 1.),
+    })
+    if "other_kernels" in c:
+        out["other_kernels"] = c["other_kernels"]
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="stromgren", choices=sorted(CONFIGS))
     ap.add_argument("--ncell", type=int, default=256)
     ap.add_argument("--packets", type=float, default=None,
-                    help="packets per rank per step (default 1e8, the "
-                         "number of photons of all three .param files)")
+                    help="packets per rank per step (default 1e8: "
+                         "BASELINE.json's configs)")
     ap.add_argument("--converge-iterations", type=int, default=None)
     ap.add_argument("--converge-packets", type=float, default=None,
                     help="packets per rank of the untimed iterations that "
                          "bring the grid to its converged state (default: "
-                         "--packets, the reference's run)")
+                         "--packets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N > 1: skip the strong-scaling leg")
     ap.add_argument("--decomposition", default="replica",
                     choices=["replica", "domain"],
                     help="N > 1: every rank holds the whole grid and the "
@@ -197,14 +305,11 @@ def main():
                                                DomainIterationDriver,
                                                default_blocks)
         dec = DomainDecomposition((ncell,) * 3, default_blocks(world))
-        # domain mode is STRONG scaling: --packets is the iteration's total.
-        # (All packets start in the one block that holds the source, which
-        # hands 7/8 of them over in the first round: with N x packets that
-        # single hand-over would be N x 7/8 x packets x 128 B.)
+        # domain mode is STRONG scaling: --packets is the iteration's total
         backend = DomainGpuBackend(dec, rank, S["anchor"], S["sides"],
                                    device=local_rank,
                                    track_heating=cfg["lexington"],
-                                   export_capacity=npk + 1024)
+                                   export_capacity=max(npk // 4, 1 << 20))
         setup_engine(backend, ncell, cfg, dec.block(rank))
         driver = DomainIterationDriver(backend, dec, rank, world, dist)
     else:
@@ -232,16 +337,25 @@ def main():
             count = float(t.item())
         return count / float(ncell) ** 3
 
-    # bring the grid to the converged state (untimed); rank 0 follows the
-    # ionized volume fraction for the iterations-to-converge figure
-    # (first iteration after which V(x_H < 0.5) / V_box changes
-    # by less than 1 % between consecutive iterations), at the reference's
-    # packet count
+    # The reference's run, untimed as far as `value` goes: from the fully
+    # ionised start to the converged state. Rank 0 follows the ionized volume
+    # fraction for the iterations-to-converge figure (first
+    # iteration after which V(x_H < 0.5) / V_box changes by less than 1 %
+    # between consecutive iterations) and the shooting times for the
+    # whole-run rate.
     loop = 0
     volume = []
+    whole_run_shoot_ms = 0.
+    whole_run_wall = 0.
+    backend.engine.get_timing(reset=True)
     for _ in range(args.converge_iterations):
+        barrier()
+        t0 = time.perf_counter()
         driver.iteration(loop, int(args.converge_packets) *
                          (1 if domain else world), 42)
+        barrier()
+        whole_run_wall += time.perf_counter() - t0
+        whole_run_shoot_ms += backend.engine.get_timing(reset=True)["shoot_ms"]
         loop += 1
         volume.append(ionized_fraction())
     # (the first iterations of a fully ionized start change little too: what
@@ -255,50 +369,73 @@ def main():
                 last_big = k
         if last_big + 1 < len(volume):
             converged_at = last_big + 2  # 1-based count of iterations run
+
+    def timed(global_packets, steps):
+        nonlocal loop
+        barrier()
+        backend.engine.get_timing(reset=True)
+        nsteps = 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            driver.iteration(loop, global_packets, 42)
+            nsteps += driver.nsteps
+            loop += 1
+        barrier()
+        elapsed = time.perf_counter() - t0
+        launches = backend.engine.get_launch_times()
+        lsteps = backend.engine.get_launch_steps()
+        # (the step counter after each launch; it restarts with every
+        # iteration's reset_grid, so after an iteration's first launch it is
+        # that launch's own step count)
+        launches = [(ms, n, st) for (ms, n), st in zip(launches, lsteps)]
+        timing = backend.engine.get_timing(reset=True)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, nsteps, timing, launches
+
     # replica mode: every rank shoots npk packets, global = npk * world (weak
     # scaling); domain mode: npk packets in total (strong scaling)
     global_packets = npk if domain else npk * world
     for _ in range(args.warmup):
         driver.iteration(loop, global_packets, 42)
         loop += 1
-    barrier()
-    backend.engine.get_timing(reset=True)
-    nsteps_total = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        driver.iteration(loop, global_packets, 42)
-        nsteps_total += driver.nsteps
-        loop += 1
-    barrier()
-    elapsed = time.perf_counter() - t0
-    timing = backend.engine.get_timing(reset=True)
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, nsteps_total, timing, launches = timed(global_packets,
+                                                    args.steps)
+    strong = None
+    if world > 1 and not domain and not args.no_strong:
+        # the same iteration with npk packets IN TOTAL (npk / world per rank)
+        for _ in range(args.warmup):
+            driver.iteration(loop, npk, 42)
+            loop += 1
+        s_elapsed, _, s_timing, _ = timed(npk, args.steps)
+        strong = {"value": float(npk) * args.steps / s_elapsed,
+                  "unit": "packets/s",
+                  "packets_per_iteration_all_gpus": npk,
+                  "ms_per_step": 1e3 * s_elapsed / args.steps,
+                  "transport_ms_per_step": s_timing["shoot_ms"] / args.steps,
+                  "cell_update_ms_per_step": s_timing["update_ms"] /
+                  max(s_timing["update_launches"], 1)}
 
     final_volume = ionized_fraction()
     if rank == 0:
         total_packets = float(global_packets) * args.steps
         value = total_packets / elapsed
         shoot_s = timing["shoot_ms"] * 1e-3
-        # the transport kernel alone (HIP events around each launch on the
-        # engine's stream); shoot_ms also holds the packet ordering kernels
+        # the first-generation transport launch of every iteration: the
+        # launches that started this rank's full packet count
+        mine = npk if not domain else None
+        first_gen = [(ms, st) for ms, n, st in launches
+                     if mine is None or n == mine]
+        first_gen_ms = float(np.mean([f[0] for f in first_gen])) \
+            if first_gen else None
+        first_gen_steps = float(np.mean([f[1] for f in first_gen])) \
+            if first_gen else None
         kernel_s = timing["kernel_ms"] * 1e-3
-        launches = max(timing["kernel_launches"], 1)
-        # DDA steps executed by THIS rank's launches (nsteps is the global sum)
-        steps_per_launch = nsteps_total / world / launches
-        achieved = (steps_per_launch * cfg["bytes_per_step"] /
-                    (kernel_s / launches)) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath)).get(args.config)
-            if tj and tj.get("ncell") == ncell:
-                # bytes per DDA step measured with rocprofv3 --pmc (separate
-                # passes, profiles/README.md), scaled to this launch
-                traffic = (tj["hbm_bytes_per_dda_step"] * steps_per_launch)
+        steps_per_iteration = nsteps_total / world / max(args.steps, 1)
+        conv_packets = float(args.converge_packets) * \
+            (1 if domain else world) * args.converge_iterations
         out = {
             "metric": "photon packets/sec, 256^3 stromgren",
             "value": value,
@@ -317,7 +454,8 @@ def main():
                             "converged ionization state; step = "
                             "reset + shoot + %s + cell update" %
                             (cfg["name"], ncell, npk,
-                             "iteration (all GPUs together)" if domain else "GPU per iteration",
+                             "iteration (all GPUs together)" if domain
+                             else "GPU per iteration",
                              "flight hand-over" if domain else "reduce"),
                 "parallelism": ("domain x%d (one block per GPU, all-to-all "
                                 "of crossing flights)" if domain else
@@ -326,10 +464,24 @@ def main():
             },
             "transport_only_packets_per_s": (float(npk) * args.steps /
                                              shoot_s),
+            "transport_kernels_ms_per_step": 1e3 * kernel_s / args.steps,
+            "transport_launches_per_step": len(launches) / args.steps,
             "dda_steps_per_packet": nsteps_total / total_packets,
             "cell_update_ms_per_step": timing["update_ms"] /
             max(timing["update_launches"], 1),
             "ionized_volume_fraction": final_volume,
+            # SURVEY 8d's metric: the whole run from the ionised start,
+            # N_iter x N_p / sum of the shooting times (and wall clock)
+            "whole_run_packets_per_s": conv_packets /
+            (whole_run_shoot_ms * 1e-3 * (1 if domain else 1)),
+            "whole_run": {
+                "iterations": args.converge_iterations,
+                "packets_per_iteration": args.converge_packets *
+                (1 if domain else world),
+                "shoot_s": whole_run_shoot_ms * 1e-3,
+                "wall_s": whole_run_wall,
+                "end_to_end_packets_per_s": conv_packets / whole_run_wall,
+            },
             "iterations_to_converge": {
                 "value": converged_at,
                 "criterion": "first iteration from which on the ionized "
@@ -339,25 +491,17 @@ def main():
                 (1 if domain else world),
                 "ionized_volume_fraction_by_iteration": volume,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel": cfg["kernel"],
-                "kernel_avg_ms": 1e3 * kernel_s / launches,
-                "kernel_launches": launches,
-                "bytes_per_dda_step": cfg["bytes_per_step"],
-                "dda_steps_per_launch": steps_per_launch,
-            },
+            "roofline": roofline(args.config, ncell, cfg, first_gen_steps,
+                                 kernel_s, len(launches), first_gen_ms),
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if args.config != "stromgren":
             out["metric"] = "photon packets/sec, 256^3 " + args.config
         if not args.no_cpu_baseline and not (domain and world > 1):
             # (needs the whole grid's state on this rank)
-            out["cpu_baseline"] = cpu_baseline(ncell, cfg, backend.engine)
+            out["cpu_baseline"] = cpu_baseline(ncell, args.config, cfg,
+                                               backend.engine)
         if domain:
             out["exchange_rounds_last_step"] = driver.rounds
             out["flights_exchanged_last_step"] = driver.flights_exchanged

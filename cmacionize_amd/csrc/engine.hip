@@ -40,7 +40,7 @@ int fail(int code, const char *fmt, ...) {
   } while (0)
 
 struct EventPair {
-  hipEvent_t start, stop;
+  hipEvent_t start = nullptr, stop = nullptr;
   uint64_t packets = 0; /* flights started by the launch */
 };
 
@@ -135,10 +135,75 @@ struct cmi_gpu_engine {
     int tile_max_rounds = 1000;
   } tune;
 
+  /* device timing (HIP events around launches) is opt-in: set_tuning
+   * ("timing", 1). Events are recycled through a pool; without timing a run
+   * of any length creates none. */
+  bool timing = false;
+  /* with timing: the DDA step counter after every transport launch */
+  unsigned long long *launch_steps = nullptr;
   std::vector<EventPair> shoot_events, update_events, kernel_events;
+  std::vector<EventPair> event_pool;
 };
 
 namespace {
+
+#define CMI_MAX_TIMED_LAUNCHES 65536
+/* start / stop of a timed region on the engine's stream; no-ops unless timing
+ * is on */
+int timer_begin(cmi_gpu_engine *e, EventPair &ev) {
+  ev = EventPair();
+  if (!e->timing)
+    return CMI_GPU_OK;
+  if (!e->event_pool.empty()) {
+    ev = e->event_pool.back();
+    e->event_pool.pop_back();
+  } else {
+    HIP_TRY(hipEventCreate(&ev.start));
+    hipError_t err = hipEventCreate(&ev.stop);
+    if (err != hipSuccess) {
+      (void)hipEventDestroy(ev.start);
+      HIP_TRY(err);
+    }
+  }
+  hipError_t err = hipEventRecord(ev.start, e->stream);
+  if (err != hipSuccess) {
+    e->event_pool.push_back(ev);
+    HIP_TRY(err);
+  }
+  return CMI_GPU_OK;
+}
+
+int timer_end(cmi_gpu_engine *e, std::vector<EventPair> &list, EventPair &ev,
+              uint64_t packets) {
+  if (!ev.start)
+    return CMI_GPU_OK;
+  ev.packets = packets;
+  hipError_t err = hipEventRecord(ev.stop, e->stream);
+  if (err != hipSuccess) {
+    e->event_pool.push_back(ev);
+    HIP_TRY(err);
+  }
+  /* a caller that never reads its timings does not grow without bound */
+  if (list.size() >= CMI_MAX_TIMED_LAUNCHES) {
+    e->event_pool.insert(e->event_pool.end(), list.begin(), list.end());
+    list.clear();
+  }
+  if (&list == &e->kernel_events) {
+    if (!e->launch_steps)
+      HIP_TRY(hipMalloc(&e->launch_steps,
+                        sizeof(unsigned long long) * CMI_MAX_TIMED_LAUNCHES));
+    HIP_TRY(hipMemcpyAsync(e->launch_steps + list.size(), &e->counters->nsteps,
+                           sizeof(unsigned long long),
+                           hipMemcpyDeviceToDevice, e->stream));
+  }
+  list.push_back(ev);
+  return CMI_GPU_OK;
+}
+
+void release_events(cmi_gpu_engine *e, std::vector<EventPair> &list) {
+  e->event_pool.insert(e->event_pool.end(), list.begin(), list.end());
+  list.clear();
+}
 
 double eV_to_Hz(double eV) {
   /* UnitConverter::to_SI<QUANTITY_FREQUENCY>(eV, "eV"),
@@ -634,11 +699,10 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
     return CMI_GPU_OK;
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
-  for (auto &p : e->shoot_events) {
-    (void)hipEventDestroy(p.start);
-    (void)hipEventDestroy(p.stop);
-  }
-  for (auto &p : e->update_events) {
+  release_events(e, e->shoot_events);
+  release_events(e, e->update_events);
+  release_events(e, e->kernel_events);
+  for (auto &p : e->event_pool) {
     (void)hipEventDestroy(p.start);
     (void)hipEventDestroy(p.stop);
   }
@@ -662,6 +726,7 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->import_rows);
   (void)hipFree(e->tile_block);
   (void)hipFree(e->tile_counts);
+  (void)hipFree(e->launch_steps);
   if (e->own_stream)
     (void)hipStreamDestroy(e->stream);
   delete e;
@@ -964,6 +1029,8 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
     e->tune.reemit_inline_below = (uint64_t)(value < 0 ? 0 : value);
   else if (k == "reemit_max_passes")
     e->tune.reemit_max_passes = (int)(value < 1 ? 1 : value);
+  else if (k == "timing")
+    e->timing = value != 0;
   else if (k == "tile_rounds")
     e->tune.tile_rounds = value != 0;
   else if (k == "tile_min_flights")
@@ -1314,9 +1381,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     }
 
     EventPair ev;
-    HIP_TRY(hipEventCreate(&ev.start));
-    HIP_TRY(hipEventCreate(&ev.stop));
-    HIP_TRY(hipEventRecord(ev.start, e->stream));
+    {
+      int trc = timer_begin(e, ev);
+      if (trc)
+        return trc;
+    }
     if (sorted) {
       KeyArgs k;
       k.model = e->model;
@@ -1358,14 +1427,18 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     if (blocks < 1)
       blocks = 1;
     EventPair kev;
-    HIP_TRY(hipEventCreate(&kev.start));
-    HIP_TRY(hipEventCreate(&kev.stop));
-    HIP_TRY(hipEventRecord(kev.start, e->stream));
+    {
+      int trc = timer_begin(e, kev);
+      if (trc)
+        return trc;
+    }
     kernel<<<(unsigned)blocks, CMI_BLOCK, 0, e->stream>>>(a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(kev.stop, e->stream));
-    kev.packets = n;
-    e->kernel_events.push_back(kev);
+    {
+      int trc = timer_end(e, e->kernel_events, kev, n);
+      if (trc)
+        return trc;
+    }
     /* later generations, in tile rounds (tile_kernels.h): the interaction
      * kernel turns the ended flights into flight rows keyed by the tile they
      * start in; every round sorts the rows by tile, flies each flight through
@@ -1511,14 +1584,18 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         if (tb > most)
           tb = most;
         EventPair tev;
-        HIP_TRY(hipEventCreate(&tev.start));
-        HIP_TRY(hipEventCreate(&tev.stop));
-        HIP_TRY(hipEventRecord(tev.start, e->stream));
+        {
+          int trc = timer_begin(e, tev);
+          if (trc)
+            return trc;
+        }
         tkernel<<<(unsigned)tb, tile_threads, 0, e->stream>>>(ta);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(tev.stop, e->stream));
-        tev.packets = nlive;
-        e->kernel_events.push_back(tev);
+        {
+          int trc = timer_end(e, e->kernel_events, tev, nlive);
+          if (trc)
+            return trc;
+        }
         ++e->tile_rounds_run;
         /* the packets absorbed in this round: re-emitted into their slots */
         ia.rows = e->tile_rows[cur];
@@ -1566,15 +1643,19 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       if (nb < 1)
         nb = 1;
       EventPair gev;
-      HIP_TRY(hipEventCreate(&gev.start));
-      HIP_TRY(hipEventCreate(&gev.stop));
-      HIP_TRY(hipEventRecord(gev.start, e->stream));
+      {
+        int trc = timer_begin(e, gev);
+        if (trc)
+          return trc;
+      }
       (last ? kernel_inline : kernel)<<<(unsigned)nb, CMI_BLOCK, 0,
                                         e->stream>>>(b);
       HIP_TRY(hipGetLastError());
-      HIP_TRY(hipEventRecord(gev.stop, e->stream));
-      gev.packets = handover_count;
-      e->kernel_events.push_back(gev);
+      {
+        int trc = timer_end(e, e->kernel_events, gev, handover_count);
+        if (trc)
+          return trc;
+      }
       if (last)
         handover_count = 0;
     }
@@ -1635,21 +1716,28 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       if (nb < 1)
         nb = 1;
       EventPair gev;
-      HIP_TRY(hipEventCreate(&gev.start));
-      HIP_TRY(hipEventCreate(&gev.stop));
-      HIP_TRY(hipEventRecord(gev.start, e->stream));
+      {
+        int trc = timer_begin(e, gev);
+        if (trc)
+          return trc;
+      }
       /* the last pass follows whatever is still re-emitted in place */
       (last ? kernel_inline : kernel)<<<(unsigned)nb, CMI_BLOCK, 0,
                                         e->stream>>>(b);
       HIP_TRY(hipGetLastError());
-      HIP_TRY(hipEventRecord(gev.stop, e->stream));
-      gev.packets = count;
-      e->kernel_events.push_back(gev);
+      {
+        int trc = timer_end(e, e->kernel_events, gev, count);
+        if (trc)
+          return trc;
+      }
       if (last)
         break;
     }
-    HIP_TRY(hipEventRecord(ev.stop, e->stream));
-    e->shoot_events.push_back(ev);
+    {
+      int trc = timer_end(e, e->shoot_events, ev, 0);
+      if (trc)
+        return trc;
+    }
   }
   return CMI_GPU_OK;
 }
@@ -1820,6 +1908,20 @@ int cmi_gpu_get_wave_steps(cmi_gpu_engine *e, uint64_t *nwavesteps) {
 int cmi_gpu_update_cells(cmi_gpu_engine *e, uint32_t loop, double totweight) {
   if (!e)
     return fail(CMI_GPU_EINVAL, "null engine");
+  return cmi_gpu_update_cells_range(e, loop, totweight, 0, e->ncell);
+}
+
+int cmi_gpu_update_cells_range(cmi_gpu_engine *e, uint32_t loop,
+                               double totweight, int64_t first_cell,
+                               int64_t ncell) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  if (first_cell < 0 || ncell < 0 || first_cell + ncell > e->ncell)
+    return fail(CMI_GPU_EINVAL, "update_cells_range: cells [%lld, %lld) are "
+                "not inside the engine's %lld cells", (long long)first_cell,
+                (long long)(first_cell + ncell), (long long)e->ncell);
+  if (ncell == 0)
+    return CMI_GPU_OK;
   if (!e->have_sources || !e->have_recomb || !e->have_cells)
     return fail(CMI_GPU_ESTATE,
                 "cmi_gpu_update_cells: sources, recombination rates and cell "
@@ -1842,12 +1944,16 @@ int cmi_gpu_update_cells(cmi_gpu_engine *e, uint32_t loop, double totweight) {
       e->grid.cellside[0] * e->grid.cellside[1] * e->grid.cellside[2];
   a.jfac = jfac / volume;
   a.hfac = hfac / volume;
+  a.first = first_cell;
+  a.count = ncell;
 
   EventPair ev;
-  HIP_TRY(hipEventCreate(&ev.start));
-  HIP_TRY(hipEventCreate(&ev.stop));
-  HIP_TRY(hipEventRecord(ev.start, e->stream));
-  const int blocks = grid_blocks(e, e->ncell, 8);
+  {
+    int trc = timer_begin(e, ev);
+    if (trc)
+      return trc;
+  }
+  const int blocks = grid_blocks(e, ncell, 8);
   if (solve_temperature)
     temperature_kernel<<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
   else if (e->full_ions)
@@ -1855,9 +1961,19 @@ int cmi_gpu_update_cells(cmi_gpu_engine *e, uint32_t loop, double totweight) {
   else
     ionization_kernel<false><<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ev.stop, e->stream));
-  e->update_events.push_back(ev);
+  {
+    int trc = timer_end(e, e->update_events, ev, 0);
+    if (trc)
+      return trc;
+  }
   return CMI_GPU_OK;
+}
+
+int cmi_gpu_refresh_transport_records(cmi_gpu_engine *e) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  return rebuild_opacity(e);
 }
 
 int cmi_gpu_emit_packets(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
@@ -2122,21 +2238,9 @@ int cmi_gpu_get_timing(cmi_gpu_engine *e, int32_t reset, double *shoot_ms,
   if (update_launches)
     *update_launches = e->update_events.size();
   if (reset) {
-    for (auto &p : e->shoot_events) {
-      (void)hipEventDestroy(p.start);
-      (void)hipEventDestroy(p.stop);
-    }
-    for (auto &p : e->update_events) {
-      (void)hipEventDestroy(p.start);
-      (void)hipEventDestroy(p.stop);
-    }
-    for (auto &p : e->kernel_events) {
-      (void)hipEventDestroy(p.start);
-      (void)hipEventDestroy(p.stop);
-    }
-    e->shoot_events.clear();
-    e->update_events.clear();
-    e->kernel_events.clear();
+    release_events(e, e->shoot_events);
+    release_events(e, e->update_events);
+    release_events(e, e->kernel_events);
   }
   return CMI_GPU_OK;
 }
@@ -2157,6 +2261,20 @@ int cmi_gpu_get_launch_times(cmi_gpu_engine *e, uint64_t capacity,
     if (packets)
       packets[i] = e->kernel_events[i].packets;
   }
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_get_launch_steps(cmi_gpu_engine *e, uint64_t capacity,
+                             uint64_t *steps, uint64_t *count) {
+  if (!e || !count)
+    return fail(CMI_GPU_EINVAL, "get_launch_steps: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *count = e->kernel_events.size();
+  const uint64_t n = *count < capacity ? *count : capacity;
+  if (n && steps)
+    HIP_TRY(hipMemcpy(steps, e->launch_steps, sizeof(uint64_t) * n,
+                      hipMemcpyDeviceToHost));
   return CMI_GPU_OK;
 }
 

@@ -1387,6 +1387,10 @@ struct UpdateArgs {
   CellsDev cells;
   double jfac; /* L / totweight / V_cell */
   double hfac;
+  /* the cells [first, first + count) of the engine's grid (the reference's
+   * MPI path gives every rank a block of cells,
+   * src/IonizationSimulation.cpp:540-618) */
+  int64_t first, count;
 };
 
 /* IonizationStateCalculator::calculate_ionization_state over the grid
@@ -1396,8 +1400,8 @@ template <bool FULL>
 __global__ void __launch_bounds__(CMI_BLOCK)
     ionization_kernel(const UpdateArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-       c < a.grid.ncell_total; c += stride) {
+  for (int64_t c = a.first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       c < a.first + a.count; c += stride) {
     const double ntot = a.cells.number_density[c];
     const double T = a.cells.temperature[c];
     double J[CMI_NION], heating[2], x[CMI_NION];
@@ -1435,8 +1439,8 @@ __global__ void __launch_bounds__(CMI_BLOCK)
 __global__ void __launch_bounds__(CMI_BLOCK, CMI_TEMPERATURE_WAVES)
     temperature_kernel(const UpdateArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-       c < a.grid.ncell_total; c += stride) {
+  for (int64_t c = a.first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       c < a.first + a.count; c += stride) {
     const double ntot = a.cells.number_density[c];
     double T = a.cells.temperature[c];
     double J[CMI_NION], heating[2], x[CMI_NION];

@@ -74,6 +74,8 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_get_export_count", "cmi_gpu_reset_exports",
     "cmi_gpu_shoot_flights", "cmi_gpu_download_exports",
     "cmi_gpu_shoot_flights_host", "cmi_gpu_physics_probe",
+    "cmi_gpu_update_cells_range", "cmi_gpu_refresh_transport_records",
+    "cmi_gpu_get_launch_steps",
 ]
 
 _lib = None
@@ -161,6 +163,12 @@ def load_library():
     L.cmi_gpu_thermal_probe.argtypes = [vp, C.c_int64, C.c_int32, _dp, _dp,
                                         _dp, _dp, _dp, _dp, _dp]
     L.cmi_gpu_physics_probe.argtypes = [vp, C.c_int32, C.c_int64, _dp, _dp]
+    L.cmi_gpu_update_cells_range.argtypes = [vp, C.c_uint32, C.c_double,
+                                             C.c_int64, C.c_int64]
+    L.cmi_gpu_refresh_transport_records.argtypes = [vp]
+    L.cmi_gpu_get_launch_steps.argtypes = [vp, C.c_uint64,
+                                           C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -201,6 +209,9 @@ class GpuEngine:
         self.ncell = tuple(int(n) for n in
                            (sub_ncell if sub_ncell is not None else ncell))
         self.n = int(np.prod(self.ncell))
+        # tests, bench and tools read device timings; the engine records them
+        # only on request
+        self.set_tuning(timing=1)
 
     def _check(self, rc):
         if rc != 0:
@@ -298,6 +309,22 @@ class GpuEngine:
         return self._lib.cmi_gpu_field_device_pointer(self._h, field)
 
     # iteration body -----------------------------------------------------------
+    def field_tensor(self, field):
+        """Zero-copy torch view of a state field ([ncell] doubles on the
+        engine's device) - for collectives on the engine's memory."""
+        import torch
+        ptr = self.field_device_pointer(field)
+        n = self.n
+
+        class _View:
+            __cuda_array_interface__ = {
+                "shape": (n,), "typestr": "<f8", "data": (int(ptr), False),
+                "version": 2}
+        return torch.as_tensor(_View(), device="cuda")
+
+    def refresh_transport_records(self):
+        self._check(self._lib.cmi_gpu_refresh_transport_records(self._h))
+
     def reset_grid(self):
         self._check(self._lib.cmi_gpu_reset_grid(self._h))
 
@@ -331,6 +358,18 @@ class GpuEngine:
             pk.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(n)))
         return list(zip(ms[:n.value].tolist(), pk[:n.value].tolist()))
 
+    def get_launch_steps(self):
+        """The DDA step counter (steps since the last reset_grid) after each
+        transport launch since the last get_timing(reset=True)."""
+        n = C.c_uint64()
+        self._check(self._lib.cmi_gpu_get_launch_steps(self._h, 0, None,
+                                                       C.byref(n)))
+        st = np.zeros(max(n.value, 1), dtype=np.uint64)
+        self._check(self._lib.cmi_gpu_get_launch_steps(
+            self._h, n.value, st.ctypes.data_as(C.POINTER(C.c_uint64)),
+            C.byref(n)))
+        return st[:n.value].tolist()
+
     # decomposed grids ---------------------------------------------------------
     def set_export_buffer(self, device_pointer, capacity):
         self._check(self._lib.cmi_gpu_set_export_buffer(
@@ -356,6 +395,10 @@ class GpuEngine:
 
     def update_cells(self, loop, totweight):
         self._check(self._lib.cmi_gpu_update_cells(self._h, loop, totweight))
+
+    def update_cells_range(self, loop, totweight, first_cell, ncell):
+        self._check(self._lib.cmi_gpu_update_cells_range(
+            self._h, loop, totweight, first_cell, ncell))
 
     def set_tuning(self, **kw):
         for k, v in kw.items():

@@ -31,6 +31,23 @@ STROMGREN = dict(
     alpha_H=4.e-13 * 1.e-6)
 
 
+def _all_gather_blocks(dist, full, first, count, world):
+    """MPICommunicator::gather (src/MPICommunicator.hpp:647-720): every rank
+    contributes cells [first, first + count) of `full` (its block of
+    distribute_packets(ncell, rank, world)), all end up with the whole array.
+    Blocks differ by at most one cell; they travel padded to equal length."""
+    import torch
+    n = full.numel()
+    longest = n // world + (1 if n % world else 0)
+    part = torch.zeros(longest, dtype=full.dtype, device=full.device)
+    part[:count] = full[first:first + count]
+    parts = [torch.empty_like(part) for _ in range(world)]
+    dist.all_gather(parts, part)
+    for r in range(world):
+        f, c = distribute_packets(n, r, world)
+        full[f:f + c] = parts[r][:c]
+
+
 def distribute_packets(n_packets, rank, world):
     """[first, first + count) of rank `rank`: MPICommunicator::distribute /
     distribute_block (src/MPICommunicator.hpp:197-239)."""
@@ -93,14 +110,41 @@ class GpuBackend:
     def update_cells(self, loop, totweight):
         self.engine.update_cells(loop, totweight)
 
+    # sharded cell update (src/IonizationSimulation.cpp:532-618) -------------
+    def sharded_update_pays(self):
+        """Solving 1/P of the cells and gathering T + 14 fractions beats every
+        rank solving all cells only when the solve is expensive: multi-ion
+        runs (the temperature solve is ~9 ns per cell, the gather moves 120 B
+        per cell); the hydrogen-only closed form (0.1 ns per cell) does not."""
+        _, cell_stride = self.engine.accumulator_layout()
+        return cell_stride != 1
+
+    def update_cells_range(self, loop, totweight, first, count):
+        self.engine.update_cells_range(loop, totweight, first, count)
+
+    def state_fields(self):
+        """The fields a cell update writes and the next iteration reads:
+        temperature and the 14 ionic fractions, as torch views of the engine's
+        memory."""
+        from .engine import FIELD_TEMPERATURE, FIELD_IONIC_FRACTION
+        return [self.engine.field_tensor(f) for f in
+                [FIELD_TEMPERATURE] +
+                [FIELD_IONIC_FRACTION + i for i in range(14)]]
+
+    def refresh_transport_records(self):
+        self.engine.refresh_transport_records()
+
     def synchronize(self):
         self.engine.synchronize()
 
 
 class ReplicaIterationDriver:
-    """One iteration = reset -> shoot my share -> sum-reduce -> update."""
+    """One iteration = reset -> shoot my share -> sum-reduce -> update (every
+    rank all cells, or - shard_update - every rank its block of cells followed
+    by a gather of the new state, the reference's MPI scheme)."""
 
-    def __init__(self, backend, rank=0, world=1, dist=None):
+    def __init__(self, backend, rank=0, world=1, dist=None,
+                 shard_update=None):
         self.backend = backend
         self.rank = rank
         self.world = world
@@ -108,6 +152,11 @@ class ReplicaIterationDriver:
         self.totweight = 0.
         self.typecount = np.zeros(4)
         self.nsteps = 0
+        if shard_update is None:
+            pays = getattr(backend, "sharded_update_pays", None)
+            shard_update = bool(pays and pays())
+        self.shard_update = bool(shard_update) and world > 1 and \
+            hasattr(backend, "update_cells_range")
 
     def iteration(self, loop, n_packets, seed):
         b = self.backend
@@ -133,7 +182,23 @@ class ReplicaIterationDriver:
             small = small.cpu().numpy()
             tw, tc, ns = small[0], small[1:5], int(small[5])
         self.totweight, self.typecount, self.nsteps = tw, np.asarray(tc), ns
-        b.update_cells(loop, tw)
+        if not self.shard_update:
+            b.update_cells(loop, tw)
+            return tw
+        # TemperatureCalculator::calculate_temperature on this rank's block of
+        # cells, then MPICommunicator::gather of the temperature and the ionic
+        # fractions (src/IonizationSimulation.cpp:532-618)
+        fields = b.state_fields()
+        first, count = distribute_packets(fields[0].numel(), self.rank,
+                                          self.world)
+        b.update_cells_range(loop, tw, first, count)
+        b.synchronize()
+        for f in fields:
+            _all_gather_blocks(self.dist, f, first, count, self.world)
+        sync = getattr(b, "torch", None)
+        if sync is not None and sync.cuda.is_available():
+            sync.cuda.synchronize()
+        b.refresh_transport_records()
         return tw
 
 

@@ -283,6 +283,22 @@ int cmi_gpu_get_wave_steps(cmi_gpu_engine *engine, uint64_t *nwavesteps);
  * Asynchronous. */
 int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
                          double totweight);
+/* Rebuild the transport records {n x_H, n x_He} of all cells from the state
+ * fields - after number density or the H / He neutral fractions were written
+ * through cmi_gpu_field_device_pointer (e.g. by the gather that follows a
+ * sharded cell update, src/IonizationSimulation.cpp:540-618).
+ * Asynchronous. */
+int cmi_gpu_refresh_transport_records(cmi_gpu_engine *engine);
+
+/* the same for the cells [first_cell, first_cell + ncell) of the engine's
+ * grid only - the `block` argument of
+ * TemperatureCalculator::calculate_temperature: in the reference's MPI path
+ * every rank solves its block of cells and the new state is gathered
+ * (src/IonizationSimulation.cpp:532-618, MPICommunicator::distribute_block,
+ * src/MPICommunicator.hpp:224-239). Asynchronous. */
+int cmi_gpu_update_cells_range(cmi_gpu_engine *engine, uint32_t loop,
+                               double totweight, int64_t first_cell,
+                               int64_t ncell);
 
 /* Performance knobs (no effect on what is computed, only on how):
  *   "sort_packets" (1)      process the packets of a launch in emission-
@@ -332,6 +348,9 @@ int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
  *                           flights of one tile), are left
  *   "tile_refill_threshold" (16)  idle lanes of a wave that trigger a refill
  *                           in the tile kernel
+ *   "timing" (0)            record HIP events around every launch for
+ *                           cmi_gpu_get_timing / _kernel_timing /
+ *                           _launch_times (off: a run creates no events)
  *   "exact_dda" (0)         march with the reference's per-step arithmetic
  *                           (bit-identical path lengths) instead of the
  *                           incremental marcher (equal up to rounding)
@@ -437,6 +456,12 @@ int cmi_gpu_get_kernel_timing(cmi_gpu_engine *engine, double *kernel_ms,
  * entries are written. Synchronous. */
 int cmi_gpu_get_launch_times(cmi_gpu_engine *engine, uint64_t capacity,
                              double *ms, uint64_t *packets, uint64_t *count);
+/* ... and the value of the DDA step counter (cmi_gpu_get_counters' nsteps:
+ * steps since the last cmi_gpu_reset_grid) after each of those launches: the
+ * steps a launch executed are the difference to the entry before. Needs
+ * "timing". Synchronous. */
+int cmi_gpu_get_launch_steps(cmi_gpu_engine *engine, uint64_t capacity,
+                             uint64_t *steps, uint64_t *count);
 
 #ifdef __cplusplus
 }

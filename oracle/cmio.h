@@ -94,6 +94,7 @@ double cmio_rng_uniform(uint32_t seed, uint32_t iteration, uint64_t packet,
                         uint32_t draw);
 
 int cmio_num_threads(void);
+void cmio_set_num_threads(int n);
 
 /* -------------------------------------------------------------- model -- */
 
@@ -238,6 +239,15 @@ void cmio_shoot(const cmio_grid *grid, const cmio_model *model,
                 uint64_t first_packet, uint64_t n_packets, double *totweight,
                 double typecount[CMIO_NTYPE]);
 
+/* The same packets with the same arithmetic, organised like the reference's
+ * classic path (cells as an array of structures, one lock per cell; lock-free
+ * single adds for hydrogen-only runs): the CPU BASELINE of bench.py. Equal to
+ * cmio_shoot up to the order of the additions (cmio_transport_fast.c). */
+void cmio_shoot_fast(const cmio_grid *grid, const cmio_model *model,
+                     cmio_cells *cells, uint32_t seed, uint32_t iteration,
+                     uint64_t first_packet, uint64_t n_packets,
+                     double *totweight, double typecount[CMIO_NTYPE]);
+
 /* Generate packet `packet` (src/PhotonSource.cpp:208-249) - also returns the
  * first optical depth tau = -ln(xi) and the number of draws consumed. */
 void cmio_emit(const cmio_model *model, uint32_t seed, uint32_t iteration,
@@ -328,6 +338,20 @@ void cmio_calculate_temperature(const cmio_grid *grid, const cmio_model *model,
  * temperature solve (src/TemperatureCalculator.cpp:567-931). */
 void cmio_update_cells(const cmio_grid *grid, const cmio_model *model,
                        cmio_cells *cells, uint32_t loop, double totweight);
+
+/* the same three for cells [first, first + count) only: the `block` the
+ * reference's MPI path gives a rank (src/IonizationSimulation.cpp:532-537) */
+void cmio_calculate_ionization_state_range(const cmio_grid *grid,
+                                           const cmio_model *model,
+                                           cmio_cells *cells, double totweight,
+                                           int64_t first, int64_t count);
+void cmio_calculate_temperature_range(const cmio_grid *grid,
+                                      const cmio_model *model,
+                                      cmio_cells *cells, double totweight,
+                                      int64_t first, int64_t count);
+void cmio_update_cells_range(const cmio_grid *grid, const cmio_model *model,
+                             cmio_cells *cells, uint32_t loop,
+                             double totweight, int64_t first, int64_t count);
 
 #ifdef __cplusplus
 }

@@ -65,4 +65,11 @@ double cmio_reemit_frequency(const cmio_model *model, const cmio_photon *photon,
                              double AHe, double T, double xH, double xHe,
                              cmio_rng *rng, int32_t *type);
 
+/* the per-packet pieces of cmio_shoot, for cmio_transport_fast.c: emission
+ * + first optical depth, and PhotonSource::reemit */
+void cmio_emit_stream(const cmio_model *model, cmio_rng *rng,
+                      cmio_photon *photon, double *tau);
+int cmio_reemit_stream(const cmio_model *model, const cmio_cells *cells,
+                       int64_t cell, cmio_photon *photon, cmio_rng *rng);
+
 #endif

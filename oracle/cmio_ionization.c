@@ -261,8 +261,18 @@ void cmio_ionization_state_cell(const cmio_model *model, double jfac,
 void cmio_calculate_ionization_state(const cmio_grid *grid,
                                      const cmio_model *model,
                                      cmio_cells *cells, double totweight) {
-  const int64_t ncell =
-      (int64_t)grid->ncell[0] * grid->ncell[1] * grid->ncell[2];
+  cmio_calculate_ionization_state_range(
+      grid, model, cells, totweight, 0,
+      (int64_t)grid->ncell[0] * grid->ncell[1] * grid->ncell[2]);
+}
+
+/* the `block` argument of
+ * IonizationStateCalculator::calculate_ionization_state
+ * (src/IonizationStateCalculator.cpp:511-530): cells [first, first + count) */
+void cmio_calculate_ionization_state_range(const cmio_grid *grid,
+                                           const cmio_model *model,
+                                           cmio_cells *cells, double totweight,
+                                           int64_t first, int64_t count) {
   const double jfac = model->total_luminosity / totweight;
   const double hfac = jfac * CMIO_PLANCK;
   /* src/CartesianDensityGrid.hpp:98-100 */
@@ -270,7 +280,7 @@ void cmio_calculate_ionization_state(const cmio_grid *grid,
                         (grid->sides[1] / grid->ncell[1]) *
                         (grid->sides[2] / grid->ncell[2]);
 #pragma omp parallel for
-  for (int64_t i = 0; i < ncell; ++i) {
+  for (int64_t i = first; i < first + count; ++i) {
     double J[CMIO_NION], heating[2], x[CMIO_NION];
     for (int ion = 0; ion < CMIO_NION; ++ion)
       J[ion] = cells->mean_intensity[ion][i];

@@ -56,6 +56,15 @@ double cmio_rng_uniform(uint32_t seed, uint32_t iteration, uint64_t packet,
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+void cmio_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0)
+    omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 /* number of OpenMP threads cmio_shoot / cmio_update_cells will use */
 int cmio_num_threads(void) {
 #ifdef _OPENMP

@@ -227,15 +227,24 @@ void cmio_temperature_cell(const cmio_model *model, double jfac, double hfac,
 
 void cmio_calculate_temperature(const cmio_grid *grid, const cmio_model *model,
                                 cmio_cells *cells, double totweight) {
-  const int64_t ncell =
-      (int64_t)grid->ncell[0] * grid->ncell[1] * grid->ncell[2];
+  cmio_calculate_temperature_range(
+      grid, model, cells, totweight, 0,
+      (int64_t)grid->ncell[0] * grid->ncell[1] * grid->ncell[2]);
+}
+
+/* the `block` argument of TemperatureCalculator::calculate_temperature
+ * (src/TemperatureCalculator.cpp:944-970): cells [first, first + count) */
+void cmio_calculate_temperature_range(const cmio_grid *grid,
+                                      const cmio_model *model,
+                                      cmio_cells *cells, double totweight,
+                                      int64_t first, int64_t count) {
   const double jfac = model->total_luminosity / totweight;
   const double hfac = jfac * CMIO_PLANCK;
   const double cellside_z = grid->sides[2] / grid->ncell[2];
   const double volume = (grid->sides[0] / grid->ncell[0]) *
                         (grid->sides[1] / grid->ncell[1]) * cellside_z;
 #pragma omp parallel for schedule(dynamic, 256)
-  for (int64_t i = 0; i < ncell; ++i) {
+  for (int64_t i = first; i < first + count; ++i) {
     double J[CMIO_NION], heating[2], x[CMIO_NION];
     for (int ion = 0; ion < CMIO_NION; ++ion) {
       J[ion] = cells->mean_intensity[ion][i];

@@ -69,6 +69,12 @@ static void random_photon(const cmio_model *model, cmio_rng *rng,
   photon->weight = 1.; /* _discrete_photon_weight */
 }
 
+void cmio_emit_stream(const cmio_model *model, cmio_rng *rng,
+                      cmio_photon *photon, double *tau) {
+  random_photon(model, rng, photon);
+  *tau = -log(cmio_rng_next(rng));
+}
+
 void cmio_emit(const cmio_model *model, uint32_t seed, uint32_t iteration,
                uint64_t packet, cmio_photon *photon, double *tau,
                uint32_t *draws) {
@@ -253,6 +259,11 @@ static int reemit(const cmio_model *model, const cmio_cells *cells,
   set_random_direction(photon, rng);
   set_cross_sections(model, photon, new_frequency);
   return 1;
+}
+
+int cmio_reemit_stream(const cmio_model *model, const cmio_cells *cells,
+                       int64_t cell, cmio_photon *photon, cmio_rng *rng) {
+  return reemit(model, cells, cell, photon, rng);
 }
 
 void cmio_shoot(const cmio_grid *grid, const cmio_model *model,

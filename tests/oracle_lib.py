@@ -104,12 +104,16 @@ def lib():
     L.cmio_shoot.argtypes = [C.POINTER(Grid), C.POINTER(Model),
                              C.POINTER(Cells), C.c_uint32, C.c_uint32,
                              C.c_uint64, C.c_uint64, dp, dp]
+    L.cmio_shoot_fast.argtypes = L.cmio_shoot.argtypes
     L.cmio_emit.argtypes = [C.POINTER(Model), C.c_uint32, C.c_uint32,
                             C.c_uint64, C.POINTER(Photon), dp,
                             C.POINTER(C.c_uint32)]
     L.cmio_reset_grid.argtypes = [C.POINTER(Grid), C.POINTER(Cells)]
     L.cmio_update_cells.argtypes = [C.POINTER(Grid), C.POINTER(Model),
                                     C.POINTER(Cells), C.c_uint32, C.c_double]
+    L.cmio_update_cells_range.argtypes = [C.POINTER(Grid), C.POINTER(Model),
+                                          C.POINTER(Cells), C.c_uint32,
+                                          C.c_double, C.c_int64, C.c_int64]
     L.cmio_wall_intersection.argtypes = [dp, dp, dp, dp, dp,
                                          C.POINTER(C.c_int32), dp, dp]
     L.cmio_ionization_state_hydrogen.restype = C.c_double
@@ -271,9 +275,32 @@ class OracleSimulation:
         self.typecount += tc
         return tw.value, tc
 
+    def shoot_fast(self, seed, iteration, first_packet, n_packets):
+        """cmio_shoot_fast: the CPU-baseline organisation of the same loop
+        (array-of-structures cells, per-cell lock); same tallies up to the
+        order of the additions."""
+        if not self.model.tables and (
+                self.model.spectrum_type == SPECTRUM_PLANCK or
+                self.model.reemit_type == REEMIT_PHYSICAL):
+            self.build_tables()
+        tw = C.c_double(0.)
+        tc = np.zeros(NTYPE)
+        lib().cmio_shoot_fast(C.byref(self.grid), C.byref(self.model),
+                              C.byref(self.cells), seed, iteration,
+                              first_packet, n_packets, C.byref(tw), _ptr(tc))
+        self.totweight += tw.value
+        self.typecount += tc
+        return tw.value, tc
+
     def update(self, loop, totweight):
         lib().cmio_update_cells(C.byref(self.grid), C.byref(self.model),
                                 C.byref(self.cells), loop, totweight)
+
+    def update_range(self, loop, totweight, first, count):
+        """The cell update for cells [first, first + count) only."""
+        lib().cmio_update_cells_range(C.byref(self.grid), C.byref(self.model),
+                                      C.byref(self.cells), loop, totweight,
+                                      first, count)
 
     def run(self, n_packets, n_iterations, seed=42):
         for loop in range(n_iterations):
@@ -286,6 +313,10 @@ class OracleSimulation:
 
 def num_threads():
     return int(lib().cmio_num_threads())
+
+
+def set_num_threads(n):
+    lib().cmio_set_num_threads(int(n))
 
 
 def stromgren_simulation(ncell=64, diffuse=False, compact=False,

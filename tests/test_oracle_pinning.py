@@ -276,3 +276,29 @@ def test_stromgren_oracle_physics(oracle):
     nion = sim.number_density * (1. - sim.x[0])
     recombinations = (nion * nion * 4.e-19 * V).sum()
     assert abs(recombinations / 4.26e49 - 1.) < 0.02
+
+
+def test_fast_shoot_equals_shoot(oracle):
+    """The CPU-baseline organisation of the transport loop (cmio_shoot_fast:
+    array-of-structures cells, one lock per cell, single lock-free adds for
+    hydrogen-only runs) flies the same packets with the same arithmetic: equal
+    tallies up to the order of the additions, for all three benchmark models."""
+    for make, n in ((lambda: oracle.stromgren_simulation(16), 20000),
+                    (lambda: oracle.stromgren_simulation(16, diffuse=True),
+                     20000),
+                    (lambda: oracle.lexington_simulation(12), 8000)):
+        a, b = make(), make()
+        for sim, shoot in ((a, a.shoot), (b, b.shoot_fast)):
+            sim.reset()
+            shoot(7, 3, 11, n)
+        assert a.totweight == b.totweight == n
+        assert np.array_equal(a.typecount, b.typecount)
+        for ion in range(14):
+            ref = np.asarray(a.J[ion])
+            assert np.allclose(np.asarray(b.J[ion]), ref, rtol=1e-12,
+                               atol=1e-15 * max(ref.max(), 1e-300)), ion
+        for k in range(2):
+            ref = np.asarray(a.heating[k])
+            assert np.allclose(np.asarray(b.heating[k]), ref, rtol=1e-12,
+                               atol=1e-15 * max(np.abs(ref).max(), 1e-300))
+        assert np.asarray(a.J[0]).max() > 0.

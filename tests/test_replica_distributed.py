@@ -46,8 +46,23 @@ class OracleBackend:
     def update_cells(self, loop, totweight):
         self.sim.update(loop, totweight)
 
+    # the sharded cell update (src/IonizationSimulation.cpp:532-618)
+    def update_cells_range(self, loop, totweight, first, count):
+        self.sim.update_range(loop, totweight, first, count)
 
-def run_rank(rank, world, port, out_dir):
+    def state_fields(self):
+        import torch
+        return [torch.from_numpy(self.sim.temperature)] + \
+            [torch.from_numpy(self.sim.x[i]) for i in range(14)]
+
+    def refresh_transport_records(self):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+def run_rank(rank, world, port, out_dir, shard=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -57,7 +72,9 @@ def run_rank(rank, world, port, out_dir):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
                             rank=rank, world_size=world)
     backend = OracleBackend(NCELL)
-    driver = ReplicaIterationDriver(backend, rank, world, dist)
+    driver = ReplicaIterationDriver(backend, rank, world, dist,
+                                    shard_update=shard)
+    assert driver.shard_update == shard
     first = None
     for loop in range(NITER):
         tw = driver.iteration(loop, NPACKET, SEED)
@@ -95,12 +112,16 @@ def test_distribute_packets():
             assert nxt == n
 
 
+@pytest.mark.parametrize("shard", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_replica_mode_matches_single_process(world, tmp_path, oracle):
+def test_replica_mode_matches_single_process(world, shard, tmp_path, oracle):
+    """shard: every rank updates its block of cells only and the new state is
+    gathered (the reference's MPI scheme) instead of every rank updating all
+    cells."""
     import torch.multiprocessing as mp
     from cmacionize_amd.simulation import ReplicaIterationDriver
     port = free_port()
-    mp.spawn(run_rank, args=(world, port, str(tmp_path)), nprocs=world,
+    mp.spawn(run_rank, args=(world, port, str(tmp_path), shard), nprocs=world,
              join=True)
     # single process reference
     os.environ["OMP_NUM_THREADS"] = "1"

@@ -125,11 +125,29 @@ struct VernerTermDev {
 };
 #define CMI_VERNER_NTERM_DEV 22
 
-/* radiative recombination fit of a metal ion
- * (src/VernerRecombinationRates.cpp:104-130), rnew[2], rnew[3] pre-inverted */
+/* Recombination rate of one ion as coefficient rows
+ * (src/VernerRecombinationRates.cpp:140-333): the radiative fit
+ *   kind 0: p0 / (tt (tt + 1)^(1 - p1) (1 + sqrt(T p3))^(1 + p1)),
+ *           tt = sqrt(T p2)   (Verner & Ferland 1996; p2, p3 pre-inverted;
+ *           H and He use the same form with their own constants, :165-190)
+ *   kind 1: p0 (T / 1e4 K)^-p1
+ * plus a dielectronic term
+ *   dkind 0: none
+ *   dkind 1: 1e-12 (d0 / t + d1 + d2 t + d3 t^2) t^-1.5 exp(-d4 / t),
+ *            t = T / 1e4 K   (Nussbaumer & Storey 1983, :197-285)
+ *   dkind 2: t^-1.5 sum_k c_k exp(-E_k / t), t = T dunit, dn terms
+ *            (Mazzotta et al. 1998 in eV, Abdel-Naby et al. 2012 in K,
+ *            :288-330)
+ * in cm^3 s^-1 (converted to m^3 s^-1 by the evaluator). */
 struct VernerRecDev {
   double p[4];
+  double d[5];    /* dkind 1 */
+  double dc[6];   /* dkind 2: c_k */
+  double dE[6];   /* dkind 2: E_k */
+  double dunit;   /* dkind 2: t = T * dunit */
   int32_t kind;
+  int32_t dkind;
+  int32_t dn;
   int32_t pad;
 };
 
@@ -167,6 +185,11 @@ struct TablesDev {
   CTFitDev ct_recomb_H[CMI_NION];
   CTFitDev ct_ion_H[CMI_NION];
   CTFitDev ct_recomb_He[CMI_NION];
+  /* the charge transfer processes that enter the balance of each metal ion
+   * (src/IonizationStateCalculator.cpp:323-501): [ion][0] recombination with
+   * H, [1] ionization by H+, [2] recombination with He; kind 0 where the
+   * reference's balance has no such term */
+  CTFitDev metal_ct[CMI_NION][3];
   LineCoolingDev lc;
 };
 

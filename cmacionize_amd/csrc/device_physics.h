@@ -177,139 +177,35 @@ __host__ __device__ inline void cmi_cross_sections_H_He(const ModelDev &m, doubl
 
 /* -------------------------------------------------- recombination rates -- */
 
-/* src/VernerRecombinationRates.cpp:104-130 */
-__device__ inline double verner_rec_fit(const VernerRecDev &r, double T) {
-  if (r.kind == 0) {
-    const double tt = sqrt(T * r.p[2]);
-    return r.p[0] / (tt * pow(tt + 1., 1. - r.p[1]) *
-                     pow(1. + sqrt(T * r.p[3]), 1. + r.p[1]));
-  } else {
-    const double tt = T * 1.e-4;
-    return r.p[0] * pow(tt, -r.p[1]);
-  }
-}
-
 /* RecombinationRates::get_recombination_rate,
- * src/VernerRecombinationRates.cpp:140-333 */
+ * src/VernerRecombinationRates.cpp:140-333, from the coefficient rows of
+ * VernerRecDev: one code path for all 14 ions. */
 __device__ inline double cmi_recombination_rate(const ModelDev &m, int ion,
                                                 double temperature) {
   if (!m.recomb_verner)
     return m.recomb_fixed[ion];
-  const VernerRecDev *rec = m.tables->verner_rec;
-  double rate = 0.;
-  switch (ion) {
-  case ION_H_n: {
-    const double T1 = temperature / 3.148;
-    const double T2 = temperature / 7.036e5;
-    rate = 7.982e-11 / (sqrt(T1) * pow(1. + sqrt(T1), 0.252) *
-                        pow(1. + sqrt(T2), 1.748));
-    break;
+  const VernerRecDev &r = m.tables->verner_rec[ion];
+  double rate;
+  if (r.kind == 0) {
+    const double tt = sqrt(temperature * r.p[2]);
+    rate = r.p[0] / (tt * pow(tt + 1., 1. - r.p[1]) *
+                     pow(1. + sqrt(temperature * r.p[3]), 1. + r.p[1]));
+  } else {
+    rate = r.p[0] * pow(temperature * 1.e-4, -r.p[1]);
   }
-  case ION_He_n: {
-    const double T1 = temperature / 15.54;
-    const double T2 = temperature / 3.676e7;
-    rate = 3.294e-11 / (sqrt(T1) * pow(1. + sqrt(T1), 0.309) *
-                        pow(1. + sqrt(T2), 1.691));
-    break;
-  }
-  case ION_C_p1: {
+  if (r.dkind == 1) {
     const double T4 = temperature * 1.e-4;
     const double T4_inv = 1. / T4;
-    rate = verner_rec_fit(rec[ion], temperature) +
-           1.e-12 *
-               (1.8267 * T4_inv + 4.1012 + 4.8443 * T4 + 0.2261 * T4 * T4) *
-               pow(T4, -1.5) * exp(-0.5960 * T4_inv);
-    break;
-  }
-  case ION_C_p2: {
-    const double T4 = temperature * 1.e-4;
-    const double T4_inv = 1. / T4;
-    rate = verner_rec_fit(rec[ion], temperature) +
-           1.e-12 *
-               (2.3196 * T4_inv + 10.7328 + 6.8830 * T4 - 0.1824 * T4 * T4) *
-               pow(T4, -1.5) * exp(-0.4101 * T4_inv);
-    break;
-  }
-  case ION_N_n: {
-    const double T4 = temperature * 1.e-4;
-    rate = verner_rec_fit(rec[ion], temperature) +
-           1.e-12 * (0.6310 + 0.1990 * T4 - 0.0197 * T4 * T4) *
-               pow(T4, -1.5) * exp(-0.4398 / T4);
-    break;
-  }
-  case ION_N_p1: {
-    const double T4 = temperature * 1.e-4;
-    const double T4_inv = 1. / T4;
-    rate = verner_rec_fit(rec[ion], temperature) +
-           1.e-12 *
-               (0.0320 * T4_inv - 0.6624 + 4.3191 * T4 + 0.0003 * T4 * T4) *
-               pow(T4, -1.5) * exp(-0.5946 * T4_inv);
-    break;
-  }
-  case ION_N_p2: {
-    const double T4 = temperature * 1.e-4;
-    const double T4_inv = 1. / T4;
-    rate = verner_rec_fit(rec[ion], temperature) +
-           1.e-12 *
-               (-0.8806 * T4_inv + 11.2406 + 30.7066 * T4 - 1.1721 * T4 * T4) *
-               pow(T4, -1.5) * exp(-0.6127 * T4_inv);
-    break;
-  }
-  case ION_O_n: {
-    const double T4 = temperature * 1.e-4;
-    const double T4_inv = 1. / T4;
-    rate = verner_rec_fit(rec[ion], temperature) +
-           1.e-12 *
-               (-0.0001 * T4_inv + 0.0001 + 0.0956 * T4 + 0.0193 * T4 * T4) *
-               pow(T4, -1.5) * exp(-0.4106 * T4_inv);
-    break;
-  }
-  case ION_O_p1: {
-    const double T4 = temperature * 1.e-4;
-    const double T4_inv = 1. / T4;
-    rate = verner_rec_fit(rec[ion], temperature) +
-           1.e-12 *
-               (-0.0036 * T4_inv + 0.7519 + 1.5252 * T4 - 0.0838 * T4 * T4) *
-               pow(T4, -1.5) * exp(-0.2769 * T4_inv);
-    break;
-  }
-  case ION_Ne_n:
-    rate = verner_rec_fit(rec[ion], temperature);
-    break;
-  case ION_Ne_p1: {
-    const double T4 = temperature * 1.e-4;
-    const double T4_inv = 1. / T4;
-    rate = verner_rec_fit(rec[ion], temperature) +
-           1.e-12 *
-               (0.0129 * T4_inv - 0.1779 + 0.9353 * T4 - 0.0682 * T4 * T4) *
-               pow(T4, -1.5) * exp(-0.4156 * T4_inv);
-    break;
-  }
-  case ION_S_p1: {
-    const double T_in_eV = temperature / 1.16045221e4;
-    rate = verner_rec_fit(rec[ion], temperature) +
-           1.37e-9 * exp(-14.95 / T_in_eV) * pow(T_in_eV, -1.5);
-    break;
-  }
-  case ION_S_p2: {
-    const double T_in_eV = temperature / 1.16045221e4;
-    const double T_in_eV_inv = 1. / T_in_eV;
-    rate = verner_rec_fit(rec[ion], temperature) +
-           (8.0729e-9 * exp(-17.56 * T_in_eV_inv) +
-            1.1012e-10 * exp(-7.07 * T_in_eV_inv)) *
-               pow(T_in_eV, -1.5);
-    break;
-  }
-  default: { /* ION_S_p3 */
-    const double T_inv = 1. / temperature;
-    rate = verner_rec_fit(rec[ion], temperature) +
-           (5.817e-7 * exp(-362.8 * T_inv) + 1.391e-6 * exp(-1058. * T_inv) +
-            1.123e-5 * exp(-7160. * T_inv) + 1.521e-4 * exp(-3.26e4 * T_inv) +
-            1.875e-3 * exp(-1.235e5 * T_inv) +
-            2.097e-2 * exp(-2.07e5 * T_inv)) *
-               pow(temperature, -1.5);
-    break;
-  }
+    rate += 1.e-12 *
+            (r.d[0] * T4_inv + r.d[1] + r.d[2] * T4 + r.d[3] * T4 * T4) *
+            pow(T4, -1.5) * exp(-r.d[4] * T4_inv);
+  } else if (r.dkind == 2) {
+    const double t = temperature * r.dunit;
+    const double t_inv = 1. / t;
+    double sum = 0.;
+    for (int k = 0; k < r.dn; ++k)
+      sum += r.dc[k] * exp(-r.dE[k] * t_inv);
+    rate += sum * pow(t, -1.5);
   }
   rate *= 1.e-6;
   return fmax(0., rate);
@@ -417,76 +313,75 @@ __device__ inline void cmi_ionization_states_hydrogen_helium(
   }
 }
 
-/* src/IonizationStateCalculator.cpp:323-501; x[2..13] out */
+/* src/IonizationStateCalculator.cpp:323-501; x[2..13] out. The balance of
+ * ion k against the next stage is always
+ *   ratio_k = (j_k + n(H+) CT_ion,k) /
+ *             (n_e alpha_k + n(H0) CT_rec,H,k + n(He0) CT_rec,He,k)
+ * with the charge transfer terms the reference's formula for that ion has
+ * (TablesDev::metal_ct; the others are zero rows): one loop body for the 12
+ * ions instead of 12 + 19 inlined fit evaluations, then the reference's
+ * products and normalisations per element. */
+template <class Integrals>
 __device__ inline void cmi_ionization_states_metals(
-    const ModelDev &m, const double j[12], double ne, double T, double T4,
+    const ModelDev &m, const Integrals &j, double ne, double T, double T4,
     double nh0, double nhe0, double nhp, double x[CMI_NION]) {
   const TablesDev *tb = m.tables;
-  double alpha[CMI_NION];
+  double ratio[12];
+#pragma unroll 1
+  for (int k = 0; k < 12; ++k) {
+    const int ion = ION_C_p1 + k;
+    const double alpha = cmi_recombination_rate(m, ion, T);
+    const double num = j(ion) + nhp * ct_eval(tb->metal_ct[ion][1], T4);
+    const double den = ne * alpha + nh0 * ct_eval(tb->metal_ct[ion][0], T4) +
+                       nhe0 * ct_eval(tb->metal_ct[ion][2], T4);
+    const double r = num / den;
+    /* static indexing keeps ratio[] in registers */
 #pragma unroll
-  for (int ion = ION_C_p1; ion < CMI_NION; ++ion)
-    alpha[ion] = cmi_recombination_rate(m, ion, T);
-#define CTRH(ion) ct_eval(tb->ct_recomb_H[ion], T4)
-#define CTIH(ion) ct_eval(tb->ct_ion_H[ion], T4)
-#define CTRHE(ion) ct_eval(tb->ct_recomb_He[ion], T4)
+    for (int i = 0; i < 12; ++i)
+      if (i == k)
+        ratio[i] = r;
+  }
+#define R(ion) ratio[(ion)-ION_C_p1]
   { /* carbon */
-    const double C21 = j[0] / (ne * alpha[ION_C_p1]);
-    const double C32 = j[1] / (ne * alpha[ION_C_p2] + nh0 * CTRH(ION_C_p2) +
-                               nhe0 * CTRHE(ION_C_p2));
-    const double C31 = C32 * C21;
+    const double C21 = R(ION_C_p1);
+    const double C31 = R(ION_C_p2) * C21;
     const double s = 1. / (1. + C21 + C31);
     x[ION_C_p1] = C21 * s;
     x[ION_C_p2] = C31 * s;
   }
   { /* nitrogen */
-    const double N21 = (j[2] + nhp * CTIH(ION_N_n)) /
-                       (ne * alpha[ION_N_n] + nh0 * CTRH(ION_N_n));
-    const double N32 = j[3] / (ne * alpha[ION_N_p1] + nh0 * CTRH(ION_N_p1) +
-                               nhe0 * CTRHE(ION_N_p1));
-    const double N43 = j[4] / (ne * alpha[ION_N_p2] + nh0 * CTRH(ION_N_p2) +
-                               nhe0 * CTRHE(ION_N_p2));
-    const double N31 = N32 * N21;
-    const double N41 = N43 * N31;
+    const double N21 = R(ION_N_n);
+    const double N31 = R(ION_N_p1) * N21;
+    const double N41 = R(ION_N_p2) * N31;
     const double s = 1. / (1. + N21 + N31 + N41);
     x[ION_N_n] = N21 * s;
     x[ION_N_p1] = N31 * s;
     x[ION_N_p2] = N41 * s;
   }
   { /* oxygen */
-    const double O21 = (j[5] + nhp * CTIH(ION_O_n)) /
-                       (ne * alpha[ION_O_n] + nh0 * CTRH(ION_O_n));
-    const double O32 = j[6] / (ne * alpha[ION_O_p1] + nh0 * CTRH(ION_O_p1) +
-                               nhe0 * CTRHE(ION_O_p1));
-    const double O31 = O32 * O21;
+    const double O21 = R(ION_O_n);
+    const double O31 = R(ION_O_p1) * O21;
     const double s = 1. / (1. + O21 + O31);
     x[ION_O_n] = O21 * s;
     x[ION_O_p1] = O31 * s;
   }
   { /* neon */
-    const double Ne21 = j[7] / (ne * alpha[ION_Ne_n]);
-    const double Ne32 = j[8] / (ne * alpha[ION_Ne_p1] + nh0 * CTRH(ION_Ne_p1) +
-                                nhe0 * CTRHE(ION_Ne_p1));
-    const double Ne31 = Ne32 * Ne21;
+    const double Ne21 = R(ION_Ne_n);
+    const double Ne31 = R(ION_Ne_p1) * Ne21;
     const double s = 1. / (1. + Ne21 + Ne31);
     x[ION_Ne_n] = Ne21 * s;
     x[ION_Ne_p1] = Ne31 * s;
   }
   { /* sulphur */
-    const double S21 = j[9] / (ne * alpha[ION_S_p1] + nh0 * CTRH(ION_S_p1));
-    const double S32 = j[10] / (ne * alpha[ION_S_p2] + nh0 * CTRH(ION_S_p2) +
-                                nhe0 * CTRHE(ION_S_p2));
-    const double S43 = j[11] / (ne * alpha[ION_S_p3] + nh0 * CTRH(ION_S_p3) +
-                                nhe0 * CTRHE(ION_S_p3));
-    const double S31 = S32 * S21;
-    const double S41 = S43 * S31;
+    const double S21 = R(ION_S_p1);
+    const double S31 = R(ION_S_p2) * S21;
+    const double S41 = R(ION_S_p3) * S31;
     const double s = 1. / (1. + S21 + S31 + S41);
     x[ION_S_p1] = S21 * s;
     x[ION_S_p2] = S31 * s;
     x[ION_S_p3] = S41 * s;
   }
-#undef CTRH
-#undef CTIH
-#undef CTRHE
+#undef R
 }
 
 /* IonizationStateCalculator::calculate_ionization_state(jfac, hfac, vars),
@@ -518,12 +413,20 @@ __device__ inline void cmi_ionization_state_cell(const ModelDev &m, double jfac,
     const double nhp = ntot * (1. - h0);
     const double ne = ntot * (1. - h0 + AHe * (1. - he0));
     const double T4 = T * 1.e-4;
-    double jm[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i)
-      jm[i] = jfac * J[ION_C_p1 + i];
     const double nh0 = ntot * h0;
     const double nhe0 = ntot * he0 * AHe;
+    /* normalised mean intensity of an ion, by ion index */
+    struct {
+      const double *J;
+      double jfac;
+      __device__ __forceinline__ double operator()(int ion) const {
+        double v = 0.; /* static indexing: J[] lives in registers */
+#pragma unroll
+        for (int i = ION_C_p1; i < CMI_NION; ++i)
+          v = (i == ion) ? J[i] : v;
+        return jfac * v;
+      }
+    } jm = {J, jfac};
     cmi_ionization_states_metals(m, jm, ne, T, T4, nh0, nhe0, nhp, x);
   } else {
 #pragma unroll

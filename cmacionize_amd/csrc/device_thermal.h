@@ -82,12 +82,21 @@ __device__ __forceinline__ double lc_collision_strength(const double *a,
 
 /* LineCoolingData::get_cooling, src/LineCoolingData.cpp:1767-1847 with
  * compute_level_populations (:1569-1701) and compute_level_population
- * (:1714-1738). abund[13]: NI NII OI OII OIII NeIII SII SIII CII CIII NIII NeII
- * SIV number fractions relative to H. */
+ * (:1714-1738). abund[k * abund_stride], k < 13: NI NII OI OII OIII NeIII SII
+ * SIII CII CIII NIII NeII SIV number fractions relative to H (the stride lets
+ * a kernel keep one such list per thread in LDS instead of 26 registers).
+ *
+ * The rate matrix of a five-level ion is filled transition by transition:
+ * transition (lo, hi) with collision rates down (hi -> lo) and up = down x
+ * Boltzmann factor contributes to four entries; nothing but the matrix, the
+ * right-hand side and five per-level sums is live across the ten transitions
+ * (a first version kept all 20 rates and spilled ~700 registers per lane:
+ * the temperature kernel moved 340 GB of scratch per 256^3 update). The sums
+ * run in a different order than the reference's sumC (same terms). */
 __device__ inline double line_cooling(const LineCoolingDev &lc,
                                       double temperature,
                                       double electron_density,
-                                      const double abund[13]) {
+                                      const double *abund, int abund_stride) {
   if (electron_density == 0.)
     return 1.e-99;
   const double kb = CMI_BOLTZMANN;
@@ -96,42 +105,44 @@ __device__ inline double line_cooling(const LineCoolingDev &lc,
   const double logT = log(temperature);
 
   double cooling = 0.;
+  /* (one loop body for the ten ions: unrolled, the ~300 exp() expansions of a
+   * balance evaluation alone are 90 KB of code - with three evaluations per
+   * secant step inlined the solve was 286 KB and ran out of the instruction
+   * cache) */
+#pragma unroll 1
   for (int e = 0; e < CMI_LC_NFIVE_DEV; ++e) {
-    double down[CMI_LC_NTRANS_DEV], up[CMI_LC_NTRANS_DEV];
-#pragma unroll
-    for (int t = 0; t < CMI_LC_NTRANS_DEV; ++t) {
-      const double cs =
-          lc_collision_strength(lc.cs[e][t], prefactor, temperature, Tinv, logT);
-      down[t] = cs;
-      up[t] = cs * exp(-lc.energy[e][t] * Tinv);
-    }
     const double *A = lc.A[e];
     const double *w = lc.inv_weight[e];
     double M[5][5];
     double pop[5] = {1., 0., 0., 0., 0.};
+    double sumC[5] = {0., 0., 0., 0., 0.}; /* collisions out of each level */
+#pragma unroll
+    for (int lo = 0; lo < 4; ++lo) {
+#pragma unroll
+      for (int hi = lo + 1; hi < 5; ++hi) {
+        const int t = lc_tr(lo, hi);
+        const double down = lc_collision_strength(lc.cs[e][t], prefactor,
+                                                  temperature, Tinv, logT);
+        const double up = down * exp(-lc.energy[e][t] * Tinv);
+        /* level hi is fed from lo, level lo from hi (row 0 is replaced by
+         * the normalisation below) */
+        M[hi][lo] = up * w[lo];
+        if (lo > 0)
+          M[lo][hi] = A[t] + w[hi] * down;
+        sumC[hi] += down;
+        sumC[lo] += up;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 5; ++k)
       M[0][k] = 1.; /* populations sum to 1 */
 #pragma unroll
     for (int i = 1; i < 5; ++i) {
-#pragma unroll
-      for (int j = 0; j < i; ++j)
-        M[i][j] = up[lc_tr(j, i)] * w[j];
       double sumA = A[lc_tr(0, i)];
 #pragma unroll
       for (int j = 1; j < i; ++j)
         sumA += A[lc_tr(j, i)];
-      double sumC = down[lc_tr(0, i)];
-#pragma unroll
-      for (int j = 1; j < i; ++j)
-        sumC += down[lc_tr(j, i)];
-#pragma unroll
-      for (int k = i + 1; k < 5; ++k)
-        sumC += up[lc_tr(i, k)];
-      M[i][i] = -(sumA + w[i] * sumC);
-#pragma unroll
-      for (int k = i + 1; k < 5; ++k)
-        M[i][k] = A[lc_tr(i, k)] + w[k] * down[lc_tr(i, k)];
+      M[i][i] = -(sumA + w[i] * sumC[i]);
     }
     /* a singular matrix aborts the reference (cmac_error); here the ion then
      * contributes the populations of the unsolved right-hand side */
@@ -147,9 +158,9 @@ __device__ inline double line_cooling(const LineCoolingDev &lc,
         s += A[lc_tr(j, i)] * E[lc_tr(j, i)];
       cl[i] = pop[i] * s;
     }
-    cooling += abund[e] * kb * (cl[1] + cl[2] + cl[3] + cl[4]);
+    cooling += abund[e * abund_stride] * kb * (cl[1] + cl[2] + cl[3] + cl[4]);
   }
-#pragma unroll
+#pragma unroll 1
   for (int i = 0; i < CMI_LC_NTWO_DEV; ++i) {
     const double ksi = lc.two_energy[i];
     const double cs = lc_collision_strength(lc.two_cs[i], prefactor,
@@ -159,18 +170,32 @@ __device__ inline double line_cooling(const LineCoolingDev &lc,
         cs * Texp * lc.two_inv_weight[i][0] /
         (lc.two_A[i] +
          cs * (lc.two_inv_weight[i][1] + Texp * lc.two_inv_weight[i][0]));
-    cooling += abund[CMI_LC_NFIVE_DEV + i] * kb * ksi * lc.two_A[i] * pop;
+    cooling += abund[(CMI_LC_NFIVE_DEV + i) * abund_stride] * kb * ksi *
+               lc.two_A[i] * pop;
   }
   return cooling;
 }
 
+/* the integrals of a cell as the solve reads them: J[k * stride], normalised
+ * on the fly (14 registers less than a normalised copy) */
+struct CellIntegrals {
+  const double *J;
+  int64_t stride;
+  double jfac;
+  __device__ __forceinline__ double operator()(int ion) const {
+    return jfac * J[ion * stride];
+  }
+};
+
 /* TemperatureCalculator::compute_cooling_and_heating_balance,
- * src/TemperatureCalculator.cpp:207-501. j[14], h[2] normalised integrals;
- * x[2..13] receive the metal fractions at temperature T. */
+ * src/TemperatureCalculator.cpp:207-501. j: normalised mean intensities,
+ * h[2]: normalised heating terms; x[2..13] receive the metal fractions at
+ * temperature T; abund / abund_stride: 13 doubles of work space
+ * (line_cooling). */
 __device__ inline void cooling_and_heating_balance(
     const ModelDev &m, double &h0, double &he0, double &gain, double &loss,
-    double T, double n, double midpoint_z, const double j[CMI_NION],
-    const double h[2], double x[CMI_NION]) {
+    double T, double n, double midpoint_z, const CellIntegrals &j,
+    const double h[2], double x[CMI_NION], double *abund, int abund_stride) {
   enum { NI = 0, NII, OI, OII, OIII, NeIII, SII, SIII, CII, CIII, NIII, NeII,
          SIV };
   const double alphaH = cmi_recombination_rate(m, ION_H_n, T);
@@ -180,8 +205,8 @@ __device__ inline void cooling_and_heating_balance(
   const double logT = log(T);
   const double AHe = m.abundance[0];
 
-  cmi_ionization_states_hydrogen_helium(alphaH, alphaHe, j[ION_H_n],
-                                        j[ION_He_n], n, AHe, T, h0, he0);
+  cmi_ionization_states_hydrogen_helium(alphaH, alphaHe, j(ION_H_n),
+                                        j(ION_He_n), n, AHe, T, h0, he0);
   const double ne = n * (1. - h0 + AHe * (1. - he0));
   const double nhp = n * (1. - h0);
   const double nhep = (1. - he0) * n * AHe;
@@ -203,26 +228,27 @@ __device__ inline void cooling_and_heating_balance(
 
   const double nh0 = n * h0;
   const double nhe0 = n * he0 * AHe;
-  cmi_ionization_states_metals(m, &j[2], ne, T, T4, nh0, nhe0, nhp, x);
+  cmi_ionization_states_metals(m, j, ne, T, T4, nh0, nhe0, nhp, x);
 
   const double AC = m.abundance[1], AN = m.abundance[2], AO = m.abundance[3],
                ANe = m.abundance[4], AS = m.abundance[5];
-  double abund[13];
-  abund[CII] = AC * (1. - x[ION_C_p1] - x[ION_C_p2]);
-  abund[CIII] = AC * x[ION_C_p1];
-  abund[NI] = AN * (1. - x[ION_N_n] - x[ION_N_p1] - x[ION_N_p2]);
-  abund[NII] = AN * x[ION_N_n];
-  abund[NIII] = AN * x[ION_N_p1];
-  abund[OI] = AO * (1. - x[ION_O_n] - x[ION_O_p1]);
-  abund[OII] = AO * x[ION_O_n];
-  abund[OIII] = AO * x[ION_O_p1];
-  abund[NeII] = ANe * x[ION_Ne_n];
-  abund[NeIII] = ANe * x[ION_Ne_p1];
-  abund[SII] = AS * (1. - x[ION_S_p1] - x[ION_S_p2] - x[ION_S_p3]);
-  abund[SIII] = AS * x[ION_S_p1];
-  abund[SIV] = AS * x[ION_S_p2];
+#define AB(k) abund[(k)*abund_stride]
+  AB(CII) = AC * (1. - x[ION_C_p1] - x[ION_C_p2]);
+  AB(CIII) = AC * x[ION_C_p1];
+  AB(NI) = AN * (1. - x[ION_N_n] - x[ION_N_p1] - x[ION_N_p2]);
+  AB(NII) = AN * x[ION_N_n];
+  AB(NIII) = AN * x[ION_N_p1];
+  AB(OI) = AO * (1. - x[ION_O_n] - x[ION_O_p1]);
+  AB(OII) = AO * x[ION_O_n];
+  AB(OIII) = AO * x[ION_O_p1];
+  AB(NeII) = ANe * x[ION_Ne_n];
+  AB(NeIII) = ANe * x[ION_Ne_p1];
+  AB(SII) = AS * (1. - x[ION_S_p1] - x[ION_S_p2] - x[ION_S_p3]);
+  AB(SIII) = AS * x[ION_S_p1];
+  AB(SIV) = AS * x[ION_S_p2];
+#undef AB
 
-  loss = line_cooling(m.tables->lc, T, ne, abund) * n;
+  loss = line_cooling(m.tables->lc, T, ne, abund, abund_stride) * n;
   const double c = 5.5 - logT;
   const double gff = 1.1 + 0.34 * exp(-c * c / 3.);
   loss += 1.42e-40 * gff * sqrtT * (nenhp + nenhep);
@@ -235,20 +261,31 @@ __device__ inline void cooling_and_heating_balance(
 }
 
 /* TemperatureCalculator::calculate_temperature(vars, jfac, hfac, midpoint),
- * src/TemperatureCalculator.cpp:567-931. J[14], heating[2] un-normalised;
- * temperature in/out; x[14] in/out. */
-__device__ inline void temperature_cell(const ModelDev &m, double jfac,
-                                        double hfac, double ntot,
-                                        double midpoint_z, double &temperature,
-                                        const double J[CMI_NION],
-                                        double heating[2],
-                                        double x[CMI_NION]) {
-  const double jH = jfac * J[ION_H_n];
-  const double jHe = jfac * J[ION_He_n];
+ * src/TemperatureCalculator.cpp:567-931, in three pieces so that a kernel can
+ * interleave the secant steps of different cells (temperature_kernel): the
+ * state of one cell's solve between two steps ... */
+struct TemperatureSolve {
+  double T0, gain0, loss0, h0, he0;
+  double Tlast; /* temperature of the last balance evaluation */
+  double h[2];  /* normalised heating terms */
+  int32_t niter;
+};
+
+/* ... its start (:567-640): returns false for a cell that needs no solve (no
+ * radiation, vacuum, or too neutral for cosmic ray heating: 500 K, H and He
+ * neutral, all metal fractions - including N0, O0, Ne0 - zero; the outputs
+ * are then final) ... */
+__device__ inline bool temperature_begin(const ModelDev &m,
+                                         const CellIntegrals &j, double hfac,
+                                         double ntot, double &temperature,
+                                         double heating[2],
+                                         double x[CMI_NION],
+                                         TemperatureSolve &s) {
+  const double jH = j(ION_H_n);
+  const double jHe = j(ION_He_n);
   bool neutral = (jH == 0. && jHe == 0.) || ntot == 0.;
-  const double crfac = m.crfac;
-  double h0 = 0., he0 = 0.;
-  if (!neutral && crfac > 0.) {
+  if (!neutral && m.crfac > 0.) {
+    double h0, he0;
     const double alphaH = cmi_recombination_rate(m, ION_H_n, 8000.);
     const double alphaHe = cmi_recombination_rate(m, ION_He_n, 8000.);
     cmi_ionization_states_hydrogen_helium(alphaH, alphaHe, jH, jHe, ntot,
@@ -256,8 +293,6 @@ __device__ inline void temperature_cell(const ModelDev &m, double jfac,
     neutral = h0 > m.crlim;
   }
   if (neutral) {
-    /* no radiation, vacuum, or too neutral for cosmic ray heating: 500 K,
-     * H and He neutral, all metal fractions (including N0, O0, Ne0) zero */
     temperature = 500.;
 #pragma unroll
     for (int i = 0; i < CMI_NION; ++i)
@@ -266,71 +301,116 @@ __device__ inline void temperature_cell(const ModelDev &m, double jfac,
     x[ION_He_n] = 1.;
     heating[0] = 0.;
     heating[1] = 0.;
-    return;
+    return false;
   }
+  s.T0 = (temperature <= 4000.) ? 8000. : temperature;
+  s.Tlast = s.T0;
+  s.h[0] = hfac * heating[0];
+  s.h[1] = hfac * heating[1];
+  s.niter = 0;
+  s.gain0 = 1.;
+  s.loss0 = 0.;
+  s.h0 = 0.;
+  s.he0 = 0.;
+  return true;
+}
 
-  double T0 = temperature;
-  if (temperature <= 4000.)
-    T0 = 8000.;
-  double j[CMI_NION];
-#pragma unroll
-  for (int i = 0; i < CMI_NION; ++i)
-    j[i] = jfac * J[i];
-  double h[2] = {hfac * heating[0], hfac * heating[1]};
+/* ... the loop condition (:652-653) ... */
+__device__ __forceinline__ bool temperature_goes_on(const ModelDev &m,
+                                                    const TemperatureSolve &s) {
+  return fabs(s.gain0 - s.loss0) > m.t_epsilon * s.gain0 &&
+         s.niter < m.t_max_iterations;
+}
 
-  int niter = 0;
-  double gain0 = 1., loss0 = 0.;
-  h0 = 0.;
-  he0 = 0.;
+/* ... one secant step (:654-745): the three balance evaluations - at 1.1 T0,
+ * 0.9 T0 and T0, in the reference's order - as three trips of one loop body
+ * ... */
+__device__ inline void temperature_step(const ModelDev &m, double ntot,
+                                        double midpoint_z,
+                                        const CellIntegrals &j,
+                                        TemperatureSolve &s, double *abund,
+                                        int abund_stride) {
   const double logtt = log(1.1 / 0.9);
-  while (fabs(gain0 - loss0) > m.t_epsilon * gain0 &&
-         niter < m.t_max_iterations) {
-    ++niter;
-    const double T1 = 1.1 * T0;
-    double h01, he01, gain1, loss1;
-    cooling_and_heating_balance(m, h01, he01, gain1, loss1, T1, ntot,
-                                midpoint_z, j, h, x);
-    const double T2 = 0.9 * T0;
-    double h02, he02, gain2, loss2;
-    cooling_and_heating_balance(m, h02, he02, gain2, loss2, T2, ntot,
-                                midpoint_z, j, h, x);
-    cooling_and_heating_balance(m, h0, he0, gain0, loss0, T0, ntot, midpoint_z,
-                                j, h, x);
-    double expgain;
-    if (gain2 > 0.)
-      expgain = (gain1 > 0.) ? log(gain1 / gain2) : -99.;
-    else
-      expgain = (gain1 > 0.) ? 99. : 0.;
-    double exploss;
-    if (loss2 > 0.)
-      exploss = (loss1 > 0.) ? log(loss1 / loss2) : -99.;
-    else
-      exploss = (loss1 > 0.) ? 99. : 0.;
-    const double expdiff = expgain - exploss;
-    if (gain0 > 0. && expdiff != 0.)
-      T0 *= pow(loss0 / gain0, logtt / expdiff);
-    else
-      T0 = T1;
-    if (T0 < m.t_min_ionized) {
-      T0 = 500.;
-      h0 = 1.;
-      he0 = 1.;
-      gain0 = 1.;
-      loss0 = 1.;
-    }
-    if (T0 > 1.e10) {
-      T0 = 1.e10;
-      h0 = 1.e-10;
-      he0 = 1.e-10;
-      gain0 = 1.;
-      loss0 = 1.;
+  ++s.niter;
+  const double T0 = s.T0;
+  const double T1 = 1.1 * T0;
+  s.Tlast = T0;
+  double gain1 = 0., loss1 = 0., gain2 = 0., loss2 = 0.;
+#pragma unroll 1
+  for (int k = 0; k < 3; ++k) {
+    const double Tk = (k == 0) ? T1 : ((k == 1) ? 0.9 * T0 : T0);
+    double h0k, he0k, gaink, lossk;
+    double x[CMI_NION]; /* the metal fractions at Tk: only feed the cooling */
+    cooling_and_heating_balance(m, h0k, he0k, gaink, lossk, Tk, ntot,
+                                midpoint_z, j, s.h, x, abund, abund_stride);
+    if (k == 0) {
+      gain1 = gaink;
+      loss1 = lossk;
+    } else if (k == 1) {
+      gain2 = gaink;
+      loss2 = lossk;
+    } else {
+      s.h0 = h0k;
+      s.he0 = he0k;
+      s.gain0 = gaink;
+      s.loss0 = lossk;
     }
   }
-  T0 = fmin(30000., T0);
-  temperature = T0;
-  if (J[ION_H_n] == 0.)
+  double expgain;
+  if (gain2 > 0.)
+    expgain = (gain1 > 0.) ? log(gain1 / gain2) : -99.;
+  else
+    expgain = (gain1 > 0.) ? 99. : 0.;
+  double exploss;
+  if (loss2 > 0.)
+    exploss = (loss1 > 0.) ? log(loss1 / loss2) : -99.;
+  else
+    exploss = (loss1 > 0.) ? 99. : 0.;
+  const double expdiff = expgain - exploss;
+  if (s.gain0 > 0. && expdiff != 0.)
+    s.T0 = T0 * pow(s.loss0 / s.gain0, logtt / expdiff);
+  else
+    s.T0 = T1;
+  if (s.T0 < m.t_min_ionized) {
+    s.T0 = 500.;
+    s.h0 = 1.;
+    s.he0 = 1.;
+    s.gain0 = 1.;
+    s.loss0 = 1.;
+  }
+  if (s.T0 > 1.e10) {
+    s.T0 = 1.e10;
+    s.h0 = 1.e-10;
+    s.he0 = 1.e-10;
+    s.gain0 = 1.;
+    s.loss0 = 1.;
+  }
+}
+
+/* ... and its end (:747-931). The reference leaves in the cell the metal
+ * fractions of the LAST balance evaluation (at Tlast, with that evaluation's
+ * h0, he0); they are evaluated here, once, from the same inputs by the same
+ * code instead of being carried through every step. */
+__device__ inline void temperature_end(const ModelDev &m, double ntot,
+                                       const CellIntegrals &j,
+                                       const TemperatureSolve &s,
+                                       double &temperature, double heating[2],
+                                       double x[CMI_NION]) {
+  temperature = fmin(30000., s.T0);
+  double h0 = s.h0, he0 = s.he0;
+  const bool clamped = (h0 == 1. || h0 <= 1.e-10); /* T out of range */
+  if (!clamped && s.niter > 0) {
+    const double AHe = m.abundance[0];
+    const double ne = ntot * (1. - h0 + AHe * (1. - he0));
+    const double nhp = ntot * (1. - h0);
+    const double nh0 = ntot * h0;
+    const double nhe0 = ntot * he0 * AHe;
+    cmi_ionization_states_metals(m, j, ne, s.Tlast, s.Tlast * 1.e-4, nh0, nhe0,
+                                 nhp, x);
+  }
+  if (j.J[ION_H_n * j.stride] == 0.)
     h0 = 1.;
-  if (J[ION_He_n] == 0.)
+  if (j.J[ION_He_n * j.stride] == 0.)
     he0 = 1.;
   x[ION_H_n] = h0;
   x[ION_He_n] = he0;
@@ -339,8 +419,26 @@ __device__ inline void temperature_cell(const ModelDev &m, double jfac,
     for (int i = ION_C_p1; i < CMI_NION; ++i)
       x[i] = 0.;
   }
-  heating[0] = h[0];
-  heating[1] = h[1];
+  heating[0] = s.h[0];
+  heating[1] = s.h[1];
+}
+
+/* one cell from start to end. J: un-normalised integrals (J.jfac normalises
+ * them), heating[2] un-normalised in, normalised out; temperature in/out;
+ * x[14] in (kept if no iteration runs) / out. */
+__device__ inline void temperature_cell(const ModelDev &m,
+                                        const CellIntegrals &J, double hfac,
+                                        double ntot, double midpoint_z,
+                                        double &temperature,
+                                        double heating[2],
+                                        double x[CMI_NION]) {
+  TemperatureSolve s;
+  double abund[13];
+  if (!temperature_begin(m, J, hfac, ntot, temperature, heating, x, s))
+    return;
+  while (temperature_goes_on(m, s))
+    temperature_step(m, ntot, midpoint_z, J, s, abund, 1);
+  temperature_end(m, ntot, J, s, temperature, heating, x);
 }
 
 #endif

@@ -268,6 +268,62 @@ void build_tables(TablesDev &t) {
     d.p[2] = (raw.kind == 0 && raw.p[2] != 0.) ? 1. / raw.p[2] : raw.p[2];
     d.p[3] = (raw.kind == 0 && raw.p[3] != 0.) ? 1. / raw.p[3] : raw.p[3];
   }
+  /* hydrogen and helium: the same fit with their own constants, :165-190 */
+  {
+    VernerRecDev &h = t.verner_rec[ION_H_n];
+    h.kind = 0;
+    h.p[0] = 7.982e-11;
+    h.p[1] = 0.748;
+    h.p[2] = 1. / 3.148;
+    h.p[3] = 1. / 7.036e5;
+    VernerRecDev &he = t.verner_rec[ION_He_n];
+    he.kind = 0;
+    he.p[0] = 3.294e-11;
+    he.p[1] = 0.691;
+    he.p[2] = 1. / 15.54;
+    he.p[3] = 1. / 3.676e7;
+  }
+  /* dielectronic terms: Nussbaumer & Storey (1983) rows {a/t, 1, t, t^2,
+   * exponent}, :197-285 */
+  auto ns = [&t](int ion, double a, double b, double c, double d, double f) {
+    VernerRecDev &r = t.verner_rec[ion];
+    r.dkind = 1;
+    r.d[0] = a;
+    r.d[1] = b;
+    r.d[2] = c;
+    r.d[3] = d;
+    r.d[4] = f;
+  };
+  ns(ION_C_p1, 1.8267, 4.1012, 4.8443, 0.2261, 0.5960);
+  ns(ION_C_p2, 2.3196, 10.7328, 6.8830, -0.1824, 0.4101);
+  ns(ION_N_n, 0., 0.6310, 0.1990, -0.0197, 0.4398);
+  ns(ION_N_p1, 0.0320, -0.6624, 4.3191, 0.0003, 0.5946);
+  ns(ION_N_p2, -0.8806, 11.2406, 30.7066, -1.1721, 0.6127);
+  ns(ION_O_n, -0.0001, 0.0001, 0.0956, 0.0193, 0.4106);
+  ns(ION_O_p1, -0.0036, 0.7519, 1.5252, -0.0838, 0.2769);
+  ns(ION_Ne_p1, 0.0129, -0.1779, 0.9353, -0.0682, 0.4156);
+  /* sulphur: sums of exponentials, in eV (:288-303) and in K (:304-312) */
+  auto esum = [&t](int ion, double unit, int n, const double *c,
+                   const double *E) {
+    VernerRecDev &r = t.verner_rec[ion];
+    r.dkind = 2;
+    r.dunit = unit;
+    r.dn = n;
+    for (int k = 0; k < n; ++k) {
+      r.dc[k] = c[k];
+      r.dE[k] = E[k];
+    }
+  };
+  {
+    const double c1[] = {1.37e-9}, E1[] = {14.95};
+    esum(ION_S_p1, 1. / 1.16045221e4, 1, c1, E1);
+    const double c2[] = {8.0729e-9, 1.1012e-10}, E2[] = {17.56, 7.07};
+    esum(ION_S_p2, 1. / 1.16045221e4, 2, c2, E2);
+    const double c3[] = {5.817e-7, 1.391e-6, 1.123e-5,
+                         1.521e-4, 1.875e-3, 2.097e-2};
+    const double E3[] = {362.8, 1058., 7160., 3.26e4, 1.235e5, 2.07e5};
+    esum(ION_S_p3, 1., 6, c3, E3);
+  }
   /* src/ChargeTransferRates.cpp: {kind, a, b, c, d, e, lo, hi};
    * kind 0 zero, 1 constant, 2 a t^b (1 + c e^{d t}), 3 same * e^{e/t},
    * 4 a t^2 */
@@ -310,6 +366,21 @@ void build_tables(TablesDev &t) {
   set(t.ct_recomb_He[ION_Ne_p1], 1, 1.e-20, 0, 0, 0, 0, 0, 0);
   set(t.ct_recomb_He[ION_S_p2], 2, 1.1e-15, 0.56, 0., 0., 0, 0.1, 3.);
   set(t.ct_recomb_He[ION_S_p3], 2, 7.6e-19, 0.32, 3.4, -5.25, 0, 0.1, 3.);
+
+  /* which charge transfer terms the balance of each metal ion contains,
+   * src/IonizationStateCalculator.cpp:323-501 */
+  {
+    const int with_rH[] = {ION_C_p2, ION_N_n,  ION_N_p1, ION_N_p2, ION_O_n,
+                           ION_O_p1, ION_Ne_p1, ION_S_p1, ION_S_p2, ION_S_p3};
+    for (int ion : with_rH)
+      t.metal_ct[ion][0] = t.ct_recomb_H[ion];
+    t.metal_ct[ION_N_n][1] = t.ct_ion_H[ION_N_n];
+    t.metal_ct[ION_O_n][1] = t.ct_ion_H[ION_O_n];
+    const int with_rHe[] = {ION_C_p2,  ION_N_p1, ION_N_p2, ION_O_p1,
+                            ION_Ne_p1, ION_S_p2, ION_S_p3};
+    for (int ion : with_rHe)
+      t.metal_ct[ion][2] = t.ct_recomb_He[ion];
+  }
 
   /* line cooling data, src/LineCoolingData.cpp:42-1399: energy levels to
    * energy differences in K, everything else copied */

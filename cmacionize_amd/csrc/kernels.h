@@ -1433,39 +1433,110 @@ __global__ void __launch_bounds__(CMI_BLOCK)
  * branch (src/TemperatureCalculator.cpp:944-964 -> :567-931): one cell per
  * lane. fp64-ALU / transcendental bound (up to 100 x 3 balance evaluations,
  * each with ten 5x5 level-population solves). */
-#ifndef CMI_TEMPERATURE_WAVES
-#define CMI_TEMPERATURE_WAVES 4
+/* registers per lane (the compiler's own occupancy estimate assumes 64 KB of
+ * LDS per CU and would hand this kernel 256) and whether the coefficient
+ * tables are staged in LDS */
+#ifndef CMI_TEMPERATURE_VGPRS
+#define CMI_TEMPERATURE_VGPRS 128
 #endif
-__global__ void __launch_bounds__(CMI_BLOCK, CMI_TEMPERATURE_WAVES)
-    temperature_kernel(const UpdateArgs a) {
+#ifndef CMI_TEMPERATURE_LDS_TABLES
+#define CMI_TEMPERATURE_LDS_TABLES 1
+#endif
+__global__ void __launch_bounds__(CMI_BLOCK)
+    __attribute__((amdgpu_num_vgpr(CMI_TEMPERATURE_VGPRS)))
+    temperature_kernel(const UpdateArgs a_in) {
+  UpdateArgs a = a_in;
+#if CMI_TEMPERATURE_LDS_TABLES
+  /* the coefficient tables (recombination, charge transfer, line cooling:
+   * 19 KB) are read ~1000 times per balance evaluation: staged in LDS */
+  __shared__ TablesDev lds_tables;
+  {
+    const uint64_t *src = reinterpret_cast<const uint64_t *>(a_in.model.tables);
+    uint64_t *dst = reinterpret_cast<uint64_t *>(&lds_tables);
+    for (unsigned k = threadIdx.x; k < sizeof(TablesDev) / 8; k += CMI_BLOCK)
+      dst[k] = src[k];
+    __syncthreads();
+  }
+  a.model.tables = &lds_tables;
+#endif
+  /* Every lane owns the cells first + lane, + stride, ... and works through
+   * them at its own pace: the secant solve of a cell takes 1 to ~10 steps (a
+   * step = three balance evaluations, ~60 k instructions), and a wave that
+   * gave each lane ONE cell would run as long as its slowest cell (measured:
+   * 5.5 steps per wave for ~3 per cell). A lane whose cell has converged - or
+   * needs no solve: 57 % of the benchmark's cells are neutral - stores it and
+   * takes its next cell while its neighbours go on iterating theirs; all
+   * lanes of a wave execute the same step code on whatever cell they hold. */
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t c = a.first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-       c < a.first + a.count; c += stride) {
-    const double ntot = a.cells.number_density[c];
-    double T = a.cells.temperature[c];
-    double J[CMI_NION], heating[2], x[CMI_NION];
-#pragma unroll
-    for (int i = 0; i < CMI_NION; ++i) {
-      J[i] = (*acc_at(a.cells, i, c));
-      x[i] = a.cells.x[i][c];
-    }
-    heating[0] = (*acc_at(a.cells, CMI_NION, c));
-    heating[1] = (*acc_at(a.cells, CMI_NION + 1, c));
-    /* z of the cell midpoint, src/CartesianDensityGrid.hpp:85-89 */
-    const int64_t iz = c % a.grid.ncell[2];
-    const double zmid = (a.grid.anchor[2] +
-                         a.grid.cellside[2] * (iz + a.grid.offset[2])) +
-                        0.5 * a.grid.cellside[2];
-    temperature_cell(a.model, a.jfac, a.hfac, ntot, zmid, T, J, heating, x);
-    a.cells.temperature[c] = T;
+  int64_t c = a.first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x - stride;
+  const int64_t end = a.first + a.count;
+  bool active = false;
+  double ntot = 0., zmid = 0., T = 0.;
+  TemperatureSolve s;
+  /* 13 doubles of work space per thread (the line-cooling abundances of a
+   * balance evaluation) */
+  __shared__ double abund_s[13 * CMI_BLOCK];
+  double *const abund = abund_s + threadIdx.x;
+  auto store = [&](int64_t cell, const double (&x)[CMI_NION],
+                   const double (&heating)[2]) {
+    a.cells.temperature[cell] = T;
 #pragma unroll
     for (int i = 0; i < CMI_NION; ++i)
-      a.cells.x[i][c] = x[i];
-    (*acc_at(a.cells, CMI_NION, c)) = heating[0];
-    (*acc_at(a.cells, CMI_NION + 1, c)) = heating[1];
-    a.cells.opacity[c] = (ntot > 0.)
-                             ? make_double2(ntot * x[ION_H_n], ntot * x[ION_He_n])
-                             : make_double2(-1., 0.);
+      a.cells.x[i][cell] = x[i];
+    (*acc_at(a.cells, CMI_NION, cell)) = heating[0];
+    (*acc_at(a.cells, CMI_NION + 1, cell)) = heating[1];
+    a.cells.opacity[cell] =
+        (ntot > 0.) ? make_double2(ntot * x[ION_H_n], ntot * x[ION_He_n])
+                    : make_double2(-1., 0.);
+  };
+  /* the cell's integrals are read where they are (one 128-B row of the
+   * accumulator block) whenever a balance evaluation needs them */
+  CellIntegrals J;
+  J.J = a.cells.acc_base;
+  J.stride = a.cells.acc_field_stride;
+  J.jfac = a.jfac;
+  for (;;) {
+    /* take the next cell(s): up to four that need no solve per trip */
+#pragma unroll 1
+    for (int tries = 0; tries < 4 && !active && c + stride < end; ++tries) {
+      c += stride;
+      ntot = a.cells.number_density[c];
+      T = a.cells.temperature[c];
+      J.J = acc_at(a.cells, 0, c);
+      double x[CMI_NION], heating[2];
+      heating[0] = (*acc_at(a.cells, CMI_NION, c));
+      heating[1] = (*acc_at(a.cells, CMI_NION + 1, c));
+      /* z of the cell midpoint, src/CartesianDensityGrid.hpp:85-89 */
+      const int64_t iz = c % a.grid.ncell[2];
+      zmid = (a.grid.anchor[2] +
+              a.grid.cellside[2] * (iz + a.grid.offset[2])) +
+             0.5 * a.grid.cellside[2];
+      active = temperature_begin(a.model, J, a.hfac, ntot, T, heating, x, s);
+      if (active && !temperature_goes_on(a.model, s)) {
+        /* (no iterations allowed: the cell keeps its fractions) */
+#pragma unroll
+        for (int i = 0; i < CMI_NION; ++i)
+          x[i] = a.cells.x[i][c];
+        temperature_end(a.model, ntot, J, s, T, heating, x);
+        active = false;
+      }
+      if (!active)
+        store(c, x, heating);
+    }
+    if (__ballot(active) == 0ull) {
+      if (__ballot(c + stride < end) == 0ull)
+        break;
+      continue;
+    }
+    if (active) {
+      temperature_step(a.model, ntot, zmid, J, s, abund, CMI_BLOCK);
+      if (!temperature_goes_on(a.model, s)) {
+        double x[CMI_NION], heating[2];
+        temperature_end(a.model, ntot, J, s, T, heating, x);
+        store(c, x, heating);
+        active = false;
+      }
+    }
   }
 }
 
@@ -1486,14 +1557,19 @@ __global__ void thermal_probe_kernel(const ModelDev model, int64_t n,
   h[0] = heating[2 * i];
   h[1] = heating[2 * i + 1];
   double T = T_in[i];
+  CellIntegrals Jc;
+  Jc.J = J + CMI_NION * i;
+  Jc.stride = 1;
+  Jc.jfac = 1.;
   if (solve) {
-    temperature_cell(model, 1., 1., ntot[i], 0.5, T, j, h, x);
+    temperature_cell(model, Jc, 1., ntot[i], 0.5, T, h, x);
     gain_loss[2 * i] = h[0];
     gain_loss[2 * i + 1] = h[1];
   } else {
     double h0, he0, gain, loss;
-    cooling_and_heating_balance(model, h0, he0, gain, loss, T, ntot[i], 0.5, j,
-                                h, x);
+    double abund[13];
+    cooling_and_heating_balance(model, h0, he0, gain, loss, T, ntot[i], 0.5,
+                                Jc, h, x, abund, 1);
     x[ION_H_n] = h0;
     x[ION_He_n] = he0;
     gain_loss[2 * i] = gain;
@@ -1533,7 +1609,7 @@ __global__ void physics_probe_kernel(const ModelDev model, int32_t kind,
     double abund[13];
     for (int k = 0; k < 13; ++k)
       abund[k] = r[2 + k];
-    o[0] = line_cooling(model.tables->lc, r[0], r[1], abund);
+    o[0] = line_cooling(model.tables->lc, r[0], r[1], abund, 1);
   } else if (kind == 3) {
     double pH, pHe[4];
     reemission_probabilities(r[0], pH, pHe);

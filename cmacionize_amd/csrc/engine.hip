@@ -2369,3 +2369,5 @@ int cmi_gpu_get_kernel_timing(cmi_gpu_engine *e, double *kernel_ms,
 }
 
 } // extern "C"
+
+#include "group.h"

@@ -1,0 +1,474 @@
+/*
+ * group.h - several engines driven by ONE host process (included at the end
+ * of engine.hip): the native multi-GPU layer of the C ABI.
+ *
+ *  replica mode   every engine holds the whole grid and flies its share of
+ *                 the packets; cmi_gpu_group_reduce_accumulators sums the
+ *                 accumulator blocks into every engine - the reference's
+ *                 MPI_Allreduce of each accumulator field
+ *                 (src/IonizationSimulation.cpp:459-528) as ONE grouped
+ *                 ncclAllReduce over RCCL / xGMI.
+ *  domain mode    every engine holds one block of the grid (one block per
+ *                 GPU); cmi_gpu_group_exchange_flights hands the flights that
+ *                 left a block to the engine that owns the cell they enter -
+ *                 the photon buffers of the reference's task-based path
+ *                 (src/PhotonTraversalTaskContext.hpp:100-278,
+ *                 src/MemorySpace.hpp:96-127) - device to device: a routing
+ *                 kernel on the SOURCE device writes every row straight into
+ *                 the destination engine's inbox over xGMI (peer access);
+ *                 nothing passes through host memory except n x n counts.
+ *
+ * RCCL is loaded at run time (dlopen) by the first reduce: a process that
+ * already has another copy of RCCL (PyTorch ships its own) never maps a
+ * second one through this library, and a host without RCCL can still use
+ * everything else.
+ */
+#ifndef CMI_GROUP_H
+#define CMI_GROUP_H
+
+#include <dlfcn.h>
+#include <stdlib.h>
+
+/* the handful of RCCL entry points used, by their rccl.h signatures */
+namespace {
+struct RcclApi {
+  void *handle = nullptr;
+  typedef struct ncclComm *comm_t;
+  int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+  int (*CommDestroy)(comm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, comm_t,
+                   hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool load() {
+    if (handle)
+      return true;
+    for (const char *name : {"librccl.so.1", "librccl.so",
+                             "/opt/rocm/lib/librccl.so.1"}) {
+      handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (handle)
+        break;
+    }
+    if (!handle)
+      return false;
+#define CMI_RCCL_SYM(member, symbol)                                           \
+  member = reinterpret_cast<decltype(member)>(dlsym(handle, symbol));          \
+  if (!member)                                                                 \
+    return false;
+    CMI_RCCL_SYM(CommInitAll, "ncclCommInitAll")
+    CMI_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    CMI_RCCL_SYM(GroupStart, "ncclGroupStart")
+    CMI_RCCL_SYM(GroupEnd, "ncclGroupEnd")
+    CMI_RCCL_SYM(AllReduce, "ncclAllReduce")
+    CMI_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef CMI_RCCL_SYM
+    return true;
+  }
+};
+RcclApi g_rccl;
+constexpr int kNcclDouble = 8; /* ncclFloat64 */
+constexpr int kNcclSum = 0;    /* ncclSum */
+} // namespace
+
+#define CMI_GROUP_MAX 64
+
+/* block of the whole grid an engine owns */
+struct GroupBoxDev {
+  int32_t offset[3], size[3];
+};
+
+struct GroupRouteArgs {
+  const double *rows;        /* exports of the source engine */
+  const unsigned int *count; /* how many */
+  unsigned int capacity;
+  int32_t n;                 /* engines */
+  GroupBoxDev box[CMI_GROUP_MAX];
+  int32_t global_ncell[3];
+  uint32_t *dest;            /* [capacity] owner of each row */
+  unsigned int *hist;        /* [n] rows per owner */
+  /* second pass */
+  double *inbox[CMI_GROUP_MAX];      /* destination buffers (peer memory) */
+  unsigned int start[CMI_GROUP_MAX]; /* first slot of this source in each */
+  unsigned int room[CMI_GROUP_MAX];  /* capacity of each inbox */
+  unsigned int *cursor;              /* [n] rows placed per owner */
+};
+
+/* pass 1: who owns the cell each exported flight enters */
+__global__ void __launch_bounds__(CMI_BLOCK)
+    group_route_count_kernel(const GroupRouteArgs a) {
+  __shared__ unsigned int s_hist[CMI_GROUP_MAX];
+  if (threadIdx.x < CMI_GROUP_MAX)
+    s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned int n = *a.count < a.capacity ? *a.count : a.capacity;
+  const unsigned int stride = gridDim.x * blockDim.x;
+  for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride) {
+    const int64_t cell =
+        __double_as_longlong(a.rows[(size_t)CMI_FLIGHT_DOUBLES * i + 12]);
+    const int32_t gz = (int32_t)(cell % a.global_ncell[2]);
+    const int32_t gy =
+        (int32_t)((cell / a.global_ncell[2]) % a.global_ncell[1]);
+    const int32_t gx =
+        (int32_t)(cell / ((int64_t)a.global_ncell[2] * a.global_ncell[1]));
+    uint32_t owner = 0;
+    for (int k = 0; k < a.n; ++k) {
+      const GroupBoxDev &b = a.box[k];
+      if (gx >= b.offset[0] && gx < b.offset[0] + b.size[0] &&
+          gy >= b.offset[1] && gy < b.offset[1] + b.size[1] &&
+          gz >= b.offset[2] && gz < b.offset[2] + b.size[2])
+        owner = (uint32_t)k;
+    }
+    a.dest[i] = owner;
+    atomicAdd(&s_hist[owner], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < (unsigned)a.n && s_hist[threadIdx.x] != 0)
+    atomicAdd(&a.hist[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+/* pass 2: every row into the inbox of its owner (8 lanes per row: a row is
+ * 8 x 16 B), written across xGMI where the owner is another device */
+__global__ void __launch_bounds__(CMI_BLOCK)
+    group_route_scatter_kernel(const GroupRouteArgs a) {
+  const unsigned int n = *a.count < a.capacity ? *a.count : a.capacity;
+  const unsigned int stride = (gridDim.x * blockDim.x) >> 3;
+  const int part = threadIdx.x & 7;
+  for (unsigned int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < n;
+       i += stride) {
+    const uint32_t owner = a.dest[i];
+    unsigned int slot = 0;
+    if (part == 0)
+      slot = a.start[owner] + atomicAdd(&a.cursor[owner], 1u);
+    slot = __shfl(slot, (threadIdx.x & 63) & ~7, 64);
+    if (slot < a.room[owner])
+      reinterpret_cast<double2 *>(a.inbox[owner] +
+                                  (size_t)CMI_FLIGHT_DOUBLES * slot)[part] =
+          reinterpret_cast<const double2 *>(
+              a.rows + (size_t)CMI_FLIGHT_DOUBLES * i)[part];
+  }
+}
+
+/* out[i] += in[i] (engines of a group that share a device: no collective) */
+__global__ void __launch_bounds__(CMI_BLOCK)
+    group_add_kernel(double *out, const double *in, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride)
+    out[i] += in[i];
+}
+
+struct cmi_gpu_group {
+  int n = 0;
+  cmi_gpu_engine *engine[CMI_GROUP_MAX];
+  bool distinct_devices = false;
+  RcclApi::comm_t comm[CMI_GROUP_MAX];
+  bool have_comm = false;
+  /* domain mode */
+  double *inbox[CMI_GROUP_MAX];
+  uint64_t inbox_capacity[CMI_GROUP_MAX];
+  uint32_t *dest[CMI_GROUP_MAX];
+  unsigned int *hist[CMI_GROUP_MAX]; /* [2 n]: rows per owner, cursors */
+  hipEvent_t routed[CMI_GROUP_MAX];
+  uint64_t rounds = 0, flights = 0;
+};
+
+extern "C" {
+
+int cmi_gpu_group_create(int32_t n, cmi_gpu_engine *const *engines,
+                         cmi_gpu_group **out) {
+  if (n < 1 || n > CMI_GROUP_MAX || !engines || !out)
+    return fail(CMI_GPU_EINVAL, "group_create: 1 to %d engines", CMI_GROUP_MAX);
+  cmi_gpu_group *g = new cmi_gpu_group();
+  g->n = n;
+  g->distinct_devices = true;
+  for (int i = 0; i < n; ++i) {
+    if (!engines[i]) {
+      delete g;
+      return fail(CMI_GPU_EINVAL, "group_create: null engine");
+    }
+    g->engine[i] = engines[i];
+    g->inbox[i] = nullptr;
+    g->inbox_capacity[i] = 0;
+    g->dest[i] = nullptr;
+    g->hist[i] = nullptr;
+    g->routed[i] = nullptr;
+    for (int k = 0; k < i; ++k)
+      if (engines[k]->device == engines[i]->device)
+        g->distinct_devices = false;
+  }
+  /* peer access between every pair of devices (flights are written straight
+   * into the owner's inbox) */
+  for (int i = 0; i < n; ++i) {
+    hipError_t err = hipSetDevice(g->engine[i]->device);
+    for (int k = 0; k < n && err == hipSuccess; ++k) {
+      const int other = g->engine[k]->device;
+      if (other == g->engine[i]->device)
+        continue;
+      int can = 0;
+      err = hipDeviceCanAccessPeer(&can, g->engine[i]->device, other);
+      if (err != hipSuccess)
+        break;
+      if (!can) {
+        delete g;
+        return fail(CMI_GPU_EDEVICE,
+                    "group_create: device %d cannot access device %d",
+                    g->engine[i]->device, other);
+      }
+      err = hipDeviceEnablePeerAccess(other, 0);
+      if (err == hipErrorPeerAccessAlreadyEnabled) {
+        (void)hipGetLastError();
+        err = hipSuccess;
+      }
+    }
+    if (err == hipSuccess)
+      err = hipEventCreateWithFlags(&g->routed[i], hipEventDisableTiming);
+    if (err != hipSuccess) {
+      delete g;
+      HIP_TRY(err);
+    }
+  }
+  *out = g;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_group_destroy(cmi_gpu_group *g) {
+  if (!g)
+    return CMI_GPU_OK;
+  for (int i = 0; i < g->n; ++i) {
+    (void)hipSetDevice(g->engine[i]->device);
+    (void)hipStreamSynchronize(g->engine[i]->stream);
+    if (g->have_comm)
+      (void)g_rccl.CommDestroy(g->comm[i]);
+    (void)hipFree(g->inbox[i]);
+    (void)hipFree(g->dest[i]);
+    (void)hipFree(g->hist[i]);
+    if (g->routed[i])
+      (void)hipEventDestroy(g->routed[i]);
+  }
+  delete g;
+  return CMI_GPU_OK;
+}
+
+/* the part of an engine's accumulator block a transport step can have
+ * written: {pointer, doubles} pieces */
+static int active_accumulators(cmi_gpu_engine *e, double *ptr[2],
+                               int64_t count[2]) {
+  if (e->cells.acc_cell_stride != 1) { /* [ncell][16]: everything */
+    ptr[0] = e->acc_block;
+    count[0] = (int64_t)CMI_NACC * e->ncell;
+    return 1;
+  }
+  ptr[0] = e->acc_block; /* hydrogen-only: J_H (+ the heating terms) */
+  count[0] = e->ncell;
+  if (!e->config.track_heating)
+    return 1;
+  ptr[1] = e->acc_block + (int64_t)CMI_NION * e->ncell;
+  count[1] = 2 * e->ncell;
+  return 2;
+}
+
+int cmi_gpu_group_reduce_accumulators(cmi_gpu_group *g) {
+  if (!g)
+    return fail(CMI_GPU_EINVAL, "null group");
+  /* (CMI_GPU_FORCE_RCCL: run the collective even for a group of one - the
+   * only way to exercise the RCCL path on a single-GPU box) */
+  if (g->n == 1 && !getenv("CMI_GPU_FORCE_RCCL"))
+    return CMI_GPU_OK;
+  for (int i = 1; i < g->n; ++i)
+    if (g->engine[i]->ncell != g->engine[0]->ncell ||
+        g->engine[i]->cells.acc_cell_stride !=
+            g->engine[0]->cells.acc_cell_stride)
+      return fail(CMI_GPU_ESTATE,
+                  "reduce_accumulators: the engines of a replica group must "
+                  "hold the same grid");
+  double *ptr[CMI_GROUP_MAX][2];
+  int64_t count[2] = {0, 0};
+  int pieces = 0;
+  for (int i = 0; i < g->n; ++i)
+    pieces = active_accumulators(g->engine[i], ptr[i], count);
+  if (!g->distinct_devices) {
+    /* replicas that share a device (tests on one GPU): plain sums, in
+     * engine order, then copies back */
+    cmi_gpu_engine *e0 = g->engine[0];
+    HIP_TRY(hipSetDevice(e0->device));
+    for (int i = 1; i < g->n; ++i)
+      HIP_TRY(hipStreamSynchronize(g->engine[i]->stream));
+    for (int p = 0; p < pieces; ++p) {
+      for (int i = 1; i < g->n; ++i) {
+        group_add_kernel<<<grid_blocks(e0, count[p], 8), CMI_BLOCK, 0,
+                           e0->stream>>>(ptr[0][p], ptr[i][p], count[p]);
+        HIP_TRY(hipGetLastError());
+      }
+      for (int i = 1; i < g->n; ++i)
+        HIP_TRY(hipMemcpyAsync(ptr[i][p], ptr[0][p],
+                               sizeof(double) * count[p],
+                               hipMemcpyDeviceToDevice, e0->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e0->stream));
+    return CMI_GPU_OK;
+  }
+  if (!g->have_comm) {
+    if (!g_rccl.load())
+      return fail(CMI_GPU_EDEVICE,
+                  "reduce_accumulators: cannot load RCCL (librccl.so.1): %s",
+                  dlerror());
+    int devices[CMI_GROUP_MAX];
+    for (int i = 0; i < g->n; ++i)
+      devices[i] = g->engine[i]->device;
+    const int rc = g_rccl.CommInitAll(g->comm, g->n, devices);
+    if (rc != 0)
+      return fail(CMI_GPU_EDEVICE, "ncclCommInitAll failed: %s",
+                  g_rccl.GetErrorString(rc));
+    g->have_comm = true;
+  }
+  /* one grouped all-reduce per piece: every engine's call is enqueued on its
+   * own stream, behind its transport kernels */
+  for (int p = 0; p < pieces; ++p) {
+    int rc = g_rccl.GroupStart();
+    for (int i = 0; i < g->n && rc == 0; ++i) {
+      HIP_TRY(hipSetDevice(g->engine[i]->device));
+      rc = g_rccl.AllReduce(ptr[i][p], ptr[i][p], (size_t)count[p],
+                            kNcclDouble, kNcclSum, g->comm[i],
+                            g->engine[i]->stream);
+    }
+    const int rc_end = g_rccl.GroupEnd();
+    if (rc == 0)
+      rc = rc_end;
+    if (rc != 0)
+      return fail(CMI_GPU_EDEVICE, "ncclAllReduce failed: %s",
+                  g_rccl.GetErrorString(rc));
+  }
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_group_exchange_flights(cmi_gpu_group *g, uint32_t seed,
+                                   uint32_t iteration, uint64_t first_packet,
+                                   uint64_t *total_flights) {
+  if (!g || !total_flights)
+    return fail(CMI_GPU_EINVAL, "exchange_flights: bad argument");
+  *total_flights = 0;
+  const int n = g->n;
+  GroupRouteArgs proto;
+  memset(&proto, 0, sizeof proto);
+  proto.n = n;
+  for (int i = 0; i < n; ++i) {
+    cmi_gpu_engine *e = g->engine[i];
+    if (!e->grid.decomposed || !e->export_rows)
+      return fail(CMI_GPU_ESTATE,
+                  "exchange_flights: every engine must be a block of a "
+                  "decomposed grid with an export buffer");
+    for (int a = 0; a < 3; ++a) {
+      proto.box[i].offset[a] = e->grid.offset[a];
+      proto.box[i].size[a] = e->grid.ncell[a];
+      proto.global_ncell[a] = e->grid.global_ncell[a];
+    }
+  }
+  /* pass 1 on every source: owners and counts */
+  for (int s = 0; s < n; ++s) {
+    cmi_gpu_engine *e = g->engine[s];
+    HIP_TRY(hipSetDevice(e->device));
+    if (!g->dest[s]) {
+      HIP_TRY(hipMalloc(&g->dest[s], sizeof(uint32_t) * e->export_capacity));
+      HIP_TRY(hipMalloc(&g->hist[s], sizeof(unsigned int) * 2 * CMI_GROUP_MAX));
+    }
+    HIP_TRY(hipMemsetAsync(g->hist[s], 0,
+                           sizeof(unsigned int) * 2 * CMI_GROUP_MAX,
+                           e->stream));
+    GroupRouteArgs a = proto;
+    a.rows = e->export_rows;
+    a.count = e->export_count;
+    a.capacity = (unsigned int)e->export_capacity;
+    a.dest = g->dest[s];
+    a.hist = g->hist[s];
+    group_route_count_kernel<<<e->num_cu * 4, CMI_BLOCK, 0, e->stream>>>(a);
+    HIP_TRY(hipGetLastError());
+  }
+  /* the n x n counts (and the overflow check of every export buffer) */
+  std::vector<unsigned int> counts((size_t)n * n);
+  std::vector<uint64_t> incoming(n, 0);
+  for (int s = 0; s < n; ++s) {
+    cmi_gpu_engine *e = g->engine[s];
+    HIP_TRY(hipSetDevice(e->device));
+    unsigned int exported = 0;
+    HIP_TRY(hipMemcpyAsync(&exported, e->export_count, sizeof exported,
+                           hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(&counts[(size_t)s * n], g->hist[s],
+                           sizeof(unsigned int) * n, hipMemcpyDeviceToHost,
+                           e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (exported > e->export_capacity)
+      return fail(CMI_GPU_ENOMEM,
+                  "export buffer overflow: %u flights left a block, room for "
+                  "%llu - flights were lost, the iteration is invalid",
+                  exported, (unsigned long long)e->export_capacity);
+    for (int d = 0; d < n; ++d)
+      incoming[d] += counts[(size_t)s * n + d];
+  }
+  uint64_t total = 0;
+  for (int d = 0; d < n; ++d)
+    total += incoming[d];
+  *total_flights = total;
+  if (total == 0)
+    return CMI_GPU_OK;
+  /* inboxes */
+  for (int d = 0; d < n; ++d) {
+    if (g->inbox_capacity[d] >= incoming[d])
+      continue;
+    cmi_gpu_engine *e = g->engine[d];
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    (void)hipFree(g->inbox[d]);
+    g->inbox[d] = nullptr;
+    const uint64_t cap = incoming[d] + incoming[d] / 4 + 1024;
+    HIP_TRY(hipMalloc(&g->inbox[d],
+                      sizeof(double) * CMI_FLIGHT_DOUBLES * cap));
+    g->inbox_capacity[d] = cap;
+  }
+  /* pass 2 on every source: rows into the owners' inboxes */
+  std::vector<unsigned int> placed(n, 0);
+  for (int s = 0; s < n; ++s) {
+    cmi_gpu_engine *e = g->engine[s];
+    HIP_TRY(hipSetDevice(e->device));
+    GroupRouteArgs a = proto;
+    a.rows = e->export_rows;
+    a.count = e->export_count;
+    a.capacity = (unsigned int)e->export_capacity;
+    a.dest = g->dest[s];
+    a.hist = g->hist[s];
+    a.cursor = g->hist[s] + CMI_GROUP_MAX;
+    for (int d = 0; d < n; ++d) {
+      a.inbox[d] = g->inbox[d];
+      a.start[d] = placed[d];
+      a.room[d] = (unsigned int)g->inbox_capacity[d];
+      placed[d] += counts[(size_t)s * n + d];
+    }
+    group_route_scatter_kernel<<<e->num_cu * 4, CMI_BLOCK, 0, e->stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(e->export_count, 0, sizeof(unsigned int),
+                           e->stream));
+    HIP_TRY(hipEventRecord(g->routed[s], e->stream));
+  }
+  /* every owner waits for all sources, then flies what it received */
+  for (int d = 0; d < n; ++d) {
+    cmi_gpu_engine *e = g->engine[d];
+    HIP_TRY(hipSetDevice(e->device));
+    for (int s = 0; s < n; ++s)
+      if (s != d)
+        HIP_TRY(hipStreamWaitEvent(e->stream, g->routed[s], 0));
+    if (incoming[d] == 0)
+      continue;
+    const int rc = cmi_gpu_shoot_flights(e, seed, iteration, first_packet,
+                                         g->inbox[d], incoming[d]);
+    if (rc)
+      return rc;
+  }
+  ++g->rounds;
+  g->flights += total;
+  return CMI_GPU_OK;
+}
+
+} // extern "C"
+
+#endif

@@ -75,7 +75,9 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_shoot_flights", "cmi_gpu_download_exports",
     "cmi_gpu_shoot_flights_host", "cmi_gpu_physics_probe",
     "cmi_gpu_update_cells_range", "cmi_gpu_refresh_transport_records",
-    "cmi_gpu_get_launch_steps",
+    "cmi_gpu_get_launch_steps", "cmi_gpu_group_create",
+    "cmi_gpu_group_destroy", "cmi_gpu_group_reduce_accumulators",
+    "cmi_gpu_group_exchange_flights",
 ]
 
 _lib = None
@@ -169,6 +171,12 @@ def load_library():
     L.cmi_gpu_get_launch_steps.argtypes = [vp, C.c_uint64,
                                            C.POINTER(C.c_uint64),
                                            C.POINTER(C.c_uint64)]
+    L.cmi_gpu_group_create.argtypes = [C.c_int32, C.POINTER(vp),
+                                       C.POINTER(vp)]
+    L.cmi_gpu_group_destroy.argtypes = [vp]
+    L.cmi_gpu_group_reduce_accumulators.argtypes = [vp]
+    L.cmi_gpu_group_exchange_flights.argtypes = [
+        vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -179,6 +187,41 @@ def _p(a):
 
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class EngineGroup:
+    """Several engines driven by this process (cmi_gpu_group_*): replicas
+    (reduce_accumulators) or the blocks of a decomposed grid
+    (exchange_flights)."""
+
+    def __init__(self, engines):
+        self._lib = load_library()
+        self.engines = list(engines)
+        handles = (C.c_void_p * len(self.engines))(
+            *[e._h for e in self.engines])
+        self._h = C.c_void_p()
+        rc = self._lib.cmi_gpu_group_create(len(self.engines), handles,
+                                            C.byref(self._h))
+        if rc != 0:
+            raise EngineError(self._lib.cmi_gpu_last_error().decode())
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(self._lib.cmi_gpu_last_error().decode())
+
+    def reduce_accumulators(self):
+        self._check(self._lib.cmi_gpu_group_reduce_accumulators(self._h))
+
+    def exchange_flights(self, seed, iteration, first_packet=0):
+        total = C.c_uint64()
+        self._check(self._lib.cmi_gpu_group_exchange_flights(
+            self._h, seed, iteration, first_packet, C.byref(total)))
+        return total.value
+
+    def close(self):
+        if self._h:
+            self._lib.cmi_gpu_group_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 class GpuEngine:

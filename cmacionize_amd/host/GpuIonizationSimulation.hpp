@@ -250,6 +250,13 @@ class GpuIonizationSimulation {
     int64_t ncell() const { return (int64_t)size[0] * size[1] * size[2]; }
   };
   std::vector<Block> _blocks;
+  /* replica mode (the reference's MPI path,
+   * src/IonizationSimulation.cpp:394-397,458-529): one engine per device,
+   * each holding the whole grid and flying its share of the packets */
+  std::vector<cmi_gpu_engine *> _replicas;
+  /* the engines of either mode as one group: RCCL all-reduce of the
+   * accumulators / device-to-device hand-over of flights */
+  cmi_gpu_group *_group = nullptr;
   std::array<int, 3> _nblock = {1, 1, 1};
   std::array<std::vector<int32_t>, 3> _block_edges;
   uint64_t _exchange_rounds = 0, _flights_exchanged = 0;
@@ -330,10 +337,8 @@ class GpuIonizationSimulation {
   }
 
   /* One iteration's transport on a decomposed grid: every block runs through
-   * the packet ids and flies those emitted inside it; then rounds of {collect
-   * the flights that left each block, hand each to the block that owns the
-   * cell it enters (through host memory here - the reference's MPI photon
-   * buffers are host memory too), continue} until no flight is left. */
+   * the packet ids and flies those emitted inside it; then hand-over rounds
+   * (cmi_gpu_group_exchange_flights) until no flight is left. */
   void shoot_decomposed(uint_fast32_t loop, uint_fast64_t numphoton,
                         double &totweight, double typecount[4]) {
     for (Block &b : _blocks) {
@@ -342,37 +347,18 @@ class GpuIonizationSimulation {
       check(cmi_gpu_shoot(b.engine, (uint32_t)_random_seed, loop, 0, numphoton),
             "shoot");
     }
-    std::vector<std::vector<double>> inbox(_blocks.size());
-    std::vector<double> rows;
+    /* rounds of {every flight that left a block into the inbox of the block
+     * that owns the cell it enters - written by the source GPU across xGMI -
+     * then every block continues what it received} until nothing moves */
     for (;;) {
       uint64_t total = 0;
-      for (Block &b : _blocks) {
-        uint64_t n = 0;
-        check(cmi_gpu_get_export_count(b.engine, &n), "get_export_count");
-        rows.resize((size_t)n * CMI_GPU_FLIGHT_DOUBLES);
-        check(cmi_gpu_download_exports(b.engine, rows.data(), n, &n),
-              "download_exports");
-        check(cmi_gpu_reset_exports(b.engine), "reset_exports");
-        for (uint64_t i = 0; i < n; ++i) {
-          const double *row = rows.data() + i * CMI_GPU_FLIGHT_DOUBLES;
-          int64_t cell;
-          std::memcpy(&cell, row + 12, sizeof cell);
-          std::vector<double> &box = inbox[owner_of_cell(cell)];
-          box.insert(box.end(), row, row + CMI_GPU_FLIGHT_DOUBLES);
-        }
-        total += n;
-      }
+      check(cmi_gpu_group_exchange_flights(_group, (uint32_t)_random_seed,
+                                           loop, 0, &total),
+            "exchange_flights");
       if (total == 0)
         break;
       ++_exchange_rounds;
       _flights_exchanged += total;
-      for (size_t k = 0; k < _blocks.size(); ++k) {
-        check(cmi_gpu_shoot_flights_host(
-                  _blocks[k].engine, (uint32_t)_random_seed, loop, 0,
-                  inbox[k].data(), inbox[k].size() / CMI_GPU_FLIGHT_DOUBLES),
-              "shoot_flights");
-        inbox[k].clear();
-      }
     }
     totweight = 0.;
     for (int i = 0; i < 4; ++i)
@@ -384,6 +370,35 @@ class GpuIonizationSimulation {
       for (int i = 0; i < 4; ++i)
         typecount[i] += tc[i];
     }
+  }
+
+  /* One iteration's transport in replica mode: rank r of P flies the packets
+   * MPICommunicator::distribute gives it (src/MPICommunicator.hpp:207-222),
+   * then the accumulators are summed over the replicas (one grouped
+   * ncclAllReduce) and the counters on the host. */
+  void shoot_replicated(uint_fast32_t loop, uint_fast64_t numphoton,
+                        double &totweight, double typecount[4]) {
+    const uint64_t P = _replicas.size();
+    uint64_t first = 0;
+    for (uint64_t r = 0; r < P; ++r) {
+      const uint64_t count = numphoton / P + (r < numphoton % P ? 1 : 0);
+      check(cmi_gpu_reset_grid(_replicas[r]), "reset_grid");
+      check(cmi_gpu_shoot(_replicas[r], (uint32_t)_random_seed, loop, first,
+                          count),
+            "shoot");
+      first += count;
+    }
+    totweight = 0.;
+    for (int i = 0; i < 4; ++i)
+      typecount[i] = 0.;
+    for (cmi_gpu_engine *e : _replicas) {
+      double tw = 0., tc[4];
+      check(cmi_gpu_get_counters(e, &tw, tc, nullptr), "get_counters");
+      totweight += tw;
+      for (int i = 0; i < 4; ++i)
+        typecount[i] += tc[i];
+    }
+    check(cmi_gpu_group_reduce_accumulators(_group), "reduce_accumulators");
   }
 
   void download_state() {
@@ -513,7 +528,22 @@ public:
       config.stream = nullptr;
       config.external_accumulators = nullptr;
       _nblock = blocks;
-      if (blocks[0] * blocks[1] * blocks[2] == 1) {
+      if (blocks[0] * blocks[1] * blocks[2] == 1 && devices.size() > 1) {
+        /* replicas: the whole grid on every device */
+        for (int d : devices) {
+          config.device = d;
+          cmi_gpu_engine *e = nullptr;
+          check(cmi_gpu_create(&config, &e), "cmi_gpu_create");
+          _replicas.push_back(e);
+          lower_model(e);
+        }
+        _engine = _replicas[0];
+        check(cmi_gpu_group_create((int32_t)_replicas.size(), _replicas.data(),
+                                   &_group),
+              "group_create");
+        status("Replica mode: " + std::to_string(_replicas.size()) +
+               " devices, accumulators reduced over RCCL.");
+      } else if (blocks[0] * blocks[1] * blocks[2] == 1) {
         check(cmi_gpu_create(&config, &_engine), "cmi_gpu_create");
         lower_model(_engine);
       } else {
@@ -550,15 +580,29 @@ public:
                             1024),
                     "set_export_buffer");
             }
+        {
+          std::vector<cmi_gpu_engine *> engines;
+          for (Block &b : _blocks)
+            engines.push_back(b.engine);
+          check(cmi_gpu_group_create((int32_t)engines.size(), engines.data(),
+                                     &_group),
+                "group_create");
+        }
         status("Domain decomposition: " + std::to_string(_blocks.size()) +
-               " blocks.");
+               " blocks, flights handed over device to device.");
       }
     }
   }
 
   ~GpuIonizationSimulation() {
-    if (_engine)
+    if (_group)
+      cmi_gpu_group_destroy(_group);
+    if (!_replicas.empty()) {
+      for (cmi_gpu_engine *e : _replicas)
+        cmi_gpu_destroy(e);
+    } else if (_engine) {
       cmi_gpu_destroy(_engine);
+    }
     for (Block &b : _blocks)
       cmi_gpu_destroy(b.engine);
   }
@@ -604,10 +648,16 @@ public:
       }
     }
     density_function->free();
-    if (_engine)
+    if (!_replicas.empty()) {
+      for (cmi_gpu_engine *e : _replicas)
+        check(cmi_gpu_upload_cells(e, g._number_density.data(),
+                                   g._temperature.data(), x.data()),
+              "cmi_gpu_upload_cells");
+    } else if (_engine) {
       check(cmi_gpu_upload_cells(_engine, g._number_density.data(),
                                  g._temperature.data(), x.data()),
             "cmi_gpu_upload_cells");
+    }
     for (Block &b : _blocks) {
       std::vector<double> dens, temp, part, xb;
       block_slice(b, g._number_density, dens);
@@ -642,6 +692,8 @@ public:
       double typecount[4] = {0., 0., 0., 0.};
       if (decomposed()) {
         shoot_decomposed(loop, lnumphoton, totweight, typecount);
+      } else if (!_replicas.empty()) {
+        shoot_replicated(loop, lnumphoton, totweight, typecount);
       } else {
         check(cmi_gpu_reset_grid(_engine), "reset_grid");
         check(cmi_gpu_shoot(_engine, (uint32_t)_random_seed, loop, 0,
@@ -682,6 +734,13 @@ public:
                 "update_cells");
         for (Block &b : _blocks)
           check(cmi_gpu_synchronize(b.engine), "synchronize");
+      } else if (!_replicas.empty()) {
+        /* every replica updates all cells from the same reduced integrals
+         * (identical results; no gather needed) */
+        for (cmi_gpu_engine *e : _replicas)
+          check(cmi_gpu_update_cells(e, loop, totweight), "update_cells");
+        for (cmi_gpu_engine *e : _replicas)
+          check(cmi_gpu_synchronize(e), "synchronize");
       } else {
         check(cmi_gpu_update_cells(_engine, loop, totweight), "update_cells");
         check(cmi_gpu_synchronize(_engine), "synchronize");

@@ -363,6 +363,42 @@ int cmi_gpu_update_cells_range(cmi_gpu_engine *engine, uint32_t loop,
  *                           6 = a quarter of the table adds */
 int cmi_gpu_set_tuning(cmi_gpu_engine *engine, const char *key, int64_t value);
 
+/* ------------------------------------------------- several GPUs, one host -- */
+
+/* A group of engines driven by one host process, one per GPU of a node:
+ * replicas of one grid, or the blocks of one decomposed grid. Replaces the
+ * reference's MPICommunicator for this path (src/MPICommunicator.hpp); the
+ * transport is RCCL over xGMI (loaded at the first reduce) and peer-to-peer
+ * device writes. The engines stay owned by the caller. */
+typedef struct cmi_gpu_group cmi_gpu_group;
+int cmi_gpu_group_create(int32_t n, cmi_gpu_engine *const *engines,
+                         cmi_gpu_group **out);
+int cmi_gpu_group_destroy(cmi_gpu_group *group);
+
+/* replaces: the MPI_Allreduce(SUM) of every accumulator field after the
+ * packets of all ranks have flown (src/IonizationSimulation.cpp:459-528,
+ * MPICommunicator::reduce, src/MPICommunicator.hpp:504-560): afterwards every
+ * engine of the (replica) group holds the sum over the group of the
+ * accumulator fields a transport step can have written - ONE grouped
+ * ncclAllReduce per contiguous piece instead of 16 chunked ones. The packet
+ * counters are summed by the caller (cmi_gpu_get_counters of each engine).
+ * Asynchronous on the engines' streams. */
+int cmi_gpu_group_reduce_accumulators(cmi_gpu_group *group);
+
+/* replaces: the photon-buffer traffic between subgrids
+ * (src/PhotonTraversalTaskContext.hpp:100-278, src/MemorySpace.hpp:96-127;
+ * message format src/PhotonBuffer.hpp:46-48): one exchange round of a
+ * decomposed grid whose blocks are the group's engines. Every flight in an
+ * engine's export buffer is written into the inbox of the engine that owns
+ * the cell it enters - by a kernel on the source device, across xGMI where
+ * the owner is another GPU - the export buffers are emptied, and every engine
+ * continues the flights it received (cmi_gpu_shoot_flights), which may export
+ * again. *total_flights = flights handed over in this round; call until 0.
+ * Only n x n counts cross the host. */
+int cmi_gpu_group_exchange_flights(cmi_gpu_group *group, uint32_t seed,
+                                   uint32_t iteration, uint64_t first_packet,
+                                   uint64_t *total_flights);
+
 /* --------------------------------------------------- test / measurement -- */
 
 /* Parity probe of PhotonSource::get_random_photon + the first optical depth

@@ -405,3 +405,90 @@ def test_decomposed_lexington_matches_oracle(oracle, tiles):
     assert sim.temperature.max() > 6000. and sim.temperature.min() == 500.
     for b in backends:
         b.engine.close()
+
+
+def test_group_exchange_equals_python_routing():
+    """cmi_gpu_group_exchange_flights (routing kernel on the source device,
+    rows written into the owner's inbox) against the Python hand-over of
+    LocalDomainDriver (torch sort by owner): same flights reach the same
+    blocks - identical counters, integrals at 1e-11."""
+    from cmacionize_amd import STROMGREN as S
+    from cmacionize_amd import engine as E
+    from cmacionize_amd.engine import EngineGroup
+    from cmacionize_amd.simulation import (DomainDecomposition,
+                                           DomainGpuBackend,
+                                           LocalDomainDriver)
+    ncell, npacket = 24, 40000
+    results = []
+    for use_group in (False, True):
+        dec = DomainDecomposition((ncell,) * 3, (2, 3, 1))
+        backends = []
+        for rank in range(dec.world):
+            b = DomainGpuBackend(dec, rank, S["anchor"], S["sides"], device=0,
+                                 export_capacity=npacket)
+            configure(b.engine, "diffuse", int(np.prod(dec.block(rank)[1])))
+            b.engine.set_tuning(reemit_inline_below=64)
+            backends.append(b)
+        if not use_group:
+            driver = LocalDomainDriver(backends, dec)
+            driver.iteration(0, npacket, 42, update=False)
+            tw, tc, ns = driver.totweight, driver.typecount, driver.nsteps
+            assert driver.flights_exchanged > 0
+        else:
+            group = EngineGroup([b.engine for b in backends])
+            for b in backends:
+                b.reset_grid()
+                b.shoot(42, 0, 0, npacket)
+            rounds = flights = 0
+            while True:
+                n = group.exchange_flights(42, 0)
+                if n == 0:
+                    break
+                rounds += 1
+                flights += n
+            assert rounds >= 1 and flights > 0
+            tw, tc, ns = 0., np.zeros(4), 0
+            for b in backends:
+                t, c, n = b.get_counters()
+                tw += t
+                tc += np.asarray(c)
+                ns += n
+            group.close()
+        J = assemble(dec, backends, E.FIELD_MEAN_INTENSITY)
+        results.append((tw, tc, ns, J))
+        for b in backends:
+            b.engine.close()
+    (tw0, tc0, ns0, J0), (tw1, tc1, ns1, J1) = results
+    assert tw0 == tw1 == npacket and np.array_equal(tc0, tc1) and ns0 == ns1
+    assert np.allclose(J1, J0, rtol=1e-11, atol=1e-13 * J0.max())
+
+
+def test_group_reduce_goes_through_rccl(monkeypatch):
+    """The accumulator reduce of a replica group is a grouped ncclAllReduce
+    (RCCL, loaded at run time). This box has one GPU, and RCCL refuses two
+    ranks on one device, so the collective runs here with a group of ONE
+    engine (CMI_GPU_FORCE_RCCL): library loading, communicator, data type and
+    reduction codes, in-place call on the engine's stream - a one-rank sum
+    must leave the accumulators as they are."""
+    from cmacionize_amd import GpuEngine, STROMGREN as S
+    from cmacionize_amd import engine as E
+    from cmacionize_amd.engine import EngineGroup
+    monkeypatch.setenv("CMI_GPU_FORCE_RCCL", "1")
+    n = 12
+    eng = GpuEngine((n,) * 3, S["anchor"], S["sides"], (0, 0, 0), device=0,
+                    track_heating=True)
+    configure(eng, "stromgren", n ** 3)
+    eng.reset_grid()
+    eng.shoot(3, 0, 0, 5000)
+    before = [eng.download_field(E.FIELD_MEAN_INTENSITY),
+              eng.download_field(E.FIELD_HEATING)]
+    group = EngineGroup([eng])
+    group.reduce_accumulators()
+    eng.synchronize()
+    after = [eng.download_field(E.FIELD_MEAN_INTENSITY),
+             eng.download_field(E.FIELD_HEATING)]
+    assert before[0].max() > 0.
+    for a, b in zip(after, before):
+        assert np.array_equal(a, b)
+    group.close()
+    eng.close()

@@ -201,8 +201,9 @@ def test_cmi_gpu_executable_end_to_end(exe, tmp_path, oracle):
                                           ("stromgren_diffuse.param", "2,2,2"),
                                           ("lexingtonHII40.param", "1,3,1")])
 def test_cmi_gpu_executable_with_blocks(exe, tmp_path, bench, blocks):
-    """--blocks: the C++ host drives one engine per block of the grid and hands
-    the flights over between them (through host memory); the snapshots equal
+    """--blocks: the C++ host drives one engine per block of the grid; the
+    flights are handed over device to device (cmi_gpu_group_exchange_flights:
+    a routing kernel writes them into the owner's inbox); the snapshots equal
     those of the undivided run of the same parameter file."""
     text = open(os.path.join(BENCH, bench)).read()
     text = text.replace("[64, 64, 64]", "[18, 18, 18]")
@@ -239,6 +240,49 @@ def test_cmi_gpu_executable_with_blocks(exe, tmp_path, bench, blocks):
     assert np.median(rel) < 1e-5
     assert (rel < 1e-2).mean() > 0.97, (rel > 1e-2).sum()
     # the reference's statistics lines agree to the printed precision
+    stats = [[l for l in out.splitlines() if "Escape fraction" in l][-1]
+             for _, out in outputs.values()]
+    assert stats[0] == stats[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bench", ["stromgren.param", "lexingtonHII40.param"])
+def test_cmi_gpu_executable_with_replicas(exe, tmp_path, bench):
+    """--devices D0,D1 without --blocks: the reference's MPI scheme in one
+    process - every device holds the whole grid and flies its share of the
+    packets (disjoint Philox counters), the accumulators are summed over the
+    replicas (cmi_gpu_group_reduce_accumulators: RCCL all-reduce between
+    distinct devices; replicas that share this box's one device are summed by
+    a kernel), every replica updates its cells. Same packets as the
+    single-engine run: equal snapshots."""
+    text = open(os.path.join(BENCH, bench)).read()
+    text = text.replace("[64, 64, 64]", "[18, 18, 18]")
+    for old in ("number of photons: 1e6", "number of photons: 1e8"):
+        text = text.replace(old, "number of photons: 20001")
+    text = text.replace("number of iterations: 20", "number of iterations: 5")
+    text = text.replace("type: Binary", "type: AsciiFile")
+    outputs = {}
+    for label, extra in (("one", []), ("three", ["--devices", "0,0,0"])):
+        d = tmp_path / label
+        d.mkdir()
+        if bench.startswith("lexington"):
+            import shutil
+            shutil.copy(os.path.join(BENCH, "lexingtonHII40.yml"), d)
+        p = d / "run.param"
+        p.write_text(text)
+        r = subprocess.run([exe, "--params", str(p), "--output-statistics"] +
+                           extra, capture_output=True, text=True, cwd=str(d))
+        assert r.returncode == 0, r.stderr
+        if extra:
+            assert "Replica mode: 3 devices" in r.stdout
+        snapshots = sorted(f for f in os.listdir(d) if f.endswith("005.txt"))
+        assert len(snapshots) == 1, os.listdir(d)
+        outputs[label] = (np.loadtxt(d / snapshots[0]), r.stdout)
+    one, three = outputs["one"][0], outputs["three"][0]
+    assert np.array_equal(one[:, :5], three[:, :5])
+    rel = np.abs(one[:, 5] - three[:, 5]) / one[:, 5]
+    assert np.median(rel) < 1e-5
+    assert (rel < 1e-2).mean() > 0.97, (rel > 1e-2).sum()
     stats = [[l for l in out.splitlines() if "Escape fraction" in l][-1]
              for _, out in outputs.values()]
     assert stats[0] == stats[1]

@@ -10,12 +10,14 @@
 #ifndef CMI_HOST_GPUIONIZATIONSIMULATION_HPP
 #define CMI_HOST_GPUIONIZATIONSIMULATION_HPP
 
+#include "Hdf5Writer.hpp"
 #include "Plugins.hpp"
 
 #include <array>
 #include <chrono>
 #include <cstring>
 #include <cstdio>
+#include <ctime>
 #include <iomanip>
 #include <iostream>
 #include <memory>
@@ -174,9 +176,8 @@ public:
   }
 };
 
-/* Raw SoA dump of every field (n, T, 14 fractions) as fp64, for checkers;
- * the role the Gadget/HDF5 writer plays in the reference (no HDF5 in this
- * image). Layout: int64 ncell[3], then 16 arrays of ncell doubles. */
+/* Raw SoA dump of every field (n, T, 14 fractions) as fp64, for checkers.
+ * Layout: int64 ncell[3], then 16 arrays of ncell doubles. */
 class BinaryDensityGridWriter : public DensityGridWriter {
   std::string _prefix;
 
@@ -200,8 +201,131 @@ public:
   }
 };
 
-/* src/DensityGridWriterFactory.hpp:100-103. The reference's default, Gadget,
- * needs HDF5, which this image does not have (listed as "next" in SURVEY 8f). */
+/* GadgetDensityGridWriter (the reference's default writer),
+ * src/GadgetDensityGridWriter.cpp:47-358: an HDF5 file in the Gadget-2 type 3
+ * layout - groups /Header /Code /Configuration /Parameters /RuntimePars
+ * /Units with attributes, /PartType0 with one dataset per output field
+ * (DensityGridWriterFields: Coordinates, NumberDensity, Temperature,
+ * NeutralFraction<ion>; src/DensityGridWriterFields.hpp:137-240,797-839 for
+ * the names, defaults and the "DensityGridWriterFields:<name>" switches) - so
+ * that the reference's own analysis scripts (benchmarks/, *.py) read the snapshots unchanged.
+ * Written with the dependency-free Hdf5Writer (the image has no HDF5). */
+class GadgetDensityGridWriter : public DensityGridWriter {
+  std::string _prefix;
+  uint_fast32_t _padding;
+  bool _coordinates, _number_density, _temperature;
+  bool _neutral_fraction[NUMBER_OF_IONNAMES];
+
+public:
+  GadgetDensityGridWriter(const std::string &output_folder,
+                          ParameterFile &params)
+      : DensityGridWriter(output_folder),
+        _prefix(params.get_string("DensityGridWriter:prefix", "snapshot")),
+        _padding((uint_fast32_t)params.get_integer("DensityGridWriter:padding",
+                                                   3)) {
+    /* defaults: DensityGridWriterFields::default_flag without hydro */
+    _coordinates =
+        params.get_integer("DensityGridWriterFields:Coordinates", 1) != 0;
+    _number_density =
+        params.get_integer("DensityGridWriterFields:NumberDensity", 1) != 0;
+    _temperature =
+        params.get_integer("DensityGridWriterFields:Temperature", 0) != 0;
+    for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+      _neutral_fraction[ion] =
+          params.get_integer(std::string("DensityGridWriterFields:"
+                                         "NeutralFraction") +
+                                 ion_name(ion),
+                             ion == ION_H_n ? 1 : 0) != 0;
+  }
+
+  void write(DensityGrid &grid, uint_fast32_t iteration, ParameterFile &params,
+             double time = 0.) override {
+    const std::string filename = compose_filename(_output_folder, _prefix,
+                                                  "hdf5", iteration, _padding);
+    Hdf5Writer file;
+    const SimulationBox &box = grid.box();
+    const uint64_t ncell = (uint64_t)grid.get_number_of_cells();
+    if (ncell >= (1ull << 32))
+      throw std::runtime_error(
+          "Gadget snapshots count cells in 32 bits (NumPart_ThisFile)");
+    /* :117-142 */
+    file.attribute("Header", "BoxSize",
+                   std::vector<double>{box.sides[0], box.sides[1],
+                                       box.sides[2]});
+    file.attribute("Header", "Dimension", (int32_t)3);
+    file.attribute("Header", "Flag_Entropy_ICs", std::vector<uint32_t>(6, 0));
+    file.attribute("Header", "MassTable", std::vector<double>(6, 0.));
+    file.attribute("Header", "NumFilesPerSnapshot", (int32_t)1);
+    std::vector<uint32_t> numpart(6, 0);
+    numpart[0] = (uint32_t)ncell;
+    file.attribute("Header", "NumPart_ThisFile", numpart);
+    file.attribute("Header", "NumPart_Total", numpart);
+    file.attribute("Header", "NumPart_Total_HighWord",
+                   std::vector<uint32_t>(6, 0));
+    file.attribute("Header", "Time", time);
+    /* :144-162: what the reference takes from its build system */
+    file.attribute("Code", "Code", std::string("cmacionize_amd (MI355X engine "
+                                               "behind the CMacIonize plugin "
+                                               "interfaces)"));
+    file.attribute("Configuration", "NUMBER_OF_IONNAMES",
+                   std::to_string(NUMBER_OF_IONNAMES));
+    /* :164-171: every parameter with the value that was used */
+    file.create_group("Parameters");
+    for (const auto &kv : params.used_values())
+      file.attribute("Parameters", kv.first, kv.second);
+    /* :173-178 */
+    {
+      const std::time_t now = std::time(nullptr);
+      char stamp[64];
+      std::strftime(stamp, sizeof stamp, "%d/%m/%Y, %H:%M:%S",
+                    std::localtime(&now));
+      file.attribute("RuntimePars", "Creation time", std::string(stamp));
+      file.attribute("RuntimePars", "Iteration", (uint32_t)iteration);
+    }
+    /* :180-196: SI units expressed in CGS */
+    file.attribute("Units", "Unit current in cgs (U_I)", 1.);
+    file.attribute("Units", "Unit length in cgs (U_L)", 100.);
+    file.attribute("Units", "Unit mass in cgs (U_M)", 1000.);
+    file.attribute("Units", "Unit temperature in cgs (U_T)", 1.);
+    file.attribute("Units", "Unit time in cgs (U_t)", 1.);
+    /* :198-352, fields in the order of the DensityGridField enum */
+    file.create_group("PartType0");
+    if (_coordinates) {
+      DensityGrid *g = &grid;
+      file.dataset("PartType0", "Coordinates", {ncell, 3},
+                   [g, ncell](std::ostream &os) {
+                     /* cell midpoint - box anchor, :517 */
+                     const SimulationBox &b = g->box();
+                     std::vector<double> chunk;
+                     const uint64_t block = 1 << 16;
+                     for (uint64_t first = 0; first < ncell; first += block) {
+                       const uint64_t last = std::min(ncell, first + block);
+                       chunk.resize(3 * (last - first));
+                       for (uint64_t i = first; i < last; ++i) {
+                         DensityGrid::iterator it(g, (int64_t)i);
+                         const CoordinateVector x = it.get_cell_midpoint();
+                         for (int a = 0; a < 3; ++a)
+                           chunk[3 * (i - first) + a] = x[a] - b.anchor[a];
+                       }
+                       os.write(reinterpret_cast<const char *>(chunk.data()),
+                                8 * chunk.size());
+                     }
+                   });
+    }
+    if (_number_density)
+      file.dataset("PartType0", "NumberDensity", grid._number_density);
+    if (_temperature)
+      file.dataset("PartType0", "Temperature", grid._temperature);
+    for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+      if (_neutral_fraction[ion])
+        file.dataset("PartType0",
+                     std::string("NeutralFraction") + ion_name(ion),
+                     grid._ionic_fraction[ion]);
+    file.write(filename);
+  }
+};
+
+/* src/DensityGridWriterFactory.hpp:100-103 */
 inline DensityGridWriter *generate_writer(const std::string &output_folder,
                                           ParameterFile &params) {
   const std::string type = params.get_string("DensityGridWriter:type", "Gadget");
@@ -210,9 +334,7 @@ inline DensityGridWriter *generate_writer(const std::string &output_folder,
   if (type == "Binary")
     return new BinaryDensityGridWriter(output_folder, params);
   if (type == "Gadget")
-    throw ParameterError(
-        "DensityGridWriter type Gadget needs HDF5, which this build does not "
-        "have; use AsciiFile or Binary");
+    return new GadgetDensityGridWriter(output_folder, params);
   throw ParameterError("Unknown DensityGridWriter type: \"" + type + "\"");
 }
 
@@ -670,6 +792,13 @@ public:
                                  xb.data()),
             "cmi_gpu_upload_cells");
     }
+  }
+
+  /* the initial snapshot (src/IonizationSimulation.cpp:347-350) without an
+   * engine: what a dry run can show of the writer and the density function */
+  void write_initial_snapshot() {
+    if (_density_grid_writer)
+      _density_grid_writer->write(*_density_grid, 0, _parameter_file);
   }
 
   /* IonizationSimulation::run, src/IonizationSimulation.cpp:334-680 */

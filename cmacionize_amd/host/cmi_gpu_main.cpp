@@ -109,6 +109,7 @@ int main(int argc, char **argv) {
       values.push_back(std::atoi(item.c_str()));
     return values;
   };
+  bool dry_snapshot = false;
   bool every_iteration = false, statistics = false, dry_run = false,
        verbose = false, do_describe = false;
   for (int i = 1; i < argc; ++i) {
@@ -141,6 +142,10 @@ int main(int argc, char **argv) {
       statistics = true;
     else if (a == "--dry-run" || a == "-n")
       dry_run = true;
+    else if (a == "--dry-run-snapshot") {
+      dry_run = true;
+      dry_snapshot = true;
+    }
     else if (a == "--verbose" || a == "-v")
       verbose = true;
     else if (a == "--describe")
@@ -153,7 +158,7 @@ int main(int argc, char **argv) {
                 << "usage: cmi-gpu --params FILE [--threads N] [--device N] "
                    "[--blocks BX,BY,BZ] [--devices D0,D1,...] "
                    "[--every-iteration-output] [--output-statistics] "
-                   "[--dry-run] [--describe] [--verbose]\n";
+                   "[--dry-run] [--dry-run-snapshot] [--describe] [--verbose]\n";
       return 1;
     }
   }
@@ -162,12 +167,18 @@ int main(int argc, char **argv) {
     return 1;
   }
   try {
-    GpuIonizationSimulation simulation(!dry_run, every_iteration, statistics,
-                                       threads, params, device,
+    GpuIonizationSimulation simulation(!dry_run || dry_snapshot,
+                                       every_iteration, statistics, threads,
+                                       params, device,
                                        verbose || !do_describe, !dry_run,
                                        blocks, devices);
     if (do_describe)
       describe(simulation);
+    if (dry_run && dry_snapshot) {
+      /* evaluate the DensityFunction on the host and write snapshot 0 */
+      simulation.initialize();
+      simulation.write_initial_snapshot();
+    }
     if (dry_run) {
       if (!do_describe)
         std::cout << "Dry run successful." << std::endl;

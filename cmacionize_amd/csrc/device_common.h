@@ -56,6 +56,12 @@ struct GridDev {
   int32_t offset[3];
   int32_t global_ncell[3];
   int32_t decomposed;
+  /* periodicity of the WHOLE grid. A block of a decomposed grid is never
+   * periodic itself (periodic[] = 0): a flight that leaves it across a
+   * periodic face of the whole box is handed to the block on the other side
+   * with its origin shifted by a box side
+   * (src/CartesianDensityGrid.cpp:187-227). */
+  int32_t global_periodic[3];
 };
 
 /* A flight handed from one block of a decomposed grid to another: the FAST

@@ -408,11 +408,13 @@ __device__ __forceinline__ void resume_flight_local(const GridDev &g,
 /* FAST, decomposed grids: the packet has stepped out of this block from
  * `last_cell` into p.cell (a long index one past a face). Returns the long
  * index of that cell in the WHOLE grid, or -1 if it lies outside the whole
- * grid. Every tied axis advanced by one cell, so the difference of the two
- * long indices decodes uniquely (blocks are at least 3 cells wide). */
+ * grid; across a periodic face of the whole box the flight's origin is
+ * shifted by a box side. Every tied axis advanced by one cell, so the
+ * difference of the two long indices decodes uniquely (blocks are at least 3
+ * cells wide). */
 template <bool FULL>
 __device__ __forceinline__ int64_t
-exit_cell_global(const GridDev &g, const Packet<FULL> &p, int32_t last_cell) {
+exit_cell_global(const GridDev &g, Packet<FULL> &p, int32_t last_cell) {
   const int32_t ny = g.ncell[1], nz = g.ncell[2];
   int32_t iz = last_cell % nz;
   int32_t iy = (last_cell / nz) % ny;
@@ -424,13 +426,20 @@ exit_cell_global(const GridDev &g, const Packet<FULL> &p, int32_t last_cell) {
   int32_t dy = ((d % ny) + ny) % ny;
   dy = (dy == ny - 1) ? -1 : dy;
   const int32_t dx = (d - dy) / ny;
-  const int64_t gx = (int64_t)ix + dx + g.offset[0];
-  const int64_t gy = (int64_t)iy + dy + g.offset[1];
-  const int64_t gz = (int64_t)iz + dz + g.offset[2];
-  if (gx < 0 || gx >= g.global_ncell[0] || gy < 0 ||
-      gy >= g.global_ncell[1] || gz < 0 || gz >= g.global_ncell[2])
-    return -1;
-  return (gx * g.global_ncell[1] + gy) * g.global_ncell[2] + gz;
+  int64_t gc[3] = {(int64_t)ix + dx + g.offset[0],
+                   (int64_t)iy + dy + g.offset[1],
+                   (int64_t)iz + dz + g.offset[2]};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (gc[a] < 0 || gc[a] >= g.global_ncell[a]) {
+      if (!g.global_periodic[a])
+        return -1;
+      /* across a periodic face of the whole box: is_inside()'s wrap */
+      p.pos[a] += (gc[a] < 0 ? 1. : -1.) * g.box_sides[a];
+      gc[a] = gc[a] < 0 ? g.global_ncell[a] - 1 : 0;
+    }
+  }
+  return (gc[0] * g.global_ncell[1] + gc[1]) * g.global_ncell[2] + gc[2];
 }
 
 /* FAST: materialise the current position (end of a flight) */

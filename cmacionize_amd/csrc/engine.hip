@@ -641,10 +641,6 @@ int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
         return fail(CMI_GPU_EINVAL,
                     "a block of a decomposed grid must lie inside the grid "
                     "and be at least 3 cells wide");
-      if (config->periodic[a])
-        return fail(CMI_GPU_EINVAL,
-                    "decomposed grids with periodic boundaries are not "
-                    "supported");
     }
   }
   {
@@ -697,7 +693,10 @@ int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
     g.global_ncell[a] = config->ncell[a];
     g.ncell[a] = decomposed ? config->sub_ncell[a] : config->ncell[a];
     g.offset[a] = decomposed ? config->sub_offset[a] : 0;
-    g.periodic[a] = config->periodic[a] ? 1 : 0;
+    g.global_periodic[a] = config->periodic[a] ? 1 : 0;
+    /* a block of a decomposed grid is not periodic itself: a flight across a
+     * periodic face of the whole box is handed over like any other */
+    g.periodic[a] = (config->periodic[a] && !decomposed) ? 1 : 0;
     g.cellside[a] = config->sides[a] / config->ncell[a];
     g.inv_cellside[a] = 1. / g.cellside[a];
   }
@@ -1329,6 +1328,19 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
 #undef PICK
   if (reemit && !passes)
     kernel = kernel_inline;
+  /* the first generation of new packets on a non-periodic grid with the
+   * block combining table (every benchmark config): the specialised build of
+   * the same kernel */
+  void (*kernel_first)(const ShootArgs) = kernel;
+  if (!flights && !exact && agg == CMI_AGG_BLOCK && kernel != kernel_inline &&
+      !(e->grid.periodic[0] | e->grid.periodic[1] | e->grid.periodic[2])) {
+    if (e->full_ions)
+      kernel_first = heat ? shoot_kernel<true, true, false, false, true>
+                          : shoot_kernel<true, false, false, false, true>;
+    else
+      kernel_first = heat ? shoot_kernel<false, true, false, false, true>
+                          : shoot_kernel<false, false, false, false, true>;
+  }
 
   auto occupancy = [&](void (*k)(const ShootArgs), int &blocks_per_cu) -> int {
     blocks_per_cu = 0;
@@ -1503,7 +1515,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       if (trc)
         return trc;
     }
-    kernel<<<(unsigned)blocks, CMI_BLOCK, 0, e->stream>>>(a);
+    kernel_first<<<(unsigned)blocks, CMI_BLOCK, 0, e->stream>>>(a);
     HIP_TRY(hipGetLastError());
     {
       int trc = timer_end(e, e->kernel_events, kev, n);

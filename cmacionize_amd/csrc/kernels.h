@@ -410,7 +410,11 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
  * read-modify-write per packet and cell; sums are associative up to
  * rounding). EXACT selects the marcher (device_transport.h).
  */
-template <bool FULL, bool HEAT, bool REEMIT, bool EXACT>
+/* TABLE: the launch is known to use the block combining table on a
+ * non-periodic grid (the first generation of every benchmark config): those
+ * choices are compile-time constants and the code of the other aggregation
+ * modes and of the periodic wrap is not in the march loop at all. */
+template <bool FULL, bool HEAT, bool REEMIT, bool EXACT, bool TABLE = false>
 __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
     shoot_kernel(const ShootArgs a) {
   const int lane = threadIdx.x & 63;
@@ -450,7 +454,9 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
   unsigned int nsteps = 0, natomics = 0; /* per lane and launch: < 2^32 */
   unsigned int nwavesteps = 0;
   const bool any_periodic =
+      !TABLE &&
       (a.grid.periodic[0] | a.grid.periodic[1] | a.grid.periodic[2]) != 0;
+  const int aggregate = TABLE ? CMI_AGG_BLOCK : a.aggregate;
 
   /* H-only: per-wave write-combining cache in LDS. Scattered fp64 atomics
    * execute at the memory side at a chip-wide rate of a few 1e10 per second
@@ -497,7 +503,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
    * loop as well - the waves of a block advance together, one Manhattan shell
    * per iteration, so a cell's contributions arrive within a few iterations
    * of each other. */
-  const bool use_table = a.aggregate == CMI_AGG_BLOCK;
+  const bool use_table = TABLE || a.aggregate == CMI_AGG_BLOCK;
   if (use_table) {
     for (int k = threadIdx.x; k < lds_slots; k += CMI_BLOCK)
       lds_tag[k] = -1;
@@ -804,7 +810,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
           window = 0;
           (void)flush_point(true);
         }
-      } else if (a.aggregate != CMI_AGG_NONE) {
+      } else if (aggregate != CMI_AGG_NONE) {
         /* lanes in the same cell: one add for the whole run */
         const int32_t key = accumulate ? last_cell : ~lane;
         const double dsw = accumulate ? ds * p.weight : 0.;

@@ -493,7 +493,15 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS, (!FULL && HEAT) ? 2 : 4)
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
               gg[ax] = (int64_t)g[ax] + a.grid.offset[ax];
-              in_whole &= gg[ax] >= 0 && gg[ax] < a.grid.global_ncell[ax];
+              if (gg[ax] < 0 || gg[ax] >= a.grid.global_ncell[ax]) {
+                if (a.grid.global_periodic[ax]) {
+                  /* across a periodic face of the whole box */
+                  pos[ax] += (gg[ax] < 0 ? 1. : -1.) * a.grid.box_sides[ax];
+                  gg[ax] = gg[ax] < 0 ? a.grid.global_ncell[ax] - 1 : 0;
+                } else {
+                  in_whole = false;
+                }
+              }
             }
             if (in_whole) {
               const int64_t cell_global =

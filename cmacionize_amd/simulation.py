@@ -284,7 +284,8 @@ class DomainGpuBackend:
     export buffer (stream handling as in GpuBackend)."""
 
     def __init__(self, decomposition, rank, anchor, sides, device=0,
-                 track_heating=False, export_capacity=1 << 22):
+                 track_heating=False, export_capacity=1 << 22,
+                 periodic=(0, 0, 0)):
         import torch
         from .engine import GpuEngine
         self.torch = torch
@@ -294,7 +295,7 @@ class DomainGpuBackend:
         self.offset, self.sub_ncell = decomposition.block(rank)
         stream = torch.cuda.current_stream().cuda_stream
         self.engine = GpuEngine(
-            decomposition.ncell, anchor, sides, (0, 0, 0), device=device,
+            decomposition.ncell, anchor, sides, periodic, device=device,
             track_heating=track_heating, stream=stream,
             sub_offset=self.offset, sub_ncell=self.sub_ncell)
         self.exports = torch.zeros((int(export_capacity), FLIGHT_DOUBLES),

@@ -341,6 +341,77 @@ def test_decomposed_diffuse_matches_oracle(oracle, blocks, tiles):
 
 
 @pytest.mark.parametrize("tiles", [0, 1])
+@pytest.mark.parametrize("blocks", [(2, 2, 2), (3, 1, 2), (1, 1, 1)])
+def test_decomposed_periodic_diffuse_matches_oracle(oracle, blocks, tiles):
+    """A box that is periodic in x and y (CartesianDensityGrid::is_inside,
+    src/CartesianDensityGrid.cpp:187-227), cut in blocks: a flight that
+    leaves the whole box through a periodic face goes on in the block on the
+    other side with its origin shifted by a box side - also when that block is
+    the one it left (one block along the axis). Counters and J against the
+    oracle on the same seeds."""
+    from cmacionize_amd import STROMGREN as S
+    from cmacionize_amd import engine as E
+    from cmacionize_amd.simulation import (DomainDecomposition,
+                                           DomainGpuBackend,
+                                           LocalDomainDriver)
+    ncell, npacket = 24, 30000
+    periodic = (1, 1, 0)
+    source = [[0.31 * S["sides"][0], -0.2 * S["sides"][0],
+               0.07 * S["sides"][0]]]
+    sim = oracle.OracleSimulation((ncell,) * 3, S["anchor"], S["sides"],
+                                  periodic=periodic)
+    sim.set_sources(source, [1.], S["luminosity"])
+    # thin enough that most packets cross the box several times
+    sim.set_homogeneous(S["density"], S["temperature"], xH=2.e-5)
+    m = sim.model
+    m.spectrum_type = oracle.SPECTRUM_MONOCHROMATIC
+    m.mono_frequency = S["frequency"]
+    m.xsec_type = oracle.XSEC_FIXED
+    m.xsec_fixed[0] = S["sigma_H"]
+    m.recomb_type = oracle.RECOMB_FIXED
+    m.recomb_fixed[0] = S["alpha_H"]
+    m.reemit_type = oracle.REEMIT_PHYSICAL
+
+    dec = DomainDecomposition((ncell,) * 3, blocks)
+    backends = []
+    for rank in range(dec.world):
+        b = DomainGpuBackend(dec, rank, S["anchor"], S["sides"], device=0,
+                             track_heating=True, export_capacity=4 * npacket,
+                             periodic=periodic)
+        eng = b.engine
+        eng.set_sources(source, [1.], S["luminosity"])
+        eng.set_spectrum_monochromatic(S["frequency"])
+        sigma = np.zeros(14)
+        sigma[0] = S["sigma_H"]
+        alpha = np.zeros(14)
+        alpha[0] = S["alpha_H"]
+        eng.set_cross_sections_fixed(sigma)
+        eng.set_recombination_rates_fixed(alpha)
+        eng.set_reemission(1)
+        eng.set_tuning(reemit_inline_below=64, tile_rounds=tiles,
+                       tile_min_flights=0, tile_min_per_item=0)
+        backends.append(b)
+    driver = LocalDomainDriver(backends, dec)
+    upload_state(dec, backends, sim, ncell)
+    for loop in range(2):
+        driver.iteration(loop, npacket, 9, update=False)
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(9, loop, 0, npacket)
+        assert driver.totweight == sim.totweight == npacket
+        assert np.array_equal(driver.typecount, sim.typecount)
+        assert driver.typecount[1] > 0 and driver.typecount[3] > 0
+        J = assemble(dec, backends, E.FIELD_MEAN_INTENSITY)
+        assert np.allclose(J, sim.J[0], rtol=1e-9, atol=1e-12 * sim.J[0].max())
+        h = assemble(dec, backends, E.FIELD_HEATING)
+        assert np.allclose(h, sim.heating[0], rtol=1e-9,
+                           atol=1e-12 * np.abs(sim.heating[0]).max())
+    for b in backends:
+        b.engine.close()
+
+
+@pytest.mark.parametrize("tiles", [0, 1])
 def test_decomposed_lexington_matches_oracle(oracle, tiles):
     """Config 5's physics and decomposition at test size: lexingtonHII40 on
     24^3 as 2 x 2 x 2 blocks through LocalDomainDriver against the ORACLE:

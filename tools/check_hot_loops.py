@@ -16,14 +16,14 @@ import sys
 path = sys.argv[1] if len(sys.argv) > 1 else "cmacionize_amd/csrc/engine.s"
 text = open(path).read().split("\n")
 starts = [i for i, l in enumerate(text)
-          if re.match(r"^_Z12shoot_kernelILb[01]ELb[01]ELb[01]ELb[01]EEv9ShootArgs:", l)]
+          if re.match(r"^_Z12shoot_kernelI(Lb[01]E){5}Ev9ShootArgs:", l)]
 bad = 0
-print("%-22s %6s %6s %6s %6s %8s" % ("variant <F,H,R,X>", "lines", "valu",
+print("%-22s %6s %6s %6s %6s %8s" % ("variant <F,H,R,X,T>", "lines", "valu",
                                      "salu", "lds", "scratch"))
 for s in starts:
     e = next(i for i in range(s, len(text)) if "s_endpgm" in text[i])
     body = text[s:e]
-    flags = re.findall(r"Lb([01])E", text[s])[:4]
+    flags = re.findall(r"Lb([01])E", text[s])[:5]
     cas = [i for i, l in enumerate(body) if "ds_cmpst" in l]
     if not cas:
         continue
@@ -50,6 +50,7 @@ for s in starts:
     # fail for the variants the benchmark configs launch (hydrogen-only, and
     # multi-ion with heating; no inline re-emission, incremental marcher);
     # elsewhere a spill in the loop is only reported
-    if scratch and tuple(flags) in (("0", "0", "0", "0"), ("1", "1", "0", "0")):
+    if scratch and tuple(flags) in (("0", "0", "0", "0", "1"),
+                                    ("1", "1", "0", "0", "1")):
         bad = 1
 sys.exit(bad)

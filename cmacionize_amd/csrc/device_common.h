@@ -62,6 +62,10 @@ struct GridDev {
    * with its origin shifted by a box side
    * (src/CartesianDensityGrid.cpp:187-227). */
   int32_t global_periodic[3];
+  /* copies of a block (DensitySubGridCreator::create_copies,
+   * src/DensitySubGridCreator.hpp:437-531): copy `copy_rank` of `copy_count`
+   * engines holding this block emits the packets whose id is congruent to it */
+  int32_t copy_rank, copy_count;
 };
 
 /* A flight handed from one block of a decomposed grid to another: the FAST

@@ -70,6 +70,7 @@ struct cmi_gpu_engine {
   bool spectra_dirty = true; /* cross sections / spectrum changed */
   double *source_position = nullptr;
   double *source_cumulative = nullptr;
+  std::vector<double> source_position_host;
 
   bool have_sources = false, have_spectrum = false, have_xsec = false,
        have_recomb = false, have_cells = false;
@@ -701,6 +702,8 @@ int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
     g.inv_cellside[a] = 1. / g.cellside[a];
   }
   g.decomposed = decomposed ? 1 : 0;
+  g.copy_rank = 0;
+  g.copy_count = 1;
   e->ncell = (int64_t)g.ncell[0] * g.ncell[1] * g.ncell[2];
   g.ncell_total = e->ncell;
 
@@ -837,6 +840,7 @@ int cmi_gpu_set_sources(cmi_gpu_engine *e, int32_t n, const double *positions,
                     hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->source_cumulative, cumulative.data(),
                     sizeof(double) * n, hipMemcpyHostToDevice));
+  e->source_position_host.assign(positions, positions + 3 * (size_t)n);
   e->model.nsource = n;
   e->model.source_position = e->source_position;
   e->model.source_cumulative = e->source_cumulative;
@@ -1267,6 +1271,32 @@ static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
 /* Transport of n_packets flights and of everything they re-emit: new packets
  * (flights == NULL) or flights handed over by other blocks of a decomposed
  * grid (device rows of CMI_FLIGHT_DOUBLES doubles). */
+/* A block of a decomposed grid flies the packets that start in it (after at
+ * most one step of length zero, see shoot_kernel): no source within one cell
+ * of the block - and, for the block at the grid's origin, none outside the
+ * whole grid - means nothing to emit, and the pass over the packet ids can be
+ * skipped altogether. */
+static bool block_emits_nothing(const cmi_gpu_engine *e) {
+  const GridDev &g = e->grid;
+  const bool at_origin = (g.offset[0] | g.offset[1] | g.offset[2]) == 0;
+  for (int32_t s = 0; s < e->model.nsource; ++s) {
+    bool near = true, in_grid = true;
+    for (int a = 0; a < 3; ++a) {
+      const double x = e->source_position_host[3 * (size_t)s + a];
+      const double lo = g.anchor[a] + g.cellside[a] * (g.offset[a] - 1);
+      const double hi =
+          g.anchor[a] + g.cellside[a] * (g.offset[a] + g.ncell[a] + 1);
+      near &= (x >= lo && x <= hi);
+      /* (a cell of margin: the kernel decides by cell index) */
+      in_grid &= (x >= g.anchor[a] + g.cellside[a] &&
+                  x <= g.anchor[a] + g.box_sides[a] - g.cellside[a]);
+    }
+    if (near || (!in_grid && at_origin))
+      return false;
+  }
+  return e->model.nsource > 0;
+}
+
 static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                       uint64_t first_packet, uint64_t n_packets,
                       const double *flights) {
@@ -1289,6 +1319,8 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                 "cmi_gpu_shoot: a block of a decomposed grid needs an export "
                 "buffer (cmi_gpu_set_export_buffer) and the incremental "
                 "marcher (fewer than 2^28 cells per block)");
+  if (!flights && e->grid.decomposed && block_emits_nothing(e))
+    return CMI_GPU_OK;
   HIP_TRY(hipSetDevice(e->device));
   {
     int rc = ensure_spectra(e);

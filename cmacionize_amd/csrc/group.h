@@ -17,6 +17,15 @@
  *                 kernel on the SOURCE device writes every row straight into
  *                 the destination engine's inbox over xGMI (peer access);
  *                 nothing passes through host memory except n x n counts.
+ *                 Engines of a group that hold the SAME block are copies of
+ *                 each other (DensitySubGridCreator::create_copies,
+ *                 src/DensitySubGridCreator.hpp:437-531): the packets emitted
+ *                 in the block and the flights that enter it are dealt to its
+ *                 copies by packet id, and cmi_gpu_group_reduce_accumulators
+ *                 sums the copies' accumulators into every copy
+ *                 (update_original_counters, :556-574) so that each then
+ *                 solves the same cells from the same integrals
+ *                 (update_copy_properties, :580-598, without the copy).
  *
  * RCCL is loaded at run time (dlopen) by the first reduce: a process that
  * already has another copy of RCCL (PyTorch ships its own) never maps a
@@ -76,6 +85,7 @@ constexpr int kNcclSum = 0;    /* ncclSum */
 /* block of the whole grid an engine owns */
 struct GroupBoxDev {
   int32_t offset[3], size[3];
+  int32_t copy_rank, copy_count;
 };
 
 struct GroupRouteArgs {
@@ -112,12 +122,16 @@ __global__ void __launch_bounds__(CMI_BLOCK)
         (int32_t)((cell / a.global_ncell[2]) % a.global_ncell[1]);
     const int32_t gx =
         (int32_t)(cell / ((int64_t)a.global_ncell[2] * a.global_ncell[1]));
+    /* (the low half of column 13 is the packet id: which copy of the block) */
+    const uint32_t packet_id = (uint32_t)__double_as_longlong(
+        a.rows[(size_t)CMI_FLIGHT_DOUBLES * i + 13]);
     uint32_t owner = 0;
     for (int k = 0; k < a.n; ++k) {
       const GroupBoxDev &b = a.box[k];
       if (gx >= b.offset[0] && gx < b.offset[0] + b.size[0] &&
           gy >= b.offset[1] && gy < b.offset[1] + b.size[1] &&
-          gz >= b.offset[2] && gz < b.offset[2] + b.size[2])
+          gz >= b.offset[2] && gz < b.offset[2] + b.size[2] &&
+          (int32_t)(packet_id % (uint32_t)b.copy_count) == b.copy_rank)
         owner = (uint32_t)k;
     }
     a.dest[i] = owner;
@@ -159,12 +173,18 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     out[i] += in[i];
 }
 
+/* engines of a group that hold the same cells: the replicas of replica
+ * mode, the copies of a block in domain mode */
+struct GroupClass {
+  std::vector<int> member;
+  bool distinct_devices = true, same_device = true;
+  std::vector<RcclApi::comm_t> comm;
+};
+
 struct cmi_gpu_group {
   int n = 0;
   cmi_gpu_engine *engine[CMI_GROUP_MAX];
-  bool distinct_devices = false;
-  RcclApi::comm_t comm[CMI_GROUP_MAX];
-  bool have_comm = false;
+  std::vector<GroupClass> classes;
   /* domain mode */
   double *inbox[CMI_GROUP_MAX];
   uint64_t inbox_capacity[CMI_GROUP_MAX];
@@ -182,7 +202,6 @@ int cmi_gpu_group_create(int32_t n, cmi_gpu_engine *const *engines,
     return fail(CMI_GPU_EINVAL, "group_create: 1 to %d engines", CMI_GROUP_MAX);
   cmi_gpu_group *g = new cmi_gpu_group();
   g->n = n;
-  g->distinct_devices = true;
   for (int i = 0; i < n; ++i) {
     if (!engines[i]) {
       delete g;
@@ -194,9 +213,48 @@ int cmi_gpu_group_create(int32_t n, cmi_gpu_engine *const *engines,
     g->dest[i] = nullptr;
     g->hist[i] = nullptr;
     g->routed[i] = nullptr;
-    for (int k = 0; k < i; ++k)
+    /* the class of engines that hold the same cells */
+    const GridDev &gi = engines[i]->grid;
+    GroupClass *cls = nullptr;
+    for (GroupClass &c : g->classes) {
+      const cmi_gpu_engine *first = engines[c.member[0]];
+      const GridDev &gf = first->grid;
+      bool same = gf.decomposed == gi.decomposed &&
+                  first->cells.acc_cell_stride ==
+                      engines[i]->cells.acc_cell_stride &&
+                  first->config.track_heating ==
+                      engines[i]->config.track_heating;
+      for (int a = 0; a < 3; ++a)
+        same &= gf.ncell[a] == gi.ncell[a] && gf.offset[a] == gi.offset[a] &&
+                gf.global_ncell[a] == gi.global_ncell[a];
+      if (same)
+        cls = &c;
+    }
+    if (!cls) {
+      g->classes.emplace_back();
+      cls = &g->classes.back();
+    }
+    for (int k : cls->member) {
       if (engines[k]->device == engines[i]->device)
-        g->distinct_devices = false;
+        cls->distinct_devices = false;
+      else
+        cls->same_device = false;
+    }
+    cls->member.push_back(i);
+  }
+  for (GroupClass &c : g->classes) {
+    if (c.member.size() > 1 && !c.distinct_devices && !c.same_device) {
+      delete g;
+      return fail(CMI_GPU_EINVAL,
+                  "group_create: the engines that hold the same cells must "
+                  "sit on different devices (or, for tests, all on one)");
+    }
+    /* copies of a block share its packets by packet id */
+    for (size_t r = 0; r < c.member.size(); ++r) {
+      GridDev &grid = engines[c.member[r]]->grid;
+      grid.copy_rank = (int32_t)r;
+      grid.copy_count = (int32_t)c.member.size();
+    }
   }
   /* peer access between every pair of devices (flights are written straight
    * into the owner's inbox) */
@@ -239,14 +297,17 @@ int cmi_gpu_group_destroy(cmi_gpu_group *g) {
   for (int i = 0; i < g->n; ++i) {
     (void)hipSetDevice(g->engine[i]->device);
     (void)hipStreamSynchronize(g->engine[i]->stream);
-    if (g->have_comm)
-      (void)g_rccl.CommDestroy(g->comm[i]);
     (void)hipFree(g->inbox[i]);
     (void)hipFree(g->dest[i]);
     (void)hipFree(g->hist[i]);
     if (g->routed[i])
       (void)hipEventDestroy(g->routed[i]);
+    g->engine[i]->grid.copy_rank = 0;
+    g->engine[i]->grid.copy_count = 1;
   }
+  for (GroupClass &c : g->classes)
+    for (RcclApi::comm_t comm : c.comm)
+      (void)g_rccl.CommDestroy(comm);
   delete g;
   return CMI_GPU_OK;
 }
@@ -269,39 +330,28 @@ static int active_accumulators(cmi_gpu_engine *e, double *ptr[2],
   return 2;
 }
 
-int cmi_gpu_group_reduce_accumulators(cmi_gpu_group *g) {
-  if (!g)
-    return fail(CMI_GPU_EINVAL, "null group");
-  /* (CMI_GPU_FORCE_RCCL: run the collective even for a group of one - the
-   * only way to exercise the RCCL path on a single-GPU box) */
-  if (g->n == 1 && !getenv("CMI_GPU_FORCE_RCCL"))
-    return CMI_GPU_OK;
-  for (int i = 1; i < g->n; ++i)
-    if (g->engine[i]->ncell != g->engine[0]->ncell ||
-        g->engine[i]->cells.acc_cell_stride !=
-            g->engine[0]->cells.acc_cell_stride)
-      return fail(CMI_GPU_ESTATE,
-                  "reduce_accumulators: the engines of a replica group must "
-                  "hold the same grid");
+/* sum the accumulators of one class of engines into every member */
+static int reduce_class(cmi_gpu_group *g, GroupClass &c) {
+  const int n = (int)c.member.size();
   double *ptr[CMI_GROUP_MAX][2];
   int64_t count[2] = {0, 0};
   int pieces = 0;
-  for (int i = 0; i < g->n; ++i)
-    pieces = active_accumulators(g->engine[i], ptr[i], count);
-  if (!g->distinct_devices) {
-    /* replicas that share a device (tests on one GPU): plain sums, in
-     * engine order, then copies back */
-    cmi_gpu_engine *e0 = g->engine[0];
+  for (int i = 0; i < n; ++i)
+    pieces = active_accumulators(g->engine[c.member[i]], ptr[i], count);
+  if (n > 1 && c.same_device) {
+    /* engines that share a device (tests on one GPU): plain sums, in engine
+     * order, then copies back */
+    cmi_gpu_engine *e0 = g->engine[c.member[0]];
     HIP_TRY(hipSetDevice(e0->device));
-    for (int i = 1; i < g->n; ++i)
-      HIP_TRY(hipStreamSynchronize(g->engine[i]->stream));
+    for (int i = 1; i < n; ++i)
+      HIP_TRY(hipStreamSynchronize(g->engine[c.member[i]]->stream));
     for (int p = 0; p < pieces; ++p) {
-      for (int i = 1; i < g->n; ++i) {
+      for (int i = 1; i < n; ++i) {
         group_add_kernel<<<grid_blocks(e0, count[p], 8), CMI_BLOCK, 0,
                            e0->stream>>>(ptr[0][p], ptr[i][p], count[p]);
         HIP_TRY(hipGetLastError());
       }
-      for (int i = 1; i < g->n; ++i)
+      for (int i = 1; i < n; ++i)
         HIP_TRY(hipMemcpyAsync(ptr[i][p], ptr[0][p],
                                sizeof(double) * count[p],
                                hipMemcpyDeviceToDevice, e0->stream));
@@ -309,29 +359,31 @@ int cmi_gpu_group_reduce_accumulators(cmi_gpu_group *g) {
     HIP_TRY(hipStreamSynchronize(e0->stream));
     return CMI_GPU_OK;
   }
-  if (!g->have_comm) {
+  if (c.comm.empty()) {
     if (!g_rccl.load())
       return fail(CMI_GPU_EDEVICE,
                   "reduce_accumulators: cannot load RCCL (librccl.so.1): %s",
                   dlerror());
     int devices[CMI_GROUP_MAX];
-    for (int i = 0; i < g->n; ++i)
-      devices[i] = g->engine[i]->device;
-    const int rc = g_rccl.CommInitAll(g->comm, g->n, devices);
-    if (rc != 0)
+    for (int i = 0; i < n; ++i)
+      devices[i] = g->engine[c.member[i]]->device;
+    c.comm.resize(n);
+    const int rc = g_rccl.CommInitAll(c.comm.data(), n, devices);
+    if (rc != 0) {
+      c.comm.clear();
       return fail(CMI_GPU_EDEVICE, "ncclCommInitAll failed: %s",
                   g_rccl.GetErrorString(rc));
-    g->have_comm = true;
+    }
   }
   /* one grouped all-reduce per piece: every engine's call is enqueued on its
    * own stream, behind its transport kernels */
   for (int p = 0; p < pieces; ++p) {
     int rc = g_rccl.GroupStart();
-    for (int i = 0; i < g->n && rc == 0; ++i) {
-      HIP_TRY(hipSetDevice(g->engine[i]->device));
+    for (int i = 0; i < n && rc == 0; ++i) {
+      cmi_gpu_engine *e = g->engine[c.member[i]];
+      HIP_TRY(hipSetDevice(e->device));
       rc = g_rccl.AllReduce(ptr[i][p], ptr[i][p], (size_t)count[p],
-                            kNcclDouble, kNcclSum, g->comm[i],
-                            g->engine[i]->stream);
+                            kNcclDouble, kNcclSum, c.comm[i], e->stream);
     }
     const int rc_end = g_rccl.GroupEnd();
     if (rc == 0)
@@ -339,6 +391,22 @@ int cmi_gpu_group_reduce_accumulators(cmi_gpu_group *g) {
     if (rc != 0)
       return fail(CMI_GPU_EDEVICE, "ncclAllReduce failed: %s",
                   g_rccl.GetErrorString(rc));
+  }
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_group_reduce_accumulators(cmi_gpu_group *g) {
+  if (!g)
+    return fail(CMI_GPU_EINVAL, "null group");
+  /* (CMI_GPU_FORCE_RCCL: run the collective even for a class of one - the
+   * only way to exercise the RCCL path on a single-GPU box) */
+  const bool force = getenv("CMI_GPU_FORCE_RCCL") != nullptr;
+  for (GroupClass &c : g->classes) {
+    if (c.member.size() == 1 && !force)
+      continue;
+    const int rc = reduce_class(g, c);
+    if (rc)
+      return rc;
   }
   return CMI_GPU_OK;
 }
@@ -364,6 +432,8 @@ int cmi_gpu_group_exchange_flights(cmi_gpu_group *g, uint32_t seed,
       proto.box[i].size[a] = e->grid.ncell[a];
       proto.global_ncell[a] = e->grid.global_ncell[a];
     }
+    proto.box[i].copy_rank = e->grid.copy_rank;
+    proto.box[i].copy_count = e->grid.copy_count;
   }
   /* pass 1 on every source: owners and counts */
   for (int s = 0; s < n; ++s) {

@@ -723,6 +723,10 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
             const bool at_origin = (a.grid.offset[0] | a.grid.offset[1] |
                                     a.grid.offset[2]) == 0;
             mine = in_block || (!in_grid && at_origin);
+            /* several engines hold this block: each emits its share */
+            if (a.grid.copy_count > 1)
+              mine &= (int32_t)(packet_id % (uint32_t)a.grid.copy_count) ==
+                      a.grid.copy_rank;
             if (skipped != 0 && mine) {
               nsteps += skipped; /* they are DDA steps of the undivided run */
 #pragma unroll

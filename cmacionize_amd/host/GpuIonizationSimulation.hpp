@@ -369,9 +369,15 @@ class GpuIonizationSimulation {
     cmi_gpu_engine *engine = nullptr;
     int32_t offset[3], size[3];
     int device = 0;
+    /* a copy of another block (DensitySubGridCreator::create_copies,
+     * src/DensitySubGridCreator.hpp:437-531): index of the original */
+    int original = -1;
     int64_t ncell() const { return (int64_t)size[0] * size[1] * size[2]; }
   };
+  /* the originals first (block (bx,by,bz) at (bx*nby + by)*nbz + bz), then
+   * the copies */
   std::vector<Block> _blocks;
+  size_t _number_of_copies = 0;
   /* replica mode (the reference's MPI path,
    * src/IonizationSimulation.cpp:394-397,458-529): one engine per device,
    * each holding the whole grid and flying its share of the packets */
@@ -452,6 +458,8 @@ class GpuIonizationSimulation {
     }
     std::vector<double> part;
     for (Block &b : _blocks) {
+      if (b.original >= 0)
+        continue; /* a copy holds what its original holds */
       part.resize((size_t)b.ncell());
       check(cmi_gpu_download_field(b.engine, field, part.data()), "download");
       block_unslice(b, part, whole);
@@ -482,6 +490,11 @@ class GpuIonizationSimulation {
       ++_exchange_rounds;
       _flights_exchanged += total;
     }
+    /* the copies of a block: sum their integrals into each of them
+     * (DensitySubGridCreator::update_original_counters,
+     * src/DensitySubGridCreator.hpp:556-574) */
+    if (_number_of_copies > 0)
+      check(cmi_gpu_group_reduce_accumulators(_group), "reduce_accumulators");
     totweight = 0.;
     for (int i = 0; i < 4; ++i)
       typecount[i] = 0.;
@@ -557,7 +570,8 @@ public:
                           const int device = 0, const bool verbose = true,
                           const bool create_engine = true,
                           const std::array<int, 3> blocks = {1, 1, 1},
-                          const std::vector<int> &devices = {})
+                          const std::vector<int> &devices = {},
+                          const int copies = 0)
       : _every_iteration_output(every_iteration_output),
         _output_statistics(output_statistics), _verbose(verbose),
         _parameter_file(parameterfile),
@@ -702,6 +716,77 @@ public:
                             1024),
                     "set_export_buffer");
             }
+        /* Copies of the blocks that contain a source: the packets of a source
+         * all start in its block, so without copies one device flies the
+         * first flight of every packet while the others wait. The reference
+         * makes 2^level copies of such a subgrid
+         * (TaskBasedIonizationSimulation:source copy level, default 4,
+         * src/TaskBasedIonizationSimulation.cpp:199,514-560); here a block
+         * is 1/P of the grid, so: one copy per device at most, 2^level at
+         * most, and no copies of the neighbours. --copies K asks for exactly
+         * K engines per source block (also on one device: tests). */
+        {
+          const int level = (int)_parameter_file.get_integer(
+              "TaskBasedIonizationSimulation:source copy level", 4);
+          std::vector<int> pool = devices;
+          if (pool.empty())
+            pool.push_back(device);
+          size_t want = copies > 0
+                            ? (size_t)copies
+                            : std::min((size_t)1 << std::min(level, 6),
+                                       pool.size());
+          const size_t originals = _blocks.size();
+          std::vector<char> has_source(originals, 0);
+          if (_photon_source_distribution && want > 1) {
+            const photonsourcenumber_t ns =
+                _photon_source_distribution->get_number_of_sources();
+            for (photonsourcenumber_t i = 0; i < ns; ++i) {
+              const CoordinateVector pos =
+                  _photon_source_distribution->get_position(i);
+              int64_t c[3];
+              bool inside = true;
+              for (int a = 0; a < 3; ++a) {
+                c[a] = (int64_t)std::floor((pos[a] - config.anchor[a]) /
+                                           config.sides[a] * _ncell[a]);
+                inside &= c[a] >= 0 && c[a] < _ncell[a];
+              }
+              if (inside)
+                has_source[owner_of_cell((c[0] * _ncell[1] + c[1]) *
+                                             _ncell[2] +
+                                         c[2])] = 1;
+            }
+          }
+          for (size_t o = 0; o < originals; ++o) {
+            if (!has_source[o])
+              continue;
+            /* on the devices after the original's, round-robin */
+            size_t at = 0;
+            while (at < pool.size() && pool[at] != _blocks[o].device)
+              ++at;
+            for (size_t k = 1; k < want; ++k) {
+              Block b = _blocks[o];
+              b.original = (int)o;
+              b.device = pool[(at + k) % pool.size()];
+              for (int a = 0; a < 3; ++a) {
+                config.sub_offset[a] = b.offset[a];
+                config.sub_ncell[a] = b.size[a];
+              }
+              config.device = b.device;
+              check(cmi_gpu_create(&config, &b.engine), "cmi_gpu_create");
+              _blocks.push_back(b);
+              lower_model(b.engine);
+              check(cmi_gpu_set_export_buffer(
+                        b.engine, nullptr,
+                        std::max(_number_of_photons, _number_of_photons_init) +
+                            1024),
+                    "set_export_buffer");
+              ++_number_of_copies;
+            }
+          }
+          if (_number_of_copies + originals > 64)
+            throw std::runtime_error(
+                "too many blocks and copies (at most 64 engines in a group)");
+        }
         {
           std::vector<cmi_gpu_engine *> engines;
           for (Block &b : _blocks)
@@ -710,8 +795,11 @@ public:
                                      &_group),
                 "group_create");
         }
-        status("Domain decomposition: " + std::to_string(_blocks.size()) +
-               " blocks, flights handed over device to device.");
+        status("Domain decomposition: " +
+               std::to_string(_blocks.size() - _number_of_copies) +
+               " blocks and " + std::to_string(_number_of_copies) +
+               " copies of source blocks, flights handed over device to "
+               "device.");
       }
     }
   }
@@ -728,6 +816,7 @@ public:
     for (Block &b : _blocks)
       cmi_gpu_destroy(b.engine);
   }
+  size_t number_of_copies() const { return _number_of_copies; }
   uint64_t exchange_rounds() const { return _exchange_rounds; }
   uint64_t flights_exchanged() const { return _flights_exchanged; }
 

@@ -11,7 +11,10 @@
  * descriptors as JSON; with --dry-run no GPU is needed), --blocks BX,BY,BZ
  * (domain decomposition: one engine per block of the grid, the counterpart of
  * the reference's DensitySubGridCreator:number of subgrids) and
- * --devices D0,D1,... (the blocks' devices, round-robin; default --device).
+ * --devices D0,D1,... (the blocks' devices, round-robin; default --device),
+ * --copies K (K engines for every block that contains a source - the
+ * reference's TaskBasedIonizationSimulation:source copy level; default: one
+ * per device, 2^level at most).
  */
 #include "GpuIonizationSimulation.hpp"
 
@@ -101,6 +104,7 @@ int main(int argc, char **argv) {
   int threads = 1, device = 0;
   std::array<int, 3> blocks = {1, 1, 1};
   std::vector<int> devices;
+  int copies = 0;
   auto int_list = [](const std::string &text) {
     std::vector<int> values;
     std::stringstream stream(text);
@@ -136,6 +140,8 @@ int main(int argc, char **argv) {
       blocks = {b[0], b[1], b[2]};
     } else if (a == "--devices")
       devices = int_list(need("--devices"));
+    else if (a == "--copies")
+      copies = std::atoi(need("--copies").c_str());
     else if (a == "--every-iteration-output" || a == "-e")
       every_iteration = true;
     else if (a == "--output-statistics" || a == "-s")
@@ -156,7 +162,7 @@ int main(int argc, char **argv) {
     else {
       std::cerr << "Unknown or unsupported option: " << a << "\n"
                 << "usage: cmi-gpu --params FILE [--threads N] [--device N] "
-                   "[--blocks BX,BY,BZ] [--devices D0,D1,...] "
+                   "[--blocks BX,BY,BZ] [--devices D0,D1,...] [--copies K] "
                    "[--every-iteration-output] [--output-statistics] "
                    "[--dry-run] [--dry-run-snapshot] [--describe] [--verbose]\n";
       return 1;
@@ -171,7 +177,7 @@ int main(int argc, char **argv) {
                                        every_iteration, statistics, threads,
                                        params, device,
                                        verbose || !do_describe, !dry_run,
-                                       blocks, devices);
+                                       blocks, devices, copies);
     if (do_describe)
       describe(simulation);
     if (dry_run && dry_snapshot) {

@@ -369,7 +369,18 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *engine, const char *key, int64_t value);
  * replicas of one grid, or the blocks of one decomposed grid. Replaces the
  * reference's MPICommunicator for this path (src/MPICommunicator.hpp); the
  * transport is RCCL over xGMI (loaded at the first reduce) and peer-to-peer
- * device writes. The engines stay owned by the caller. */
+ * device writes. The engines stay owned by the caller.
+ *
+ * Engines of a group that hold the same cells form a CLASS: the replicas of
+ * replica mode are one class; in domain mode several engines may hold the
+ * same block - the reference's copies of a busy subgrid
+ * (DensitySubGridCreator::create_copies, src/DensitySubGridCreator.hpp:437-531,
+ * used for the subgrids that contain a source,
+ * src/TaskBasedIonizationSimulation.cpp:514-560). cmi_gpu_group_create finds
+ * the classes itself; copy r of c engines of a block emits the packets of
+ * that block whose id is congruent to r modulo c and receives the flights of
+ * those packets. The members of a class must sit on distinct devices (or all
+ * on one: tests). */
 typedef struct cmi_gpu_group cmi_gpu_group;
 int cmi_gpu_group_create(int32_t n, cmi_gpu_engine *const *engines,
                          cmi_gpu_group **out);
@@ -382,7 +393,12 @@ int cmi_gpu_group_destroy(cmi_gpu_group *group);
  * accumulator fields a transport step can have written - ONE grouped
  * ncclAllReduce per contiguous piece instead of 16 chunked ones. The packet
  * counters are summed by the caller (cmi_gpu_get_counters of each engine).
- * Asynchronous on the engines' streams. */
+ * Asynchronous on the engines' streams.
+ * Also replaces DensitySubGridCreator::update_original_counters
+ * (src/DensitySubGridCreator.hpp:556-574): the sum runs within every class
+ * of the group, so in domain mode the copies of a block end with the block's
+ * summed integrals - each then runs cmi_gpu_update_cells on identical input,
+ * which stands in for update_copy_properties (:580-598). */
 int cmi_gpu_group_reduce_accumulators(cmi_gpu_group *group);
 
 /* replaces: the photon-buffer traffic between subgrids

@@ -534,6 +534,108 @@ def test_group_exchange_equals_python_routing():
     assert np.allclose(J1, J0, rtol=1e-11, atol=1e-13 * J0.max())
 
 
+def test_group_with_copies_of_the_source_block_matches_oracle(oracle):
+    """A star in the middle of one octant of a 2x2x2 decomposition and THREE
+    engines for that block: the copies share the block's packets by packet id
+    (emission and incoming flights), cmi_gpu_group_reduce_accumulators sums
+    their integrals into each (DensitySubGridCreator::update_original_counters,
+    src/DensitySubGridCreator.hpp:556-574), each then solves the same cells.
+    Counters and J against the oracle on the undivided grid; the copies end
+    bit-identical to each other."""
+    from cmacionize_amd import STROMGREN as S
+    from cmacionize_amd import engine as E
+    from cmacionize_amd.engine import EngineGroup
+    from cmacionize_amd.simulation import DomainDecomposition, DomainGpuBackend
+    ncell, npacket = 24, 40000
+    side = S["sides"][0]
+    source = [[0.27 * side, -0.23 * side, 0.21 * side]]
+    sim = oracle.OracleSimulation((ncell,) * 3, S["anchor"], S["sides"])
+    sim.set_sources(source, [1.], S["luminosity"])
+    sim.set_homogeneous(S["density"], S["temperature"], xH=1.e-6)
+    m = sim.model
+    m.spectrum_type = oracle.SPECTRUM_MONOCHROMATIC
+    m.mono_frequency = S["frequency"]
+    m.xsec_type = oracle.XSEC_FIXED
+    m.xsec_fixed[0] = S["sigma_H"]
+    m.recomb_type = oracle.RECOMB_FIXED
+    m.recomb_fixed[0] = S["alpha_H"]
+    m.reemit_type = oracle.REEMIT_PHYSICAL
+
+    dec = DomainDecomposition((ncell,) * 3, (2, 2, 2))
+    idx = [int((source[0][a] - S["anchor"][a]) / side * ncell) >= ncell // 2
+           for a in range(3)]
+    hot = (idx[0] * 2 + idx[1]) * 2 + idx[2]
+    ranks = list(range(dec.world)) + [hot, hot]
+    backends = []
+    for rank in ranks:
+        b = DomainGpuBackend(dec, rank, S["anchor"], S["sides"], device=0,
+                             export_capacity=2 * npacket)
+        configure(b.engine, "diffuse", int(np.prod(dec.block(rank)[1])))
+        b.engine.set_sources(source, [1.], S["luminosity"])
+        b.engine.set_tuning(reemit_inline_below=64, tile_min_flights=0,
+                            tile_min_per_item=0)
+        backends.append(b)
+    group = EngineGroup([b.engine for b in backends])
+    for loop in range(3):
+        emitted = []
+        for b in backends:
+            b.reset_grid()
+            b.shoot(42, loop, 0, npacket)
+            emitted.append(b.get_counters()[2])
+        # only the three engines of the source block fly first flights
+        assert [n > 0 for n in emitted] == \
+            [r == hot for r in ranks], emitted
+        while group.exchange_flights(42, loop):
+            pass
+        group.reduce_accumulators()
+        tw, tc = 0., np.zeros(4)
+        for b in backends:
+            b.synchronize()
+            t, c, n = b.get_counters()
+            tw += t
+            tc += np.asarray(c)
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(42, loop, 0, npacket)
+        assert tw == sim.totweight == npacket
+        assert np.array_equal(tc, sim.typecount)
+        J = assemble(dec, backends[:dec.world], E.FIELD_MEAN_INTENSITY)
+        assert np.allclose(J, sim.J[0], rtol=1e-9,
+                           atol=1e-12 * sim.J[0].max()), loop
+        copies = [backends[i] for i, r in enumerate(ranks) if r == hot]
+        J0 = copies[0].engine.download_field(E.FIELD_MEAN_INTENSITY)
+        for c in copies[1:]:
+            assert np.array_equal(
+                c.engine.download_field(E.FIELD_MEAN_INTENSITY), J0)
+        for b in backends:
+            b.update_cells(loop, tw)
+        sim.update(loop, sim.totweight)
+        x = assemble(dec, backends[:dec.world], E.FIELD_IONIC_FRACTION)
+        assert np.allclose(x, sim.x[0], rtol=1e-8)
+        x0 = copies[0].engine.download_field(E.FIELD_IONIC_FRACTION)
+        for c in copies[1:]:
+            assert np.array_equal(
+                c.engine.download_field(E.FIELD_IONIC_FRACTION), x0)
+        # keep in lockstep with the oracle: its sums have another order, and
+        # 1e-16 in x moves an absorption across a cell wall now and then
+        shape = (ncell,) * 3
+        for rank, b in zip(ranks, backends):
+            off, size = dec.block(rank)
+            sl = tuple(slice(off[a], off[a] + size[a]) for a in range(3))
+            b.engine.upload_cells(
+                np.asarray(sim.number_density).reshape(shape)[sl].ravel(),
+                np.asarray(sim.temperature).reshape(shape)[sl].ravel(),
+                np.array([np.asarray(x_).reshape(shape)[sl].ravel()
+                          for x_ in sim.x]))
+    # every copy did a share of the block's work
+    steps = [c.get_counters()[2] for c in copies]
+    assert min(steps) > 0.25 * max(steps), steps
+    group.close()
+    for b in backends:
+        b.engine.close()
+
+
 def test_group_reduce_goes_through_rccl(monkeypatch):
     """The accumulator reduce of a replica group is a grouped ncclAllReduce
     (RCCL, loaded at run time). This box has one GPU, and RCCL refuses two

@@ -286,3 +286,52 @@ def test_cmi_gpu_executable_with_replicas(exe, tmp_path, bench):
     stats = [[l for l in out.splitlines() if "Escape fraction" in l][-1]
              for _, out in outputs.values()]
     assert stats[0] == stats[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bench", ["stromgren_diffuse.param",
+                                   "lexingtonHII40.param"])
+def test_cmi_gpu_executable_with_copies_of_the_source_block(exe, tmp_path,
+                                                            bench):
+    """--copies: a star in the middle of ONE octant, so that every packet
+    starts in one block of a 2x2x2 decomposition. Three engines hold that
+    block (DensitySubGridCreator::create_copies,
+    src/DensitySubGridCreator.hpp:437-531): they share its packets by packet
+    id, their integrals are summed into each of them after the transport
+    (update_original_counters, :556-574) and each solves the block's cells.
+    The snapshots equal those of the undivided run."""
+    text = open(os.path.join(BENCH, bench)).read()
+    text = text.replace("[64, 64, 64]", "[18, 18, 18]")
+    for old in ("number of photons: 1e6", "number of photons: 1e8"):
+        text = text.replace(old, "number of photons: 20000")
+    text = text.replace("number of iterations: 20", "number of iterations: 5")
+    text = text.replace("type: Binary", "type: AsciiFile")
+    assert "position: [0. pc, 0. pc, 0. pc]" in text
+    text = text.replace("position: [0. pc, 0. pc, 0. pc]",
+                        "position: [1.3 pc, -1.2 pc, 1.1 pc]")
+    outputs = {}
+    for label, extra in (("whole", []),
+                         ("copies", ["--blocks", "2,2,2", "--copies", "3"])):
+        d = tmp_path / label
+        d.mkdir()
+        if bench.startswith("lexington"):
+            import shutil
+            shutil.copy(os.path.join(BENCH, "lexingtonHII40.yml"), d)
+        p = d / "run.param"
+        p.write_text(text)
+        r = subprocess.run([exe, "--params", str(p), "--output-statistics"] +
+                           extra, capture_output=True, text=True, cwd=str(d))
+        assert r.returncode == 0, r.stderr
+        if extra:
+            assert "8 blocks and 2 copies of source blocks" in r.stdout
+        snapshots = sorted(f for f in os.listdir(d) if f.endswith("005.txt"))
+        assert len(snapshots) == 1, os.listdir(d)
+        outputs[label] = (np.loadtxt(d / snapshots[0]), r.stdout)
+    whole, copies = outputs["whole"][0], outputs["copies"][0]
+    assert np.array_equal(whole[:, :5], copies[:, :5])
+    rel = np.abs(whole[:, 5] - copies[:, 5]) / whole[:, 5]
+    assert np.median(rel) < 1e-5
+    assert (rel < 1e-2).mean() > 0.97, (rel > 1e-2).sum()
+    stats = [[l for l in out.splitlines() if "Escape fraction" in l][-1]
+             for _, out in outputs.values()]
+    assert stats[0] == stats[1]

@@ -217,6 +217,10 @@ struct SpectraDev {
   double lyc_cdf[2][CMI_NTEMP][CMI_NFREQ]; /* [H, He][T][nu] */
   double he2pc_freq[CMI_NFREQ];
   double he2pc_cdf[CMI_NFREQ];
+  /* the Planck spectrum of the continuous source, if it has one */
+  double planck2_logfreq[CMI_NFREQ];
+  double planck2_cdf[CMI_NFREQ];
+  double planck2_logcdf[CMI_NFREQ];
 };
 
 /* Physics set-up passed by value to the kernels */
@@ -250,7 +254,18 @@ struct ModelDev {
   double pahfac, crfac, crlim, crscale;
   double t_min_ionized;
   int32_t t_max_iterations;
+  /* ContinuousPhotonSource + its spectrum, and the mix of the two kinds of
+   * sources (PhotonSource ctor, src/PhotonSource.cpp:104-130): a packet comes
+   * from the continuous source with probability continuous_probability and
+   * carries photon_weight[1], from a discrete one otherwise, with
+   * photon_weight[0] */
+  int32_t continuous_type;          /* 0 none, 1 isotropic on the box */
+  int32_t continuous_spectrum_type; /* as spectrum_type */
   int32_t pad1;
+  double continuous_probability;
+  double photon_weight[2];
+  double continuous_mono_frequency;
+  double continuous_planck_temperature;
 };
 
 /* SoA cell state, all device pointers to [ncell] doubles */
@@ -297,10 +312,21 @@ struct QueueDev {
   unsigned int *count;
 };
 
+/* the word that travels with a packet id: position of the packet's random
+ * stream (24 bits of block counter, 1 bit "second half of the block unread"),
+ * bit 25 = the packet came from the continuous source (its weight is
+ * ModelDev::photon_weight[1]), bits 28-31 the photon type */
+#define CMI_META_ORIGIN_SHIFT 25
+#define CMI_META_KEEP_MASK 0x03ffffffu /* everything but the type */
 __host__ __device__ inline uint32_t cmi_pack_meta(uint32_t rng_block,
                                                   uint32_t rng_have,
-                                                  uint32_t type) {
-  return (rng_block & 0xffffffu) | ((rng_have & 1u) << 24) | (type << 28);
+                                                  uint32_t type,
+                                                  uint32_t origin) {
+  return (rng_block & 0xffffffu) | ((rng_have & 1u) << 24) |
+         ((origin & 1u) << CMI_META_ORIGIN_SHIFT) | (type << 28);
+}
+__host__ __device__ inline uint32_t cmi_meta_origin(uint32_t meta) {
+  return (meta >> CMI_META_ORIGIN_SHIFT) & 1u;
 }
 
 /* packet counters accumulated by the transport kernel */

@@ -11,16 +11,22 @@
 
 /* PlanckPhotonSourceSpectrum::get_random_frequency,
  * src/PlanckPhotonSourceSpectrum.cpp:149-165: log-log interpolation */
-__device__ inline double sample_planck(const SpectraDev *s, PacketRng &rng) {
+__device__ inline double sample_planck_table(const double *cdf,
+                                             const double *logcdf,
+                                             const double *logfreq,
+                                             PacketRng &rng) {
   const double x = rng.next();
-  const uint32_t ix = cmi_locate(x, s->planck_cdf, CMI_NFREQ);
+  const uint32_t ix = cmi_locate(x, cdf, CMI_NFREQ);
   const double log_random_frequency =
-      (log10(x) - s->planck_logcdf[ix]) /
-          (s->planck_logcdf[ix + 1] - s->planck_logcdf[ix]) *
-          (s->planck_logfreq[ix + 1] - s->planck_logfreq[ix]) +
-      s->planck_logfreq[ix];
+      (log10(x) - logcdf[ix]) / (logcdf[ix + 1] - logcdf[ix]) *
+          (logfreq[ix + 1] - logfreq[ix]) +
+      logfreq[ix];
   const double frequency = pow(10., log_random_frequency);
   return frequency * 3.288465385e15;
+}
+__device__ inline double sample_planck(const SpectraDev *s, PacketRng &rng) {
+  return sample_planck_table(s->planck_cdf, s->planck_logcdf,
+                             s->planck_logfreq, rng);
 }
 
 /* Hydrogen/HeliumLymanContinuumSpectrum::get_random_frequency,
@@ -51,9 +57,17 @@ __device__ inline double sample_he_two_photon(const SpectraDev *s,
                                   (s->he2pc_cdf[inu + 1] - s->he2pc_cdf[inu]);
 }
 
-/* PhotonSourceSpectrum::get_random_frequency of the discrete sources */
+/* PhotonSourceSpectrum::get_random_frequency of the discrete sources
+ * (origin 0) or of the continuous source (origin 1) */
 __device__ inline double sample_source_spectrum(const ModelDev &m,
-                                                PacketRng &rng) {
+                                                PacketRng &rng,
+                                                uint32_t origin = 0) {
+  if (origin != 0) {
+    if (m.continuous_spectrum_type == 0)
+      return m.continuous_mono_frequency;
+    return sample_planck_table(m.spectra->planck2_cdf, m.spectra->planck2_logcdf,
+                               m.spectra->planck2_logfreq, rng);
+  }
   if (m.spectrum_type == 0) {
     /* MonochromaticPhotonSourceSpectrum: no random number is drawn
      * (src/MonochromaticPhotonSourceSpectrum.hpp:97-100) */

@@ -178,40 +178,75 @@ __device__ __forceinline__ void start_flight(const GridDev &g,
  * that starts elsewhere before paying for its frequency and cross sections:
  * where and in which direction (draws 1-4) ... */
 template <bool FULL, bool EXACT>
-__device__ inline void emit_geometry(const GridDev &g, const ModelDev &m,
-                                     PacketRng &rng, Packet<FULL> &p) {
-  /* first uniform: continuous vs discrete source; no continuous source on
-   * this path, so it is drawn and ignored */
+__device__ inline uint32_t emit_geometry(const GridDev &g, const ModelDev &m,
+                                         PacketRng &rng, Packet<FULL> &p) {
+  /* first uniform: continuous or discrete source (drawn also when there is
+   * no continuous source: continuous_probability = 0) */
   double x = rng.next();
-  x = rng.next();
-  int i = 0;
-  while (x > m.source_cumulative[i])
-    ++i;
+  uint32_t origin = 0;
+  if (x >= m.continuous_probability) {
+    x = rng.next();
+    int i = 0;
+    while (x > m.source_cumulative[i])
+      ++i;
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
-    p.pos[a] = m.source_position[3 * i + a];
-  random_direction(p, rng);
+    for (int a = 0; a < 3; ++a)
+      p.pos[a] = m.source_position[3 * i + a];
+    random_direction(p, rng);
+  } else {
+    /* IsotropicContinuousPhotonSource::get_random_incoming_direction
+     * (src/IsotropicContinuousPhotonSource.hpp:95-191): a focus point in the
+     * box, an isotropic direction through it, and the point where that line
+     * enters the box */
+    origin = 1;
+    double focus[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      focus[a] = g.anchor[a] + g.box_sides[a] * rng.next();
+    random_direction(p, rng);
+    double l[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double top = g.anchor[a] + g.box_sides[a];
+      l[a] = (p.dir[a] < 0.)
+                 ? (top - focus[a]) / p.dir[a]
+                 : ((p.dir[a] > 0.) ? (g.anchor[a] - focus[a]) / p.dir[a]
+                                    : -DBL_MAX);
+    }
+    const double maxl = fmax(fmax(l[0], l[1]), l[2]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double top = g.anchor[a] + g.box_sides[a];
+      double q = focus[a] + maxl * p.dir[a];
+      /* the top anchor itself lies outside the box */
+      q = fmin(q, top - 2.220446049250313e-16 * g.box_sides[a]);
+      p.pos[a] = fmax(q, g.anchor[a]);
+    }
+  }
   p.type = TYPE_PRIMARY;
-  p.weight = 1.;
+  p.weight = m.photon_weight[origin];
   start_flight<FULL, EXACT>(g, p);
+  return origin;
 }
 
 /* ... and what it is: frequency, cross sections, first optical depth */
 template <bool FULL>
 __device__ inline void emit_physics(const ModelDev &m, PacketRng &rng,
                                     Packet<FULL> &p,
-                                    double (&weights)[CMI_NACC]) {
-  p.nu = sample_source_spectrum(m, rng);
+                                    double (&weights)[CMI_NACC],
+                                    uint32_t origin = 0) {
+  p.nu = sample_source_spectrum(m, rng, origin);
   set_cross_sections(m, p, weights);
   p.tau = -log(rng.next());
 }
 
 template <bool FULL, bool EXACT>
-__device__ inline void emit_packet(const GridDev &g, const ModelDev &m,
-                                   PacketRng &rng, Packet<FULL> &p,
-                                   double (&weights)[CMI_NACC]) {
-  emit_geometry<FULL, EXACT>(g, m, rng, p);
-  emit_physics<FULL>(m, rng, p, weights);
+__device__ inline uint32_t emit_packet(const GridDev &g, const ModelDev &m,
+                                       PacketRng &rng, Packet<FULL> &p,
+                                       double (&weights)[CMI_NACC]) {
+  const uint32_t origin = emit_geometry<FULL, EXACT>(g, m, rng, p);
+  emit_physics<FULL>(m, rng, p, weights, origin);
+  return origin;
 }
 
 /* EXACT: one iteration of the loop of CartesianDensityGrid::interact

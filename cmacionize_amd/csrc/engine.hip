@@ -71,6 +71,8 @@ struct cmi_gpu_engine {
   double *source_position = nullptr;
   double *source_cumulative = nullptr;
   std::vector<double> source_position_host;
+  double discrete_luminosity = 0., continuous_luminosity = 0.;
+  bool have_continuous_spectrum = false;
 
   bool have_sources = false, have_spectrum = false, have_xsec = false,
        have_recomb = false, have_cells = false;
@@ -442,8 +444,23 @@ void build_tables(TablesDev &t) {
 void build_spectra(const ModelDev &host_model, SpectraDev &s) {
   memset(&s, 0, sizeof s);
   const double h = CMI_PLANCK, k = CMI_BOLTZMANN;
-  if (host_model.spectrum_type == CMI_GPU_SPECTRUM_PLANCK) {
-    const double temperature = host_model.planck_temperature;
+  for (int which_planck = 0; which_planck < 2; ++which_planck) {
+    /* 0: the discrete sources' spectrum, 1: the continuous source's */
+    const bool wanted =
+        which_planck == 0
+            ? host_model.spectrum_type == CMI_GPU_SPECTRUM_PLANCK
+            : (host_model.continuous_type != 0 &&
+               host_model.continuous_spectrum_type == CMI_GPU_SPECTRUM_PLANCK);
+    if (!wanted)
+      continue;
+    const double temperature = which_planck == 0
+                                   ? host_model.planck_temperature
+                                   : host_model.continuous_planck_temperature;
+    double *planck_cdf = which_planck == 0 ? s.planck_cdf : s.planck2_cdf;
+    double *planck_logcdf =
+        which_planck == 0 ? s.planck_logcdf : s.planck2_logcdf;
+    double *planck_logfreq =
+        which_planck == 0 ? s.planck_logfreq : s.planck2_logfreq;
     const double max_frequency = 4.;
     const double min_frequency = 3.289e15;
     std::vector<double> frequency(CMI_NFREQ), luminosity(CMI_NFREQ);
@@ -454,19 +471,19 @@ void build_spectra(const ModelDev &host_model, SpectraDev &s) {
                                 (k * temperature)) -
                        1.);
     }
-    s.planck_cdf[0] = 0.;
+    planck_cdf[0] = 0.;
     for (int i = 1; i < CMI_NFREQ; ++i)
-      s.planck_cdf[i] = s.planck_cdf[i - 1] +
+      planck_cdf[i] = planck_cdf[i - 1] +
                         0.5 *
                             (luminosity[i] / frequency[i] +
                              luminosity[i - 1] / frequency[i - 1]) *
                             (frequency[i] - frequency[i - 1]);
-    s.planck_logcdf[0] = -10.;
-    s.planck_logfreq[0] = 0.;
+    planck_logcdf[0] = -10.;
+    planck_logfreq[0] = 0.;
     for (int i = 1; i < CMI_NFREQ; ++i) {
-      s.planck_cdf[i] /= s.planck_cdf[CMI_NFREQ - 1];
-      s.planck_logcdf[i] = std::log10(s.planck_cdf[i]);
-      s.planck_logfreq[i] = std::log10(frequency[i]);
+      planck_cdf[i] /= planck_cdf[CMI_NFREQ - 1];
+      planck_logcdf[i] = std::log10(planck_cdf[i]);
+      planck_logfreq[i] = std::log10(frequency[i]);
     }
   }
   for (int which = 0; which < 2; ++which) {
@@ -547,8 +564,11 @@ void build_spectra(const ModelDev &host_model, SpectraDev &s) {
 
 /* (re)build and upload the spectra tables if a sampled spectrum is in use */
 int ensure_spectra(cmi_gpu_engine *e) {
-  const bool needed = e->model.spectrum_type == CMI_GPU_SPECTRUM_PLANCK ||
-                      e->model.reemit_type == CMI_GPU_REEMIT_PHYSICAL;
+  const bool needed =
+      e->model.spectrum_type == CMI_GPU_SPECTRUM_PLANCK ||
+      (e->model.continuous_type != 0 &&
+       e->model.continuous_spectrum_type == CMI_GPU_SPECTRUM_PLANCK) ||
+      e->model.reemit_type == CMI_GPU_REEMIT_PHYSICAL;
   if (!needed || !e->spectra_dirty)
     return CMI_GPU_OK;
   if (!e->spectra)
@@ -745,6 +765,8 @@ int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
   m.nu_H = eV_to_Hz(13.6);
   m.nu_He = eV_to_Hz(24.6);
   m.reemit_type = CMI_GPU_REEMIT_NONE;
+  m.photon_weight[0] = 1.;
+  m.photon_weight[1] = 1.;
 
   cmi_gpu_temperature_params &tp = e->tparams;
   tp.do_temperature_calculation = 0;
@@ -817,23 +839,65 @@ int64_t cmi_gpu_number_of_cells(const cmi_gpu_engine *e) {
   return e ? e->ncell : -1;
 }
 
+/* PhotonSource ctor, src/PhotonSource.cpp:104-130: how the packets are
+ * shared between the discrete sources and the continuous one, and the weight
+ * a packet of either kind carries */
+static void mix_sources(cmi_gpu_engine *e) {
+  ModelDev &m = e->model;
+  const double discrete = m.nsource > 0 ? e->discrete_luminosity : 0.;
+  const double continuous =
+      m.continuous_type != 0 ? e->continuous_luminosity : 0.;
+  m.total_luminosity = discrete + continuous;
+  m.continuous_probability = 0.;
+  m.photon_weight[0] = 1.;
+  m.photon_weight[1] = 1.;
+  if (m.total_luminosity > 0.) {
+    if (discrete > 0.) {
+      m.continuous_probability = continuous > 0. ? 0.5 : 0.;
+      m.photon_weight[0] = 1.;
+      m.photon_weight[1] =
+          continuous > 0. ? (1. - m.continuous_probability) * continuous /
+                                m.continuous_probability / discrete
+                          : 1.;
+    } else {
+      m.continuous_probability = 1.;
+      m.photon_weight[0] = 0.;
+      m.photon_weight[1] = 1.;
+    }
+  }
+  e->have_sources = m.total_luminosity > 0.;
+}
+
 int cmi_gpu_set_sources(cmi_gpu_engine *e, int32_t n, const double *positions,
                         const double *weights, double total_luminosity) {
-  if (!e || n <= 0 || !positions || !weights)
+  if (!e || n < 0 || (n > 0 && (!positions || !weights)))
     return fail(CMI_GPU_EINVAL, "cmi_gpu_set_sources: bad argument");
-  /* PhotonSource ctor, src/PhotonSource.cpp:74-93 */
-  std::vector<double> cumulative(n);
-  for (int i = 0; i < n; ++i)
-    cumulative[i] = (i > 0 ? cumulative[i - 1] : 0.) + weights[i];
-  if (std::abs(cumulative.back() - 1.) > 1.e-9)
-    return fail(CMI_GPU_EINVAL,
-                "Discrete source weights do not sum to 1.0 (%g)!",
-                cumulative.back());
-  cumulative.back() = 1.;
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   (void)hipFree(e->source_position);
   (void)hipFree(e->source_cumulative);
+  e->source_position = nullptr;
+  e->source_cumulative = nullptr;
+  e->source_position_host.clear();
+  e->model.nsource = 0;
+  e->model.source_position = nullptr;
+  e->model.source_cumulative = nullptr;
+  e->discrete_luminosity = 0.;
+  if (n == 0) { /* no discrete sources (a continuous source only) */
+    mix_sources(e);
+    return CMI_GPU_OK;
+  }
+  /* PhotonSource ctor, src/PhotonSource.cpp:74-93 */
+  std::vector<double> cumulative(n);
+  for (int i = 0; i < n; ++i)
+    cumulative[i] = (i > 0 ? cumulative[i - 1] : 0.) + weights[i];
+  if (std::abs(cumulative.back() - 1.) > 1.e-9) {
+    mix_sources(e);
+    return fail(CMI_GPU_EINVAL,
+                "Discrete source weights do not sum to 1.0 (%g)!",
+                cumulative.back());
+  }
+  cumulative.back() = 1.;
   HIP_TRY(hipMalloc(&e->source_position, sizeof(double) * 3 * n));
   HIP_TRY(hipMalloc(&e->source_cumulative, sizeof(double) * n));
   HIP_TRY(hipMemcpy(e->source_position, positions, sizeof(double) * 3 * n,
@@ -844,8 +908,42 @@ int cmi_gpu_set_sources(cmi_gpu_engine *e, int32_t n, const double *positions,
   e->model.nsource = n;
   e->model.source_position = e->source_position;
   e->model.source_cumulative = e->source_cumulative;
-  e->model.total_luminosity = total_luminosity;
-  e->have_sources = true;
+  e->discrete_luminosity = total_luminosity;
+  mix_sources(e);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_continuous_source(cmi_gpu_engine *e, int32_t type,
+                                  double luminosity) {
+  if (!e || (type != CMI_GPU_CONTINUOUS_NONE &&
+             type != CMI_GPU_CONTINUOUS_ISOTROPIC) ||
+      (type != CMI_GPU_CONTINUOUS_NONE && !(luminosity > 0.)))
+    return fail(CMI_GPU_EINVAL, "cmi_gpu_set_continuous_source: bad argument");
+  e->model.continuous_type = type;
+  e->continuous_luminosity = type != CMI_GPU_CONTINUOUS_NONE ? luminosity : 0.;
+  e->spectra_dirty = true;
+  mix_sources(e);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_continuous_spectrum_monochromatic(cmi_gpu_engine *e,
+                                                  double frequency) {
+  if (!e || !(frequency > 0.))
+    return fail(CMI_GPU_EINVAL, "monochromatic spectrum: bad argument");
+  e->model.continuous_spectrum_type = CMI_GPU_SPECTRUM_MONOCHROMATIC;
+  e->model.continuous_mono_frequency = frequency;
+  e->have_continuous_spectrum = true;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_continuous_spectrum_planck(cmi_gpu_engine *e,
+                                           double temperature) {
+  if (!e || !(temperature > 0.))
+    return fail(CMI_GPU_EINVAL, "Planck spectrum: bad argument");
+  e->model.continuous_spectrum_type = CMI_GPU_SPECTRUM_PLANCK;
+  e->model.continuous_planck_temperature = temperature;
+  e->have_continuous_spectrum = true;
+  e->spectra_dirty = true;
   return CMI_GPU_OK;
 }
 
@@ -1277,6 +1375,8 @@ static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
  * whole grid - means nothing to emit, and the pass over the packet ids can be
  * skipped altogether. */
 static bool block_emits_nothing(const cmi_gpu_engine *e) {
+  if (e->model.continuous_type != 0)
+    return false; /* its packets enter through every face of the box */
   const GridDev &g = e->grid;
   const bool at_origin = (g.offset[0] | g.offset[1] | g.offset[2]) == 0;
   for (int32_t s = 0; s < e->model.nsource; ++s) {
@@ -1302,11 +1402,12 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                       const double *flights) {
   if (!e)
     return fail(CMI_GPU_EINVAL, "null engine");
-  if (!e->have_sources || !e->have_spectrum || !e->have_xsec ||
-      !e->have_cells)
+  if (!e->have_sources || (e->model.nsource > 0 && !e->have_spectrum) ||
+      (e->model.continuous_type != 0 && !e->have_continuous_spectrum) ||
+      !e->have_xsec || !e->have_cells)
     return fail(CMI_GPU_ESTATE,
-                "cmi_gpu_shoot: sources, spectrum, cross sections and cell "
-                "data must be set first");
+                "cmi_gpu_shoot: sources, their spectra, cross sections and "
+                "cell data must be set first");
   if (n_packets == 0)
     return CMI_GPU_OK;
   if (n_packets >= (1ull << 32))
@@ -1456,7 +1557,9 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                             sigma_He);
   }
   uint32_t source_bits = 0;
-  for (int s = e->model.nsource - 1; s > 0; s >>= 1)
+  /* (the continuous source counts as one more) */
+  for (int s = e->model.nsource - (e->model.continuous_type != 0 ? 0 : 1);
+       s > 0; s >>= 1)
     ++source_bits;
   if (source_bits > 10u - tau_bits)
     source_bits = 10u - tau_bits;
@@ -2097,7 +2200,9 @@ int cmi_gpu_emit_packets(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                          double *cross_sections, double *tau) {
   if (!e || !position || !direction || !frequency || !cross_sections || !tau)
     return fail(CMI_GPU_EINVAL, "emit_packets: bad argument");
-  if (!e->have_sources || !e->have_spectrum || !e->have_xsec)
+  if (!e->have_sources || (e->model.nsource > 0 && !e->have_spectrum) ||
+      (e->model.continuous_type != 0 && !e->have_continuous_spectrum) ||
+      !e->have_xsec)
     return fail(CMI_GPU_ESTATE, "emit_packets: model not complete");
   if (n == 0)
     return CMI_GPU_OK;

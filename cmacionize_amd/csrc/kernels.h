@@ -448,9 +448,13 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
   int32_t last_cell = -1; /* EXACT marcher on grids >= 2^31 cells: see below */
   int64_t last_cell_wide = -1;
 
-  /* packets finished per type; every packet on this path has weight 1
-   * (discrete sources, src/PhotonSource.cpp:244), so totweight is their sum */
+  /* packets finished per type (their weights are summed at the end:
+   * src/IonizationPhotonShootJob.hpp:143-144); those that came from the
+   * continuous source are counted a second time, per wave, in LDS */
   unsigned int tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
+  __shared__ unsigned int s_continuous[CMI_BLOCK / 64][4];
+  if (lane < 4)
+    s_continuous[threadIdx.x >> 6][lane] = 0;
   unsigned int nsteps = 0, natomics = 0; /* per lane and launch: < 2^32 */
   unsigned int nwavesteps = 0;
   const bool any_periodic =
@@ -648,7 +652,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
             rng.resume(a.seed, a.iteration, a.first_packet + packet_id,
                        lane_meta & 0xffffffu, (lane_meta >> 24) & 1u);
           p.type = (int32_t)(lane_meta >> 28);
-          p.weight = 1.;
+          p.weight = a.model.photon_weight[cmi_meta_origin(lane_meta)];
           set_cross_sections(a.model, p, weights);
           if (!EXACT) {
             if (a.xin_local)
@@ -670,7 +674,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
             p.inv_dir[ax] = 1. / p.dir[ax];
           }
           p.type = (int32_t)(lane_meta >> 28);
-          p.weight = 1.;
+          p.weight = a.model.photon_weight[cmi_meta_origin(lane_meta)];
           p.nu = a.qin.nu[i];
           p.tau = a.qin.tau[i];
           set_cross_sections(a.model, p, weights);
@@ -679,7 +683,8 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
           packet_id =
               (uint32_t)a.batch_offset + (a.order ? a.order[i] : (uint32_t)i);
           rng.init(a.seed, a.iteration, a.first_packet + packet_id);
-          emit_geometry<FULL, EXACT>(a.grid, a.model, rng, p);
+          const uint32_t origin =
+              emit_geometry<FULL, EXACT>(a.grid, a.model, rng, p);
           if (a.grid.decomposed) {
             /* Every block runs through all packets of the iteration but only
              * flies those that start in it; a source outside the whole grid
@@ -742,8 +747,8 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
             }
           }
           if (mine) {
-            emit_physics<FULL>(a.model, rng, p, weights);
-            lane_meta = cmi_pack_meta(rng.block, rng.have, 0);
+            emit_physics<FULL>(a.model, rng, p, weights, origin);
+            lane_meta = cmi_pack_meta(rng.block, rng.have, 0, origin);
           }
         }
         if (FULL) {
@@ -896,8 +901,10 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
                 r[12] = __longlong_as_double(cell_global);
                 const uint32_t meta =
                     REEMIT
-                        ? cmi_pack_meta(rng.block, rng.have, (uint32_t)p.type)
-                        : ((lane_meta & 0x01ffffffu) | ((uint32_t)p.type << 28));
+                        ? cmi_pack_meta(rng.block, rng.have, (uint32_t)p.type,
+                                        cmi_meta_origin(lane_meta))
+                        : ((lane_meta & CMI_META_KEEP_MASK) |
+                           ((uint32_t)p.type << 28));
                 r[13] = __longlong_as_double((long long)(
                     ((unsigned long long)meta << 32) | packet_id));
                 r[14] = 0.;
@@ -927,8 +934,10 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
           a.qout.cell[q] = (int32_t)cell_now;
           a.qout.id[q] = packet_id;
           a.qout.meta[q] =
-              REEMIT ? cmi_pack_meta(rng.block, rng.have, (uint32_t)p.type)
-                     : ((lane_meta & 0x01ffffffu) | ((uint32_t)p.type << 28));
+              REEMIT ? cmi_pack_meta(rng.block, rng.have, (uint32_t)p.type,
+                                     cmi_meta_origin(lane_meta))
+                     : ((lane_meta & CMI_META_KEEP_MASK) |
+                        ((uint32_t)p.type << 28));
           active = false; /* leaves this launch, not finished */
           last_cell = -1;
           last_cell_wide = -1;
@@ -958,16 +967,28 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
           tc1 += (p.type == TYPE_DIFFUSE_HI) ? 1u : 0u;
           tc2 += (p.type == TYPE_DIFFUSE_HeI) ? 1u : 0u;
           tc3 += (p.type == TYPE_ABSORBED) ? 1u : 0u;
+          if (cmi_meta_origin(lane_meta) != 0)
+            atomicAdd(&s_continuous[threadIdx.x >> 6][p.type], 1u);
           active = false;
         }
       }
     }
   }
   /* IonizationPhotonShootJobMarket::update_counters */
-  const double s0 = wave_sum((double)tc0);
-  const double s1 = wave_sum((double)tc1);
-  const double s2 = wave_sum((double)tc2);
-  const double s3 = wave_sum((double)tc3);
+  double s0 = wave_sum((double)tc0);
+  double s1 = wave_sum((double)tc1);
+  double s2 = wave_sum((double)tc2);
+  double s3 = wave_sum((double)tc3);
+  {
+    /* n packets of a type, c of them from the continuous source:
+     * (n - c) w_discrete + c w_continuous */
+    const unsigned int *c = s_continuous[threadIdx.x >> 6];
+    const double w0 = a.model.photon_weight[0], w1 = a.model.photon_weight[1];
+    s0 = (s0 - c[0]) * w0 + c[0] * w1;
+    s1 = (s1 - c[1]) * w0 + c[1] * w1;
+    s2 = (s2 - c[2]) * w0 + c[2] * w1;
+    s3 = (s3 - c[3]) * w0 + c[3] * w1;
+  }
   double ns = wave_sum((double)nsteps);
   double na = wave_sum((double)natomics);
   if (lane == 0) {
@@ -1119,10 +1140,13 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     double new_frequency = 0.;
     int32_t type = TYPE_ABSORBED;
     PacketRng rng;
-    uint32_t id = 0;
+    uint32_t id = 0, origin = 0;
+    double w = 0.; /* the packet's weight */
     if (valid) {
       id = a.qin.id[i];
       const uint32_t meta = a.qin.meta[i];
+      origin = cmi_meta_origin(meta);
+      w = a.model.photon_weight[origin];
       rng.resume(a.seed, a.iteration, a.first_packet + id, meta & 0xffffffu,
                  (meta >> 24) & 1u);
       new_frequency =
@@ -1141,16 +1165,17 @@ __global__ void __launch_bounds__(CMI_BLOCK)
         fly = interaction_new_flight<FULL>(a, new_frequency, type, rng, p,
                                            weights, plc, key);
         if (!fly) {
-          tw += 1.;
-          tc1 += (type == TYPE_DIFFUSE_HI) ? 1. : 0.;
-          tc2 += (type == TYPE_DIFFUSE_HeI) ? 1. : 0.;
+          tw += w;
+          tc1 += (type == TYPE_DIFFUSE_HI) ? w : 0.;
+          tc2 += (type == TYPE_DIFFUSE_HeI) ? w : 0.;
         }
       }
       const unsigned int q = block_reserve(fly, a.rows.count, s_count, &s_base);
       if (fly && q < a.rows.capacity)
         write_flight_row<FULL>(
             a.rows, q, p, plc, key, id,
-            cmi_pack_meta(rng.block, rng.have, (uint32_t)type), weights);
+            cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin),
+            weights);
     } else {
       const unsigned int q = block_reserve(again, a.qout.count, s_count, &s_base);
       if (again) {
@@ -1165,12 +1190,13 @@ __global__ void __launch_bounds__(CMI_BLOCK)
         a.qout.tau[q] = tau;
         a.qout.nu[q] = new_frequency;
         a.qout.id[q] = id;
-        a.qout.meta[q] = cmi_pack_meta(rng.block, rng.have, (uint32_t)type);
+        a.qout.meta[q] =
+            cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin);
       }
     }
     if (valid && !again) {
-      tw += 1.;
-      tc3 += 1.;
+      tw += w;
+      tc3 += w;
     }
   }
   tw = wave_sum(tw);
@@ -1259,6 +1285,8 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     const uint32_t slot = a.ended_slot[i];
     const uint32_t id = a.qin.id[i];
     const uint32_t meta = a.qin.meta[i];
+    const uint32_t origin = cmi_meta_origin(meta);
+    const double w = a.model.photon_weight[origin]; /* the packet's weight */
     PacketRng rng;
     rng.resume(a.seed, a.iteration, a.first_packet + id, meta & 0xffffffu,
                (meta >> 24) & 1u);
@@ -1277,16 +1305,17 @@ __global__ void __launch_bounds__(CMI_BLOCK)
                                        plc, key)) {
         write_flight_row<FULL>(
             a.rows, slot, p, plc, key, id,
-            cmi_pack_meta(rng.block, rng.have, (uint32_t)type), weights);
+            cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin),
+            weights);
       } else {
         key = key_dead;
-        tw += 1.;
-        tc1 += (type == TYPE_DIFFUSE_HI) ? 1. : 0.;
-        tc2 += (type == TYPE_DIFFUSE_HeI) ? 1. : 0.;
+        tw += w;
+        tc1 += (type == TYPE_DIFFUSE_HI) ? w : 0.;
+        tc2 += (type == TYPE_DIFFUSE_HeI) ? w : 0.;
       }
     } else {
-      tw += 1.;
-      tc3 += 1.;
+      tw += w;
+      tc3 += w;
     }
     if (key == key_dead)
       a.rows.keys[slot] = key;
@@ -1353,11 +1382,21 @@ __global__ void __launch_bounds__(CMI_BLOCK)
        i < a.n_packets; i += stride) {
     PacketRng rng;
     rng.init(a.seed, a.iteration, a.first_packet + i);
-    (void)rng.next();            /* continuous / discrete choice */
-    const double xs = rng.next(); /* source pick */
+    const uint32_t origin =
+        rng.next() >= a.model.continuous_probability ? 0u : 1u;
     uint32_t src = 0;
-    while (xs > a.model.source_cumulative[src])
-      ++src;
+    if (origin == 0) {
+      const double xs = rng.next(); /* source pick */
+      while (xs > a.model.source_cumulative[src])
+        ++src;
+    } else {
+      /* the continuous source: one more "source", its packets ordered by
+       * direction like the others (they enter all over the box) */
+      src = (uint32_t)a.model.nsource;
+      (void)rng.next(); /* the focus point */
+      (void)rng.next();
+      (void)rng.next();
+    }
     const double u_cost = rng.next(); /* cos(theta) = 2 u - 1 */
     const double u_phi = rng.next();  /* phi = 2 pi u */
     const uint32_t ic = (uint32_t)(u_cost * 2048.);
@@ -1366,11 +1405,11 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     uint32_t tau_class = 0;
     if (a.tau_bits != 0) {
       if (!a.full_ions) {
-        (void)sample_source_spectrum(a.model, rng); /* the frequency's draws */
+        (void)sample_source_spectrum(a.model, rng, origin); /* its draws */
         const double u_tau = rng.next();            /* tau = -ln u */
         tau_class = (uint32_t)(u_tau * (double)(1u << a.tau_bits));
       } else {
-        const double nu = sample_source_spectrum(a.model, rng);
+        const double nu = sample_source_spectrum(a.model, rng, origin);
         const double tau = -log(rng.next());
         double sigma_H, sigma_He;
         cmi_cross_sections_H_He(a.model, nu, sigma_H, sigma_He);

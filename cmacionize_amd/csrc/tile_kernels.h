@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS, (!FULL && HEAT) ? 2 : 4)
   int32_t lc[3] = {0, 0, 0}, lsgn[3] = {0, 0, 0};
   int32_t type = 0;
   uint32_t packet_id = 0, lane_meta = 0, slot = 0;
-  unsigned int tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
+  double tc0 = 0., tc1 = 0., tc2 = 0., tc3 = 0.; /* sums of packet weights */
   unsigned int nsteps = 0, natomics = 0, nwavesteps = 0;
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax)
@@ -358,6 +358,9 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS, (!FULL && HEAT) ? 2 : 4)
           const uint32_t plc =
               (uint32_t)((unsigned long long)__double_as_longlong(r3.y) >> 32);
           type = (int32_t)(lane_meta >> 28);
+          /* the packet's weight (Photon::get_weight; 1 unless both kinds of
+           * sources are present) goes into the accumulation weights once */
+          const double pw = a.model.photon_weight[cmi_meta_origin(lane_meta)];
           if (FULL) {
             const double4 *w = reinterpret_cast<const double4 *>(
                 a.rows.weights + (size_t)CMI_NACC * slot);
@@ -371,10 +374,13 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS, (!FULL && HEAT) ? 2 : 4)
             }
             sigma_H = weights[ION_H_n];
             sigma_He_corr = a.model.abundance[0] * weights[ION_He_n];
+#pragma unroll
+            for (int k = 0; k < CMI_NACC; ++k)
+              weights[k] *= pw;
           } else {
             sigma_H = a.model.xsec_fixed[ION_H_n];
-            weights[ION_H_n] = sigma_H;
-            weights[CMI_NION] = sigma_H * (nu - a.model.nu_H);
+            weights[ION_H_n] = sigma_H * pw;
+            weights[CMI_NION] = sigma_H * (nu - a.model.nu_H) * pw;
           }
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax) {
@@ -586,10 +592,11 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS, (!FULL && HEAT) ? 2 : 4)
         if (!absorbed)
           a.rows.keys[slot] = key;
         if (done) {
-          tc0 += (type == TYPE_PRIMARY) ? 1u : 0u;
-          tc1 += (type == TYPE_DIFFUSE_HI) ? 1u : 0u;
-          tc2 += (type == TYPE_DIFFUSE_HeI) ? 1u : 0u;
-          tc3 += (type == TYPE_ABSORBED) ? 1u : 0u;
+          const double w = a.model.photon_weight[cmi_meta_origin(lane_meta)];
+          tc0 += (type == TYPE_PRIMARY) ? w : 0.;
+          tc1 += (type == TYPE_DIFFUSE_HI) ? w : 0.;
+          tc2 += (type == TYPE_DIFFUSE_HeI) ? w : 0.;
+          tc3 += (type == TYPE_ABSORBED) ? w : 0.;
         }
         active = false;
       }
@@ -642,10 +649,10 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS, (!FULL && HEAT) ? 2 : 4)
     __syncthreads();
   }
 
-  const double s0 = wave_sum((double)tc0);
-  const double s1 = wave_sum((double)tc1);
-  const double s2 = wave_sum((double)tc2);
-  const double s3 = wave_sum((double)tc3);
+  const double s0 = wave_sum(tc0);
+  const double s1 = wave_sum(tc1);
+  const double s2 = wave_sum(tc2);
+  const double s3 = wave_sum(tc3);
   const double ns = wave_sum((double)nsteps);
   const double na = wave_sum((double)natomics);
   if (lane == 0) {

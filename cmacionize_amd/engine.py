@@ -25,6 +25,7 @@ FIELD_MEAN_INTENSITY = 16
 FIELD_HEATING = 30
 
 REEMIT_NONE, REEMIT_PHYSICAL, REEMIT_FIXED = 0, 1, 2
+CONTINUOUS_NONE, CONTINUOUS_ISOTROPIC = 0, 1
 
 _dp = C.POINTER(C.c_double)
 
@@ -59,6 +60,9 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_create", "cmi_gpu_destroy", "cmi_gpu_last_error",
     "cmi_gpu_synchronize", "cmi_gpu_number_of_cells", "cmi_gpu_set_sources",
     "cmi_gpu_set_spectrum_monochromatic", "cmi_gpu_set_spectrum_planck",
+    "cmi_gpu_set_continuous_source",
+    "cmi_gpu_set_continuous_spectrum_monochromatic",
+    "cmi_gpu_set_continuous_spectrum_planck",
     "cmi_gpu_set_cross_sections_fixed", "cmi_gpu_set_cross_sections_verner",
     "cmi_gpu_set_recombination_rates_fixed",
     "cmi_gpu_set_recombination_rates_verner", "cmi_gpu_set_abundances",
@@ -115,6 +119,9 @@ def load_library():
     L.cmi_gpu_set_sources.argtypes = [vp, C.c_int32, _dp, _dp, C.c_double]
     L.cmi_gpu_set_spectrum_monochromatic.argtypes = [vp, C.c_double]
     L.cmi_gpu_set_spectrum_planck.argtypes = [vp, C.c_double]
+    L.cmi_gpu_set_continuous_source.argtypes = [vp, C.c_int32, C.c_double]
+    L.cmi_gpu_set_continuous_spectrum_monochromatic.argtypes = [vp, C.c_double]
+    L.cmi_gpu_set_continuous_spectrum_planck.argtypes = [vp, C.c_double]
     L.cmi_gpu_set_cross_sections_fixed.argtypes = [vp, _dp]
     L.cmi_gpu_set_cross_sections_verner.argtypes = [vp]
     L.cmi_gpu_set_recombination_rates_fixed.argtypes = [vp, _dp]
@@ -274,10 +281,28 @@ class GpuEngine:
 
     # plugin descriptors -----------------------------------------------------
     def set_sources(self, positions, weights, luminosity):
-        pos = _f64(positions).reshape(-1, 3)
         w = _f64(weights)
+        if len(w) == 0:  # no discrete sources
+            self._check(self._lib.cmi_gpu_set_sources(self._h, 0, None, None,
+                                                      0.))
+            return
+        pos = _f64(positions).reshape(-1, 3)
         self._check(self._lib.cmi_gpu_set_sources(self._h, len(w), _p(pos),
                                                   _p(w), luminosity))
+
+    def set_continuous_source(self, kind, luminosity):
+        """ContinuousPhotonSource (CONTINUOUS_ISOTROPIC on the box) with the
+        luminosity the PhotonSource ctor computes for it."""
+        self._check(self._lib.cmi_gpu_set_continuous_source(self._h, kind,
+                                                            luminosity))
+
+    def set_continuous_spectrum_monochromatic(self, frequency):
+        self._check(self._lib.cmi_gpu_set_continuous_spectrum_monochromatic(
+            self._h, frequency))
+
+    def set_continuous_spectrum_planck(self, temperature):
+        self._check(self._lib.cmi_gpu_set_continuous_spectrum_planck(
+            self._h, temperature))
 
     def set_spectrum_monochromatic(self, frequency):
         self._check(self._lib.cmi_gpu_set_spectrum_monochromatic(self._h,

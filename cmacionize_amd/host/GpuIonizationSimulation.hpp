@@ -356,6 +356,8 @@ class GpuIonizationSimulation {
   std::array<long long, 3> _ncell;
   std::unique_ptr<PhotonSourceDistribution> _photon_source_distribution;
   std::unique_ptr<PhotonSourceSpectrum> _photon_source_spectrum;
+  std::unique_ptr<ContinuousPhotonSource> _continuous_photon_source;
+  std::unique_ptr<PhotonSourceSpectrum> _continuous_photon_source_spectrum;
   DiffuseReemission _reemission;
   cmi_gpu_temperature_params _temperature_params;
   std::unique_ptr<DensityGridWriter> _density_grid_writer;
@@ -405,7 +407,22 @@ class GpuIonizationSimulation {
   void lower_model(cmi_gpu_engine *engine) {
     if (_photon_source_distribution)
       check(_photon_source_distribution->lower(engine), "sources");
-    check(_photon_source_spectrum->lower(engine), "spectrum");
+    else
+      check(cmi_gpu_set_sources(engine, 0, nullptr, nullptr, 0.), "sources");
+    if (_photon_source_spectrum)
+      check(_photon_source_spectrum->lower(engine), "spectrum");
+    if (_continuous_photon_source) {
+      /* PhotonSource ctor, src/PhotonSource.cpp:104-111 */
+      const double luminosity =
+          _continuous_photon_source->has_total_luminosity()
+              ? _continuous_photon_source->get_total_luminosity()
+              : _continuous_photon_source->get_total_surface_area() *
+                    _continuous_photon_source_spectrum->get_total_flux();
+      check(_continuous_photon_source_spectrum->lower_continuous(engine),
+            "continuous spectrum");
+      check(_continuous_photon_source->lower(engine, luminosity),
+            "continuous source");
+    }
     check(_cross_sections->lower(engine), "cross sections");
     check(_recombination_rates->lower(engine), "recombination rates");
     check(_abundances.lower(engine), "abundances");
@@ -600,11 +617,15 @@ public:
     if (grid_type != "Cartesian")
       throw ParameterError("DensityGrid type \"" + grid_type +
                            "\" is not on this path (Cartesian only)");
-    const std::string continuous =
-        _parameter_file.get_string("ContinuousPhotonSource:type", "None");
-    if (continuous != "None")
-      throw ParameterError("ContinuousPhotonSource type \"" + continuous +
-                           "\" is not on this path");
+    /* src/IonizationSimulation.cpp:164-176 */
+    _continuous_photon_source.reset(generate_continuous_photon_source(
+        _simulation_box.sides.data(), _parameter_file));
+    _continuous_photon_source_spectrum.reset(generate_photon_source_spectrum(
+        "ContinuousPhotonSourceSpectrum", _parameter_file,
+        _continuous_photon_source ? "Monochromatic" : "None"));
+    if (_continuous_photon_source && !_continuous_photon_source_spectrum)
+      throw ParameterError(
+          "No spectrum provided for the continuous photon sources!");
     if (_photon_source_distribution && !_photon_source_spectrum)
       throw ParameterError(
           "No spectrum provided for the discrete photon sources!");

@@ -304,6 +304,8 @@ public:
                                       double temperature = 0.) const = 0;
   virtual double get_total_flux() const = 0;
   virtual int lower(cmi_gpu_engine *engine) const = 0;
+  /* the same spectrum in the role of ContinuousPhotonSourceSpectrum */
+  virtual int lower_continuous(cmi_gpu_engine *engine) const = 0;
 };
 
 /* src/MonochromaticPhotonSourceSpectrum.hpp:40-113 */
@@ -324,10 +326,19 @@ public:
   double get_random_frequency(RandomGenerator &, double = 0.) const override {
     return _frequency;
   }
-  double get_total_flux() const override { return _total_flux; }
+  /* src/MonochromaticPhotonSourceSpectrum.hpp:107-112 */
+  double get_total_flux() const override {
+    if (_total_flux < 0.)
+      throw ParameterError(
+          "Total flux was not provided for the monochromatic spectrum!");
+    return _total_flux;
+  }
   double get_frequency() const { return _frequency; }
   int lower(cmi_gpu_engine *engine) const override {
     return cmi_gpu_set_spectrum_monochromatic(engine, _frequency);
+  }
+  int lower_continuous(cmi_gpu_engine *engine) const override {
+    return cmi_gpu_set_continuous_spectrum_monochromatic(engine, _frequency);
   }
 };
 
@@ -348,18 +359,29 @@ public:
   double get_random_frequency(RandomGenerator &, double = 0.) const override {
     throw ParameterError("Planck spectrum is sampled on the device");
   }
-  double get_total_flux() const override { return _ionizing_flux; }
+  /* src/PlanckPhotonSourceSpectrum.cpp:172-178 */
+  double get_total_flux() const override {
+    if (_ionizing_flux < 0.)
+      throw ParameterError(
+          "Ionizing flux was not provided for the Planck spectrum!");
+    return _ionizing_flux;
+  }
   double get_temperature() const { return _temperature; }
   int lower(cmi_gpu_engine *engine) const override {
     return cmi_gpu_set_spectrum_planck(engine, _temperature);
+  }
+  int lower_continuous(cmi_gpu_engine *engine) const override {
+    return cmi_gpu_set_continuous_spectrum_planck(engine, _temperature);
   }
 };
 
 /* src/PhotonSourceSpectrumFactory.hpp:93-113 (types on this path) */
 inline PhotonSourceSpectrum *
 generate_photon_source_spectrum(const std::string &role,
-                                ParameterFile &params) {
-  const std::string type = params.get_string(role + ":type", "Monochromatic");
+                                ParameterFile &params,
+                                const std::string &default_type =
+                                    "Monochromatic") {
+  const std::string type = params.get_string(role + ":type", default_type);
   if (type == "Monochromatic")
     return new MonochromaticPhotonSourceSpectrum(role, params);
   if (type == "Planck")
@@ -367,6 +389,52 @@ generate_photon_source_spectrum(const std::string &role,
   if (type == "None")
     return nullptr;
   throw ParameterError("Unknown PhotonSourceSpectrum type: \"" + type + "\"");
+}
+
+/* ------------------------------------------------- ContinuousPhotonSource */
+
+/* src/ContinuousPhotonSource.hpp:40-100 */
+class ContinuousPhotonSource {
+public:
+  virtual ~ContinuousPhotonSource() {}
+  virtual double get_total_surface_area() const = 0;
+  virtual bool has_total_luminosity() const { return false; }
+  virtual double get_total_luminosity() const { return 0.; }
+  /* luminosity = what the PhotonSource ctor computes
+   * (src/PhotonSource.cpp:104-111) */
+  virtual int lower(cmi_gpu_engine *engine, double luminosity) const = 0;
+};
+
+/* src/IsotropicContinuousPhotonSource.hpp:40-203: radiation that enters the
+ * simulation box isotropically through its faces */
+class IsotropicContinuousPhotonSource : public ContinuousPhotonSource {
+  const double _sides[3];
+
+public:
+  IsotropicContinuousPhotonSource(const double sides[3])
+      : _sides{sides[0], sides[1], sides[2]} {}
+  double get_total_surface_area() const override {
+    return 2. * _sides[0] * _sides[1] + 2. * _sides[0] * _sides[2] +
+           2. * _sides[1] * _sides[2];
+  }
+  int lower(cmi_gpu_engine *engine, double luminosity) const override {
+    return cmi_gpu_set_continuous_source(engine, CMI_GPU_CONTINUOUS_ISOTROPIC,
+                                         luminosity);
+  }
+};
+
+/* src/ContinuousPhotonSourceFactory.hpp (types on this path) */
+inline ContinuousPhotonSource *
+generate_continuous_photon_source(const double box_sides[3],
+                                  ParameterFile &params) {
+  const std::string type =
+      params.get_string("ContinuousPhotonSource:type", "None");
+  if (type == "Isotropic")
+    return new IsotropicContinuousPhotonSource(box_sides);
+  if (type == "None")
+    return nullptr;
+  throw ParameterError("ContinuousPhotonSource type \"" + type +
+                       "\" is not on this path (Isotropic, None)");
 }
 
 /* -------------------------------------- CrossSections / RecombinationRates */

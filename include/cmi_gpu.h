@@ -115,10 +115,31 @@ int64_t cmi_gpu_number_of_cells(const cmi_gpu_engine *engine);
  * get_weight, get_total_luminosity} as consumed by the PhotonSource ctor
  * (src/PhotonSourceDistribution.hpp:54-80, src/PhotonSource.cpp:60-146).
  * positions: host [n][3] (m); weights: host [n], must sum to 1 within 1e-9
- * (same check as the reference); total_luminosity in s^-1. */
+ * (same check as the reference); total_luminosity in s^-1. n = 0 removes the
+ * discrete sources (a run with a continuous source only). */
 int cmi_gpu_set_sources(cmi_gpu_engine *engine, int32_t n,
                         const double *positions, const double *weights,
                         double total_luminosity);
+
+/* replaces: ContinuousPhotonSource as consumed by the PhotonSource ctor and
+ * get_random_photon (src/ContinuousPhotonSource.hpp,
+ * src/PhotonSource.cpp:104-130,230-238). ISOTROPIC is
+ * IsotropicContinuousPhotonSource on the simulation box
+ * (src/IsotropicContinuousPhotonSource.hpp:95-191). luminosity (s^-1) is what
+ * the PhotonSource ctor computes: get_total_luminosity(), or
+ * get_total_surface_area() x the spectrum's get_total_flux(). With both kinds
+ * of sources half of the packets come from each and the continuous ones carry
+ * the weight L_continuous / L_discrete; all tallies (mean intensities, heating,
+ * totweight, the per-type counts) are sums of weights, as in the reference. */
+enum { CMI_GPU_CONTINUOUS_NONE = 0, CMI_GPU_CONTINUOUS_ISOTROPIC = 1 };
+int cmi_gpu_set_continuous_source(cmi_gpu_engine *engine, int32_t type,
+                                  double luminosity);
+/* the continuous source's PhotonSourceSpectrum (role
+ * "ContinuousPhotonSourceSpectrum", src/IonizationSimulation.cpp:164-168) */
+int cmi_gpu_set_continuous_spectrum_monochromatic(cmi_gpu_engine *engine,
+                                                  double frequency);
+int cmi_gpu_set_continuous_spectrum_planck(cmi_gpu_engine *engine,
+                                           double temperature);
 
 /* replaces: PhotonSourceSpectrum::get_random_frequency for
  * MonochromaticPhotonSourceSpectrum (src/MonochromaticPhotonSourceSpectrum.hpp:97-100) */

@@ -156,7 +156,25 @@ typedef struct {
   /* sampling tables built by cmio_tables_create (needed for the Planck
    * spectrum and for physical re-emission) */
   const struct cmio_tables *tables;
+
+  /* ContinuousPhotonSource + ContinuousPhotonSourceSpectrum and the mix of
+   * the two kinds of sources (src/PhotonSource.cpp:104-130), set by
+   * cmio_mix_sources: continuous_type 0 = none, 1 =
+   * IsotropicContinuousPhotonSource on `continuous_box` */
+  int32_t continuous_type;
+  int32_t continuous_spectrum_type;
+  double continuous_mono_frequency;
+  double continuous_planck_temperature;
+  double continuous_box_anchor[3], continuous_box_sides[3];
+  double discrete_luminosity, continuous_luminosity; /* inputs of the mix */
+  double continuous_probability;
+  double discrete_photon_weight, continuous_photon_weight;
 } cmio_model;
+
+/* PhotonSource ctor, src/PhotonSource.cpp:104-130: total_luminosity,
+ * continuous_probability and the two photon weights from
+ * discrete_luminosity / continuous_luminosity */
+void cmio_mix_sources(cmio_model *model);
 
 #define CMIO_NFREQ 1000 /* frequency bins of every sampled spectrum */
 #define CMIO_NTEMP 100  /* temperature bins of the Lyman continua */
@@ -173,6 +191,10 @@ typedef struct cmio_tables {
   double lyc_cdf[2][CMIO_NTEMP][CMIO_NFREQ]; /* [H, He][T][nu] */
   double he2pc_freq[CMIO_NFREQ];
   double he2pc_cdf[CMIO_NFREQ];
+  /* the continuous source's Planck spectrum */
+  double planck2_logfreq[CMIO_NFREQ];
+  double planck2_cdf[CMIO_NFREQ];
+  double planck2_logcdf[CMIO_NFREQ];
 } cmio_tables;
 
 /* builds every table from the model's spectrum and cross sections */

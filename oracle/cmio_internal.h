@@ -60,6 +60,7 @@ static inline uint_fast32_t cmio_locate(double x, const double *xarr,
 double cmio_cross_section(const cmio_model *model, int ion, double frequency);
 double cmio_recombination_rate(const cmio_model *model, int ion, double T);
 double cmio_spectrum_sample(const cmio_model *model, cmio_rng *rng);
+double cmio_continuous_spectrum_sample(const cmio_model *model, cmio_rng *rng);
 /* returns new frequency (0 = absorbed for good) and sets *type */
 double cmio_reemit_frequency(const cmio_model *model, const cmio_photon *photon,
                              double AHe, double T, double xH, double xHe,

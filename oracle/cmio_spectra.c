@@ -24,9 +24,22 @@ cmio_tables *cmio_tables_create(const cmio_model *model) {
   const double h = CMIO_PLANCK;
   const double k = CMIO_BOLTZMANN;
 
-  /* ---- Planck source spectrum ---- */
-  if (model->spectrum_type == CMIO_SPECTRUM_PLANCK) {
-    const double temperature = model->planck_temperature;
+  /* ---- Planck source spectra (src/PlanckPhotonSourceSpectrum.cpp:53-113):
+   * the discrete sources', the continuous source's ---- */
+  for (int which = 0; which < 2; ++which) {
+    const int wanted =
+        which == 0 ? model->spectrum_type == CMIO_SPECTRUM_PLANCK
+                   : (model->continuous_type != 0 &&
+                      model->continuous_spectrum_type == CMIO_SPECTRUM_PLANCK);
+    if (!wanted)
+      continue;
+    const double temperature = which == 0
+                                   ? model->planck_temperature
+                                   : model->continuous_planck_temperature;
+    double *planck_cdf = which == 0 ? t->planck_cdf : t->planck2_cdf;
+    double *planck_logcdf = which == 0 ? t->planck_logcdf : t->planck2_logcdf;
+    double *planck_logfreq =
+        which == 0 ? t->planck_logfreq : t->planck2_logfreq;
     const double max_frequency = 4.;
     const double min_frequency = 3.289e15;
     static double frequency[CMIO_NFREQ], luminosity[CMIO_NFREQ];
@@ -36,20 +49,20 @@ cmio_tables *cmio_tables_create(const cmio_model *model) {
           frequency[i] * frequency[i] * frequency[i] /
           (exp(h * frequency[i] * min_frequency / (k * temperature)) - 1.);
     }
-    t->planck_cdf[0] = 0.;
+    planck_cdf[0] = 0.;
     for (int i = 1; i < CMIO_NFREQ; ++i) {
-      t->planck_cdf[i] = t->planck_cdf[i - 1] +
-                         0.5 *
-                             (luminosity[i] / frequency[i] +
-                              luminosity[i - 1] / frequency[i - 1]) *
-                             (frequency[i] - frequency[i - 1]);
+      planck_cdf[i] = planck_cdf[i - 1] +
+                      0.5 *
+                          (luminosity[i] / frequency[i] +
+                           luminosity[i - 1] / frequency[i - 1]) *
+                          (frequency[i] - frequency[i - 1]);
     }
-    t->planck_logcdf[0] = -10.;
-    t->planck_logfreq[0] = 0.;
+    planck_logcdf[0] = -10.;
+    planck_logfreq[0] = 0.;
     for (int i = 1; i < CMIO_NFREQ; ++i) {
-      t->planck_cdf[i] /= t->planck_cdf[CMIO_NFREQ - 1];
-      t->planck_logcdf[i] = log10(t->planck_cdf[i]);
-      t->planck_logfreq[i] = log10(frequency[i]);
+      planck_cdf[i] /= planck_cdf[CMIO_NFREQ - 1];
+      planck_logcdf[i] = log10(planck_cdf[i]);
+      planck_logfreq[i] = log10(frequency[i]);
     }
   }
 
@@ -144,16 +157,20 @@ double cmio_he2pc_integral(void) {
   return integral * 4.98e15 / 3.289e15;
 }
 
-static double sample_planck(const cmio_tables *t, cmio_rng *rng) {
+static double sample_planck_table(const double *cdf, const double *logcdf,
+                                  const double *logfreq, cmio_rng *rng) {
   const double x = cmio_rng_next(rng);
-  const uint_fast32_t ix = cmio_locate(x, t->planck_cdf, CMIO_NFREQ);
+  const uint_fast32_t ix = cmio_locate(x, cdf, CMIO_NFREQ);
   const double log_random_frequency =
-      (log10(x) - t->planck_logcdf[ix]) /
-          (t->planck_logcdf[ix + 1] - t->planck_logcdf[ix]) *
-          (t->planck_logfreq[ix + 1] - t->planck_logfreq[ix]) +
-      t->planck_logfreq[ix];
+      (log10(x) - logcdf[ix]) / (logcdf[ix + 1] - logcdf[ix]) *
+          (logfreq[ix + 1] - logfreq[ix]) +
+      logfreq[ix];
   const double frequency = pow(10., log_random_frequency);
   return frequency * 3.288465385e15;
+}
+static double sample_planck(const cmio_tables *t, cmio_rng *rng) {
+  return sample_planck_table(t->planck_cdf, t->planck_logcdf,
+                             t->planck_logfreq, rng);
 }
 
 static double sample_lyc(const cmio_tables *t, int s, double temperature,
@@ -184,6 +201,21 @@ double cmio_spectrum_sample(const cmio_model *model, cmio_rng *rng) {
     abort();
   }
   return sample_planck(model->tables, rng);
+}
+
+/* the continuous source's spectrum */
+double cmio_continuous_spectrum_sample(const cmio_model *model,
+                                       cmio_rng *rng) {
+  if (model->continuous_spectrum_type == CMIO_SPECTRUM_MONOCHROMATIC) {
+    return model->continuous_mono_frequency;
+  }
+  if (!model->tables) {
+    fprintf(stderr, "cmio: Planck spectrum needs cmio_tables_create\n");
+    abort();
+  }
+  const cmio_tables *t = model->tables;
+  return sample_planck_table(t->planck2_cdf, t->planck2_logcdf,
+                             t->planck2_logfreq, rng);
 }
 
 void cmio_sample_spectrum(const cmio_model *model, int kind,

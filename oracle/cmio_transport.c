@@ -45,28 +45,98 @@ static void set_random_direction(cmio_photon *photon, cmio_rng *rng) {
   }
 }
 
-/* src/PhotonSource.cpp:208-249, discrete branch (the continuous-source branch
- * is out of scope: ContinuousPhotonSource type None in every config, so
- * _continuous_probability = 0 and x >= 0 always holds). The first uniform is
- * still drawn, as in the reference. */
+/* PhotonSource ctor, src/PhotonSource.cpp:104-130 */
+void cmio_mix_sources(cmio_model *model) {
+  const double discrete_luminosity =
+      model->nsource > 0 ? model->discrete_luminosity : 0.;
+  const double continuous_luminosity =
+      model->continuous_type != 0 ? model->continuous_luminosity : 0.;
+  model->total_luminosity = discrete_luminosity + continuous_luminosity;
+  model->continuous_probability = 0.;
+  model->discrete_photon_weight = 1.;
+  model->continuous_photon_weight = 1.;
+  if (model->total_luminosity > 0.) {
+    if (discrete_luminosity > 0.) {
+      if (continuous_luminosity > 0.) {
+        model->continuous_probability = 0.5;
+      } else {
+        model->continuous_probability = 0.;
+      }
+      model->discrete_photon_weight = 1.;
+      if (continuous_luminosity > 0.) {
+        model->continuous_photon_weight =
+            (1. - model->continuous_probability) * continuous_luminosity /
+            model->continuous_probability / discrete_luminosity;
+      }
+    } else {
+      model->continuous_probability = 1.;
+      model->discrete_photon_weight = 0.;
+      model->continuous_photon_weight = 1.;
+    }
+  }
+}
+
+/* IsotropicContinuousPhotonSource::get_random_incoming_direction,
+ * src/IsotropicContinuousPhotonSource.hpp:95-191 */
+static void isotropic_incoming(const cmio_model *model, cmio_rng *rng,
+                               cmio_photon *photon) {
+  const double *anchor = model->continuous_box_anchor;
+  const double *sides = model->continuous_box_sides;
+  double focus[3];
+  for (int a = 0; a < 3; ++a) {
+    focus[a] = anchor[a] + sides[a] * cmio_rng_next(rng);
+  }
+  set_random_direction(photon, rng);
+  const double *direction = photon->direction;
+  double l[3];
+  for (int a = 0; a < 3; ++a) {
+    const double top = anchor[a] + sides[a];
+    if (direction[a] < 0.) {
+      l[a] = (top - focus[a]) / direction[a];
+    } else if (direction[a] > 0.) {
+      l[a] = (anchor[a] - focus[a]) / direction[a];
+    } else {
+      l[a] = -DBL_MAX;
+    }
+  }
+  const double maxl = fmax(fmax(l[0], l[1]), l[2]);
+  for (int a = 0; a < 3; ++a) {
+    const double top = anchor[a] + sides[a];
+    double x = focus[a] + maxl * direction[a];
+    x = fmin(x, top - DBL_EPSILON * sides[a]);
+    photon->position[a] = fmax(x, anchor[a]);
+  }
+}
+
+/* src/PhotonSource.cpp:208-249. The first uniform is drawn also when there is
+ * no continuous source (continuous_probability = 0). */
 static void random_photon(const cmio_model *model, cmio_rng *rng,
                           cmio_photon *photon) {
   double x = cmio_rng_next(rng);
-  (void)x; /* x >= _continuous_probability (= 0) */
-  x = cmio_rng_next(rng);
-  int i = 0;
-  while (x > model->source_cumulative[i]) {
-    ++i;
+  double energy;
+  if (x >= model->continuous_probability) {
+    x = cmio_rng_next(rng);
+    int i = 0;
+    while (x > model->source_cumulative[i]) {
+      ++i;
+    }
+    for (int a = 0; a < 3; ++a) {
+      photon->position[a] = model->source_position[3 * i + a];
+    }
+    set_random_direction(photon, rng);
+    energy = cmio_spectrum_sample(model, rng);
+    /* (models filled in by hand leave the mix at zero: weight 1) */
+    photon->weight = model->continuous_type != 0
+                         ? model->discrete_photon_weight
+                         : 1.;
+  } else {
+    isotropic_incoming(model, rng, photon);
+    energy = cmio_continuous_spectrum_sample(model, rng);
+    photon->weight = model->continuous_photon_weight;
   }
-  for (int a = 0; a < 3; ++a) {
-    photon->position[a] = model->source_position[3 * i + a];
-  }
-  set_random_direction(photon, rng);
-  const double energy = cmio_spectrum_sample(model, rng);
   photon->energy = energy;
   photon->type = CMIO_TYPE_PRIMARY;
   set_cross_sections(model, photon, energy);
-  photon->weight = 1.; /* _discrete_photon_weight */
 }
 
 void cmio_emit_stream(const cmio_model *model, cmio_rng *rng,

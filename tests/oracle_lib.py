@@ -65,6 +65,17 @@ class Model(C.Structure):
         ("crscale", C.c_double),
         ("t_min_ionized", C.c_double),
         ("tables", C.c_void_p),
+        ("continuous_type", C.c_int32),
+        ("continuous_spectrum_type", C.c_int32),
+        ("continuous_mono_frequency", C.c_double),
+        ("continuous_planck_temperature", C.c_double),
+        ("continuous_box_anchor", C.c_double * 3),
+        ("continuous_box_sides", C.c_double * 3),
+        ("discrete_luminosity", C.c_double),
+        ("continuous_luminosity", C.c_double),
+        ("continuous_probability", C.c_double),
+        ("discrete_photon_weight", C.c_double),
+        ("continuous_photon_weight", C.c_double),
     ]
 
 
@@ -108,6 +119,7 @@ def lib():
     L.cmio_emit.argtypes = [C.POINTER(Model), C.c_uint32, C.c_uint32,
                             C.c_uint64, C.POINTER(Photon), dp,
                             C.POINTER(C.c_uint32)]
+    L.cmio_mix_sources.argtypes = [C.POINTER(Model)]
     L.cmio_reset_grid.argtypes = [C.POINTER(Grid), C.POINTER(Cells)]
     L.cmio_update_cells.argtypes = [C.POINTER(Grid), C.POINTER(Model),
                                     C.POINTER(Cells), C.c_uint32, C.c_double]
@@ -242,6 +254,29 @@ class OracleSimulation:
         self.model.source_position = _ptr(self._src_pos)
         self.model.source_cumulative = _ptr(self._src_cum)
         self.model.total_luminosity = luminosity
+        self.model.discrete_luminosity = luminosity
+        if self.model.continuous_type:
+            lib().cmio_mix_sources(C.byref(self.model))
+
+    def set_continuous_source(self, luminosity, frequency=None,
+                              planck_temperature=None):
+        """IsotropicContinuousPhotonSource on the simulation box with a
+        monochromatic or Planck ContinuousPhotonSourceSpectrum; the mix with
+        the discrete sources as the PhotonSource ctor computes it
+        (src/PhotonSource.cpp:104-130)."""
+        m = self.model
+        m.continuous_type = 1
+        for a in range(3):
+            m.continuous_box_anchor[a] = self.grid.anchor[a]
+            m.continuous_box_sides[a] = self.grid.sides[a]
+        if frequency is not None:
+            m.continuous_spectrum_type = SPECTRUM_MONOCHROMATIC
+            m.continuous_mono_frequency = frequency
+        else:
+            m.continuous_spectrum_type = SPECTRUM_PLANCK
+            m.continuous_planck_temperature = planck_temperature
+        m.continuous_luminosity = luminosity
+        lib().cmio_mix_sources(C.byref(m))
 
     def set_homogeneous(self, density, temperature, xH=1.e-6, xHe=1.e-6):
         """src/HomogeneousDensityFunction.hpp:99-107"""
@@ -264,6 +299,8 @@ class OracleSimulation:
     def shoot(self, seed, iteration, first_packet, n_packets):
         if not self.model.tables and (
                 self.model.spectrum_type == SPECTRUM_PLANCK or
+                (self.model.continuous_type and
+                 self.model.continuous_spectrum_type == SPECTRUM_PLANCK) or
                 self.model.reemit_type == REEMIT_PHYSICAL):
             self.build_tables()
         tw = C.c_double(0.)

@@ -335,3 +335,46 @@ def test_cmi_gpu_executable_with_copies_of_the_source_block(exe, tmp_path,
     stats = [[l for l in out.splitlines() if "Escape fraction" in l][-1]
              for _, out in outputs.values()]
     assert stats[0] == stats[1]
+
+
+@pytest.mark.gpu
+def test_cmi_gpu_executable_with_a_continuous_source(exe, tmp_path, oracle):
+    """stromgren.param plus `ContinuousPhotonSource: type: Isotropic` with a
+    monochromatic ContinuousPhotonSourceSpectrum of given total flux: the host
+    computes the continuous luminosity as surface area x flux
+    (src/PhotonSource.cpp:104-111), half of the packets come from either kind
+    of source; result equal to the oracle with the same mix."""
+    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = text.replace("[64, 64, 64]", "[16, 16, 16]")
+    text = text.replace("number of photons: 1e6", "number of photons: 20000")
+    text = text.replace("number of iterations: 20", "number of iterations: 3")
+    assert "ContinuousPhotonSource" not in text
+    flux = 2.e14  # m^-2 s^-1: about 2.7 times the star over the 10 pc box
+    text += ("\nContinuousPhotonSource:\n  type: Isotropic\n"
+             "\nContinuousPhotonSourceSpectrum:\n  type: Monochromatic\n"
+             "  frequency: 3.6e15 Hz\n  total flux: %g m^-2 s^-1\n" % flux)
+    p = tmp_path / "small.param"
+    p.write_text(text)
+    r = subprocess.run([exe, "--params", str(p), "--output-statistics"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    last = np.loadtxt(tmp_path / "stromgren_003.txt")
+    d = describe(exe, str(tmp_path / "small.param"), str(tmp_path))
+    sim = oracle.OracleSimulation((16,) * 3, d["anchor"], d["sides"])
+    sim.set_sources([[0., 0., 0.]], [1.], d["total_luminosity"])
+    sim.set_homogeneous(100. * (1. / 0.01 / 0.01 / 0.01), 8000.)
+    m = sim.model
+    m.spectrum_type = oracle.SPECTRUM_MONOCHROMATIC
+    m.mono_frequency = d["spectrum"]["frequency"]
+    m.xsec_type = oracle.XSEC_FIXED
+    m.recomb_type = oracle.RECOMB_FIXED
+    for i in range(14):
+        m.xsec_fixed[i] = d["cross_sections"][i]
+        m.recomb_fixed[i] = d["recombination_rates"][i]
+    area = 6. * d["sides"][0] ** 2
+    sim.set_continuous_source(area * flux, frequency=3.6e15)
+    assert 2. < m.continuous_photon_weight < 3.5
+    sim.run(20000, 3, seed=42)
+    assert np.allclose(last[:, 5], sim.x[0], rtol=2e-3, atol=0.)
+    # the background keeps the corners of the box ionized too
+    assert last[0, 5] < 0.5

@@ -261,6 +261,19 @@ void cmio_shoot(const cmio_grid *grid, const cmio_model *model,
                 uint64_t first_packet, uint64_t n_packets, double *totweight,
                 double typecount[CMIO_NTYPE]);
 
+/* The reference's TASK-BASED transport semantics (DensitySubGrid::interact,
+ * src/DensitySubGrid.hpp:1137-1274, on nsub[0] x nsub[1] x nsub[2] subgrids)
+ * for the same packets: see cmio_subgrid.c. The mean intensity of an ion of
+ * element E comes out A_E times cmio_shoot's, the heating terms with the
+ * thresholds 3.288e15 / 5.948e15 Hz. nsteps / handovers (may be NULL) count
+ * cell crossings and subgrid changes. */
+void cmio_subgrid_shoot(const cmio_grid *grid, const int32_t nsub[3],
+                        const cmio_model *model, cmio_cells *cells,
+                        uint32_t seed, uint32_t iteration,
+                        uint64_t first_packet, uint64_t n_packets,
+                        double *totweight, double typecount[CMIO_NTYPE],
+                        uint64_t *nsteps, uint64_t *handovers);
+
 /* The same packets with the same arithmetic, organised like the reference's
  * classic path (cells as an array of structures, one lock per cell; lock-free
  * single adds for hydrogen-only runs): the CPU BASELINE of bench.py. Equal to

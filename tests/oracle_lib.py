@@ -116,6 +116,12 @@ def lib():
                              C.POINTER(Cells), C.c_uint32, C.c_uint32,
                              C.c_uint64, C.c_uint64, dp, dp]
     L.cmio_shoot_fast.argtypes = L.cmio_shoot.argtypes
+    L.cmio_subgrid_shoot.argtypes = [C.POINTER(Grid), C.POINTER(C.c_int32),
+                                     C.POINTER(Model), C.POINTER(Cells),
+                                     C.c_uint32, C.c_uint32, C.c_uint64,
+                                     C.c_uint64, dp, dp,
+                                     C.POINTER(C.c_uint64),
+                                     C.POINTER(C.c_uint64)]
     L.cmio_emit.argtypes = [C.POINTER(Model), C.c_uint32, C.c_uint32,
                             C.c_uint64, C.POINTER(Photon), dp,
                             C.POINTER(C.c_uint32)]
@@ -311,6 +317,27 @@ class OracleSimulation:
         self.totweight += tw.value
         self.typecount += tc
         return tw.value, tc
+
+    def shoot_subgrids(self, nsub, seed, iteration, first_packet, n_packets):
+        """cmio_subgrid_shoot: the reference's task-based semantics
+        (DensitySubGrid::interact on nsub subgrids per axis) for the same
+        packets; returns (totweight, typecount, cell crossings, subgrid
+        changes)."""
+        if not self.model.tables and (
+                self.model.spectrum_type == SPECTRUM_PLANCK or
+                self.model.reemit_type == REEMIT_PHYSICAL):
+            self.build_tables()
+        tw = C.c_double(0.)
+        tc = np.zeros(NTYPE)
+        ns, nh = C.c_uint64(0), C.c_uint64(0)
+        lib().cmio_subgrid_shoot(C.byref(self.grid), (C.c_int32 * 3)(*nsub),
+                                 C.byref(self.model), C.byref(self.cells),
+                                 seed, iteration, first_packet, n_packets,
+                                 C.byref(tw), _ptr(tc), C.byref(ns),
+                                 C.byref(nh))
+        self.totweight += tw.value
+        self.typecount += tc
+        return tw.value, tc, ns.value, nh.value
 
     def shoot_fast(self, seed, iteration, first_packet, n_packets):
         """cmio_shoot_fast: the CPU-baseline organisation of the same loop

@@ -478,6 +478,72 @@ def test_decomposed_lexington_matches_oracle(oracle, tiles):
         b.engine.close()
 
 
+@pytest.mark.parametrize("model,blocks", [("diffuse", (2, 2, 2)),
+                                          ("lexington", (2, 2, 2)),
+                                          ("lexington", (3, 1, 2))])
+def test_decomposed_matches_task_based_oracle(oracle, model, blocks):
+    """The decomposed mode against the oracle of the reference's TASK-BASED
+    semantics (oracle/cmio_subgrid.c: DensitySubGrid::interact,
+    src/DensitySubGrid.hpp:1137-1274, one subgrid per block): same packets,
+    same subgrid changes. The task-based tallies carry the abundance of the
+    ion's element and other heating thresholds
+    (src/SourceDiscretePhotonTaskContext.hpp:172-180,
+    src/DensitySubGrid.hpp:607,611); the engine keeps the classic path's
+    definitions in every mode, so the comparison goes through those two exact
+    relations (tests/test_oracle_subgrid.py)."""
+    from cmacionize_amd import engine as E
+    from test_oracle_subgrid import ION_ELEMENT
+    ncell, npacket = 24, 40000
+    sim = (oracle.lexington_simulation(ncell) if model == "lexington"
+           else oracle.stromgren_simulation(ncell, diffuse=True))
+    dec, backends, driver = decomposed_backends(model, ncell, blocks, npacket,
+                                                sim)
+    upload_state(dec, backends, sim, ncell)
+    for b in backends:
+        b.engine.set_tuning(tile_min_flights=0, tile_min_per_item=0)
+    driver.iteration(0, npacket, 42, update=False)
+    sim.reset()
+    sim.totweight = 0.
+    sim.typecount[:] = 0.
+    tw, tc, ns, nh = sim.shoot_subgrids(blocks, 42, 0, 0, npacket)
+    assert driver.totweight == tw == npacket
+    assert np.abs(driver.typecount - tc).max() <= (3 if model == "lexington"
+                                                   else 0)
+    # every change of subgrid is a flight handed over - except the first,
+    # zero-length steps out of the star's corner, which every block of the
+    # engine takes itself before asking whose packet it is
+    assert 0 < driver.flights_exchanged <= nh
+    if model == "diffuse":
+        assert driver.nsteps == ns
+    gas = np.asarray(sim.number_density) > 0.
+    m = sim.model
+    tol = 1e-6 if model == "lexington" else 1e-9
+    nuH, nuHe = oracle.eV_to_Hz(13.6), oracle.eV_to_Hz(24.6)
+    Jc = []
+    for ion in range(14 if model == "lexington" else 1):
+        J = assemble(dec, backends, E.FIELD_MEAN_INTENSITY + ion)
+        Jc.append(J)
+        A = 1. if ion == 0 else m.abundance[ION_ELEMENT[ion]]
+        ref = np.asarray(sim.J[ion])
+        assert np.allclose(A * J[gas], ref[gas], rtol=tol,
+                           atol=tol * 1e-3 * max(ref.max(), 1e-300)), ion
+        # (cells without gas: tallied by the task-based path only)
+        assert np.all(J[~gas] == 0.)
+    if model == "lexington":
+        hH = assemble(dec, backends, E.FIELD_HEATING)
+        ref = np.asarray(sim.heating[0])
+        assert np.allclose((hH + Jc[0] * (nuH - 3.288e15))[gas], ref[gas],
+                           rtol=1e-6, atol=1e-6 * np.abs(ref).max())
+        hHe = assemble(dec, backends, E.FIELD_HEATING + 1)
+        ref = np.asarray(sim.heating[1])
+        AHe = m.abundance[1]
+        assert np.allclose(AHe * (hHe + Jc[1] * (nuHe - 5.948e15))[gas],
+                           ref[gas], rtol=1e-6,
+                           atol=1e-6 * np.abs(ref).max())
+    for b in backends:
+        b.engine.close()
+
+
 def test_group_exchange_equals_python_routing():
     """cmi_gpu_group_exchange_flights (routing kernel on the source device,
     rows written into the owner's inbox) against the Python hand-over of

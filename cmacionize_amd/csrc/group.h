@@ -49,6 +49,8 @@ struct RcclApi {
   int (*GroupEnd)() = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, comm_t,
                    hipStream_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, comm_t,
+                   hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
   bool load() {
     if (handle)
@@ -70,6 +72,7 @@ struct RcclApi {
     CMI_RCCL_SYM(GroupStart, "ncclGroupStart")
     CMI_RCCL_SYM(GroupEnd, "ncclGroupEnd")
     CMI_RCCL_SYM(AllReduce, "ncclAllReduce")
+    CMI_RCCL_SYM(AllGather, "ncclAllGather")
     CMI_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef CMI_RCCL_SYM
     return true;
@@ -181,6 +184,25 @@ struct GroupClass {
   std::vector<RcclApi::comm_t> comm;
 };
 
+/* dst[f][i] = src[f][i] for the state fields a cell update writes
+ * (temperature and the 14 ionic fractions: fields 1..15 of the state block)
+ * and the transport records, cells [first, first + count): an engine pulls
+ * the slab another engine of its class has solved (peer memory) */
+__global__ void __launch_bounds__(CMI_BLOCK)
+    group_pull_slab_kernel(double *dst_state, double2 *dst_opacity,
+                           const double *src_state, const double2 *src_opacity,
+                           int64_t ncell, int64_t first, int64_t count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count;
+       k += stride) {
+    const int64_t i = first + k;
+#pragma unroll
+    for (int f = 1; f < 16; ++f)
+      dst_state[f * ncell + i] = src_state[f * ncell + i];
+    dst_opacity[i] = src_opacity[i];
+  }
+}
+
 struct cmi_gpu_group {
   int n = 0;
   cmi_gpu_engine *engine[CMI_GROUP_MAX];
@@ -191,6 +213,7 @@ struct cmi_gpu_group {
   uint32_t *dest[CMI_GROUP_MAX];
   unsigned int *hist[CMI_GROUP_MAX]; /* [2 n]: rows per owner, cursors */
   hipEvent_t routed[CMI_GROUP_MAX];
+  hipEvent_t solved[CMI_GROUP_MAX];
   uint64_t rounds = 0, flights = 0;
 };
 
@@ -213,6 +236,7 @@ int cmi_gpu_group_create(int32_t n, cmi_gpu_engine *const *engines,
     g->dest[i] = nullptr;
     g->hist[i] = nullptr;
     g->routed[i] = nullptr;
+    g->solved[i] = nullptr;
     /* the class of engines that hold the same cells */
     const GridDev &gi = engines[i]->grid;
     GroupClass *cls = nullptr;
@@ -282,6 +306,8 @@ int cmi_gpu_group_create(int32_t n, cmi_gpu_engine *const *engines,
     }
     if (err == hipSuccess)
       err = hipEventCreateWithFlags(&g->routed[i], hipEventDisableTiming);
+    if (err == hipSuccess)
+      err = hipEventCreateWithFlags(&g->solved[i], hipEventDisableTiming);
     if (err != hipSuccess) {
       delete g;
       HIP_TRY(err);
@@ -302,6 +328,8 @@ int cmi_gpu_group_destroy(cmi_gpu_group *g) {
     (void)hipFree(g->hist[i]);
     if (g->routed[i])
       (void)hipEventDestroy(g->routed[i]);
+    if (g->solved[i])
+      (void)hipEventDestroy(g->solved[i]);
     g->engine[i]->grid.copy_rank = 0;
     g->engine[i]->grid.copy_count = 1;
   }
@@ -328,6 +356,27 @@ static int active_accumulators(cmi_gpu_engine *e, double *ptr[2],
   ptr[1] = e->acc_block + (int64_t)CMI_NION * e->ncell;
   count[1] = 2 * e->ncell;
   return 2;
+}
+
+/* the RCCL communicator of a class (one rank per member), made on first use */
+static int class_comm(cmi_gpu_group *g, GroupClass &c) {
+  if (!c.comm.empty())
+    return CMI_GPU_OK;
+  const int n = (int)c.member.size();
+  if (!g_rccl.load())
+    return fail(CMI_GPU_EDEVICE, "cannot load RCCL (librccl.so.1): %s",
+                dlerror());
+  int devices[CMI_GROUP_MAX];
+  for (int i = 0; i < n; ++i)
+    devices[i] = g->engine[c.member[i]]->device;
+  c.comm.resize(n);
+  const int rc = g_rccl.CommInitAll(c.comm.data(), n, devices);
+  if (rc != 0) {
+    c.comm.clear();
+    return fail(CMI_GPU_EDEVICE, "ncclCommInitAll failed: %s",
+                g_rccl.GetErrorString(rc));
+  }
+  return CMI_GPU_OK;
 }
 
 /* sum the accumulators of one class of engines into every member */
@@ -359,21 +408,10 @@ static int reduce_class(cmi_gpu_group *g, GroupClass &c) {
     HIP_TRY(hipStreamSynchronize(e0->stream));
     return CMI_GPU_OK;
   }
-  if (c.comm.empty()) {
-    if (!g_rccl.load())
-      return fail(CMI_GPU_EDEVICE,
-                  "reduce_accumulators: cannot load RCCL (librccl.so.1): %s",
-                  dlerror());
-    int devices[CMI_GROUP_MAX];
-    for (int i = 0; i < n; ++i)
-      devices[i] = g->engine[c.member[i]]->device;
-    c.comm.resize(n);
-    const int rc = g_rccl.CommInitAll(c.comm.data(), n, devices);
-    if (rc != 0) {
-      c.comm.clear();
-      return fail(CMI_GPU_EDEVICE, "ncclCommInitAll failed: %s",
-                  g_rccl.GetErrorString(rc));
-    }
+  {
+    const int rc = class_comm(g, c);
+    if (rc)
+      return rc;
   }
   /* one grouped all-reduce per piece: every engine's call is enqueued on its
    * own stream, behind its transport kernels */
@@ -405,6 +443,101 @@ int cmi_gpu_group_reduce_accumulators(cmi_gpu_group *g) {
     if (c.member.size() == 1 && !force)
       continue;
     const int rc = reduce_class(g, c);
+    if (rc)
+      return rc;
+  }
+  return CMI_GPU_OK;
+}
+
+/* the cell update of one class: member r solves the r-th slab of the cells
+ * (MPICommunicator::distribute, src/MPICommunicator.hpp:207-222), then every
+ * member gets the slabs of the others */
+static int update_class(cmi_gpu_group *g, GroupClass &c, uint32_t loop,
+                        double totweight) {
+  const int n = (int)c.member.size();
+  cmi_gpu_engine *e0 = g->engine[c.member[0]];
+  const bool force = getenv("CMI_GPU_FORCE_RCCL") != nullptr;
+  if (n == 1 && !force)
+    return cmi_gpu_update_cells(e0, loop, totweight);
+  const int64_t ncell = e0->ncell;
+  std::vector<int64_t> first(n + 1, 0);
+  for (int r = 0; r < n; ++r)
+    first[r + 1] = first[r] + ncell / n + (r < ncell % n ? 1 : 0);
+  for (int r = 0; r < n; ++r) {
+    cmi_gpu_engine *e = g->engine[c.member[r]];
+    const int rc = cmi_gpu_update_cells_range(e, loop, totweight, first[r],
+                                              first[r + 1] - first[r]);
+    if (rc)
+      return rc;
+    HIP_TRY(hipEventRecord(g->solved[c.member[r]], e->stream));
+  }
+  if ((c.distinct_devices || force) && ncell % n == 0) {
+    /* MPICommunicator::gather of the temperature and the ionic fractions
+     * (src/IonizationSimulation.cpp:540-618) as grouped in-place
+     * ncclAllGathers: slab r of a field sits at its place in every engine */
+    const int rc0 = class_comm(g, c);
+    if (rc0)
+      return rc0;
+    const int64_t count = ncell / n;
+    int rc = g_rccl.GroupStart();
+    for (int r = 0; r < n && rc == 0; ++r) {
+      cmi_gpu_engine *e = g->engine[c.member[r]];
+      HIP_TRY(hipSetDevice(e->device));
+      for (int f = 1; f < 16 && rc == 0; ++f) {
+        double *field = e->state_block + (int64_t)f * ncell;
+        rc = g_rccl.AllGather(field + r * count, field, (size_t)count,
+                              kNcclDouble, c.comm[r], e->stream);
+      }
+      if (rc == 0) {
+        double *records = reinterpret_cast<double *>(e->opacity);
+        rc = g_rccl.AllGather(records + 2 * r * count, records,
+                              (size_t)(2 * count), kNcclDouble, c.comm[r],
+                              e->stream);
+      }
+    }
+    const int rc_end = g_rccl.GroupEnd();
+    if (rc == 0)
+      rc = rc_end;
+    if (rc != 0)
+      return fail(CMI_GPU_EDEVICE, "ncclAllGather failed: %s",
+                  g_rccl.GetErrorString(rc));
+    return CMI_GPU_OK;
+  }
+  /* engines that share a device, or slabs of unequal size: every engine
+   * pulls the others' slabs itself (peer reads over xGMI) */
+  for (int d = 0; d < n; ++d) {
+    cmi_gpu_engine *e = g->engine[c.member[d]];
+    HIP_TRY(hipSetDevice(e->device));
+    for (int r = 0; r < n; ++r) {
+      if (r == d)
+        continue;
+      cmi_gpu_engine *src = g->engine[c.member[r]];
+      const int64_t count = first[r + 1] - first[r];
+      if (count == 0)
+        continue;
+      HIP_TRY(hipStreamWaitEvent(e->stream, g->solved[c.member[r]], 0));
+      group_pull_slab_kernel<<<grid_blocks(e, count, 8), CMI_BLOCK, 0,
+                               e->stream>>>(e->state_block, e->opacity,
+                                            src->state_block, src->opacity,
+                                            ncell, first[r], count);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  /* nobody's next transport may overwrite what a peer still reads */
+  for (int d = 0; d < n; ++d) {
+    cmi_gpu_engine *e = g->engine[c.member[d]];
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_group_update_cells(cmi_gpu_group *g, uint32_t loop,
+                               double totweight) {
+  if (!g)
+    return fail(CMI_GPU_EINVAL, "null group");
+  for (GroupClass &c : g->classes) {
+    const int rc = update_class(g, c, loop, totweight);
     if (rc)
       return rc;
   }

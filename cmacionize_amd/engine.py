@@ -81,6 +81,7 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_update_cells_range", "cmi_gpu_refresh_transport_records",
     "cmi_gpu_get_launch_steps", "cmi_gpu_group_create",
     "cmi_gpu_group_destroy", "cmi_gpu_group_reduce_accumulators",
+    "cmi_gpu_group_update_cells",
     "cmi_gpu_group_exchange_flights",
 ]
 
@@ -182,6 +183,7 @@ def load_library():
                                        C.POINTER(vp)]
     L.cmi_gpu_group_destroy.argtypes = [vp]
     L.cmi_gpu_group_reduce_accumulators.argtypes = [vp]
+    L.cmi_gpu_group_update_cells.argtypes = [vp, C.c_uint32, C.c_double]
     L.cmi_gpu_group_exchange_flights.argtypes = [
         vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
     _lib = L
@@ -218,6 +220,12 @@ class EngineGroup:
 
     def reduce_accumulators(self):
         self._check(self._lib.cmi_gpu_group_reduce_accumulators(self._h))
+
+    def update_cells(self, loop, totweight):
+        """Sharded cell update of every class of the group (slab r solved
+        by member r, then gathered into every member)."""
+        self._check(self._lib.cmi_gpu_group_update_cells(self._h, loop,
+                                                         totweight))
 
     def exchange_flights(self, seed, iteration, first_packet=0):
         total = C.c_uint64()

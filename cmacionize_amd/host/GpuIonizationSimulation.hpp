@@ -967,17 +967,15 @@ public:
       status("Calculating ionization state after shooting " +
              std::to_string(lnumphoton) + " photons...");
       t0 = std::chrono::steady_clock::now();
-      if (decomposed()) {
-        for (Block &b : _blocks)
-          check(cmi_gpu_update_cells(b.engine, loop, totweight),
-                "update_cells");
+      if (_group) {
+        /* replicas, or the copies of a block: member r of the engines that
+         * hold the same cells solves slab r, the slabs are gathered into all
+         * of them (src/IonizationSimulation.cpp:532-618); a block without
+         * copies updates its own cells */
+        check(cmi_gpu_group_update_cells(_group, loop, totweight),
+              "group_update_cells");
         for (Block &b : _blocks)
           check(cmi_gpu_synchronize(b.engine), "synchronize");
-      } else if (!_replicas.empty()) {
-        /* every replica updates all cells from the same reduced integrals
-         * (identical results; no gather needed) */
-        for (cmi_gpu_engine *e : _replicas)
-          check(cmi_gpu_update_cells(e, loop, totweight), "update_cells");
         for (cmi_gpu_engine *e : _replicas)
           check(cmi_gpu_synchronize(e), "synchronize");
       } else {

@@ -422,6 +422,20 @@ int cmi_gpu_group_destroy(cmi_gpu_group *group);
  * which stands in for update_copy_properties (:580-598). */
 int cmi_gpu_group_reduce_accumulators(cmi_gpu_group *group);
 
+/* replaces: the cell update of the reference's MPI path
+ * (src/IonizationSimulation.cpp:532-618): every rank solves a block of the
+ * cells (MPICommunicator::distribute, src/MPICommunicator.hpp:207-222), then
+ * the temperature and the ionic fractions are gathered
+ * (MPICommunicator::gather). Here per class of the group: member r solves
+ * slab r of the class's cells (cmi_gpu_update_cells_range) and every member
+ * ends with all slabs and their transport records - grouped in-place
+ * ncclAllGathers over RCCL / xGMI between distinct devices; peer reads by a
+ * kernel where the slabs are unequal or the engines share a device. A class
+ * of one engine (a block without copies) simply updates its cells. Call after
+ * cmi_gpu_group_reduce_accumulators. */
+int cmi_gpu_group_update_cells(cmi_gpu_group *group, uint32_t loop,
+                               double totweight);
+
 /* replaces: the photon-buffer traffic between subgrids
  * (src/PhotonTraversalTaskContext.hpp:100-278, src/MemorySpace.hpp:96-127;
  * message format src/PhotonBuffer.hpp:46-48): one exchange round of a

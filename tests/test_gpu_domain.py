@@ -729,5 +729,86 @@ def test_group_reduce_goes_through_rccl(monkeypatch):
     assert before[0].max() > 0.
     for a, b in zip(after, before):
         assert np.array_equal(a, b)
+    # ... and the gather of the sharded cell update: grouped in-place
+    # ncclAllGathers of the 15 state fields and the transport records; with
+    # one rank they must leave what the update wrote
+    twin = GpuEngine((n,) * 3, S["anchor"], S["sides"], (0, 0, 0), device=0,
+                     track_heating=True)
+    configure(twin, "stromgren", n ** 3)
+    twin.upload_field(E.FIELD_MEAN_INTENSITY, before[0])
+    twin.update_cells(0, 5000.)
+    group.update_cells(0, 5000.)
+    eng.synchronize()
+    assert np.array_equal(eng.download_field(E.FIELD_IONIC_FRACTION),
+                          twin.download_field(E.FIELD_IONIC_FRACTION))
+    for e in (eng, twin):
+        e.reset_grid()
+        e.shoot(3, 1, 0, 5000)
+    ref = twin.download_field(E.FIELD_MEAN_INTENSITY)
+    assert np.allclose(eng.download_field(E.FIELD_MEAN_INTENSITY), ref,
+                       rtol=1e-11, atol=1e-14 * ref.max())
     group.close()
     eng.close()
+    twin.close()
+
+
+def test_group_sharded_cell_update():
+    """cmi_gpu_group_update_cells on three replicas of a 15^3 lexington grid
+    (3375 cells: equal slabs; 4 replicas of it: unequal slabs): member r
+    solves slab r - ionization balance and, from loop 4, the temperature
+    solve - and pulls the other slabs and their transport records. Every
+    replica ends bit-identical to a single engine that updated all cells
+    (src/IonizationSimulation.cpp:532-618), also in what the next transport
+    step deposits."""
+    from cmacionize_amd import GpuEngine, STROMGREN as S
+    from cmacionize_amd import engine as E
+    from cmacionize_amd.engine import EngineGroup
+    n, npacket = 15, 30000
+    dens, temp = lexington_fields(n)
+    for world in (3, 4):
+        engines = []
+        for k in range(world + 1):
+            e = GpuEngine((n,) * 3, S["anchor"], S["sides"], (0, 0, 0),
+                          device=0, track_heating=True)
+            configure(e, "lexington", n ** 3, dens.ravel(), temp.ravel())
+            engines.append(e)
+        single, replicas = engines[0], engines[1:]
+        group = EngineGroup(replicas)
+        for loop in (0, 4, 5):
+            single.reset_grid()
+            single.shoot(7, loop, 0, npacket)
+            tw = single.get_counters()[0]
+            first = 0
+            for r, e in enumerate(replicas):
+                count = npacket // world + (1 if r < npacket % world else 0)
+                e.reset_grid()
+                e.shoot(7, loop, first, count)
+                first += count
+            group.reduce_accumulators()
+            # same integrals everywhere (the sums differ in order only):
+            # start all engines from the single engine's
+            for f in range(16):
+                J = single.download_field(E.FIELD_MEAN_INTENSITY + f)
+                for e in replicas:
+                    e.upload_field(E.FIELD_MEAN_INTENSITY + f, J)
+            single.update_cells(loop, tw)
+            group.update_cells(loop, tw)
+            for e in replicas:
+                e.synchronize()
+                for f in range(15):
+                    a = e.download_field(E.FIELD_TEMPERATURE + f)
+                    b = single.download_field(E.FIELD_TEMPERATURE + f)
+                    assert np.array_equal(a, b, equal_nan=True), (world, loop, f)
+        T = single.download_field(E.FIELD_TEMPERATURE)
+        assert T.max() > 6000.  # the temperature was solved
+        # the transport records were gathered too: same next step
+        for e in engines:
+            e.reset_grid()
+            e.shoot(7, 6, 0, npacket)
+        ref = single.download_field(E.FIELD_MEAN_INTENSITY)
+        for e in replicas:
+            assert np.allclose(e.download_field(E.FIELD_MEAN_INTENSITY), ref,
+                               rtol=1e-11, atol=1e-14 * ref.max())
+        group.close()
+        for e in engines:
+            e.close()

@@ -374,23 +374,30 @@ class DomainIterationDriver:
         self.flights_exchanged = 0
 
     def _exchange(self, rows, counts):
-        """all-to-all of the routed flights; returns the incoming rows."""
+        """One hand-over round: ONE all-gather of every rank's per-owner
+        counts (the n x n matrix: what this rank receives, and whether anybody
+        sends anything at all - the round's control in a single collective
+        and a single read-back), then the all-to-all of the rows. Returns
+        (incoming rows, flights moved by all ranks) - (None, 0) when no rank
+        has a flight left."""
         import torch
         d = self.dist
-        send = counts.to(torch.int64)
-        recv = torch.empty_like(send)
         dev = rows.device
-        # the split sizes travel first (on the payload's device: NCCL/RCCL
-        # moves device tensors, gloo host tensors)
-        send_dev, recv_dev = send.to(dev), recv.to(dev)
-        d.all_to_all_single(recv_dev, send_dev)
-        recv = recv_dev.cpu()
+        send = counts.to(torch.int64).to(dev)
+        flat = torch.empty(self.world * self.world, dtype=torch.int64,
+                           device=dev)
+        d.all_gather_into_tensor(flat, send.contiguous())
+        matrix = flat.view(self.world, self.world).cpu()
+        total = int(matrix.sum())
+        if total == 0:
+            return None, 0
+        recv = matrix[:, self.rank]
         incoming = torch.empty((int(recv.sum()), FLIGHT_DOUBLES),
                                dtype=rows.dtype, device=dev)
         d.all_to_all_single(incoming, rows.contiguous(),
                             output_split_sizes=recv.tolist(),
-                            input_split_sizes=send.tolist())
-        return incoming
+                            input_split_sizes=matrix[self.rank].tolist())
+        return incoming, total
 
     def iteration(self, loop, n_packets, seed):
         import torch
@@ -402,13 +409,9 @@ class DomainIterationDriver:
         while True:
             rows, counts = route_flights(self.decomposition, b.take_exports())
             if self.world > 1:
-                total = torch.tensor([float(rows.shape[0])],
-                                     dtype=torch.float64, device=rows.device)
-                self.dist.all_reduce(total, op=self.dist.ReduceOp.SUM)
-                total = int(total.item())
+                incoming, total = self._exchange(rows, counts)
                 if total == 0:
                     break
-                incoming = self._exchange(rows, counts)
             else:
                 total = rows.shape[0]
                 if total == 0:

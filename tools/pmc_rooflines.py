@@ -23,9 +23,12 @@ import sys
 from collections import defaultdict
 
 root, steps = sys.argv[1], int(sys.argv[2])
-DOMINANT = {"stromgren": "shoot_kernel<false, false, false, false>",
-            "stromgren_diffuse": "shoot_kernel<false, false, false, false>",
-            "lexington": "shoot_kernel<true, true, false, false>"}
+# (template arguments: FULL, HEAT, REEMIT, EXACT, TABLE - the first
+# generation of an iteration runs the TABLE variant)
+DOMINANT = {"stromgren": "shoot_kernel<false, false, false, false, true>",
+            "stromgren_diffuse":
+                "shoot_kernel<false, false, false, false, true>",
+            "lexington": "shoot_kernel<true, true, false, false, true>"}
 N_SIMD, N_CU, MAXCLK = 1024, 256, 2.4e9
 
 

@@ -1,13 +1,23 @@
 #!/bin/bash
 # GPU box: the round's measurement set. usage: tools/round_measure.sh OUTDIR
-# - bench.py line of every single-GPU config
-# - rocprofv3 --kernel-trace --stats of the same command
-# - FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs) for roofline.traffic
+#  1. PMC passes of `bench.py --config C --steps 3 --warmup 0` per config
+#     (tools/pmc_profile.sh: separate rocprofv3 --pmc runs) and from them
+#     OUTDIR/counters.json (tools/pmc_rooflines.py) - copy it to
+#     profiles/rNN/counters.json, bench.py's roofline reads it from there
+#  2. the bench.py line of every single-GPU config
+#  3. rocprofv3 --kernel-trace --stats of the same bench command
 set -u
 REPO=$(pwd)
 OUT=$REPO/$1
+ROUND=${2:-r02}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+for CFG in stromgren stromgren_diffuse lexington; do
+  tools/pmc_profile.sh "$1/pmc_$CFG" -- bench.py --config $CFG --steps 3 --warmup 0 --no-cpu-baseline
+done
+python3 tools/pmc_rooflines.py "$OUT" 3 > "$OUT/counters.json"
+mkdir -p "$REPO/profiles/$ROUND"
+cp "$OUT/counters.json" "$REPO/profiles/$ROUND/counters.json"
 for CFG in stromgren stromgren_diffuse lexington; do
   python3 bench.py --config $CFG > "$OUT/bench_$CFG.json" 2> "$OUT/bench_$CFG.err"
   echo "bench $CFG rc=$?"
@@ -17,14 +27,9 @@ for CFG in stromgren stromgren_diffuse lexington; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$CFG" -- \
     python3 "$REPO/bench.py" --config $CFG --no-cpu-baseline > "$OUT/stats_$CFG.log" 2>&1
   echo "stats $CFG rc=$?"
-  for PMC in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$OUT/pmc_${CFG}_$PMC" -- \
-      python3 "$REPO/bench.py" --config $CFG --no-cpu-baseline --steps 2 --warmup 0 > "$OUT/pmc_${CFG}_$PMC.log" 2>&1
-    echo "pmc $CFG $PMC rc=$?"
-  done
 done
 # keep only the small summaries (the traces are large)
 cd "$OUT"
-find . -name "*kernel_trace.csv" -size +8M -delete
-find . -name "*counter_collection.csv" -size +8M -delete
+find . -name "*kernel_trace.csv" -delete
+find . -name "*counter_collection.csv" -size +2M -delete
 du -sh .

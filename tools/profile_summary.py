@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Compact summary of a `rocprofv3 --kernel-trace --stats` directory made by
 tools/round_measure.sh: the kernel_stats table with the template noise cut from
-the names, plus the durations of the bench's TIMED transport launches (the last
-`steps` batches of the process; the untimed converge iterations shoot 10x fewer
-packets and pull the all-calls average down).
+the names, plus the durations of the bench's TIMED launches of the dominant
+kernel (the last `steps` of the process; the all-calls average also holds the
+untimed iterations that bring the grid to its converged state, whose packets
+fly further) next to the HIP-event figure bench.py printed in the same run.
 
-    python tools/profile_summary.py gpurun_out/r01_final/stats_stromgren \
-        gpurun_out/r01_final/stats_stromgren.log > profiles/r01/...txt
+    python tools/profile_summary.py OUT/stats_stromgren OUT/stats_stromgren.log \
+        > profiles/r02/bench_stromgren_kernel_stats.txt
 """
 import csv
 import glob
@@ -43,19 +44,21 @@ for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
           (k[:60], a[0], a[1], a[1] // a[0], a[2], a[3], a[4]))
 
 bench = json.loads([l for l in open(log) if l.startswith("{")][-1])
-n = bench["roofline"]["kernel_launches"]
+# the dominant kernel of the bench line (the first generation of every
+# iteration); the timed launches are the last `steps` of the process
+dominant = bench["roofline"]["kernel"]
+n = bench["steps"]
 trace = glob.glob(root + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(trace))
-        if "shoot_kernel" in r["Kernel_Name"]]
+        if r["Kernel_Name"].replace("void ", "").startswith(dominant + "(")]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 timed = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
          for r in rows[-n:]]
 print()
-print("# the %d timed shoot_kernel launches of this run (ns): total %d, "
-      "average %d" % (n, sum(timed), sum(timed) // n))
-print("# bench.py (HIP events, same run): kernel_avg_ms %.4f, "
+print("# %s: %d launches in the process; the %d timed ones (ns): total %d, "
+      "average %d" % (dominant, len(rows), n, sum(timed), sum(timed) // n))
+print("# bench.py (HIP events, same run): roofline.kernel_avg_ms %.4f, "
       "transport_only %.4g packets/s, value %.4g packets/s" %
       (bench["roofline"]["kernel_avg_ms"],
        bench["transport_only_packets_per_s"], bench["value"]))
-if n <= 16:
-    print("# " + " ".join(str(t) for t in timed))
+print("# timed launches (ns): " + " ".join(str(t) for t in timed))

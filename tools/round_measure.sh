@@ -5,7 +5,8 @@
 #     OUTDIR/counters.json (tools/pmc_rooflines.py) - copy it to
 #     profiles/rNN/counters.json, bench.py's roofline reads it from there
 #  2. the bench.py line of every single-GPU config
-#  3. rocprofv3 --kernel-trace --stats of the same bench command
+#  3. rocprofv3 --kernel-trace --stats of the same bench command, summarised
+#     (tools/profile_summary.py) into OUTDIR/bench_<config>_kernel_stats.txt
 set -u
 REPO=$(pwd)
 OUT=$REPO/$1
@@ -27,6 +28,8 @@ for CFG in stromgren stromgren_diffuse lexington; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$CFG" -- \
     python3 "$REPO/bench.py" --config $CFG --no-cpu-baseline > "$OUT/stats_$CFG.log" 2>&1
   echo "stats $CFG rc=$?"
+  python3 "$REPO/tools/profile_summary.py" "$OUT/stats_$CFG" "$OUT/stats_$CFG.log" \
+    > "$OUT/bench_${CFG}_kernel_stats.txt"
 done
 # keep only the small summaries (the traces are large)
 cd "$OUT"

@@ -185,27 +185,32 @@ __device__ inline double cmi_recombination_rate(const ModelDev &m, int ion,
   if (!m.recomb_verner)
     return m.recomb_fixed[ion];
   const VernerRecDev &r = m.tables->verner_rec[ion];
+  /* powers as exp(y ln x) and x^-1.5 as 1 / (x sqrt x): a few 1e-16 from
+   * pow() (the reference's test of these fits passes at 1e-13 here), a
+   * fraction of its instructions - the temperature solve evaluates all of
+   * them three times per secant step */
   double rate;
   if (r.kind == 0) {
     const double tt = sqrt(temperature * r.p[2]);
-    rate = r.p[0] / (tt * pow(tt + 1., 1. - r.p[1]) *
-                     pow(1. + sqrt(temperature * r.p[3]), 1. + r.p[1]));
+    rate = r.p[0] /
+           (tt * exp((1. - r.p[1]) * log(tt + 1.) +
+                     (1. + r.p[1]) * log(1. + sqrt(temperature * r.p[3]))));
   } else {
-    rate = r.p[0] * pow(temperature * 1.e-4, -r.p[1]);
+    rate = r.p[0] * exp(-r.p[1] * log(temperature * 1.e-4));
   }
   if (r.dkind == 1) {
     const double T4 = temperature * 1.e-4;
     const double T4_inv = 1. / T4;
     rate += 1.e-12 *
             (r.d[0] * T4_inv + r.d[1] + r.d[2] * T4 + r.d[3] * T4 * T4) *
-            pow(T4, -1.5) * exp(-r.d[4] * T4_inv);
+            (T4_inv / sqrt(T4)) * exp(-r.d[4] * T4_inv);
   } else if (r.dkind == 2) {
     const double t = temperature * r.dunit;
     const double t_inv = 1. / t;
     double sum = 0.;
     for (int k = 0; k < r.dn; ++k)
       sum += r.dc[k] * exp(-r.dE[k] * t_inv);
-    rate += sum * pow(t, -1.5);
+    rate += sum * (t_inv / sqrt(t));
   }
   rate *= 1.e-6;
   return fmax(0., rate);
@@ -223,7 +228,7 @@ __device__ inline double ct_eval(const CTFitDev &f, double T4) {
   t = fmin(t, f.hi);
   if (f.kind == 4)
     return f.a * t * t;
-  const double base = f.a * pow(t, f.b) * (1. + f.c * exp(f.d * t));
+  const double base = f.a * exp(f.b * log(t)) * (1. + f.c * exp(f.d * t));
   if (f.kind == 3)
     return base * exp(f.e / t);
   return base;
@@ -256,7 +261,7 @@ __device__ inline void cmi_ionization_states_hydrogen_helium(
     he0 = 1.;
     return;
   }
-  const double alpha_e_2sP = 4.17e-20 * pow(T * 1.e-4, -0.861);
+  const double alpha_e_2sP = 4.17e-20 * exp(-0.861 * log(T * 1.e-4));
   const double ch1 = alphaH * nH / jH;
   const double ch2 = AHe * alpha_e_2sP * nH / jH;
   double che = 0.;

@@ -14,14 +14,16 @@
  * where needed instead of costing 5 fields of HBM. */
 __device__ inline void reemission_probabilities(double temperature,
                                                 double &pH, double pHe[4]) {
-  const double T4 = temperature * 1.e-4;
-  const double alpha_1_H = 1.58e-13 * pow(T4, -0.53);
-  const double alpha_A_agn = 4.18e-13 * pow(T4, -0.7);
+  /* (the powers T4^y as exp(y ln T4) with ONE logarithm: a few 1e-16 from
+   * pow, a fifth of its instructions) */
+  const double lnT4 = log(temperature * 1.e-4);
+  const double alpha_1_H = 1.58e-13 * exp(-0.53 * lnT4);
+  const double alpha_A_agn = 4.18e-13 * exp(-0.7 * lnT4);
   pH = alpha_1_H / alpha_A_agn;
-  const double alpha_1_He = 1.54e-13 * pow(T4, -0.486);
-  const double alpha_e_2tS = 2.1e-13 * pow(T4, -0.381);
-  const double alpha_e_2sS = 2.06e-14 * pow(T4, -0.451);
-  const double alpha_e_2sP = 4.17e-14 * pow(T4, -0.695);
+  const double alpha_1_He = 1.54e-13 * exp(-0.486 * lnT4);
+  const double alpha_e_2tS = 2.1e-13 * exp(-0.381 * lnT4);
+  const double alpha_e_2sS = 2.06e-14 * exp(-0.451 * lnT4);
+  const double alpha_e_2sP = 4.17e-14 * exp(-0.695 * lnT4);
   const double alphaHe = alpha_1_He + alpha_e_2tS + alpha_e_2sS + alpha_e_2sP;
   pHe[0] = alpha_1_He / alphaHe;
   pHe[1] = pHe[0] + alpha_e_2tS / alphaHe;
@@ -47,8 +49,9 @@ __device__ inline double physical_reemit(const ModelDev &m, double sigma_H,
   double x = rng.next();
   if (x <= pHabs) {
     /* absorbed by hydrogen: Lyman continuum photon or lost */
-    const double pH = (1.58e-13 * pow(T * 1.e-4, -0.53)) /
-                      (4.18e-13 * pow(T * 1.e-4, -0.7));
+    const double lnT4 = log(T * 1.e-4);
+    const double pH = (1.58e-13 * exp(-0.53 * lnT4)) /
+                      (4.18e-13 * exp(-0.7 * lnT4));
     x = rng.next();
     if (x <= pH) {
       new_frequency = sample_lyman_continuum(s, 0, T, rng);

@@ -214,7 +214,9 @@ __device__ inline void cooling_and_heating_balance(
   const double nenhep = ne * nhep;
 
   gain = n * (h[0] * h0 + h[1] * AHe * he0);
-  const double alpha_e_2sP = 4.17e-20 * pow(T4, -0.861);
+  /* T4^-0.861 and T^0.3647 from the logarithm at hand (ln 1e4 = 9.2103...) */
+  const double alpha_e_2sP =
+      4.17e-20 * exp(-0.861 * (logT - 9.210340371976184));
   const double pHots = 1. / (1. + 77. * he0 / (sqrtT * h0));
   gain += pHots * 1.21765423e-18 * alpha_e_2sP * nenhep;
   gain += 1.5e-37 * n * ne * m.pahfac;
@@ -254,7 +256,7 @@ __device__ inline void cooling_and_heating_balance(
   loss += 1.42e-40 * gff * sqrtT * (nenhp + nenhep);
   const double Lhp =
       2.85e-40 * nenhp * sqrtT * (5.914 - 0.5 * logT + 0.01184 * cbrt(T));
-  const double Lhep = 1.55e-39 * nenhep * pow(T, 0.3647);
+  const double Lhep = 1.55e-39 * nenhep * exp(0.3647 * logT);
   loss += Lhp + Lhep;
   loss = fmax(loss, 0.);
   gain = fmax(gain, 0.);

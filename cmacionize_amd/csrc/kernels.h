@@ -207,9 +207,10 @@ template <int R> __device__ __forceinline__ int row_bcast_i32(int v) {
                                      true);
 }
 template <int R> __device__ __forceinline__ double row_bcast_f64(double v) {
-  const int lo = row_bcast_i32<R>(__double2loint(v));
-  const int hi = row_bcast_i32<R>(__double2hiint(v));
-  return __hiloint2double(hi, lo);
+  /* ONE v_mov_b64_dpp: row_newbcast is the DPP control gfx90a and later
+   * accept on 64-bit operands */
+  return __builtin_amdgcn_update_dpp(0., v, CMI_DPP_ROW_NEWBCAST(R), 0xf, 0xf,
+                                     true);
 }
 
 /* the transposed weights of the lane's quarter, after (re)launches */
@@ -269,7 +270,7 @@ walk_part(const ShootArgs &a, const double (&wq)[CMI_NACC], int32_t dest,
   /* ... and one add where a run ends */
 #pragma unroll
   for (int r = 0; r < N; ++r) {
-    if (d[r] != d[r + 1] && d[r] != -1 && mine &&
+    if (d[r] != d[r + 1] && d[r] != -1 && mine && sum[r] != 0. &&
         CMI_EXP(a) != 3) { /* 3 = experiment: walk without the adds */
       if (d[r] >= 0) {
         atomicAdd(table_i + d[r] * CMI_NACC, sum[r]); /* ds_add_f64 */
@@ -286,14 +287,22 @@ walk_part(const ShootArgs &a, const double (&wq)[CMI_NACC], int32_t dest,
  * merges what the running sums would have merged. Lanes without a slot add
  * (zero, or a term that is also added elsewhere - see below) to a dummy row
  * after the table that is never written back. */
+/* `row_offset` = the BYTE offset of the lane's slot row in the table (the
+ * dummy row for lanes without a slot), so that a row costs three vector
+ * instructions and the add: v_add_u32_dpp (address), v_mov_b64_dpp (path
+ * length), v_mul_f64, ds_add_f64 */
 template <int R>
 __device__ __forceinline__ void table_row(const double (&wq)[CMI_NACC],
-                                          int32_t dest, double dsw,
+                                          int32_t row_offset, double dsw,
                                           double *table_i) {
-  const int32_t d = row_bcast_i32<R>(dest);
+  const int32_t offset = row_bcast_i32<R>(row_offset);
   const double term = row_bcast_f64<R>(dsw) * wq[R];
-  const int32_t slot = d >= 0 ? d : CMI_FTABLE_SLOTS;
-  atomicAdd(table_i + slot * CMI_NACC, term); /* ds_add_f64 */
+  /* (skipping the adds of zero - most cross sections of a photon are zero -
+   * was measured: the branch costs the first generation more than the LDS
+   * unit gains) */
+  atomicAdd(reinterpret_cast<double *>(reinterpret_cast<char *>(table_i) +
+                                       offset),
+            term); /* ds_add_f64 */
 }
 
 template <bool HEAT>
@@ -331,24 +340,27 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
     }
     if (CMI_EXP(a) == 2 || CMI_EXP(a) >= 4) /* exp.: no walk */
       return;
-    table_row<0>(wq, dest, term, table_i);
-    table_row<1>(wq, dest, term, table_i);
-    table_row<2>(wq, dest, term, table_i);
-    table_row<3>(wq, dest, term, table_i);
+    const int32_t row_offset =
+        (dest >= 0 ? dest : CMI_FTABLE_SLOTS) *
+        (int32_t)(CMI_NACC * sizeof(double));
+    table_row<0>(wq, row_offset, term, table_i);
+    table_row<1>(wq, row_offset, term, table_i);
+    table_row<2>(wq, row_offset, term, table_i);
+    table_row<3>(wq, row_offset, term, table_i);
     if (CMI_EXP(a) == 6) /* experiment: a quarter of the adds */
       return;
-    table_row<4>(wq, dest, term, table_i);
-    table_row<5>(wq, dest, term, table_i);
-    table_row<6>(wq, dest, term, table_i);
-    table_row<7>(wq, dest, term, table_i);
-    table_row<8>(wq, dest, term, table_i);
-    table_row<9>(wq, dest, term, table_i);
-    table_row<10>(wq, dest, term, table_i);
-    table_row<11>(wq, dest, term, table_i);
-    table_row<12>(wq, dest, term, table_i);
-    table_row<13>(wq, dest, term, table_i);
-    table_row<14>(wq, dest, term, table_i);
-    table_row<15>(wq, dest, term, table_i);
+    table_row<4>(wq, row_offset, term, table_i);
+    table_row<5>(wq, row_offset, term, table_i);
+    table_row<6>(wq, row_offset, term, table_i);
+    table_row<7>(wq, row_offset, term, table_i);
+    table_row<8>(wq, row_offset, term, table_i);
+    table_row<9>(wq, row_offset, term, table_i);
+    table_row<10>(wq, row_offset, term, table_i);
+    table_row<11>(wq, row_offset, term, table_i);
+    table_row<12>(wq, row_offset, term, table_i);
+    table_row<13>(wq, row_offset, term, table_i);
+    table_row<14>(wq, row_offset, term, table_i);
+    table_row<15>(wq, row_offset, term, table_i);
     /* rare: packets that found no slot go the general way below, alone */
     const bool direct = dest < -1;
     if (__ballot(direct) == 0ull)

@@ -450,7 +450,9 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS, (!FULL && HEAT) ? 2 : 4)
             if (FULL) {
 #pragma unroll
               for (int i = 0; i < CMI_NACC; ++i)
-                if (HEAT || i < CMI_NION)
+                /* (most cross sections of a re-emitted photon are zero - it
+                 * sits below those ions' thresholds: no add, same sum) */
+                if ((HEAT || i < CMI_NION) && weights[i] != 0.)
                   atomicAdd(&acc[i * TC + last_lidx], ds * weights[i]);
             } else {
               atomicAdd(&acc[last_lidx], ds * weights[ION_H_n]);

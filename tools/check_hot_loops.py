@@ -27,20 +27,24 @@ for s in starts:
     cas = [i for i, l in enumerate(body) if "ds_cmpst" in l]
     if not cas:
         continue
-    headers = [i for i, l in enumerate(body)
-               if "Loop Header: Depth=2" in l and i < cas[0]]
-    if not headers:
+    # all loops of the kernel: (label line, line of the last branch back to it)
+    loops = []
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if not m:
+            continue
+        back = [j for j in range(i + 1, len(body))
+                if re.search(r"s_cbranch\w*\s+" + re.escape(m.group(1)) + r"\b",
+                             body[j])]
+        if back:
+            loops.append((i, back[-1]))
+    # the march loop: the smallest loop around the table's compare-and-swap
+    # that is more than the probing loop itself
+    around = [(e2 - h2, h2, e2) for h2, e2 in loops
+              if h2 < cas[0] < e2 and e2 - h2 > 150]
+    if not around:
         continue
-    h = headers[-1]
-    label = None
-    for j in range(h, max(h - 6, 0), -1):
-        m = re.match(r"^(\.LBB\d+_\d+):", body[j])
-        if m:
-            label = m.group(1)
-            break
-    ends = [i for i, l in enumerate(body)
-            if label and re.search(r"s_cbranch\w*\s+" + re.escape(label) + r"\b", l)]
-    end = ends[-1] if ends else h
+    _, h, end = min(around)
     loop = body[h:end + 1]
     count = lambda p: sum(1 for l in loop if l.strip().startswith(p))
     scratch = sum(1 for l in loop if "scratch_" in l)

@@ -26,11 +26,15 @@
 #define CMI_TABLE_SCAN_ROUNDS 2
 #endif
 /* multi-ion kernels: slots (of 16 doubles) of the block's combining table and
- * march-loop iterations between two write-backs of it */
+ * march-loop iterations between two write-backs of it (measured on
+ * lexingtonHII40 256^3, first generation of 1e8 packets: 4 -> 206 ms, 6 -> 199,
+ * 8 -> 196, 10 -> 196, 16 -> 201, 24 -> 215, 32 -> 240: a longer window
+ * overflows the table into per-lane atomics, a shorter one meets at the
+ * barrier more often) */
 #define CMI_FTABLE_BITS 7
 #define CMI_FTABLE_SLOTS (1 << CMI_FTABLE_BITS)
 #ifndef CMI_FTABLE_WINDOW
-#define CMI_FTABLE_WINDOW 16
+#define CMI_FTABLE_WINDOW 8
 #endif
 /* a.aggregate: what happens to a step's contributions before HBM sees them */
 #define CMI_AGG_NONE 0  /* one atomic per lane and step */

@@ -1139,8 +1139,11 @@ block_reserve(bool mine, unsigned int *counter, unsigned int *s_count,
   return q;
 }
 
+#ifndef CMI_INTERACT_WAVES_H
+#define CMI_INTERACT_WAVES_H 4
+#endif
 template <bool FULL, bool ROWS>
-__global__ void __launch_bounds__(CMI_BLOCK)
+__global__ void __launch_bounds__(CMI_BLOCK, FULL ? 1 : CMI_INTERACT_WAVES_H)
     interaction_kernel(const InteractArgs a) {
   __shared__ unsigned int s_count[CMI_BLOCK / 64], s_base;
   const int lane = threadIdx.x & 63;
@@ -1270,7 +1273,7 @@ __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
  * long and divergent - for multi-ion transport it ends with 14 Verner cross
  * sections - so every lane should have one) */
 template <bool FULL>
-__global__ void __launch_bounds__(CMI_BLOCK)
+__global__ void __launch_bounds__(CMI_BLOCK, FULL ? 1 : CMI_INTERACT_WAVES_H)
     interaction_slots_kernel(const InteractArgs a) {
   const int lane = threadIdx.x & 63;
   const uint32_t key_dead = CMI_TILE_KEY_DEAD(a.tiles);

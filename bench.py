@@ -66,7 +66,7 @@ CONFIGS = {
 
 # The CPU baseline (oracle/cmio_transport_fast.c) against the REFERENCE on the
 # same cores: 8-thread Xeon 2.1 GHz of the build container, 64^3, the whole
-# 20-iteration run of each .param file (tools/
+# 20-iteration run of each .param file (tests/
 # calibrate_cpu_baseline.py reproduces the port's side).
 CALIBRATION = {
     "stromgren": dict(port=1.50e6, reference_classic=1.24e6,

@@ -4,7 +4,7 @@ this machine's cores, to set beside the reference's own numbers for the same
 runs: the figures in bench.py's CALIBRATION table."""
 import sys, time
 import os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import oracle_lib as O
 O.build()

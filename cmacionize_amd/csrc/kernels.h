@@ -1501,9 +1501,12 @@ __global__ void __launch_bounds__(CMI_BLOCK)
  * branch (src/TemperatureCalculator.cpp:944-964 -> :567-931): one cell per
  * lane. fp64-ALU / transcendental bound (up to 100 x 3 balance evaluations,
  * each with ten 5x5 level-population solves). */
-/* registers per lane (the compiler's own occupancy estimate assumes 64 KB of
- * LDS per CU and would hand this kernel 256) and whether the coefficient
- * tables are staged in LDS */
+/* register budget of the solve (left alone the compiler takes 256 VGPRs
+ * without a spill and the kernel is a third slower; with 128 it spills ~140
+ * values to scratch, also inside the solve loop, still runs at 2 waves per
+ * SIMD - and is the fastest of 96 / 128 / 192 / 256 and of
+ * amdgpu_waves_per_eu 3 / 4: DESIGN.md 4.4) and whether the coefficient tables
+ * are staged in LDS */
 #ifndef CMI_TEMPERATURE_VGPRS
 #define CMI_TEMPERATURE_VGPRS 128
 #endif

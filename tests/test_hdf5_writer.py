@@ -28,8 +28,6 @@ PC = 3.086e16
 def make_snapshot(exe, tmp_path, bench, ncell=12):
     text = open(os.path.join(BENCH, bench)).read()
     text = text.replace("[64, 64, 64]", "[%d, %d, %d]" % ((ncell,) * 3))
-    text = text.replace("type: Binary", "type: Gadget")
-    text = text.replace("type: AsciiFile", "type: Gadget")
     if bench.startswith("lexington"):
         import shutil
         shutil.copy(os.path.join(BENCH, "lexingtonHII40.yml"), tmp_path)
@@ -205,7 +203,7 @@ def test_gadget_snapshots_of_a_run(exe, tmp_path):  # noqa: F811
         d = tmp_path / kind
         d.mkdir()
         p = d / "run.param"
-        p.write_text(text.replace("type: AsciiFile", "type: " + kind))
+        p.write_text(text.replace("type: Gadget", "type: " + kind))
         r = subprocess.run([exe, "--params", str(p)], capture_output=True,
                            text=True, cwd=str(d))
         assert r.returncode == 0, r.stderr

@@ -161,6 +161,7 @@ def test_cmi_gpu_executable_end_to_end(exe, tmp_path, oracle):
     text = text.replace("[64, 64, 64]", "[16, 16, 16]")
     text = text.replace("number of photons: 1e6", "number of photons: 20000")
     text = text.replace("number of iterations: 20", "number of iterations: 3")
+    text = text.replace("type: Gadget", "type: AsciiFile")
     p = tmp_path / "small.param"
     p.write_text(text)
     r = subprocess.run([exe, "--params", str(p), "--output-statistics"],
@@ -210,7 +211,7 @@ def test_cmi_gpu_executable_with_blocks(exe, tmp_path, bench, blocks):
     for old in ("number of photons: 1e6", "number of photons: 1e8"):
         text = text.replace(old, "number of photons: 20000")
     text = text.replace("number of iterations: 20", "number of iterations: 5")
-    text = text.replace("type: Binary", "type: AsciiFile")
+    text = text.replace("type: Gadget", "type: AsciiFile")
     outputs = {}
     for label, extra in (("whole", []), ("blocks", ["--blocks", blocks])):
         d = tmp_path / label
@@ -260,7 +261,7 @@ def test_cmi_gpu_executable_with_replicas(exe, tmp_path, bench):
     for old in ("number of photons: 1e6", "number of photons: 1e8"):
         text = text.replace(old, "number of photons: 20001")
     text = text.replace("number of iterations: 20", "number of iterations: 5")
-    text = text.replace("type: Binary", "type: AsciiFile")
+    text = text.replace("type: Gadget", "type: AsciiFile")
     outputs = {}
     for label, extra in (("one", []), ("three", ["--devices", "0,0,0"])):
         d = tmp_path / label
@@ -305,7 +306,7 @@ def test_cmi_gpu_executable_with_copies_of_the_source_block(exe, tmp_path,
     for old in ("number of photons: 1e6", "number of photons: 1e8"):
         text = text.replace(old, "number of photons: 20000")
     text = text.replace("number of iterations: 20", "number of iterations: 5")
-    text = text.replace("type: Binary", "type: AsciiFile")
+    text = text.replace("type: Gadget", "type: AsciiFile")
     assert "position: [0. pc, 0. pc, 0. pc]" in text
     text = text.replace("position: [0. pc, 0. pc, 0. pc]",
                         "position: [1.3 pc, -1.2 pc, 1.1 pc]")
@@ -348,6 +349,7 @@ def test_cmi_gpu_executable_with_a_continuous_source(exe, tmp_path, oracle):
     text = text.replace("[64, 64, 64]", "[16, 16, 16]")
     text = text.replace("number of photons: 1e6", "number of photons: 20000")
     text = text.replace("number of iterations: 20", "number of iterations: 3")
+    text = text.replace("type: Gadget", "type: AsciiFile")
     assert "ContinuousPhotonSource" not in text
     flux = 2.e14  # m^-2 s^-1: about 2.7 times the star over the 10 pc box
     text += ("\nContinuousPhotonSource:\n  type: Isotropic\n"

@@ -170,6 +170,13 @@ for config, dominant in DOMINANT.items():
         for k in ("valu_busy", "lds_busy", "wave_wait_frac", "clock_GHz"):
             if k in f:
                 row[k] = f[k]
+        if "valu_insts" in f:
+            # vector instructions per iteration (one per wave = 64 lane
+            # operations) and the rate of lane operations
+            row["valu_insts_per_iteration"] = f["valu_insts"]
+            pv, _ = m("SQ_INSTS_VALU", src)
+            row["valu_lane_ops_per_s"] = 64. * f["valu_insts"] / \
+                (src[pv + ":ns"] * 1e-9)
         pa, atom = m("TCC_EA0_ATOMIC_sum", src)
         if pa:
             row["atomic_requests_per_s"] = atom / (src[pa + ":ns"] * 1e-9)

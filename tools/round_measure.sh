@@ -5,6 +5,7 @@
 #     OUTDIR/counters.json (tools/pmc_rooflines.py) - copy it to
 #     profiles/rNN/counters.json, bench.py's roofline reads it from there
 #  2. the bench.py line of every single-GPU config
+#  4. the three .param files through cmi-gpu (OUTDIR/cmi_gpu_param_files.txt)
 #  3. rocprofv3 --kernel-trace --stats of the same bench command, summarised
 #     (tools/profile_summary.py) into OUTDIR/bench_<config>_kernel_stats.txt
 set -u
@@ -31,6 +32,19 @@ for CFG in stromgren stromgren_diffuse lexington; do
   python3 "$REPO/tools/profile_summary.py" "$OUT/stats_$CFG" "$OUT/stats_$CFG.log" \
     > "$OUT/bench_${CFG}_kernel_stats.txt"
 done
+# 4. the reference's three .param files, unchanged, through the cmi-gpu
+#    executable (Gadget / HDF5 snapshots, written and deleted)
+mkdir -p "$OUT/params" && cd "$OUT/params" && cp "$REPO/benchmarks/lexingtonHII40.yml" .
+{
+  for F in stromgren stromgren_diffuse lexingtonHII40; do
+    echo "== cmi-gpu --params benchmarks/$F.param --output-statistics"
+    "$REPO/cmacionize_amd/cmi-gpu" --params "$REPO/benchmarks/$F.param" --output-statistics 2>&1 |
+      grep -E "Escape fraction|scattered|non-ionizing|Maximum number|Total photon|Total cell|Done shooting" | tail -9
+    ls -l *.hdf5 | awk '{print $5, $9}'
+    rm -f *.hdf5
+  done
+} > "$OUT/cmi_gpu_param_files.txt" 2>&1
+cd "$OUT" && rm -rf params
 # keep only the small summaries (the traces are large)
 cd "$OUT"
 find . -name "*kernel_trace.csv" -delete

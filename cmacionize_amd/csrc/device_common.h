@@ -259,13 +259,20 @@ struct ModelDev {
    * from the continuous source with probability continuous_probability and
    * carries photon_weight[1], from a discrete one otherwise, with
    * photon_weight[0] */
-  int32_t continuous_type;          /* 0 none, 1 isotropic on the box */
+  int32_t continuous_type; /* 0 none, 1 isotropic on the box, 2 planar */
   int32_t continuous_spectrum_type; /* as spectrum_type */
   int32_t pad1;
   double continuous_probability;
   double photon_weight[2];
   double continuous_mono_frequency;
   double continuous_planck_temperature;
+  /* PlanarContinuousPhotonSource: the plane x[axis] = intercept, the
+   * rectangle [anchor, anchor + side] along the two other axes (in their
+   * natural order) */
+  int32_t continuous_axis;
+  int32_t pad2;
+  double continuous_intercept;
+  double continuous_anchor[2], continuous_side[2];
 };
 
 /* SoA cell state, all device pointers to [ncell] doubles */

@@ -193,6 +193,23 @@ __device__ inline uint32_t emit_geometry(const GridDev &g, const ModelDev &m,
     for (int a = 0; a < 3; ++a)
       p.pos[a] = m.source_position[3 * i + a];
     random_direction(p, rng);
+  } else if (m.continuous_type == 2) {
+    /* PlanarContinuousPhotonSource::get_random_incoming_direction
+     * (src/PlanarContinuousPhotonSource.hpp:165-188): a point of a rectangle
+     * in the plane x[axis] = intercept, an isotropic direction */
+    origin = 1;
+    const int i0 = m.continuous_axis == 0 ? 1 : 0;
+    const int i1 = m.continuous_axis == 2 ? 1 : 2;
+    const double u0 = rng.next();
+    const double u1 = rng.next();
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      p.pos[a] = a == m.continuous_axis
+                     ? m.continuous_intercept
+                     : (a == i0 ? m.continuous_anchor[0] + u0 * m.continuous_side[0]
+                                : m.continuous_anchor[1] + u1 * m.continuous_side[1]);
+    (void)i1;
+    random_direction(p, rng);
   } else {
     /* IsotropicContinuousPhotonSource::get_random_incoming_direction
      * (src/IsotropicContinuousPhotonSource.hpp:95-191): a focus point in the

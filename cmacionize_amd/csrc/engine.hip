@@ -926,6 +926,29 @@ int cmi_gpu_set_continuous_source(cmi_gpu_engine *e, int32_t type,
   return CMI_GPU_OK;
 }
 
+int cmi_gpu_set_continuous_source_planar(cmi_gpu_engine *e, int32_t axis,
+                                         double intercept,
+                                         const double *anchor,
+                                         const double *sides,
+                                         double luminosity) {
+  if (!e || axis < 0 || axis > 2 || !anchor || !sides || !(sides[0] > 0.) ||
+      !(sides[1] > 0.) || !(luminosity > 0.))
+    return fail(CMI_GPU_EINVAL,
+                "cmi_gpu_set_continuous_source_planar: bad argument");
+  ModelDev &m = e->model;
+  m.continuous_type = CMI_GPU_CONTINUOUS_PLANAR;
+  m.continuous_axis = axis;
+  m.continuous_intercept = intercept;
+  for (int k = 0; k < 2; ++k) {
+    m.continuous_anchor[k] = anchor[k];
+    m.continuous_side[k] = sides[k];
+  }
+  e->continuous_luminosity = luminosity;
+  e->spectra_dirty = true;
+  mix_sources(e);
+  return CMI_GPU_OK;
+}
+
 int cmi_gpu_set_continuous_spectrum_monochromatic(cmi_gpu_engine *e,
                                                   double frequency) {
   if (!e || !(frequency > 0.))

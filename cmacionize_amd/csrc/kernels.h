@@ -1412,9 +1412,10 @@ __global__ void __launch_bounds__(CMI_BLOCK)
       /* the continuous source: one more "source", its packets ordered by
        * direction like the others (they enter all over the box) */
       src = (uint32_t)a.model.nsource;
-      (void)rng.next(); /* the focus point */
+      (void)rng.next(); /* the focus point, or the point in the plane */
       (void)rng.next();
-      (void)rng.next();
+      if (a.model.continuous_type == 1)
+        (void)rng.next();
     }
     const double u_cost = rng.next(); /* cos(theta) = 2 u - 1 */
     const double u_phi = rng.next();  /* phi = 2 pi u */

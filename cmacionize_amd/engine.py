@@ -25,7 +25,7 @@ FIELD_MEAN_INTENSITY = 16
 FIELD_HEATING = 30
 
 REEMIT_NONE, REEMIT_PHYSICAL, REEMIT_FIXED = 0, 1, 2
-CONTINUOUS_NONE, CONTINUOUS_ISOTROPIC = 0, 1
+CONTINUOUS_NONE, CONTINUOUS_ISOTROPIC, CONTINUOUS_PLANAR = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
 
@@ -61,6 +61,7 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_synchronize", "cmi_gpu_number_of_cells", "cmi_gpu_set_sources",
     "cmi_gpu_set_spectrum_monochromatic", "cmi_gpu_set_spectrum_planck",
     "cmi_gpu_set_continuous_source",
+    "cmi_gpu_set_continuous_source_planar",
     "cmi_gpu_set_continuous_spectrum_monochromatic",
     "cmi_gpu_set_continuous_spectrum_planck",
     "cmi_gpu_set_cross_sections_fixed", "cmi_gpu_set_cross_sections_verner",
@@ -121,6 +122,8 @@ def load_library():
     L.cmi_gpu_set_spectrum_monochromatic.argtypes = [vp, C.c_double]
     L.cmi_gpu_set_spectrum_planck.argtypes = [vp, C.c_double]
     L.cmi_gpu_set_continuous_source.argtypes = [vp, C.c_int32, C.c_double]
+    L.cmi_gpu_set_continuous_source_planar.argtypes = [
+        vp, C.c_int32, C.c_double, _dp, _dp, C.c_double]
     L.cmi_gpu_set_continuous_spectrum_monochromatic.argtypes = [vp, C.c_double]
     L.cmi_gpu_set_continuous_spectrum_planck.argtypes = [vp, C.c_double]
     L.cmi_gpu_set_cross_sections_fixed.argtypes = [vp, _dp]
@@ -303,6 +306,15 @@ class GpuEngine:
         luminosity the PhotonSource ctor computes for it."""
         self._check(self._lib.cmi_gpu_set_continuous_source(self._h, kind,
                                                             luminosity))
+
+    def set_continuous_source_planar(self, axis, intercept, anchor, sides,
+                                     luminosity):
+        """PlanarContinuousPhotonSource: the rectangle [anchor, anchor +
+        sides] of the plane x[axis] = intercept."""
+        a = _f64(anchor)
+        s = _f64(sides)
+        self._check(self._lib.cmi_gpu_set_continuous_source_planar(
+            self._h, axis, intercept, _p(a), _p(s), luminosity))
 
     def set_continuous_spectrum_monochromatic(self, frequency):
         self._check(self._lib.cmi_gpu_set_continuous_spectrum_monochromatic(

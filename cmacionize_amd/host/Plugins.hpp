@@ -423,6 +423,55 @@ public:
   }
 };
 
+/* src/PlanarContinuousPhotonSource.hpp:40-196: a luminous rectangle in a
+ * plane perpendicular to a coordinate axis */
+class PlanarContinuousPhotonSource : public ContinuousPhotonSource {
+  int _axis;
+  double _intercept, _anchor[2], _sides[2], _luminosity;
+
+public:
+  explicit PlanarContinuousPhotonSource(ParameterFile &params)
+      : _axis(0),
+        _intercept(params.get_physical_value(
+            QUANTITY_LENGTH, "ContinuousPhotonSource:intercept", "0. m")),
+        _anchor{params.get_physical_value(QUANTITY_LENGTH,
+                                          "ContinuousPhotonSource:anchor 0",
+                                          "0. m"),
+                params.get_physical_value(QUANTITY_LENGTH,
+                                          "ContinuousPhotonSource:anchor 1",
+                                          "0. m")},
+        _sides{params.get_physical_value(QUANTITY_LENGTH,
+                                         "ContinuousPhotonSource:side 0",
+                                         "1. m"),
+               params.get_physical_value(QUANTITY_LENGTH,
+                                         "ContinuousPhotonSource:side 1",
+                                         "1. m")},
+        _luminosity(params.get_physical_value(
+            QUANTITY_FREQUENCY, "ContinuousPhotonSource:luminosity",
+            "1.e48 s^-1")) {
+    /* get_coordinate_index, :52-67 */
+    const std::string name =
+        params.get_string("ContinuousPhotonSource:normal axis", "z");
+    if (name == "x")
+      _axis = 0;
+    else if (name == "y")
+      _axis = 1;
+    else if (name == "z")
+      _axis = 2;
+    else
+      throw ParameterError("Unknown coordinate name: " + name + "!");
+  }
+  double get_total_surface_area() const override {
+    return _sides[0] * _sides[1];
+  }
+  bool has_total_luminosity() const override { return true; }
+  double get_total_luminosity() const override { return _luminosity; }
+  int lower(cmi_gpu_engine *engine, double luminosity) const override {
+    return cmi_gpu_set_continuous_source_planar(engine, _axis, _intercept,
+                                                _anchor, _sides, luminosity);
+  }
+};
+
 /* src/ContinuousPhotonSourceFactory.hpp (types on this path) */
 inline ContinuousPhotonSource *
 generate_continuous_photon_source(const double box_sides[3],
@@ -431,10 +480,12 @@ generate_continuous_photon_source(const double box_sides[3],
       params.get_string("ContinuousPhotonSource:type", "None");
   if (type == "Isotropic")
     return new IsotropicContinuousPhotonSource(box_sides);
+  if (type == "Planar")
+    return new PlanarContinuousPhotonSource(params);
   if (type == "None")
     return nullptr;
   throw ParameterError("ContinuousPhotonSource type \"" + type +
-                       "\" is not on this path (Isotropic, None)");
+                       "\" is not on this path (Isotropic, Planar, None)");
 }
 
 /* -------------------------------------- CrossSections / RecombinationRates */

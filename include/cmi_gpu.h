@@ -131,9 +131,23 @@ int cmi_gpu_set_sources(cmi_gpu_engine *engine, int32_t n,
  * of sources half of the packets come from each and the continuous ones carry
  * the weight L_continuous / L_discrete; all tallies (mean intensities, heating,
  * totweight, the per-type counts) are sums of weights, as in the reference. */
-enum { CMI_GPU_CONTINUOUS_NONE = 0, CMI_GPU_CONTINUOUS_ISOTROPIC = 1 };
+enum {
+  CMI_GPU_CONTINUOUS_NONE = 0,
+  CMI_GPU_CONTINUOUS_ISOTROPIC = 1,
+  CMI_GPU_CONTINUOUS_PLANAR = 2
+};
 int cmi_gpu_set_continuous_source(cmi_gpu_engine *engine, int32_t type,
                                   double luminosity);
+/* ... PlanarContinuousPhotonSource (src/PlanarContinuousPhotonSource.hpp:
+ * 96-196): packets start on the rectangle [anchor, anchor + sides] (host [2],
+ * along the two axes other than `axis`, in their natural order) of the plane
+ * x[axis] = intercept, in an isotropic direction; it has its own luminosity
+ * (has_total_luminosity()). */
+int cmi_gpu_set_continuous_source_planar(cmi_gpu_engine *engine, int32_t axis,
+                                         double intercept,
+                                         const double *anchor,
+                                         const double *sides,
+                                         double luminosity);
 /* the continuous source's PhotonSourceSpectrum (role
  * "ContinuousPhotonSourceSpectrum", src/IonizationSimulation.cpp:164-168) */
 int cmi_gpu_set_continuous_spectrum_monochromatic(cmi_gpu_engine *engine,

@@ -160,7 +160,8 @@ typedef struct {
   /* ContinuousPhotonSource + ContinuousPhotonSourceSpectrum and the mix of
    * the two kinds of sources (src/PhotonSource.cpp:104-130), set by
    * cmio_mix_sources: continuous_type 0 = none, 1 =
-   * IsotropicContinuousPhotonSource on `continuous_box` */
+   * IsotropicContinuousPhotonSource on `continuous_box`, 2 =
+   * PlanarContinuousPhotonSource (the fields at the end of the struct) */
   int32_t continuous_type;
   int32_t continuous_spectrum_type;
   double continuous_mono_frequency;
@@ -169,6 +170,12 @@ typedef struct {
   double discrete_luminosity, continuous_luminosity; /* inputs of the mix */
   double continuous_probability;
   double discrete_photon_weight, continuous_photon_weight;
+  /* PlanarContinuousPhotonSource (src/PlanarContinuousPhotonSource.hpp): the
+   * plane x[axis] = intercept, the rectangle [anchor, anchor + side] along the
+   * two other axes in their natural order */
+  int32_t continuous_axis;
+  double continuous_intercept;
+  double continuous_anchor[2], continuous_side[2];
 } cmio_model;
 
 /* PhotonSource ctor, src/PhotonSource.cpp:104-130: total_luminosity,

@@ -108,6 +108,22 @@ static void isotropic_incoming(const cmio_model *model, cmio_rng *rng,
   }
 }
 
+/* PlanarContinuousPhotonSource::get_random_incoming_direction,
+ * src/PlanarContinuousPhotonSource.hpp:165-188 */
+static void planar_incoming(const cmio_model *model, cmio_rng *rng,
+                            cmio_photon *photon) {
+  const int fixed = model->continuous_axis;
+  /* get_non_fixed_index, :69-76: the two other axes in their natural order */
+  const int i0 = (fixed + 1) % 3, i1 = (fixed + 2) % 3;
+  const int n0 = i0 < i1 ? i0 : i1, n1 = i0 < i1 ? i1 : i0;
+  photon->position[n0] = model->continuous_anchor[0] +
+                         cmio_rng_next(rng) * model->continuous_side[0];
+  photon->position[n1] = model->continuous_anchor[1] +
+                         cmio_rng_next(rng) * model->continuous_side[1];
+  photon->position[fixed] = model->continuous_intercept;
+  set_random_direction(photon, rng);
+}
+
 /* src/PhotonSource.cpp:208-249. The first uniform is drawn also when there is
  * no continuous source (continuous_probability = 0). */
 static void random_photon(const cmio_model *model, cmio_rng *rng,
@@ -130,7 +146,11 @@ static void random_photon(const cmio_model *model, cmio_rng *rng,
                          ? model->discrete_photon_weight
                          : 1.;
   } else {
-    isotropic_incoming(model, rng, photon);
+    if (model->continuous_type == 2) {
+      planar_incoming(model, rng, photon);
+    } else {
+      isotropic_incoming(model, rng, photon);
+    }
     energy = cmio_continuous_spectrum_sample(model, rng);
     photon->weight = model->continuous_photon_weight;
   }

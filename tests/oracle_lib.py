@@ -76,6 +76,10 @@ class Model(C.Structure):
         ("continuous_probability", C.c_double),
         ("discrete_photon_weight", C.c_double),
         ("continuous_photon_weight", C.c_double),
+        ("continuous_axis", C.c_int32),
+        ("continuous_intercept", C.c_double),
+        ("continuous_anchor", C.c_double * 2),
+        ("continuous_side", C.c_double * 2),
     ]
 
 
@@ -263,6 +267,21 @@ class OracleSimulation:
         self.model.discrete_luminosity = luminosity
         if self.model.continuous_type:
             lib().cmio_mix_sources(C.byref(self.model))
+
+    def set_planar_continuous_source(self, axis, intercept, anchor, sides,
+                                     luminosity, frequency):
+        """PlanarContinuousPhotonSource with a monochromatic spectrum."""
+        m = self.model
+        m.continuous_type = 2
+        m.continuous_axis = axis
+        m.continuous_intercept = intercept
+        for k in range(2):
+            m.continuous_anchor[k] = anchor[k]
+            m.continuous_side[k] = sides[k]
+        m.continuous_spectrum_type = SPECTRUM_MONOCHROMATIC
+        m.continuous_mono_frequency = frequency
+        m.continuous_luminosity = luminosity
+        lib().cmio_mix_sources(C.byref(m))
 
     def set_continuous_source(self, luminosity, frequency=None,
                               planck_temperature=None):

@@ -262,3 +262,105 @@ def test_continuous_source_on_a_decomposed_grid(oracle):
     group.close()
     for b in backends:
         b.engine.close()
+
+
+# ---------------------------------------------------------------------------
+# PlanarContinuousPhotonSource (src/PlanarContinuousPhotonSource.hpp:96-196)
+# ---------------------------------------------------------------------------
+
+def planar_setup(oracle, sim, axis):
+    from cmacionize_amd import STROMGREN as S
+    side = S["sides"][0]
+    intercept = 0.125 * side          # on a cell wall of a 16^3 / 24^3 grid
+    anchor = (-0.3 * side, -0.2 * side)
+    sides = (0.5 * side, 0.35 * side)
+    L = 1.5 * S["luminosity"]
+    sim.set_planar_continuous_source(axis, intercept, anchor, sides, L, FREQ_C)
+    return intercept, anchor, sides, L
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_planar_source_starts_on_its_rectangle(oracle, axis):
+    """Every packet starts on the rectangle of the plane x[axis] = intercept
+    (the two other axes in their natural order, get_non_fixed_index, :69-76)
+    in an isotropic direction; the source has its own luminosity, so with a
+    star of luminosity L the packets weigh 1.5 L / L."""
+    sim = oracle.stromgren_simulation(8)
+    intercept, anchor, sides, L = planar_setup(oracle, sim, axis)
+    assert sim.model.continuous_probability == 0.5
+    assert sim.model.continuous_photon_weight == 1.5
+    others = [a for a in range(3) if a != axis]
+    n = 4000
+    dirs = []
+    seen = 0
+    for pos, dirn, nu, w, tau in emit(oracle, sim, 3, n):
+        if w == 1.:
+            continue  # a packet of the star
+        seen += 1
+        assert w == 1.5 and nu == FREQ_C
+        assert pos[axis] == intercept
+        for k, a in enumerate(others):
+            assert anchor[k] <= pos[a] <= anchor[k] + sides[k]
+        dirs.append(dirn)
+    dirs = np.array(dirs)
+    assert abs(seen / n - 0.5) < 4. * np.sqrt(0.25 / n)
+    assert np.all(np.abs(dirs.mean(axis=0)) < 5. / np.sqrt(seen))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("axis", [0, 2])
+def test_planar_source_matches_oracle(oracle, axis):
+    """Emission (same stream -> same packets) and one transport step with a
+    star and a planar source, tile rounds on: weighted tallies against the
+    oracle."""
+    from cmacionize_amd import GpuEngine, STROMGREN as S
+    from cmacionize_amd import engine as E
+    ncell, npacket = 16, 30000
+    eng = GpuEngine((ncell,) * 3, S["anchor"], S["sides"], (0, 0, 0),
+                    device=0, track_heating=True)
+    sim = oracle.OracleSimulation((ncell,) * 3, S["anchor"], S["sides"])
+    sim.set_homogeneous(S["density"], S["temperature"], xH=3.e-5)
+    m = sim.model
+    m.spectrum_type = oracle.SPECTRUM_MONOCHROMATIC
+    m.mono_frequency = S["frequency"]
+    m.xsec_type = oracle.XSEC_FIXED
+    m.xsec_fixed[0] = S["sigma_H"]
+    m.recomb_type = oracle.RECOMB_FIXED
+    m.recomb_fixed[0] = S["alpha_H"]
+    m.reemit_type = oracle.REEMIT_PHYSICAL
+    star = [[0.2 * S["sides"][0], -0.1 * S["sides"][0], 0.05 * S["sides"][0]]]
+    sim.set_sources(star, [1.], S["luminosity"])
+    intercept, anchor, sides, L = planar_setup(oracle, sim, axis)
+    sigma = np.zeros(14)
+    sigma[0] = S["sigma_H"]
+    alpha = np.zeros(14)
+    alpha[0] = S["alpha_H"]
+    eng.set_cross_sections_fixed(sigma)
+    eng.set_recombination_rates_fixed(alpha)
+    eng.set_sources(star, [1.], S["luminosity"])
+    eng.set_spectrum_monochromatic(S["frequency"])
+    eng.set_continuous_spectrum_monochromatic(FREQ_C)
+    eng.set_continuous_source_planar(axis, intercept, anchor, sides, L)
+    eng.set_reemission(1)
+    eng.set_tuning(reemit_inline_below=64, tile_min_flights=0,
+                   tile_min_per_item=0)
+    eng.upload_cells(sim.number_density, sim.temperature,
+                     np.array([np.asarray(x) for x in sim.x]))
+    pos, dirn, nu, sig, tau = eng.emit_packets(5, 0, 0, 1024)
+    for i, (p, d, f, w, t) in enumerate(emit(oracle, sim, 5, 1024)):
+        assert np.array_equal(pos[i], p)
+        assert np.allclose(dirn[i], d, rtol=0, atol=4e-16)
+        assert nu[i] == f
+    eng.reset_grid()
+    eng.shoot(5, 1, 0, npacket)
+    tw, tc, ns = eng.get_counters()
+    sim.reset()
+    sim.totweight = 0.
+    sim.typecount[:] = 0.
+    sim.shoot(5, 1, 0, npacket)
+    assert abs(tw - sim.totweight) <= 1e-12 * sim.totweight
+    assert np.allclose(tc, sim.typecount, rtol=1e-12, atol=0.)
+    assert tw > 1.2 * npacket
+    J = eng.download_field(E.FIELD_MEAN_INTENSITY)
+    assert np.allclose(J, sim.J[0], rtol=1e-9, atol=1e-12 * sim.J[0].max())
+    eng.close()

@@ -1,0 +1,151 @@
+/*
+ * CMILibrary.cpp - the reference's library mode on top of the GPU engine:
+ * the C entry points of src/CMILibrary.hpp / src/CMILibrary.cpp:48-222, with
+ * the same names, arguments and meaning, built into libcmi_gpu_library.so. A
+ * code that links the reference's libCMILibrary (SPH codes, the Fortran
+ * bindings of the reference's fortran/ directory) links this instead.
+ *
+ *   cmi_init(parameter_file, num_thread, unit_length_in_SI, unit_mass_in_SI,
+ *            mapping_type)            (+ the periodic dp / sp variants)
+ *   cmi_compute_neutral_fraction_dp / _mp / _sp (x, y, z, h, m, nH, N)
+ *   cmi_destroy()
+ *
+ * cmi_compute_neutral_fraction_*: SPHArrayInterface::reset with the caller's
+ * particle arrays, IonizationSimulation::initialize(interface) - the
+ * interface is the DensityFunction -, IonizationSimulation::run(interface) -
+ * the interface is the extra DensityGridWriter - and fill_array
+ * (src/CMILibrary.cpp:149-158).
+ *
+ * Errors: the reference aborts (cmac_error); here a message goes to stderr
+ * and the neutral fractions are left untouched / cmi_init leaves the library
+ * uninitialised - a host code checks cmi_gpu_library_status() (0 = fine).
+ * CMI_GPU_DEVICE in the environment selects the HIP device (default 0).
+ */
+#include "SPHArrayInterface.hpp"
+
+#include <cstdlib>
+#include <iostream>
+#include <memory>
+
+using namespace cmi;
+
+namespace {
+std::unique_ptr<GpuIonizationSimulation> global_ionization_simulation;
+std::unique_ptr<SPHArrayInterface> global_interface;
+int global_status = 0;
+
+int device_from_environment() {
+  const char *d = std::getenv("CMI_GPU_DEVICE");
+  return d ? std::atoi(d) : 0;
+}
+
+template <typename Make>
+void init(const char *parameter_file, int num_thread, bool talk, Make make) {
+  global_status = 1;
+  try {
+    /* IonizationSimulation(write_output = true, every_iteration_output =
+     * false, output_statistics = false, ...), src/CMILibrary.cpp:58-60 */
+    global_ionization_simulation.reset(new GpuIonizationSimulation(
+        true, false, false, num_thread, parameter_file,
+        device_from_environment(), talk));
+    global_interface.reset(make());
+    global_status = 0;
+  } catch (const std::exception &e) {
+    std::cerr << "cmi_init: " << e.what() << std::endl;
+    global_ionization_simulation.reset();
+    global_interface.reset();
+  }
+}
+
+template <typename TX, typename TH, typename TN>
+void compute(const TX *x, const TX *y, const TX *z, const TH *h, const TH *m,
+             TN *nH, size_t N) {
+  if (!global_ionization_simulation || !global_interface) {
+    std::cerr << "cmi_compute_neutral_fraction: cmi_init has not succeeded"
+              << std::endl;
+    global_status = 1;
+    return;
+  }
+  try {
+    global_interface->reset(x, y, z, h, m, N);
+    global_ionization_simulation->initialize(global_interface.get());
+    global_ionization_simulation->run(global_interface.get());
+    global_interface->fill_array(nH);
+    global_status = 0;
+  } catch (const std::exception &e) {
+    std::cerr << "cmi_compute_neutral_fraction: " << e.what() << std::endl;
+    global_status = 1;
+  }
+}
+} // namespace
+
+extern "C" {
+
+/* src/CMILibrary.cpp:48-62 */
+void cmi_init(const char *parameter_file, const int num_thread,
+              const double unit_length_in_SI, const double unit_mass_in_SI,
+              const char *mapping_type) {
+  init(parameter_file, num_thread, false, [&]() {
+    return new SPHArrayInterface(unit_length_in_SI, unit_mass_in_SI,
+                                 mapping_type);
+  });
+}
+
+/* :78-92 */
+void cmi_init_periodic_dp(const char *parameter_file, const int num_thread,
+                          const double unit_length_in_SI,
+                          const double unit_mass_in_SI,
+                          const double *box_anchor, const double *box_sides,
+                          const char *mapping_type, const int talk) {
+  init(parameter_file, num_thread, talk != 0, [&]() {
+    return new SPHArrayInterface(unit_length_in_SI, unit_mass_in_SI,
+                                 box_anchor, box_sides, mapping_type);
+  });
+}
+
+/* :110-124 */
+void cmi_init_periodic_sp(const char *parameter_file, const int num_thread,
+                          const double unit_length_in_SI,
+                          const double unit_mass_in_SI, const float *box_anchor,
+                          const float *box_sides, const char *mapping_type,
+                          const int talk) {
+  init(parameter_file, num_thread, talk != 0, [&]() {
+    return new SPHArrayInterface(unit_length_in_SI, unit_mass_in_SI,
+                                 box_anchor, box_sides, mapping_type);
+  });
+}
+
+/* :129-133 */
+void cmi_destroy() {
+  global_ionization_simulation.reset();
+  global_interface.reset();
+}
+
+/* :149-158 */
+void cmi_compute_neutral_fraction_dp(const double *x, const double *y,
+                                     const double *z, const double *h,
+                                     const double *m, double *nH,
+                                     const size_t N) {
+  compute(x, y, z, h, m, nH, N);
+}
+
+/* :174-183 */
+void cmi_compute_neutral_fraction_mp(const double *x, const double *y,
+                                     const double *z, const float *h,
+                                     const float *m, double *nH,
+                                     const size_t N) {
+  compute(x, y, z, h, m, nH, N);
+}
+
+/* :199-208 */
+void cmi_compute_neutral_fraction_sp(const float *x, const float *y,
+                                     const float *z, const float *h,
+                                     const float *m, float *nH,
+                                     const size_t N) {
+  compute(x, y, z, h, m, nH, N);
+}
+
+/* not in the reference (it aborts on errors): 0 = the last call succeeded */
+int cmi_gpu_library_status() { return global_status; }
+
+} // extern "C"

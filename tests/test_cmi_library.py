@@ -43,7 +43,7 @@ def library():
     return L
 
 
-def test_library_exports_the_reference_entry_points(library):
+def test_library_exports_the_reference_entry_points(library, tmp_path):
     """src/CMILibrary.hpp:46-72 (no compute calls: runs without a GPU)."""
     for name in ("cmi_init", "cmi_init_periodic_dp", "cmi_init_periodic_sp",
                  "cmi_destroy", "cmi_compute_neutral_fraction_dp",
@@ -51,8 +51,9 @@ def test_library_exports_the_reference_entry_points(library):
                  "cmi_compute_neutral_fraction_sp"):
         getattr(library, name)
     # a wrong mapping type is reported, not fatal
-    library.cmi_init(os.path.join(BENCH, "stromgren.param").encode(), 1, 1.,
-                     1., b"Petkova")
+    p = tmp_path / "lib.param"
+    p.write_text(open(os.path.join(BENCH, "stromgren.param")).read())
+    library.cmi_init(str(p).encode(), 1, 1., 1., b"Petkova")
     assert library.cmi_gpu_library_status() == 1
     library.cmi_destroy()
 

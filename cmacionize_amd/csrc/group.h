@@ -38,6 +38,9 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 
+#include <string>
+#include <thread>
+
 /* the handful of RCCL entry points used, by their rccl.h signatures */
 namespace {
 struct RcclApi {
@@ -653,20 +656,45 @@ int cmi_gpu_group_exchange_flights(cmi_gpu_group *g, uint32_t seed,
                            e->stream));
     HIP_TRY(hipEventRecord(g->routed[s], e->stream));
   }
-  /* every owner waits for all sources, then flies what it received */
+  /* every owner waits for all sources, then flies what it received. With
+   * re-emission cmi_gpu_shoot_flights reads a few bytes back per generation
+   * and blocks its caller: one host thread per owner, so that the devices
+   * work at the same time (the error string of the C ABI is per thread: a
+   * failure is carried back to the caller's) */
   for (int d = 0; d < n; ++d) {
     cmi_gpu_engine *e = g->engine[d];
     HIP_TRY(hipSetDevice(e->device));
     for (int s = 0; s < n; ++s)
       if (s != d)
         HIP_TRY(hipStreamWaitEvent(e->stream, g->routed[s], 0));
-    if (incoming[d] == 0)
-      continue;
-    const int rc = cmi_gpu_shoot_flights(e, seed, iteration, first_packet,
-                                         g->inbox[d], incoming[d]);
-    if (rc)
-      return rc;
   }
+  std::vector<int> rcs(n, CMI_GPU_OK);
+  std::vector<std::string> messages(n);
+  auto fly = [&](int d) {
+    rcs[d] = cmi_gpu_shoot_flights(g->engine[d], seed, iteration, first_packet,
+                                   g->inbox[d], incoming[d]);
+    if (rcs[d])
+      messages[d] = cmi_gpu_last_error();
+  };
+  int owners = 0, last_owner = -1;
+  for (int d = 0; d < n; ++d)
+    if (incoming[d] != 0) {
+      ++owners;
+      last_owner = d;
+    }
+  if (owners == 1) {
+    fly(last_owner);
+  } else {
+    std::vector<std::thread> threads;
+    for (int d = 0; d < n; ++d)
+      if (incoming[d] != 0)
+        threads.emplace_back(fly, d);
+    for (std::thread &t : threads)
+      t.join();
+  }
+  for (int d = 0; d < n; ++d)
+    if (rcs[d])
+      return fail(rcs[d], "%s", messages[d].c_str());
   ++g->rounds;
   g->flights += total;
   return CMI_GPU_OK;

@@ -15,6 +15,8 @@
 
 #include <array>
 #include <chrono>
+#include <exception>
+#include <thread>
 #include <cstring>
 #include <cstdio>
 #include <ctime>
@@ -404,6 +406,32 @@ class GpuIonizationSimulation {
   }
   bool decomposed() const { return !_blocks.empty(); }
 
+  /* f(k) for k = 0 .. n - 1, each on its own host thread; the first
+   * exception (check() throws with the thread's own error string) is
+   * rethrown in the caller */
+  template <typename F> static void for_each_engine_in_parallel(size_t n, F f) {
+    if (n <= 1) {
+      if (n == 1)
+        f(0);
+      return;
+    }
+    std::vector<std::exception_ptr> errors(n);
+    std::vector<std::thread> threads;
+    for (size_t k = 0; k < n; ++k)
+      threads.emplace_back([&, k]() {
+        try {
+          f(k);
+        } catch (...) {
+          errors[k] = std::current_exception();
+        }
+      });
+    for (std::thread &t : threads)
+      t.join();
+    for (size_t k = 0; k < n; ++k)
+      if (errors[k])
+        std::rethrow_exception(errors[k]);
+  }
+
   void lower_model(cmi_gpu_engine *engine) {
     if (_photon_source_distribution)
       check(_photon_source_distribution->lower(engine), "sources");
@@ -488,12 +516,15 @@ class GpuIonizationSimulation {
    * (cmi_gpu_group_exchange_flights) until no flight is left. */
   void shoot_decomposed(uint_fast32_t loop, uint_fast64_t numphoton,
                         double &totweight, double typecount[4]) {
-    for (Block &b : _blocks) {
+    /* (with re-emission cmi_gpu_shoot blocks its caller while a device
+     * works through the generations: one host thread per engine) */
+    for_each_engine_in_parallel(_blocks.size(), [&](size_t k) {
+      Block &b = _blocks[k];
       check(cmi_gpu_reset_grid(b.engine), "reset_grid");
       check(cmi_gpu_reset_exports(b.engine), "reset_exports");
       check(cmi_gpu_shoot(b.engine, (uint32_t)_random_seed, loop, 0, numphoton),
             "shoot");
-    }
+    });
     /* rounds of {every flight that left a block into the inbox of the block
      * that owns the cell it enters - written by the source GPU across xGMI -
      * then every block continues what it received} until nothing moves */
@@ -531,15 +562,15 @@ class GpuIonizationSimulation {
   void shoot_replicated(uint_fast32_t loop, uint_fast64_t numphoton,
                         double &totweight, double typecount[4]) {
     const uint64_t P = _replicas.size();
-    uint64_t first = 0;
-    for (uint64_t r = 0; r < P; ++r) {
-      const uint64_t count = numphoton / P + (r < numphoton % P ? 1 : 0);
+    std::vector<uint64_t> first(P + 1, 0);
+    for (uint64_t r = 0; r < P; ++r)
+      first[r + 1] = first[r] + numphoton / P + (r < numphoton % P ? 1 : 0);
+    for_each_engine_in_parallel(P, [&](size_t r) {
       check(cmi_gpu_reset_grid(_replicas[r]), "reset_grid");
-      check(cmi_gpu_shoot(_replicas[r], (uint32_t)_random_seed, loop, first,
-                          count),
+      check(cmi_gpu_shoot(_replicas[r], (uint32_t)_random_seed, loop, first[r],
+                          first[r + 1] - first[r]),
             "shoot");
-      first += count;
-    }
+    });
     totweight = 0.;
     for (int i = 0; i < 4; ++i)
       typecount[i] = 0.;

@@ -238,7 +238,7 @@ def roofline(config, ncell, cfg, steps_per_launch, kernel_s, launches,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="stromgren", choices=sorted(CONFIGS))
     ap.add_argument("--ncell", type=int, default=256)

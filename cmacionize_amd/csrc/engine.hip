@@ -68,6 +68,8 @@ struct cmi_gpu_engine {
   TablesDev *host_tables = nullptr; /* host copy, for host-side tabulation */
   SpectraDev *spectra = nullptr;
   bool spectra_dirty = true; /* cross sections / spectrum changed */
+  /* counters the host needs between launches: pinned host memory, mapped */
+  unsigned int *mailbox = nullptr, *mailbox_dev = nullptr;
   double *source_position = nullptr;
   double *source_cumulative = nullptr;
   std::vector<double> source_position_host;
@@ -176,6 +178,19 @@ int timer_begin(cmi_gpu_engine *e, EventPair &ev) {
   return CMI_GPU_OK;
 }
 
+/* A few counters from device memory into the engine's mailbox - pinned host
+ * memory the device writes directly - so that reading them costs a tiny
+ * kernel and a stream synchronisation, not a staged copy. */
+__global__ void mailbox_kernel(const unsigned int *src, unsigned int *dst,
+                               int n) {
+  if ((int)threadIdx.x < n)
+    dst[threadIdx.x] = src[threadIdx.x];
+}
+__global__ void snapshot_u64_kernel(const unsigned long long *src,
+                                    unsigned long long *dst) {
+  *dst = *src;
+}
+
 int timer_end(cmi_gpu_engine *e, std::vector<EventPair> &list, EventPair &ev,
               uint64_t packets) {
   if (!ev.start)
@@ -195,9 +210,9 @@ int timer_end(cmi_gpu_engine *e, std::vector<EventPair> &list, EventPair &ev,
     if (!e->launch_steps)
       HIP_TRY(hipMalloc(&e->launch_steps,
                         sizeof(unsigned long long) * CMI_MAX_TIMED_LAUNCHES));
-    HIP_TRY(hipMemcpyAsync(e->launch_steps + list.size(), &e->counters->nsteps,
-                           sizeof(unsigned long long),
-                           hipMemcpyDeviceToDevice, e->stream));
+    snapshot_u64_kernel<<<1, 1, 0, e->stream>>>(
+        &e->counters->nsteps, e->launch_steps + list.size());
+    HIP_TRY(hipGetLastError());
   }
   list.push_back(ev);
   return CMI_GPU_OK;
@@ -815,6 +830,8 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->sort_temp);
   (void)hipFree(e->queue_block);
   (void)hipFree(e->queue_counts);
+  if (e->mailbox)
+    (void)hipHostFree(e->mailbox);
   (void)hipFree(e->export_count);
   if (e->own_export_rows)
     (void)hipFree(e->export_rows);
@@ -1397,6 +1414,23 @@ static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
  * of the block - and, for the block at the grid's origin, none outside the
  * whole grid - means nothing to emit, and the pass over the packet ids can be
  * skipped altogether. */
+/* n <= 16 counters at `src` (device memory) as they are once the stream has
+ * run dry */
+static int read_counters(cmi_gpu_engine *e, const unsigned int *src, int n,
+                         unsigned int *out) {
+  if (!e->mailbox) {
+    HIP_TRY(hipHostMalloc(&e->mailbox, 16 * sizeof(unsigned int),
+                          hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&e->mailbox_dev, e->mailbox, 0));
+  }
+  mailbox_kernel<<<1, 16, 0, e->stream>>>(src, e->mailbox_dev, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < n; ++k)
+    out[k] = ((volatile unsigned int *)e->mailbox)[k];
+  return CMI_GPU_OK;
+}
+
 static bool block_emits_nothing(const cmi_gpu_engine *e) {
   if (e->model.continuous_type != 0)
     return false; /* its packets enter through every face of the box */
@@ -1730,9 +1764,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         HIP_TRY(hipGetLastError());
       }
       unsigned int nslots = 0;
-      HIP_TRY(hipMemcpyAsync(&nslots, d_nrows, sizeof(unsigned int),
-                             hipMemcpyDeviceToHost, e->stream));
-      HIP_TRY(hipStreamSynchronize(e->stream));
+      {
+        int rrc = read_counters(e, d_nrows, 1, &nslots);
+        if (rrc)
+          return rrc;
+      }
       if (nslots > e->tile_rows[cur].capacity)
         return fail(CMI_GPU_ENOMEM,
                     "tile rounds: %u flights, room for %u - flights were "
@@ -1761,9 +1797,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         tile_plan_kernel<<<1, CMI_TILE_PLAN_THREADS, 0, e->stream>>>(pa);
         HIP_TRY(hipGetLastError());
         unsigned int plan[2] = {0, 0}; /* flights, units of work */
-        HIP_TRY(hipMemcpyAsync(plan, d_nlive, 2 * sizeof(unsigned int),
-                               hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        {
+          int rrc = read_counters(e, d_nlive, 2, plan);
+          if (rrc)
+            return rrc;
+        }
         const unsigned int nlive = plan[0];
         if (nlive == 0)
           break;
@@ -1928,10 +1966,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
             <<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);
       HIP_TRY(hipGetLastError());
       unsigned int count = 0;
-      HIP_TRY(hipMemcpyAsync(&count, e->ready_queue.count,
-                             sizeof(unsigned int), hipMemcpyDeviceToHost,
-                             e->stream));
-      HIP_TRY(hipStreamSynchronize(e->stream));
+      {
+        int rrc = read_counters(e, e->ready_queue.count, 1, &count);
+        if (rrc)
+          return rrc;
+      }
       if (count == 0)
         break;
       const bool last = count < e->tune.reemit_inline_below ||

@@ -252,6 +252,58 @@ public:
   }
 };
 
+/* src/AsciiFilePhotonSourceDistribution.hpp:45-120: several stars, positions
+ * and luminosities from a YAML file
+ *   number of sources: N
+ *   source[i]:
+ *     position: [x, y, z]
+ *     luminosity: L
+ * The weights are the luminosities over their sum; the engine picks a source
+ * per packet by the cumulative weights (PhotonSource.cpp:74-93,222-227). */
+class AsciiFilePhotonSourceDistribution : public PhotonSourceDistribution {
+  std::vector<CoordinateVector> _source_positions;
+  std::vector<double> _source_luminosities;
+  double _total_luminosity = 0.;
+
+public:
+  explicit AsciiFilePhotonSourceDistribution(const std::string &filename) {
+    ParameterFile blocks(filename);
+    const long long n = blocks.get_integer("number of sources", -1);
+    if (n < 0)
+      throw ParameterError("Parameter \"number of sources\" not found in \"" +
+                           filename + "\"!");
+    for (long long i = 0; i < n; ++i) {
+      const std::string b = "source[" + std::to_string(i) + "]:";
+      if (!blocks.has_value(b + "position") ||
+          !blocks.has_value(b + "luminosity"))
+        throw ParameterError("Source " + std::to_string(i) + " of \"" +
+                             filename +
+                             "\" needs a position and a luminosity!");
+      const std::array<double, 3> pos = blocks.get_physical_vector(
+          QUANTITY_LENGTH, b + "position", "[0. m, 0. m, 0. m]");
+      _source_positions.push_back(CoordinateVector(pos[0], pos[1], pos[2]));
+      _source_luminosities.push_back(blocks.get_physical_value(
+          QUANTITY_FREQUENCY, b + "luminosity", "0. s^-1"));
+      _total_luminosity += _source_luminosities.back();
+    }
+    std::ofstream ofile(filename + ".used-values");
+    blocks.print_contents(ofile);
+  }
+  explicit AsciiFilePhotonSourceDistribution(ParameterFile &params)
+      : AsciiFilePhotonSourceDistribution(params.get_string(
+            "PhotonSourceDistribution:filename", "sources.yml")) {}
+  photonsourcenumber_t get_number_of_sources() const override {
+    return (photonsourcenumber_t)_source_positions.size();
+  }
+  CoordinateVector get_position(photonsourcenumber_t index) override {
+    return _source_positions[index];
+  }
+  double get_weight(photonsourcenumber_t index) const override {
+    return _source_luminosities[index] / _total_luminosity;
+  }
+  double get_total_luminosity() const override { return _total_luminosity; }
+};
+
 /* src/SingleStarPhotonSourceDistribution.hpp:41-100 */
 class SingleStarPhotonSourceDistribution : public PhotonSourceDistribution {
   const CoordinateVector _position;
@@ -285,10 +337,12 @@ generate_photon_source_distribution(ParameterFile &params) {
       params.get_string("PhotonSourceDistribution:type", "SingleStar");
   if (type == "SingleStar")
     return new SingleStarPhotonSourceDistribution(params);
+  if (type == "AsciiFile")
+    return new AsciiFilePhotonSourceDistribution(params);
   if (type == "None")
     return nullptr;
-  throw ParameterError("Unknown PhotonSourceDistribution type: \"" + type +
-                       "\"");
+  throw ParameterError("PhotonSourceDistribution type \"" + type +
+                       "\" is not on this path (SingleStar, AsciiFile, None)");
 }
 
 /* -------------------------------------------------- PhotonSourceSpectrum */

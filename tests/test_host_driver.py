@@ -380,3 +380,39 @@ def test_cmi_gpu_executable_with_a_continuous_source(exe, tmp_path, oracle):
     assert np.allclose(last[:, 5], sim.x[0], rtol=2e-3, atol=0.)
     # the background keeps the corners of the box ionized too
     assert last[0, 5] < 0.5
+
+
+def test_ascii_file_source_distribution(exe, tmp_path):
+    """PhotonSourceDistribution type AsciiFile
+    (src/AsciiFilePhotonSourceDistribution.hpp:45-120): several stars from a
+    YAML file; weights = luminosities over their sum."""
+    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    old = ("PhotonSourceDistribution:\n  type: SingleStar\n"
+           "  position: [0. pc, 0. pc, 0. pc]\n  luminosity: 4.26e49 s^-1\n")
+    assert old in text
+    text = text.replace(old, "PhotonSourceDistribution:\n  type: AsciiFile\n"
+                             "  filename: stars.yml\n")
+    (tmp_path / "stars.yml").write_text(
+        "number of sources: 3\n"
+        "source[0]:\n  position: [1. pc, 0. pc, 0. pc]\n"
+        "  luminosity: 1.e49 s^-1\n"
+        "source[1]:\n  position: [-2. pc, 1. pc, 0.5 pc]\n"
+        "  luminosity: 3.e49 s^-1\n"
+        "source[2]:\n  position: [0. pc, -3. pc, 2. pc]\n"
+        "  luminosity: 4.e49 s^-1\n")
+    p = tmp_path / "multi.param"
+    p.write_text(text)
+    d = describe(exe, str(p), str(tmp_path))
+    pc = 3.086e16
+    assert abs(d["total_luminosity"] - 8.e49) <= 1e-15 * 8.e49
+    assert np.allclose([s["weight"] for s in d["sources"]],
+                       [0.125, 0.375, 0.5], rtol=1e-15)
+    assert np.allclose([s["position"] for s in d["sources"]],
+                       [[pc, 0., 0.], [-2. * pc, pc, 0.5 * pc],
+                        [0., -3. * pc, 2. * pc]], rtol=1e-12)
+    assert os.path.exists(tmp_path / "stars.yml.used-values")
+    # a file without the count is an error message, not an abort
+    (tmp_path / "stars.yml").write_text("source[0]:\n  luminosity: 1 s^-1\n")
+    r = subprocess.run([exe, "--params", str(p), "--dry-run"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 1 and "number of sources" in r.stderr

@@ -2249,6 +2249,54 @@ int cmi_gpu_update_cells_range(cmi_gpu_engine *e, uint32_t loop,
   return CMI_GPU_OK;
 }
 
+int cmi_gpu_compute_emissivities(cmi_gpu_engine *e, int32_t nlines,
+                                 const int32_t *lines, int64_t first_cell,
+                                 int64_t ncell, double *emissivities) {
+  if (!e || !lines || !emissivities)
+    return fail(CMI_GPU_EINVAL, "compute_emissivities: null argument");
+  if (nlines < 1 || nlines > CMI_NEMISSIONLINE)
+    return fail(CMI_GPU_EINVAL, "compute_emissivities: %d lines asked for, "
+                "there are %d", (int)nlines, CMI_NEMISSIONLINE);
+  if (first_cell < 0 || ncell < 0 || first_cell + ncell > e->ncell)
+    return fail(CMI_GPU_EINVAL, "compute_emissivities: cells [%lld, %lld) are "
+                "not inside the engine's %lld cells", (long long)first_cell,
+                (long long)(first_cell + ncell), (long long)e->ncell);
+  if (!e->have_cells)
+    return fail(CMI_GPU_ESTATE,
+                "compute_emissivities: cell data must be set first");
+  EmissivityArgs a;
+  a.model = e->model;
+  a.cells = e->cells;
+  a.first = first_cell;
+  a.count = ncell;
+  a.nlines = nlines;
+  for (int32_t l = 0; l < nlines; ++l) {
+    if (lines[l] < 0 || lines[l] >= CMI_NEMISSIONLINE)
+      return fail(CMI_GPU_EINVAL, "compute_emissivities: no emission line %d",
+                  (int)lines[l]);
+    a.lines[l] = lines[l];
+  }
+  if (ncell == 0)
+    return CMI_GPU_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  double *d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(double) * (size_t)nlines * (size_t)ncell));
+  a.out = d;
+  emissivity_kernel<<<grid_blocks(e, ncell, 8), CMI_BLOCK, 0, e->stream>>>(a);
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess)
+    err = hipStreamSynchronize(e->stream);
+  if (err == hipSuccess)
+    err = hipMemcpy(emissivities, d,
+                    sizeof(double) * (size_t)nlines * (size_t)ncell,
+                    hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (err != hipSuccess)
+    return fail(CMI_GPU_EDEVICE, "compute_emissivities: %s",
+                hipGetErrorString(err));
+  return CMI_GPU_OK;
+}
+
 int cmi_gpu_refresh_transport_records(cmi_gpu_engine *e) {
   if (!e)
     return fail(CMI_GPU_EINVAL, "null engine");

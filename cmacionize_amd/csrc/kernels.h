@@ -7,6 +7,7 @@
 #include "device_transport.h"
 #include "device_reemit.h"
 #include "device_thermal.h"
+#include "device_emissivity.h"
 
 #define CMI_BLOCK 256
 /* the "exp_no_atomics" experiments (results are wrong by design) exist only in
@@ -1495,6 +1496,35 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     a.cells.opacity[c] = (ntot > 0.)
                              ? make_double2(ntot * x[ION_H_n], ntot * x[ION_He_n])
                              : make_double2(-1., 0.);
+  }
+}
+
+/* EmissivityCalculator::calculate_emissivities over the grid
+ * (src/EmissivityCalculator.cpp:439-470): one cell per lane, the selected
+ * lines written as out[k][cell - first]. Post-processing of the final grid. */
+struct EmissivityArgs {
+  ModelDev model;
+  CellsDev cells;
+  int64_t first, count;
+  int32_t nlines;
+  int32_t lines[CMI_NEMISSIONLINE];
+  double *out;
+};
+
+__global__ void __launch_bounds__(CMI_BLOCK)
+    emissivity_kernel(const EmissivityArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.count;
+       k += stride) {
+    const int64_t c = a.first + k;
+    double x[CMI_NION], values[CMI_NEMISSIONLINE];
+#pragma unroll
+    for (int i = 0; i < CMI_NION; ++i)
+      x[i] = a.cells.x[i][c];
+    cell_emissivities(a.model, a.cells.number_density[c],
+                      a.cells.temperature[c], x, values);
+    for (int l = 0; l < a.nlines; ++l)
+      a.out[(int64_t)l * a.count + k] = values[a.lines[l]];
   }
 }
 

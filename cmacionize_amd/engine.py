@@ -83,8 +83,20 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_get_launch_steps", "cmi_gpu_group_create",
     "cmi_gpu_group_destroy", "cmi_gpu_group_reduce_accumulators",
     "cmi_gpu_group_update_cells",
-    "cmi_gpu_group_exchange_flights",
+    "cmi_gpu_group_exchange_flights", "cmi_gpu_compute_emissivities",
 ]
+
+# the emission lines of EmissivityValues (src/EmissivityValues.hpp:36-81), in
+# the order cmi_gpu_compute_emissivities numbers them
+EMISSION_LINES = [
+    "HAlpha", "HBeta", "HII", "BALMER_JUMP_LOW", "BALMER_JUMP_HIGH",
+    "OI_6300", "OI_6364", "OII_3727", "OIII_5007", "OIII_4959", "OIII_4363",
+    "OIII_52mu", "OIII_88mu", "NII_5755", "NII_6548", "NII_6584",
+    "NeIII_3869", "NeIII_3968", "SII_6725", "SII_4072", "SIII_9405",
+    "SIII_6312", "SIII_19mu", "SIII_33mu", "avg_T", "avg_T_count",
+    "avg_nH_nHe", "avg_nH_nHe_count", "NeII_12mu", "NIII_57mu", "NeIII_15mu",
+    "NII_122mu", "CII_158mu", "CII_2325", "CIII_1908", "OII_7325", "SIV_10mu",
+    "HeI_5876", "Hrec_s", "WFC2_F439W", "WFC2_F555W", "WFC2_F675W"]
 
 _lib = None
 
@@ -176,6 +188,9 @@ def load_library():
     L.cmi_gpu_thermal_probe.argtypes = [vp, C.c_int64, C.c_int32, _dp, _dp,
                                         _dp, _dp, _dp, _dp, _dp]
     L.cmi_gpu_physics_probe.argtypes = [vp, C.c_int32, C.c_int64, _dp, _dp]
+    L.cmi_gpu_compute_emissivities.argtypes = [
+        vp, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_int64,
+        C.POINTER(C.c_double)]
     L.cmi_gpu_update_cells_range.argtypes = [vp, C.c_uint32, C.c_double,
                                              C.c_int64, C.c_int64]
     L.cmi_gpu_refresh_transport_records.argtypes = [vp]
@@ -487,6 +502,22 @@ class GpuEngine:
     def update_cells_range(self, loop, totweight, first_cell, ncell):
         self._check(self._lib.cmi_gpu_update_cells_range(
             self._h, loop, totweight, first_cell, ncell))
+
+    def compute_emissivities(self, lines=None, first_cell=0, ncell=None):
+        """EmissivityCalculator::calculate_emissivities
+        (src/EmissivityCalculator.cpp:439-470) for the cells [first_cell,
+        first_cell + ncell): {line name: array over those cells}. `lines` are
+        names from EMISSION_LINES (all of them by default)."""
+        names = list(EMISSION_LINES if lines is None else lines)
+        idx = np.array([EMISSION_LINES.index(n) for n in names],
+                       dtype=np.int32)
+        if ncell is None:
+            ncell = self.n - first_cell
+        out = np.empty((len(names), ncell))
+        self._check(self._lib.cmi_gpu_compute_emissivities(
+            self._h, len(names), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+            first_cell, ncell, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return dict(zip(names, out))
 
     def set_tuning(self, **kw):
         for k, v in kw.items():

@@ -335,6 +335,22 @@ int cmi_gpu_update_cells_range(cmi_gpu_engine *engine, uint32_t loop,
                                double totweight, int64_t first_cell,
                                int64_t ncell);
 
+/* replaces: EmissivityCalculator::calculate_emissivities over a block of the
+ * grid (src/EmissivityCalculator.cpp:126-430 per cell, :439-470 over the
+ * grid; LineCoolingData::get_line_strengths, src/LineCoolingData.cpp:1859-1952,
+ * and EmissivityCalculator::get_balmer_jump_emission, :42-116, under it).
+ * lines[nlines] picks emission lines by their index in EmissivityValues
+ * (src/EmissivityValues.hpp:36-81; CMI_GPU_NUMBER_OF_EMISSIONLINES of them),
+ * emissivities[k * ncell + c] receives line lines[k] of cell first_cell + c
+ * (J m^-3 s^-1; the avg_* entries are the reference's weights; all zero in a
+ * cell with x_H >= 0.2 or T <= 3000 K, :134). Needs the abundances
+ * (cmi_gpu_set_abundances) and a full-ion state; reads the cells as they are
+ * on the device. Synchronous: returns with the host array filled. */
+#define CMI_GPU_NUMBER_OF_EMISSIONLINES 42
+int cmi_gpu_compute_emissivities(cmi_gpu_engine *engine, int32_t nlines,
+                                 const int32_t *lines, int64_t first_cell,
+                                 int64_t ncell, double *emissivities);
+
 /* Performance knobs (no effect on what is computed, only on how):
  *   "sort_packets" (1)      process the packets of a launch in emission-
  *                           direction order, so that the lanes of a wave cross

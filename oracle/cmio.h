@@ -350,6 +350,17 @@ int cmio_solve_5x5(double A[5][5], double B[5]);
 double cmio_line_cooling(double temperature, double electron_density,
                          const double abundances[13]);
 /* accessors used to pin the data table (src/LineCoolingData.cpp:1410-1450) */
+/* LineCoolingData::get_line_strengths (src/LineCoolingData.cpp:1859-1952):
+ * out[10 e + t] = luminosity per hydrogen atom (J s^-1) of transition t
+ * (0-1, 0-2, 0-3, 0-4, 1-2, 1-3, 1-4, 2-3, 2-4, 3-4) of five-level ion e,
+ * out[100 + i] of the line of two-level ion i; 103 values */
+void cmio_line_strengths(double temperature, double electron_density,
+                         const double abundances[13], double *out);
+/* EmissivityCalculator (src/EmissivityCalculator.cpp): see cmio_emissivity.c */
+#define CMIO_NEMISSIONLINE 42
+void cmio_balmer_jump(double T, double out[4]);
+void cmio_emissivities(const cmio_model *model, double ntot, double T,
+                       const double *x, double *out);
 double cmio_lc_energy_difference(int element, int transition);
 double cmio_lc_transition_probability(int element, int transition);
 double cmio_lc_statistical_weight(int element, int level);

@@ -212,3 +212,43 @@ double cmio_line_cooling(double temperature, double electron_density,
   }
   return cooling;
 }
+
+/* LineCoolingData::get_line_strengths, src/LineCoolingData.cpp:1859-1952: the
+ * luminosity of every line per hydrogen atom (J s^-1): out[10 e + t] for
+ * transition t (order 0-1, 0-2, 0-3, 0-4, 1-2, 1-3, 1-4, 2-3, 2-4, 3-4) of the
+ * five-level ion e, out[100 + i] for the line of two-level ion i */
+void cmio_line_strengths(double temperature, double electron_density,
+                         const double abundances[13], double *out) {
+  lc_ensure();
+  const double kb = CMIO_BOLTZMANN;
+  const double prefactor =
+      g_lc.prefactor * electron_density / sqrt(temperature);
+  const double Tinv = 1. / temperature;
+  const double logT = log(temperature);
+  for (int e = 0; e < CMI_LC_NFIVE; ++e) {
+    double pop[5];
+    if (level_populations(e, prefactor, temperature, Tinv, logT, pop)) {
+      fprintf(stderr, "cmio: singular level matrix (element %d, T %g)\n", e,
+              temperature);
+      abort();
+    }
+    const cmi_lc_five_level *d = &cmi_lc_five[e];
+    const double pre = abundances[e] * kb;
+    for (int lo = 0; lo < 4; ++lo)
+      for (int hi = lo + 1; hi < 5; ++hi) {
+        const int t = TR[lo][hi];
+        out[CMI_LC_NTRANS * e + t] = pre * pop[hi] * d->A[t] * g_lc.energy[e][t];
+      }
+  }
+  for (int i = 0; i < CMI_LC_NTWO; ++i) {
+    const cmi_lc_two_level *d = &cmi_lc_two[i];
+    const double ksi = g_lc.two_energy[i];
+    const double cs = collision_strength(d->cs, prefactor, temperature, Tinv,
+                                         logT);
+    const double Texp = exp(-ksi * Tinv);
+    const double pop = cs * Texp * d->inv_weight[0] /
+                       (d->A + cs * (d->inv_weight[1] + Texp * d->inv_weight[0]));
+    out[CMI_LC_NTRANS * CMI_LC_NFIVE + i] =
+        abundances[CMI_LC_NFIVE + i] * kb * pop * ksi * d->A;
+  }
+}

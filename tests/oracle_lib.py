@@ -130,6 +130,10 @@ def lib():
                             C.c_uint64, C.POINTER(Photon), dp,
                             C.POINTER(C.c_uint32)]
     L.cmio_mix_sources.argtypes = [C.POINTER(Model)]
+    L.cmio_line_strengths.argtypes = [C.c_double, C.c_double, dp, dp]
+    L.cmio_balmer_jump.argtypes = [C.c_double, dp]
+    L.cmio_emissivities.argtypes = [C.POINTER(Model), C.c_double, C.c_double,
+                                    dp, dp]
     L.cmio_reset_grid.argtypes = [C.POINTER(Grid), C.POINTER(Cells)]
     L.cmio_update_cells.argtypes = [C.POINTER(Grid), C.POINTER(Model),
                                     C.POINTER(Cells), C.c_uint32, C.c_double]
@@ -392,6 +396,40 @@ class OracleSimulation:
             self.typecount[:] = 0.
             self.shoot(seed, loop, 0, n_packets)
             self.update(loop, self.totweight)
+
+
+NEMISSIONLINE = 42
+# EmissivityValues.hpp:36-81
+EMISSION_LINES = [
+    "HAlpha", "HBeta", "HII", "BALMER_JUMP_LOW", "BALMER_JUMP_HIGH",
+    "OI_6300", "OI_6364", "OII_3727", "OIII_5007", "OIII_4959", "OIII_4363",
+    "OIII_52mu", "OIII_88mu", "NII_5755", "NII_6548", "NII_6584",
+    "NeIII_3869", "NeIII_3968", "SII_6725", "SII_4072", "SIII_9405",
+    "SIII_6312", "SIII_19mu", "SIII_33mu", "avg_T", "avg_T_count",
+    "avg_nH_nHe", "avg_nH_nHe_count", "NeII_12mu", "NIII_57mu", "NeIII_15mu",
+    "NII_122mu", "CII_158mu", "CII_2325", "CIII_1908", "OII_7325", "SIV_10mu",
+    "HeI_5876", "Hrec_s", "WFC2_F439W", "WFC2_F555W", "WFC2_F675W"]
+
+
+def line_strengths(T, ne, abundances):
+    """LineCoolingData::get_line_strengths: 103 values (10 x 10 + 3)."""
+    a = np.ascontiguousarray(abundances, dtype=np.float64)
+    out = np.zeros(103)
+    lib().cmio_line_strengths(T, ne, _ptr(a), _ptr(out))
+    return out
+
+
+def balmer_jump(T):
+    out = np.zeros(4)
+    lib().cmio_balmer_jump(T, _ptr(out))
+    return out
+
+
+def emissivities(model, n, T, x):
+    xx = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros(NEMISSIONLINE)
+    lib().cmio_emissivities(C.byref(model), n, T, _ptr(xx), _ptr(out))
+    return out
 
 
 def num_threads():

@@ -1,0 +1,104 @@
+"""Pins the oracle's emissivity restatement (oracle/cmio_emissivity.c,
+cmio_line_strengths) against the reference's own fixtures:
+bjump_testdata.txt (test/testEmissivityCalculator.cpp:50-86, tolerance 1e-3)
+and linestr_testdata.txt (test/testLineCoolingData.cpp:151-330, 1e-5), both
+generated from Kenny Wood's Fortran code."""
+import numpy as np
+import pytest
+
+from test_oracle_pinning import load, rel_ok
+
+NI, NII, OI, OII, OIII, NeIII, SII, SIII, CII, CIII, NIII, NeII, SIV = range(13)
+T01, T02, T03, T04, T12, T13, T14, T23, T24, T34 = range(10)
+
+
+def five(ion, t):
+    return 10 * ion + t
+
+
+def test_balmer_jump(oracle):
+    data = load("bjump_testdata.txt")
+    assert len(data) > 50
+    for row in data:
+        got = oracle.balmer_jump(row[0])
+        for k in range(4):
+            # 1e-20 erg cm^3 s^-1 angstrom^-1 -> J m^3 s^-1 angstrom^-1
+            assert rel_ok(got[k], 1.e-20 * row[1 + k] * 1.e-13, 1.e-3), \
+                (row[0], k)
+
+
+def kennys_lines(ls):
+    """the quantities of Kenny's code, from the line strengths
+    (test/testLineCoolingData.cpp:187-250); None = not set there"""
+    return [
+        ls[five(OI, T03)] + ls[five(OI, T13)],                       # c6300
+        ls[five(SIII, T13)] + ls[five(SIII, T23)],                   # c9405
+        ls[five(SIII, T34)],                                         # c6312
+        ls[five(SIII, T01)],                                         # c33mu
+        ls[five(SIII, T12)],                                         # c19mu
+        ls[five(OII, T01)],                                          # c3729
+        ls[five(OII, T01)] + ls[five(OII, T02)],                     # c3727
+        None,                                                        # c7330
+        ls[five(OIII, T34)],                                         # c4363
+        ls[five(OIII, T23)],                                         # c5007
+        ls[five(OIII, T12)],                                         # c52mu
+        ls[five(OIII, T01)],                                         # c88mu
+        ls[five(NII, T34)],                                          # c5755
+        ls[five(NII, T23)],                                          # c6584
+        ls[five(SII, T03)] + ls[five(SII, T04)],                     # c4072
+        ls[five(SII, T02)],                                          # c6717
+        ls[five(SII, T01)] + ls[five(SII, T02)],                     # c6725
+        ls[five(NeIII, T03)],                                        # c3869
+        ls[100 + 0],                                                 # NIII 57
+        ls[100 + 1],                                                 # NeII 12
+        ls[five(NeIII, T01)],                                        # NeIII 15
+        ls[five(NII, T12)],                                          # NII 122
+        sum(ls[five(CII, t)] for t in (T02, T12, T03, T13, T04, T14)),
+        ls[five(CIII, T01)] + ls[five(CIII, T02)] + ls[five(CIII, T03)],
+        sum(ls[five(OII, t)] for t in (T14, T24, T13, T23)),         # 7325
+        None,                                                        # csiv10
+    ]
+
+
+def test_line_strengths(oracle):
+    data = load("linestr_testdata.txt")
+    assert len(data) > 50 and data.shape[1] == 2 + 13 + 26
+    for row in data:
+        T, ne, abund, ref = row[0], row[1] * 1.e6, row[2:15], row[15:]
+        got = kennys_lines(oracle.line_strengths(T, ne, abund))
+        for k, g in enumerate(got):
+            if g is None:
+                continue  # the reference's test compares them with 0
+            assert rel_ok(g, ref[k] * 1.e-7, 1.e-5), (T, ne, k, g, ref[k])
+
+
+def test_emissivities_of_a_cell(oracle):
+    """calculate_emissivities (src/EmissivityCalculator.cpp:126-430): the
+    cut-offs, the sums of line strengths, the recombination lines."""
+    sim = oracle.lexington_simulation(8)
+    m = sim.model
+    x = np.array([1.e-3, 2.e-2, 0.3, 0.1, 0.05, 0.4, 0.2, 0.02, 0.5, 0.3,
+                  0.2, 0.6, 0.2, 0.05])
+    n, T = 1.e8, 8500.
+    e = dict(zip(oracle.EMISSION_LINES, oracle.emissivities(m, n, T, x)))
+    # neutral or cold cells emit nothing (:131-134)
+    assert not oracle.emissivities(m, n, T, np.r_[0.25, x[1:]]).any()
+    assert not oracle.emissivities(m, n, 2900., x).any()
+    AHe = m.abundance[1]
+    nhp, nhep = n * (1. - x[0]), n * (1. - x[1]) * AHe
+    ne = nhp + nhep
+    assert e["HBeta"] == ne * nhp * 1.24e-38 * (T * 1.e-4) ** -0.878
+    assert abs(e["HAlpha"] / e["HBeta"] - 2.87 * (T * 1.e-4) ** -0.06) < 1e-12
+    assert e["avg_T"] == ne * nhp * T and e["avg_T_count"] == ne * nhp
+    jump = oracle.balmer_jump(T)
+    assert e["BALMER_JUMP_HIGH"] == ne * (nhp * jump[0] + nhep * jump[2])
+    # a sum of line strengths, by hand
+    AO = m.abundance[4]
+    abund = np.zeros(13)
+    abund[OIII] = AO * x[8]
+    ls = oracle.line_strengths(T, ne, abund)
+    assert rel_ok(e["OIII_5007"], n * ls[five(OIII, T23)], 1e-14)
+    assert rel_ok(e["OIII_5007"] / e["OIII_4959"],
+                  ls[five(OIII, T23)] / ls[five(OIII, T13)], 1e-13)
+    assert all(v >= 0. for v in e.values())
+    assert e["WFC2_F675W"] > e["HAlpha"] and e["WFC2_F555W"] > e["HBeta"]

@@ -113,6 +113,9 @@ public:
   std::array<std::vector<double>, NUMBER_OF_IONNAMES> _ionic_fraction,
       _mean_intensity;
   std::array<std::vector<double>, 2> _heating;
+  /* emission lines asked for with "EmissivityValues:<name>: true", computed
+   * for the final state (name of the dataset, values) */
+  std::vector<std::pair<std::string, std::vector<double>>> _emissivity;
 
 private:
   SimulationBox _box;
@@ -323,6 +326,10 @@ public:
         file.dataset("PartType0",
                      std::string("NeutralFraction") + ion_name(ion),
                      grid._ionic_fraction[ion]);
+    /* the datasets EmissivityCalculationSimulation appends to a snapshot,
+     * src/EmissivityCalculationSimulation.cpp:181-193,258-263 */
+    for (const auto &line : grid._emissivity)
+      file.dataset("PartType0", line.first, line.second);
     file.write(filename);
   }
 };
@@ -606,7 +613,73 @@ class GpuIonizationSimulation {
             "download");
   }
 
+  /* EmissivityCalculationSimulation (src/EmissivityCalculationSimulation.cpp:
+   * 58-299: reads a snapshot back, computes the lines flagged in
+   * "EmissivityValues:<name>" and appends them to the file) folded into the
+   * run: the final state is still on the device, so the flagged lines are
+   * computed there (cmi_gpu_compute_emissivities) and go into the last
+   * snapshot as the same datasets. */
+  std::vector<int32_t> _emission_lines;
+
+  void compute_emissivities() {
+    DensityGrid &g = *_density_grid;
+    g._emissivity.clear();
+    if (_emission_lines.empty())
+      return;
+    const int32_t nlines = (int32_t)_emission_lines.size();
+    const size_t n = (size_t)g.get_number_of_cells();
+    for (int32_t line : _emission_lines)
+      g._emissivity.emplace_back(emission_line_name(line),
+                                 std::vector<double>(n));
+    std::vector<double> values, part;
+    if (!decomposed()) {
+      values.resize((size_t)nlines * n);
+      check(cmi_gpu_compute_emissivities(_engine, nlines,
+                                         _emission_lines.data(), 0,
+                                         (int64_t)n, values.data()),
+            "compute_emissivities");
+      for (int32_t k = 0; k < nlines; ++k)
+        std::copy(values.begin() + (size_t)k * n,
+                  values.begin() + (size_t)(k + 1) * n,
+                  g._emissivity[k].second.begin());
+      return;
+    }
+    for (Block &b : _blocks) {
+      if (b.original >= 0)
+        continue;
+      const size_t nb = (size_t)b.ncell();
+      values.resize((size_t)nlines * nb);
+      check(cmi_gpu_compute_emissivities(b.engine, nlines,
+                                         _emission_lines.data(), 0,
+                                         (int64_t)nb, values.data()),
+            "compute_emissivities");
+      for (int32_t k = 0; k < nlines; ++k) {
+        part.assign(values.begin() + (size_t)k * nb,
+                    values.begin() + (size_t)(k + 1) * nb);
+        block_unslice(b, part, g._emissivity[k].second);
+      }
+    }
+  }
+
 public:
+  /* EmissivityValues::get_name, src/EmissivityValues.hpp:126-216 (the
+   * dataset names; [SIII] 6312 is spelled "SIII_6213" there) */
+  static const char *emission_line_name(int32_t line) {
+    static const char *const names[CMI_GPU_NUMBER_OF_EMISSIONLINES] = {
+        "Halpha",     "Hbeta",      "HII",        "BaLow",
+        "BaHigh",     "OI_6300",    "OI_6364",    "OII_3727",
+        "OIII_5007",  "OIII_4959",  "OIII_4363",  "OIII_52mu",
+        "OIII_88mu",  "NII_5755",   "NII_6548",   "NII_6584",
+        "NeIII_3869", "NeIII_3968", "SII_6725",   "SII_4072",
+        "SIII_9405",  "SIII_6213",  "SIII_19mu",  "SIII_33mu",
+        "avg_T",      "avg_T_count", "avg_nH_nHe", "avg_nH_nHe_count",
+        "NeII_12mu",  "NIII_57mu",  "NeIII_15mu", "NII_122mu",
+        "CII_158mu",  "CII_2325",   "CIII_1908",  "OII_7325",
+        "SIV_10mu",   "HeI_5876",   "Hrec_s",     "WFC2_F439W",
+        "WFC2_F555W", "WFC2_F675W"};
+    return names[line];
+  }
+
   /* IonizationSimulation ctor, src/IonizationSimulation.cpp:101-231.
    * num_thread is accepted for command-line compatibility; the device id
    * replaces it as the degree of freedom. */
@@ -660,6 +733,13 @@ public:
     if (_photon_source_distribution && !_photon_source_spectrum)
       throw ParameterError(
           "No spectrum provided for the discrete photon sources!");
+
+    /* src/EmissivityCalculationSimulation.cpp:70-74 */
+    for (int32_t line = 0; line < CMI_GPU_NUMBER_OF_EMISSIONLINES; ++line)
+      if (_parameter_file.get_bool(
+              std::string("EmissivityValues:") + emission_line_name(line),
+              false))
+        _emission_lines.push_back(line);
 
     const std::string output_folder = _parameter_file.get_string(
         "IonizationSimulation:output folder", ".");
@@ -1029,6 +1109,7 @@ public:
              std::to_string(_number_of_iterations) + ") reached, stopping.");
 
     download_state();
+    compute_emissivities();
     if (_density_grid_writer)
       _density_grid_writer->write(*_density_grid, _number_of_iterations,
                                   _parameter_file);

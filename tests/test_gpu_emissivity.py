@@ -146,13 +146,14 @@ def test_bad_arguments_are_refused():
     eng = lexington_engine(4)
     lib = E.load_library()
     out = (C.c_double * 64)()
-    line = (C.c_int32 * 1)(42)
-    assert lib.cmi_gpu_compute_emissivities(eng._h, 1, line, 0, 64, out) != 0
-    assert b"no emission line 42" in lib.cmi_gpu_last_error()
-    line[0] = 0
+    line = (C.c_int32 * 1)(0)
     assert lib.cmi_gpu_compute_emissivities(eng._h, 1, line, 0, 64, out) != 0
     assert b"cell data" in lib.cmi_gpu_last_error()
     eng.upload_cells(np.full(64, 1e8), np.full(64, 8000.), np.zeros((14, 64)))
+    line[0] = 42
+    assert lib.cmi_gpu_compute_emissivities(eng._h, 1, line, 0, 64, out) != 0
+    assert b"no emission line 42" in lib.cmi_gpu_last_error()
+    line[0] = 0
     assert lib.cmi_gpu_compute_emissivities(eng._h, 1, line, 60, 5, out) != 0
     assert lib.cmi_gpu_compute_emissivities(eng._h, 0, line, 0, 64, out) != 0
     assert lib.cmi_gpu_compute_emissivities(eng._h, 1, line, 0, 64, out) == 0

@@ -225,3 +225,50 @@ def test_gadget_snapshots_of_a_run(exe, tmp_path):  # noqa: F811
     assert sorted(n for n in os.listdir(out["Gadget"])
                   if n.endswith(".hdf5")) == ["stromgren_000.hdf5",
                                               "stromgren_003.hdf5"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks", [None, "2,1,2"])
+def test_emission_lines_in_the_final_snapshot(exe, tmp_path, oracle, blocks):
+    """"EmissivityValues:<name>: true" (the switches of the reference's
+    emission mode, src/EmissivityCalculationSimulation.cpp:70-74): the lines
+    are computed on the device from the final state and written as the
+    datasets that mode appends to a snapshot (:181-193) - checked against the
+    oracle's calculate_emissivities of the snapshot's own fields."""
+    import shutil
+    text = open(os.path.join(BENCH, "lexingtonHII40.param")).read()
+    text = text.replace("[64, 64, 64]", "[16, 16, 16]")
+    text = text.replace("number of photons: 1e8", "number of photons: 30000")
+    text = text.replace("number of iterations: 20", "number of iterations: 6")
+    text = text.replace("NumberDensity: 0", "NumberDensity: 1")
+    text += ("\nEmissivityValues:\n  Halpha: true\n  OIII_5007: true\n"
+             "  SIII_6213: true\n  BaHigh: true\n  NII_6584: false\n")
+    shutil.copy(os.path.join(BENCH, "lexingtonHII40.yml"), tmp_path)
+    p = tmp_path / "run.param"
+    p.write_text(text)
+    r = subprocess.run([exe, "--params", str(p)] +
+                       (["--blocks", blocks] if blocks else []),
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    first = hdf5_mini.read(str(tmp_path / "lexingtonHII40_000.hdf5"))
+    assert "Halpha" not in first["/PartType0"].members
+    f = hdf5_mini.read(str(tmp_path / "lexingtonHII40_006.hdf5"))
+    assert "NII_6584" not in f["/PartType0"].members
+    ions = ["H", "He", "C+", "C++", "N", "N+", "N++", "O", "O+", "Ne", "Ne+",
+            "S+", "S++", "S+++"]
+    x = np.array([f["/PartType0/NeutralFraction" + i].data for i in ions])
+    n = f["/PartType0/NumberDensity"].data
+    T = f["/PartType0/Temperature"].data
+    sim = oracle.lexington_simulation(4)
+    index = {"Halpha": "HAlpha", "OIII_5007": "OIII_5007",
+             "SIII_6213": "SIII_6312", "BaHigh": "BALMER_JUMP_HIGH"}
+    lit = np.flatnonzero((x[0] < 0.2) & (T > 3000.))
+    assert len(lit) > 100
+    for name, line in index.items():
+        values = f["/PartType0/" + name].data
+        assert values.shape == (16 ** 3,)
+        assert not values[(x[0] >= 0.2) | (T <= 3000.)].any()
+        k = oracle.EMISSION_LINES.index(line)
+        for c in lit[::5]:
+            ref = oracle.emissivities(sim.model, n[c], T[c], x[:, c])[k]
+            assert abs(values[c] - ref) <= 1e-10 * ref, (name, c)

@@ -345,4 +345,19 @@ struct CountersDev {
   unsigned long long nwavesteps; /* hot-loop iterations summed over waves */
 };
 
+/* The counters exist CMI_COUNTER_SHARDS times, one 64-B line each; a wave adds
+ * its sums to the shard its index picks and the host adds the shards up.
+ * (Atomics on ONE line are served one after the other, ~100 per us on MI355X:
+ * the 8 adds of each of the ~8000 waves of a launch kept the last wave of
+ * every launch waiting for ~0.4 ms - more than the work of a late tile round.) */
+#define CMI_COUNTER_SHARDS 1024
+static_assert(sizeof(CountersDev) == 64, "one counter shard per 64-B line");
+
+#ifdef __HIPCC__
+__device__ __forceinline__ CountersDev *counter_shard(CountersDev *counters) {
+  return counters + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) &
+                     (CMI_COUNTER_SHARDS - 1));
+}
+#endif
+
 #endif

@@ -186,9 +186,35 @@ __global__ void mailbox_kernel(const unsigned int *src, unsigned int *dst,
   if ((int)threadIdx.x < n)
     dst[threadIdx.x] = src[threadIdx.x];
 }
-__global__ void snapshot_u64_kernel(const unsigned long long *src,
-                                    unsigned long long *dst) {
-  *dst = *src;
+/* the steps counted so far (summed over the shards) */
+__global__ void snapshot_steps_kernel(const CountersDev *counters,
+                                      unsigned long long *dst) {
+  unsigned long long sum = 0;
+  for (int k = threadIdx.x; k < CMI_COUNTER_SHARDS; k += 64)
+    sum += counters[k].nsteps;
+  for (int off = 32; off > 0; off >>= 1)
+    sum += __shfl_down(sum, off, 64);
+  if (threadIdx.x == 0)
+    *dst = sum;
+}
+
+/* all shards of the counters, added up */
+static int download_counters(cmi_gpu_engine *e, CountersDev &sum) {
+  std::vector<CountersDev> host(CMI_COUNTER_SHARDS);
+  HIP_TRY(hipMemcpyAsync(host.data(), e->counters,
+                         sizeof(CountersDev) * CMI_COUNTER_SHARDS,
+                         hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  sum = CountersDev();
+  for (const CountersDev &c : host) {
+    sum.totweight += c.totweight;
+    for (int i = 0; i < 4; ++i)
+      sum.typecount[i] += c.typecount[i];
+    sum.nsteps += c.nsteps;
+    sum.natomics += c.natomics;
+    sum.nwavesteps += c.nwavesteps;
+  }
+  return CMI_GPU_OK;
 }
 
 int timer_end(cmi_gpu_engine *e, std::vector<EventPair> &list, EventPair &ev,
@@ -210,8 +236,8 @@ int timer_end(cmi_gpu_engine *e, std::vector<EventPair> &list, EventPair &ev,
     if (!e->launch_steps)
       HIP_TRY(hipMalloc(&e->launch_steps,
                         sizeof(unsigned long long) * CMI_MAX_TIMED_LAUNCHES));
-    snapshot_u64_kernel<<<1, 1, 0, e->stream>>>(
-        &e->counters->nsteps, e->launch_steps + list.size());
+    snapshot_steps_kernel<<<1, 64, 0, e->stream>>>(
+        e->counters, e->launch_steps + list.size());
     HIP_TRY(hipGetLastError());
   }
   list.push_back(ev);
@@ -753,8 +779,9 @@ int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
   }
   HIP_TRY(hipMemsetAsync(e->acc_block, 0, CMI_NACC * field_bytes, e->stream));
   HIP_TRY(hipMalloc(&e->opacity, (size_t)e->ncell * sizeof(double2)));
-  HIP_TRY(hipMalloc(&e->counters, sizeof(CountersDev)));
-  HIP_TRY(hipMemsetAsync(e->counters, 0, sizeof(CountersDev), e->stream));
+  HIP_TRY(hipMalloc(&e->counters, sizeof(CountersDev) * CMI_COUNTER_SHARDS));
+  HIP_TRY(hipMemsetAsync(e->counters, 0,
+                         sizeof(CountersDev) * CMI_COUNTER_SHARDS, e->stream));
   HIP_TRY(hipMalloc(&e->tables, sizeof(TablesDev)));
   {
     e->host_tables = new TablesDev;
@@ -1203,7 +1230,8 @@ int cmi_gpu_reset_grid(cmi_gpu_engine *e) {
   HIP_TRY(hipMemsetAsync(e->acc_block, 0,
                          (size_t)CMI_NACC * e->ncell * sizeof(double),
                          e->stream));
-  HIP_TRY(hipMemsetAsync(e->counters, 0, sizeof(CountersDev), e->stream));
+  HIP_TRY(hipMemsetAsync(e->counters, 0,
+                         sizeof(CountersDev) * CMI_COUNTER_SHARDS, e->stream));
   return CMI_GPU_OK;
 }
 
@@ -2148,9 +2176,11 @@ int cmi_gpu_get_counters(cmi_gpu_engine *e, double *totweight,
     return fail(CMI_GPU_EINVAL, "null engine");
   HIP_TRY(hipSetDevice(e->device));
   CountersDev host;
-  HIP_TRY(hipMemcpyAsync(&host, e->counters, sizeof host,
-                         hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  {
+    int rc = download_counters(e, host);
+    if (rc)
+      return rc;
+  }
   if (totweight)
     *totweight = host.totweight;
   if (typecount)
@@ -2166,9 +2196,11 @@ int cmi_gpu_get_atomic_count(cmi_gpu_engine *e, uint64_t *natomics) {
     return fail(CMI_GPU_EINVAL, "get_atomic_count: bad argument");
   HIP_TRY(hipSetDevice(e->device));
   CountersDev host;
-  HIP_TRY(hipMemcpyAsync(&host, e->counters, sizeof host,
-                         hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  {
+    int rc = download_counters(e, host);
+    if (rc)
+      return rc;
+  }
   *natomics = host.natomics;
   return CMI_GPU_OK;
 }
@@ -2178,9 +2210,11 @@ int cmi_gpu_get_wave_steps(cmi_gpu_engine *e, uint64_t *nwavesteps) {
     return fail(CMI_GPU_EINVAL, "get_wave_steps: bad argument");
   HIP_TRY(hipSetDevice(e->device));
   CountersDev host;
-  HIP_TRY(hipMemcpyAsync(&host, e->counters, sizeof host,
-                         hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  {
+    int rc = download_counters(e, host);
+    if (rc)
+      return rc;
+  }
   *nwavesteps = host.nwavesteps;
   return CMI_GPU_OK;
 }

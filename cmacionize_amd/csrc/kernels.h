@@ -1009,14 +1009,14 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
   double ns = wave_sum((double)nsteps);
   double na = wave_sum((double)natomics);
   if (lane == 0) {
-    atomic_add_f64(&a.counters->totweight, (s0 + s1) + (s2 + s3));
-    atomic_add_f64(&a.counters->typecount[0], s0);
-    atomic_add_f64(&a.counters->typecount[1], s1);
-    atomic_add_f64(&a.counters->typecount[2], s2);
-    atomic_add_f64(&a.counters->typecount[3], s3);
-    atomicAdd(&a.counters->nsteps, (unsigned long long)ns);
-    atomicAdd(&a.counters->natomics, (unsigned long long)na);
-    atomicAdd(&a.counters->nwavesteps, (unsigned long long)nwavesteps);
+    atomic_add_f64(&counter_shard(a.counters)->totweight, (s0 + s1) + (s2 + s3));
+    atomic_add_f64(&counter_shard(a.counters)->typecount[0], s0);
+    atomic_add_f64(&counter_shard(a.counters)->typecount[1], s1);
+    atomic_add_f64(&counter_shard(a.counters)->typecount[2], s2);
+    atomic_add_f64(&counter_shard(a.counters)->typecount[3], s3);
+    atomicAdd(&counter_shard(a.counters)->nsteps, (unsigned long long)ns);
+    atomicAdd(&counter_shard(a.counters)->natomics, (unsigned long long)na);
+    atomicAdd(&counter_shard(a.counters)->nwavesteps, (unsigned long long)nwavesteps);
   }
 }
 
@@ -1226,11 +1226,11 @@ __global__ void __launch_bounds__(CMI_BLOCK, FULL ? 1 : CMI_INTERACT_WAVES_H)
     tc2 = wave_sum(tc2);
   }
   if (lane == 0 && tw != 0.) {
-    atomic_add_f64(&a.counters->totweight, tw);
-    atomic_add_f64(&a.counters->typecount[3], tc3);
+    atomic_add_f64(&counter_shard(a.counters)->totweight, tw);
+    atomic_add_f64(&counter_shard(a.counters)->typecount[3], tc3);
     if (ROWS && tc1 + tc2 != 0.) {
-      atomic_add_f64(&a.counters->typecount[1], tc1);
-      atomic_add_f64(&a.counters->typecount[2], tc2);
+      atomic_add_f64(&counter_shard(a.counters)->typecount[1], tc1);
+      atomic_add_f64(&counter_shard(a.counters)->typecount[2], tc2);
     }
   }
 }
@@ -1345,10 +1345,10 @@ __global__ void __launch_bounds__(CMI_BLOCK, FULL ? 1 : CMI_INTERACT_WAVES_H)
   tc2 = wave_sum(tc2);
   tc3 = wave_sum(tc3);
   if (lane == 0 && tw != 0.) {
-    atomic_add_f64(&a.counters->totweight, tw);
-    atomic_add_f64(&a.counters->typecount[1], tc1);
-    atomic_add_f64(&a.counters->typecount[2], tc2);
-    atomic_add_f64(&a.counters->typecount[3], tc3);
+    atomic_add_f64(&counter_shard(a.counters)->totweight, tw);
+    atomic_add_f64(&counter_shard(a.counters)->typecount[1], tc1);
+    atomic_add_f64(&counter_shard(a.counters)->typecount[2], tc2);
+    atomic_add_f64(&counter_shard(a.counters)->typecount[3], tc3);
   }
 }
 

@@ -659,15 +659,15 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS, (!FULL && HEAT) ? 2 : 4)
   const double na = wave_sum((double)natomics);
   if (lane == 0) {
     if ((s0 + s1) + (s2 + s3) != 0.) {
-      atomic_add_f64(&a.counters->totweight, (s0 + s1) + (s2 + s3));
-      atomic_add_f64(&a.counters->typecount[0], s0);
-      atomic_add_f64(&a.counters->typecount[1], s1);
-      atomic_add_f64(&a.counters->typecount[2], s2);
-      atomic_add_f64(&a.counters->typecount[3], s3);
+      atomic_add_f64(&counter_shard(a.counters)->totweight, (s0 + s1) + (s2 + s3));
+      atomic_add_f64(&counter_shard(a.counters)->typecount[0], s0);
+      atomic_add_f64(&counter_shard(a.counters)->typecount[1], s1);
+      atomic_add_f64(&counter_shard(a.counters)->typecount[2], s2);
+      atomic_add_f64(&counter_shard(a.counters)->typecount[3], s3);
     }
-    atomicAdd(&a.counters->nsteps, (unsigned long long)ns);
-    atomicAdd(&a.counters->natomics, (unsigned long long)na);
-    atomicAdd(&a.counters->nwavesteps, (unsigned long long)nwavesteps);
+    atomicAdd(&counter_shard(a.counters)->nsteps, (unsigned long long)ns);
+    atomicAdd(&counter_shard(a.counters)->natomics, (unsigned long long)na);
+    atomicAdd(&counter_shard(a.counters)->nwavesteps, (unsigned long long)nwavesteps);
   }
 }
 

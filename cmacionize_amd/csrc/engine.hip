@@ -108,6 +108,8 @@ struct cmi_gpu_engine {
   uint32_t *tile_iota = nullptr;
   TileItemDev *tile_items = nullptr;
   uint32_t *tile_begin = nullptr;      /* [ntiles + 2] */
+  /* counting sort of the slots by tile (null: too many tiles, radix sort) */
+  uint32_t *tile_blockhist = nullptr, *tile_total = nullptr;
   uint32_t *tile_ended_slot = nullptr; /* slot of each absorption record */
   unsigned int *tile_absorbed_count = nullptr; /* [units of work] */
   unsigned int *tile_absorbed_before = nullptr; /* their running totals */
@@ -138,6 +140,7 @@ struct cmi_gpu_engine {
     int tile_min_per_item = -1; /* flights per unit of work; -1 = auto */
     int tile_refill_threshold = 16;
     int tile_max_rounds = 1000;
+    bool tile_counting_sort = true; /* false: rocPRIM radix sort of the slots */
   } tune;
 
   /* device timing (HIP events around launches) is opt-in: set_tuning
@@ -1280,6 +1283,8 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
   else if (k == "tile_refill_threshold")
     e->tune.tile_refill_threshold =
         (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
+  else if (k == "tile_counting_sort")
+    e->tune.tile_counting_sort = value != 0;
   else if (k == "tile_max_rounds")
     e->tune.tile_max_rounds = (int)(value < 0 ? 0 : value);
   else
@@ -1397,9 +1402,12 @@ static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
       (sizeof(uint32_t) * ((size_t)t.ntiles + 2) + 255) & ~(size_t)255;
   const size_t count_bytes =
       (sizeof(unsigned int) * nitems + 255) & ~(size_t)255;
+  const bool counting = t.ntiles <= CMI_TILE_SORT_MAX_TILES;
+  const size_t hist_bytes =
+      counting ? sizeof(uint32_t) * (size_t)t.ntiles * CMI_TILE_SORT_BLOCKS : 0;
   const size_t total = 2 * (row_bytes + weight_bytes + key_bytes) +
-                       2 * key_bytes + begin_bytes + 2 * count_bytes +
-                       item_bytes;
+                       2 * key_bytes + 2 * begin_bytes + 2 * count_bytes +
+                       item_bytes + hist_bytes;
   HIP_TRY(hipMalloc(&e->tile_block, total));
   if (!e->tile_counts)
     HIP_TRY(hipMalloc(&e->tile_counts, 8 * sizeof(unsigned int)));
@@ -1421,11 +1429,15 @@ static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
   at += key_bytes;
   e->tile_begin = (uint32_t *)at;
   at += begin_bytes;
+  e->tile_total = counting ? (uint32_t *)at : nullptr;
+  at += begin_bytes;
   e->tile_absorbed_count = (unsigned int *)at;
   at += count_bytes;
   e->tile_absorbed_before = (unsigned int *)at;
   at += count_bytes;
   e->tile_items = (TileItemDev *)at;
+  at += item_bytes;
+  e->tile_blockhist = counting ? (uint32_t *)at : nullptr;
   iota_kernel<<<grid_blocks(e, (int64_t)n, 8), CMI_BLOCK, 0, e->stream>>>(
       e->tile_iota, n);
   HIP_TRY(hipGetLastError());
@@ -1805,10 +1817,6 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       for (int round = 0; nslots != 0; ++round) {
         /* sort the slots by tile (free slots last), cut the flights into
          * units of work */
-        HIP_TRY(cmi_sort_pairs(e->sort_temp, e->sort_temp_bytes,
-                               e->tile_rows[cur].keys, e->sort_keys[1],
-                               e->tile_iota, e->sort_ids[1], nslots, tile_bits,
-                               e->stream));
         TilePlanArgs pa;
         pa.tiles = tg;
         pa.sorted_keys = e->sort_keys[1];
@@ -1819,9 +1827,32 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         pa.nitems = d_nitems;
         pa.next_item = d_next;
         pa.nlive = d_nlive;
-        tile_begin_kernel<<<grid_blocks(e, (int64_t)nslots + 1, 8), CMI_BLOCK,
-                            0, e->stream>>>(pa);
-        HIP_TRY(hipGetLastError());
+        if (e->tile_blockhist && e->tune.tile_counting_sort) {
+          TileSortArgs sa;
+          sa.keys = e->tile_rows[cur].keys;
+          sa.nslots = nslots;
+          sa.ntiles = (uint32_t)tg.ntiles;
+          sa.blockhist = e->tile_blockhist;
+          sa.total = e->tile_total;
+          sa.tile_begin = e->tile_begin;
+          sa.order = e->sort_ids[1];
+          tile_count_kernel<<<CMI_TILE_SORT_BLOCKS, CMI_TILE_SORT_THREADS, 0,
+                              e->stream>>>(sa);
+          tile_column_kernel<<<(sa.ntiles + CMI_BLOCK - 1) / CMI_BLOCK,
+                               CMI_BLOCK, 0, e->stream>>>(sa);
+          tile_offsets_kernel<<<1, CMI_TILE_SORT_THREADS, 0, e->stream>>>(sa);
+          tile_scatter_kernel<<<CMI_TILE_SORT_BLOCKS, CMI_TILE_SORT_THREADS, 0,
+                                e->stream>>>(sa);
+          HIP_TRY(hipGetLastError());
+        } else {
+          HIP_TRY(cmi_sort_pairs(e->sort_temp, e->sort_temp_bytes,
+                                 e->tile_rows[cur].keys, e->sort_keys[1],
+                                 e->tile_iota, e->sort_ids[1], nslots,
+                                 tile_bits, e->stream));
+          tile_begin_kernel<<<grid_blocks(e, (int64_t)nslots + 1, 8),
+                              CMI_BLOCK, 0, e->stream>>>(pa);
+          HIP_TRY(hipGetLastError());
+        }
         tile_plan_kernel<<<1, CMI_TILE_PLAN_THREADS, 0, e->stream>>>(pa);
         HIP_TRY(hipGetLastError());
         unsigned int plan[2] = {0, 0}; /* flights, units of work */
@@ -1850,7 +1881,6 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
           ca.from = e->tile_rows[cur];
           ca.to = e->tile_rows[1 - cur];
           ca.order = e->sort_ids[1];
-          ca.sorted_keys = e->sort_keys[1];
           ca.nlive = d_nlive;
           ca.with_weights = e->full_ions ? 1 : 0;
           tile_compact_kernel<<<grid_blocks(e, 8ll * nlive, 8), CMI_BLOCK, 0,

@@ -118,6 +118,130 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   }
 }
 
+/* The slots in tile order by counting, when a workgroup's LDS holds one
+ * counter per tile (a radix sort needs two passes over 13..15 key bits and
+ * carries the dead slots along; counting reads the keys twice and writes only
+ * the order of the live ones): CMI_TILE_SORT_BLOCKS workgroups own one
+ * contiguous chunk of the slots each;
+ *   tile_count_kernel   the chunk's flights per tile -> blockhist[b][tile]
+ *   tile_column_kernel  per tile, over the chunks: blockhist[b][tile] becomes
+ *                       the number of that tile's flights in earlier chunks,
+ *                       total[tile] their number in all
+ *   tile_offsets_kernel exclusive scan of total -> tile_begin (one workgroup)
+ *   tile_scatter_kernel order[tile_begin[tile] + blockhist[b][tile] + rank in
+ *                       the chunk] = slot
+ * The order of a tile's flights within a chunk is whatever the LDS atomics
+ * make it: it only decides which unit of work a flight lands in. */
+#define CMI_TILE_SORT_BLOCKS 256
+#define CMI_TILE_SORT_THREADS 1024
+#define CMI_TILE_SORT_MAX_TILES 32768
+
+struct TileSortArgs {
+  const uint32_t *keys;
+  unsigned int nslots;
+  uint32_t ntiles;
+  uint32_t *blockhist; /* [CMI_TILE_SORT_BLOCKS][ntiles] */
+  uint32_t *total;     /* [ntiles] */
+  uint32_t *tile_begin; /* [ntiles + 2] */
+  uint32_t *order;
+};
+
+__device__ __forceinline__ void tile_sort_chunk(const TileSortArgs &a,
+                                                uint64_t &first,
+                                                uint64_t &last) {
+  const uint64_t chunk =
+      ((uint64_t)a.nslots + CMI_TILE_SORT_BLOCKS - 1) / CMI_TILE_SORT_BLOCKS;
+  first = (uint64_t)blockIdx.x * chunk;
+  last = first + chunk < a.nslots ? first + chunk : a.nslots;
+}
+
+__global__ void __launch_bounds__(CMI_TILE_SORT_THREADS)
+    tile_count_kernel(const TileSortArgs a) {
+  __shared__ uint32_t count[CMI_TILE_SORT_MAX_TILES];
+  for (uint32_t t = threadIdx.x; t < a.ntiles; t += CMI_TILE_SORT_THREADS)
+    count[t] = 0;
+  __syncthreads();
+  uint64_t first, last;
+  tile_sort_chunk(a, first, last);
+  for (uint64_t i = first + threadIdx.x; i < last; i += CMI_TILE_SORT_THREADS) {
+    const uint32_t key = a.keys[i];
+    if (key < a.ntiles)
+      atomicAdd(&count[key], 1u);
+  }
+  __syncthreads();
+  uint32_t *mine = a.blockhist + (size_t)blockIdx.x * a.ntiles;
+  for (uint32_t t = threadIdx.x; t < a.ntiles; t += CMI_TILE_SORT_THREADS)
+    mine[t] = count[t];
+}
+
+__global__ void __launch_bounds__(CMI_BLOCK)
+    tile_column_kernel(const TileSortArgs a) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.ntiles)
+    return;
+  uint32_t run = 0;
+  uint32_t *column = a.blockhist + t;
+  for (int b = 0; b < CMI_TILE_SORT_BLOCKS; b += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      v[k] = column[(size_t)(b + k) * a.ntiles];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      column[(size_t)(b + k) * a.ntiles] = run;
+      run += v[k];
+    }
+  }
+  a.total[t] = run;
+}
+
+__global__ void __launch_bounds__(CMI_TILE_SORT_THREADS)
+    tile_offsets_kernel(const TileSortArgs a) {
+  __shared__ uint32_t partial[CMI_TILE_SORT_THREADS];
+  const uint32_t per =
+      (a.ntiles + CMI_TILE_SORT_THREADS - 1) / CMI_TILE_SORT_THREADS;
+  const uint32_t t0 = threadIdx.x * per;
+  const uint32_t t1 = t0 + per < a.ntiles ? t0 + per : a.ntiles;
+  uint32_t mine = 0;
+  for (uint32_t t = t0; t < t1; ++t)
+    mine += a.total[t];
+  partial[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 1; off < CMI_TILE_SORT_THREADS; off <<= 1) {
+    const uint32_t v =
+        threadIdx.x >= (unsigned)off ? partial[threadIdx.x - off] : 0u;
+    __syncthreads();
+    partial[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t at = partial[threadIdx.x] - mine;
+  for (uint32_t t = t0; t < t1; ++t) {
+    a.tile_begin[t] = at;
+    at += a.total[t];
+  }
+  if (threadIdx.x == CMI_TILE_SORT_THREADS - 1) {
+    /* the dead slots follow the flights (tile_begin_kernel's convention) */
+    a.tile_begin[a.ntiles] = partial[threadIdx.x];
+    a.tile_begin[a.ntiles + 1] = a.nslots;
+  }
+}
+
+__global__ void __launch_bounds__(CMI_TILE_SORT_THREADS)
+    tile_scatter_kernel(const TileSortArgs a) {
+  __shared__ uint32_t cursor[CMI_TILE_SORT_MAX_TILES];
+  const uint32_t *mine = a.blockhist + (size_t)blockIdx.x * a.ntiles;
+  for (uint32_t t = threadIdx.x; t < a.ntiles; t += CMI_TILE_SORT_THREADS)
+    cursor[t] = a.tile_begin[t] + mine[t];
+  __syncthreads();
+  uint64_t first, last;
+  tile_sort_chunk(a, first, last);
+  for (uint64_t i = first + threadIdx.x; i < last; i += CMI_TILE_SORT_THREADS) {
+    const uint32_t key = a.keys[i];
+    if (key < a.ntiles)
+      a.order[atomicAdd(&cursor[key], 1u)] = (uint32_t)i;
+  }
+}
+
 /* ... then the units of work: at most item_flights flights of one tile each.
  * One workgroup. */
 __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
@@ -167,7 +291,6 @@ __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
 struct TileCompactArgs {
   FlightRowsDev from, to;
   const uint32_t *order;
-  const uint32_t *sorted_keys;
   const unsigned int *nlive;
   int32_t with_weights;
 };
@@ -192,7 +315,7 @@ __global__ void __launch_bounds__(CMI_BLOCK)
           w[part];
     }
     if (part == 0)
-      a.to.keys[j] = a.sorted_keys[j];
+      a.to.keys[j] = a.from.keys[src];
   }
 }
 

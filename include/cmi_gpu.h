@@ -399,6 +399,9 @@ int cmi_gpu_compute_emissivities(cmi_gpu_engine *engine, int32_t nlines,
  *                           flights of one tile), are left
  *   "tile_refill_threshold" (16)  idle lanes of a wave that trigger a refill
  *                           in the tile kernel
+ *   "tile_counting_sort" (1)  the slots are put in tile order by counting
+ *                           (per-tile counters in LDS; up to 32768 tiles) -
+ *                           0: by rocPRIM's radix sort
  *   "timing" (0)            record HIP events around every launch for
  *                           cmi_gpu_get_timing / _kernel_timing /
  *                           _launch_times (off: a run creates no events)

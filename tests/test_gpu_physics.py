@@ -141,6 +141,8 @@ def test_temperature_solve_fixture(oracle):
     # hand-over to the transport kernel / refilling lane by lane
     dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0),
     dict(tile_rounds=1, tile_min_flights=700, tile_min_per_item=0),
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0,
+         tile_counting_sort=0),
     dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=3,
          reemit_inline_below=0),
     dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0, tile_refill_threshold=1,
@@ -188,6 +190,8 @@ def test_diffuse_stromgren_shoot_matches_oracle(oracle, tuning):
 @pytest.mark.parametrize("tuning", [
     dict(),
     dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0),
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0,
+         tile_counting_sort=0),
     dict(tile_rounds=0),
 ])
 def test_lexington_iteration_matches_oracle(oracle, tuning):

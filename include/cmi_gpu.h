@@ -391,14 +391,15 @@ int cmi_gpu_compute_emissivities(cmi_gpu_engine *engine, int32_t nlines,
  *                           with the tile's transport records and accumulators
  *                           in LDS (written back with full-line atomics)
  *                           instead of one memory-side atomic per DDA step
- *   "tile_min_flights" (100000), "tile_min_per_item" (-1 = auto: 400, or 200
- *                           for multi-ion transport), "tile_max_rounds" (1000)
+ *   "tile_min_flights" (100000), "tile_min_per_item" (-1 = auto: 200), "tile_max_rounds" (1000)
  *                           the rounds end - and passes of the transport
  *                           kernel take over - once fewer flights than this,
  *                           or fewer than this per unit of work (<= 4096
  *                           flights of one tile), are left
- *   "tile_refill_threshold" (16)  idle lanes of a wave that trigger a refill
+ *   "tile_refill_threshold" (48)  idle lanes of a wave that trigger a refill
  *                           in the tile kernel
+ *   "tile_compact_ratio" (2)  free slots are squeezed out of the flight rows
+ *                           once there are this many slots per flight
  *   "tile_counting_sort" (1)  the slots are put in tile order by counting
  *                           (per-tile counters in LDS; up to 32768 tiles) -
  *                           0: by rocPRIM's radix sort

@@ -26,6 +26,7 @@
 #define CMI_HOST_PLUGINS_HPP
 
 #include "../../include/cmi_gpu.h"
+#include "Hdf5Reader.hpp"
 #include "ParameterFile.hpp"
 
 #include <array>
@@ -213,6 +214,171 @@ public:
 };
 
 /* src/DensityFunctionFactory.hpp:138-172 (types on this path) */
+/* src/CMacIonizeSnapshotDensityFunction.cpp:42-549: the density field of a
+ * snapshot this code (or the reference) wrote - restart from a snapshot, or
+ * start a run on another resolution from it. Snapshots of Cartesian grids
+ * only (the grid of this path); the cells of the snapshot are found by their
+ * midpoints (:298-311), a cell of the new grid takes the values of the
+ * snapshot cell its midpoint lies in (:478-496). Read with the dependency-free
+ * Hdf5Reader. */
+class CMacIonizeSnapshotDensityFunction : public DensityFunction {
+  const std::string _filename;
+  const bool _use_density, _use_pressure;
+  const double _initial_neutral_fraction;
+  std::array<double, 3> _anchor, _sides;
+  std::array<long long, 3> _ncell;
+  std::vector<double> _number_density, _temperature;
+  std::array<std::vector<double>, NUMBER_OF_IONNAMES> _ionic_fraction;
+
+public:
+  CMacIonizeSnapshotDensityFunction(const std::string &filename,
+                                    bool use_density, bool use_pressure,
+                                    double initial_neutral_fraction)
+      : _filename(filename), _use_density(use_density),
+        _use_pressure(use_pressure),
+        _initial_neutral_fraction(initial_neutral_fraction) {
+    std::ifstream file(filename);
+    if (!file.is_open())
+      throw ParameterError("Could not open file \"" + filename + "\"!");
+  }
+  explicit CMacIonizeSnapshotDensityFunction(ParameterFile &params)
+      : CMacIonizeSnapshotDensityFunction(
+            params.get_filename("DensityFunction:filename"),
+            params.get_bool("DensityFunction:use density", false),
+            params.get_bool("DensityFunction:use pressure", false),
+            params.get_double("DensityFunction:initial neutral fraction",
+                              1.e-6)) {}
+
+  /* :118-436 */
+  void initialize() override {
+    Hdf5Reader file(_filename);
+    ParameterFile parameters;
+    for (const auto &kv : file.open("/Parameters").attributes)
+      parameters.add_value(kv.first, Hdf5Reader::as_string(kv.second));
+    _anchor = parameters.get_physical_vector(QUANTITY_LENGTH,
+                                             "SimulationBox:anchor", "");
+    _sides = parameters.get_physical_vector(QUANTITY_LENGTH,
+                                            "SimulationBox:sides", "");
+    _ncell = parameters.get_integer_vector("DensityGrid:number of cells",
+                                           {-1, -1, -1});
+    const std::string type =
+        parameters.get_string("DensityGrid:type", "TaskBased");
+    if (type != "Cartesian")
+      throw ParameterError("Reconstructing a density field from a " + type +
+                           "DensityGrid snapshot is not on this path "
+                           "(Cartesian only)");
+    /* :155-176 */
+    double unit_length_in_SI = 1., unit_density_in_SI = 1.,
+           unit_temperature_in_SI = 1.;
+    if (file.exists("/Units")) {
+      const Hdf5Reader::Object units = file.open("/Units");
+      auto number = [&](const char *name) {
+        const auto it = units.attributes.find(name);
+        if (it == units.attributes.end())
+          throw ParameterError(std::string("snapshot without \"") + name +
+                               "\"");
+        return Hdf5Reader::as_doubles(it->second).at(0);
+      };
+      unit_length_in_SI = 0.01 * number("Unit length in cgs (U_L)");
+      unit_density_in_SI =
+          1. / unit_length_in_SI / unit_length_in_SI / unit_length_in_SI;
+      unit_temperature_in_SI = number("Unit temperature in cgs (U_T)");
+    }
+    const std::vector<double> midpoints =
+        file.read_doubles("/PartType0/Coordinates");
+    std::vector<double> densities;
+    if (file.exists("/PartType0/NumberDensity") && !_use_density) {
+      densities = file.read_doubles("/PartType0/NumberDensity");
+    } else {
+      densities = file.read_doubles("/PartType0/Density");
+      unit_density_in_SI /= constants::proton_mass;
+    }
+    const size_t n = densities.size();
+    if (midpoints.size() != 3 * n)
+      throw ParameterError("snapshot with " + std::to_string(n) +
+                           " densities and " +
+                           std::to_string(midpoints.size() / 3) +
+                           " coordinates");
+    /* :213-224 */
+    std::array<std::vector<double>, NUMBER_OF_IONNAMES> fractions;
+    for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion) {
+      const std::string name =
+          std::string("/PartType0/NeutralFraction") + ion_name(ion);
+      if (file.exists(name))
+        fractions[ion] = file.read_doubles(name);
+      else
+        fractions[ion].assign(n, _initial_neutral_fraction);
+      if (fractions[ion].size() != n)
+        throw ParameterError("snapshot dataset " + name + " has the wrong size");
+    }
+    /* :230-243 */
+    std::vector<double> temperatures;
+    if (file.exists("/PartType0/Temperature") && !_use_pressure) {
+      temperatures = file.read_doubles("/PartType0/Temperature");
+    } else {
+      temperatures = file.read_doubles("/PartType0/Pressure");
+      for (size_t i = 0; i < temperatures.size(); ++i) {
+        const double mu = 0.5 * (1. + fractions[ION_H_n][i]);
+        temperatures[i] *= mu / (densities[i] * unit_density_in_SI *
+                                 constants::boltzmann * unit_temperature_in_SI);
+      }
+    }
+    if (temperatures.size() != n)
+      throw ParameterError("snapshot temperatures have the wrong size");
+    /* :298-330: every cell of the snapshot's grid from the cell that has its
+     * midpoint in it (the box anchor is the origin in the file) */
+    const size_t total = (size_t)_ncell[0] * _ncell[1] * _ncell[2];
+    _number_density.assign(total, -1.);
+    _temperature.assign(total, 0.);
+    for (auto &f : _ionic_fraction)
+      f.assign(total, 0.);
+    for (size_t i = 0; i < n; ++i) {
+      size_t index = 0;
+      for (int a = 0; a < 3; ++a) {
+        const double p = midpoints[3 * i + a] * unit_length_in_SI;
+        const long long k = (long long)(_ncell[a] * p / _sides[a]);
+        if (k < 0 || k >= _ncell[a])
+          throw ParameterError("snapshot cell outside the snapshot's box");
+        index = index * _ncell[a] + (size_t)k;
+      }
+      _number_density[index] = densities[i] * unit_density_in_SI;
+      _temperature[index] = temperatures[i] * unit_temperature_in_SI;
+      for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+        _ionic_fraction[ion][index] = fractions[ion][i];
+    }
+    for (size_t index = 0; index < total; ++index)
+      if (_number_density[index] < 0.)
+        throw ParameterError("No values found for cell " +
+                             std::to_string(index) + " of the snapshot!");
+  }
+
+  void free() override {
+    std::vector<double>().swap(_number_density);
+    std::vector<double>().swap(_temperature);
+    for (auto &f : _ionic_fraction)
+      std::vector<double>().swap(f);
+  }
+
+  /* :470-496 */
+  DensityValues operator()(const Cell &cell) override {
+    const CoordinateVector position = cell.get_cell_midpoint();
+    size_t index = 0;
+    for (int a = 0; a < 3; ++a) {
+      const long long k = (long long)(_ncell[a] * (position[a] - _anchor[a]) /
+                                      _sides[a]);
+      if (k < 0 || k >= _ncell[a])
+        throw ParameterError("cell midpoint outside the snapshot's box");
+      index = index * _ncell[a] + (size_t)k;
+    }
+    DensityValues values;
+    values.set_number_density(_number_density[index]);
+    values.set_temperature(_temperature[index]);
+    for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+      values.set_ionic_fraction(ion, _ionic_fraction[ion][index]);
+    return values;
+  }
+};
+
 inline DensityFunction *generate_density_function(ParameterFile &params) {
   const std::string type =
       params.get_string("DensityFunction:type", "Homogeneous");
@@ -220,9 +386,12 @@ inline DensityFunction *generate_density_function(ParameterFile &params) {
     return new HomogeneousDensityFunction(params);
   if (type == "BlockSyntax")
     return new BlockSyntaxDensityFunction(params);
+  if (type == "CMacIonizeSnapshot")
+    return new CMacIonizeSnapshotDensityFunction(params);
   throw ParameterError("Unknown DensityFunction type: \"" + type +
-                       "\" (this engine provides Homogeneous and BlockSyntax; "
-                       "pass your own DensityFunction to initialize())");
+                       "\" (this engine provides Homogeneous, BlockSyntax and "
+                       "CMacIonizeSnapshot; pass your own DensityFunction to "
+                       "initialize())");
 }
 
 /* ---------------------------------------------- PhotonSourceDistribution */

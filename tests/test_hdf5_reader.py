@@ -1,0 +1,380 @@
+"""Tests of the host's HDF5 reader (cmacionize_amd/host/Hdf5Reader.hpp) and of
+the CMacIonizeSnapshotDensityFunction on top of it
+(src/CMacIonizeSnapshotDensityFunction.cpp): CPU only.
+
+ * snapshots written by the host's own writer are read back, through a small
+   C++ helper (tests/support/hdf5_reader_cli.cpp), to the values the
+   independent pure-Python reader (tests/hdf5_mini.py) finds;
+ * a file laid out by hand below, after the HDF5 File Format Specification,
+   the way libhdf5 writes the reference's snapshots - chunked datasets behind
+   version-1 chunk B-trees (one and two levels), deflate and shuffle filters,
+   partial edge chunks, a continuation block in an object header - is read
+   correctly (the image has no libhdf5 to write it with);
+ * a run initialised from a snapshot (same grid, finer grid, coarser grid)."""
+import json
+import os
+import shutil
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import hdf5_mini
+from test_host_driver import BENCH, exe  # noqa: F401 (fixture)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def cli(tmp_path_factory):
+    out = tmp_path_factory.mktemp("hdf5cli") / "hdf5_reader_cli"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror",
+                    "-I", os.path.join(ROOT, "cmacionize_amd", "host"),
+                    "-o", str(out),
+                    os.path.join(ROOT, "tests", "support",
+                                 "hdf5_reader_cli.cpp"), "-lz"], check=True)
+    return str(out)
+
+
+def read(cli, filename, path):
+    r = subprocess.run([cli, filename, path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout)
+
+
+def lexington_params(ncell, extra=""):
+    text = open(os.path.join(BENCH, "lexingtonHII40.param")).read()
+    text = text.replace("[64, 64, 64]", "[%d, %d, %d]" % ((ncell,) * 3))
+    text = text.replace("NumberDensity: 0", "NumberDensity: 1")
+    return text + extra
+
+
+def dry_run_snapshot(exe, folder, text):
+    shutil.copy(os.path.join(BENCH, "lexingtonHII40.yml"), folder)
+    p = folder / "run.param"
+    p.write_text(text)
+    r = subprocess.run([exe, "--params", str(p), "--dry-run",
+                        "--dry-run-snapshot"], capture_output=True, text=True,
+                       cwd=str(folder))
+    assert r.returncode == 0, r.stderr + r.stdout
+    return str(folder / "lexingtonHII40_000.hdf5")
+
+
+def test_reader_against_the_python_reader(exe, cli, tmp_path):
+    snapshot = dry_run_snapshot(exe, tmp_path, lexington_params(10))
+    mine = hdf5_mini.read(snapshot)
+    root = read(cli, snapshot, "/")
+    assert sorted(root["members"]) == sorted(mine.root.members)
+    units = read(cli, snapshot, "/Units")["attributes"]
+    assert units["Unit length in cgs (U_L)"] == [100.]
+    header = read(cli, snapshot, "/Header")["attributes"]
+    assert header["NumPart_Total"] == [1000, 0, 0, 0, 0, 0]
+    assert header["BoxSize"] == list(mine["/Header"].attrs["BoxSize"])
+    params = read(cli, snapshot, "/Parameters")["attributes"]
+    assert params["DensityGrid:number of cells"] == "[10, 10, 10]"
+    assert params == dict(mine["/Parameters"].attrs)
+    group = read(cli, snapshot, "/PartType0")
+    assert sorted(group["members"]) == sorted(mine["/PartType0"].members)
+    for name in group["members"]:
+        got = read(cli, snapshot, "/PartType0/" + name)
+        ref = mine["/PartType0/" + name].data
+        assert got["dims"] == list(ref.shape)
+        assert np.array_equal(np.array(got["data"]), ref.ravel()), name
+    r = subprocess.run([cli, snapshot, "/PartType0/NoSuchThing"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "no object" in r.stderr
+
+
+# ---------------------------------------------------------------------------
+# an HDF5 file as libhdf5 lays the reference's snapshots out, by hand
+
+
+class Layout:
+    """appends blocks to a growing file image, 8-byte aligned"""
+
+    def __init__(self):
+        self.b = bytearray(96)  # room for the superblock
+
+    def add(self, block):
+        while len(self.b) % 8:
+            self.b.append(0)
+        at = len(self.b)
+        self.b += block
+        return at
+
+
+def message(mtype, body):
+    body = bytes(body) + b"\0" * (-len(body) % 8)
+    return struct.pack("<HHBBBB", mtype, len(body), 0, 0, 0, 0) + body
+
+
+def object_header(f, messages, continuation=None):
+    """version-1 object header; `continuation` = messages that go into a
+    second block, reached through a continuation message"""
+    n = len(messages) + (1 + len(continuation) if continuation else 0)
+    first = b"".join(messages)
+    if continuation:
+        second = b"".join(continuation)
+        at_second = f.add(second)
+        first += message(0x0010, struct.pack("<QQ", at_second, len(second)))
+    head = struct.pack("<BBHII", 1, 0, n, 1, len(first)) + b"\0" * 4
+    return f.add(head + first)
+
+
+DOUBLE = struct.pack("<BBBBIHHBBBBI", 0x11, 0x20, 63, 0, 8, 0, 64, 52, 11, 0,
+                     52, 1023)
+FLOAT = struct.pack("<BBBBIHHBBBBI", 0x11, 0x20, 31, 0, 4, 0, 32, 23, 8, 0, 23,
+                    127)
+INT32 = struct.pack("<BBBBIHH", 0x10, 0x08, 0, 0, 4, 0, 32)
+
+
+def dataspace(dims):
+    return struct.pack("<BBB5x", 1, len(dims), 0) + struct.pack(
+        "<%dQ" % len(dims), *dims)
+
+
+def filter_pipeline(ids):
+    """version 1: deflate (1) with its level, shuffle (2) with the size"""
+    out = struct.pack("<BB6x", 1, len(ids))
+    for i in ids:
+        out += struct.pack("<HHHH", i, 0, 1, 1) + struct.pack("<II", 8, 0)
+    return out
+
+
+def chunked_dataset(f, array, chunk, type_message, filters, levels=1,
+                    continuation=False):
+    array = np.ascontiguousarray(array)
+    rank = array.ndim
+    element = array.dtype.itemsize
+    keys = []
+    grid = [range(0, array.shape[d], chunk[d]) for d in range(rank)]
+    for offset in np.array(np.meshgrid(*grid, indexing="ij")).reshape(
+            rank, -1).T:
+        block = np.zeros(chunk, dtype=array.dtype)
+        sl = tuple(slice(o, min(o + c, s))
+                   for o, c, s in zip(offset, chunk, array.shape))
+        part = array[sl]
+        block[tuple(slice(0, n) for n in part.shape)] = part
+        data = block.tobytes()
+        for fid in filters:  # applied first to last when writing
+            if fid == 2:
+                data = np.frombuffer(data, np.uint8).reshape(
+                    -1, element).T.tobytes()
+            elif fid == 1:
+                data = zlib.compress(data, 6)
+        at = f.add(data)
+        keys.append((len(data), [int(o) for o in offset], at))
+
+    def key(nbytes, offset):
+        return struct.pack("<II", nbytes, 0) + struct.pack(
+            "<%dQ" % (rank + 1), *(offset + [0]))
+
+    def node(level, entries):
+        """entries: (size, offset, child address)"""
+        body = b""
+        for nbytes, offset, child in entries:
+            body += key(nbytes, offset) + struct.pack("<Q", child)
+        body += key(0, [int(s) for s in array.shape])
+        return f.add(b"TREE" + struct.pack("<BBHQQ", 1, level, len(entries),
+                                           UNDEF, UNDEF) + body)
+
+    if levels == 1:
+        btree = node(0, keys)
+    else:
+        half = (len(keys) + 1) // 2
+        leaves = [keys[:half], keys[half:]]
+        children = [(part[0][0], part[0][1], node(0, part))
+                    for part in leaves if part]
+        btree = node(1, children)
+    layout = struct.pack("<BBBQ", 3, 2, rank + 1, btree) + struct.pack(
+        "<%dI" % (rank + 1), *(list(chunk) + [element]))
+    msgs = [message(0x0001, dataspace(array.shape)),
+            message(0x0003, type_message)]
+    rest = [message(0x0008, layout)]
+    if filters:
+        rest.append(message(0x000B, filter_pipeline(filters)))
+    if continuation:
+        return object_header(f, msgs, continuation=rest)
+    return object_header(f, msgs + rest)
+
+
+def group(f, members):
+    """old-style group: local heap, one B-tree node, one symbol-table node"""
+    names = sorted(members)
+    heap = bytearray(8)  # offset 0: the empty name
+    offsets = {}
+    for name in names:
+        offsets[name] = len(heap)
+        heap += name.encode() + b"\0"
+        heap += b"\0" * (-len(heap) % 8)
+    segment = f.add(bytes(heap))
+    heap_at = f.add(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap), UNDEF,
+                                          segment))
+    snod = b"SNOD" + struct.pack("<BBH", 1, 0, len(names))
+    for name in names:
+        snod += struct.pack("<QQII16x", offsets[name], members[name], 0, 0)
+    snod_at = f.add(snod)
+    btree = f.add(b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, UNDEF, UNDEF) +
+                  struct.pack("<QQQ", 0, snod_at, offsets[names[-1]]))
+    return object_header(f, [message(0x0011,
+                                     struct.pack("<QQ", btree, heap_at))])
+
+
+def finish(f, root, filename):
+    sb = bytes([0x89]) + b"HDF\r\n\x1a\n" + struct.pack(
+        "<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, 4, 16, 0)
+    sb += struct.pack("<QQQQ", 0, UNDEF, len(f.b), UNDEF)
+    sb += struct.pack("<QQII16x", 0, root, 0, 0)
+    assert len(sb) == 96
+    f.b[:96] = sb
+    with open(filename, "wb") as out:
+        out.write(f.b)
+
+
+def test_chunked_and_filtered_datasets(cli, tmp_path):
+    rng = np.random.default_rng(3)
+    density = rng.uniform(1., 2., 1000)
+    coords = rng.uniform(0., 1., (37, 3))
+    temps = rng.uniform(10., 1e4, 700).astype(np.float32)
+    ids = rng.integers(-1000, 1000, 130).astype(np.int32)
+    cube = rng.uniform(0., 1., (5, 6, 7))
+    f = Layout()
+    members = {
+        # deflate + shuffle, a partial last chunk, a two-level B-tree
+        "Density": chunked_dataset(f, density, (256,), DOUBLE, [2, 1],
+                                   levels=2),
+        # [n][3] as the reference chunks Coordinates, deflate only
+        "Coordinates": chunked_dataset(f, coords, (16, 3), DOUBLE, [1]),
+        # no filter; layout and pipeline in a continuation block
+        "Temperature": chunked_dataset(f, temps, (300,), FLOAT, [],
+                                       continuation=True),
+        "ParticleIDs": chunked_dataset(f, ids, (64,), INT32, [1],
+                                       continuation=True),
+        # chunks that overhang in every dimension
+        "Cube": chunked_dataset(f, cube, (2, 4, 4), DOUBLE, [2, 1]),
+    }
+    part = group(f, members)
+    root = group(f, {"PartType0": part})
+    filename = str(tmp_path / "chunked.hdf5")
+    finish(f, root, filename)
+    assert read(cli, filename, "/")["members"] == ["PartType0"]
+    assert sorted(read(cli, filename, "/PartType0")["members"]) == \
+        sorted(members)
+    for name, ref in (("Density", density), ("Coordinates", coords),
+                      ("Temperature", temps), ("ParticleIDs", ids),
+                      ("Cube", cube)):
+        got = read(cli, filename, "/PartType0/" + name)
+        assert got["layout"] == 2
+        assert got["dims"] == list(ref.shape)
+        assert np.array_equal(np.array(got["data"]),
+                              ref.astype(np.float64).ravel()), name
+
+
+def test_unreadable_files_are_reported(cli, tmp_path):
+    bad = tmp_path / "bad.hdf5"
+    bad.write_bytes(b"not an HDF5 file" * 100)
+    r = subprocess.run([cli, str(bad), "/"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HDF5 signature" in r.stderr
+    r = subprocess.run([cli, str(tmp_path / "missing.hdf5"), "/"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "Could not open" in r.stderr
+
+
+# ---------------------------------------------------------------------------
+
+
+def snapshot_params(ncell, filename):
+    text = lexington_params(ncell)
+    old = "DensityFunction:\n  type: BlockSyntax\n  filename: lexingtonHII40.yml"
+    assert old in text
+    return text.replace(old, "DensityFunction:\n  type: CMacIonizeSnapshot\n"
+                        "  filename: " + filename)
+
+
+def test_run_initialised_from_a_snapshot(exe, tmp_path):
+    """DensityFunction type CMacIonizeSnapshot: the grid of a new run from the
+    cells of a snapshot - cell for cell on the same grid, by the cell that
+    holds the midpoint on a finer or coarser one."""
+    a = tmp_path / "a"
+    a.mkdir()
+    first = dry_run_snapshot(exe, a, lexington_params(12))
+    ref = hdf5_mini.read(first)
+    fields = sorted(ref["/PartType0"].members)
+    assert "NumberDensity" in fields and "Temperature" in fields
+    box = ref["/Header"].attrs["BoxSize"]
+    for ncell in (12, 24, 4):
+        d = tmp_path / ("n%d" % ncell)
+        d.mkdir()
+        again = hdf5_mini.read(dry_run_snapshot(
+            exe, d, snapshot_params(ncell, first)))
+        coords = again["/PartType0/Coordinates"].data
+        idx = np.floor(coords / box * 12).astype(int)
+        source = (idx[:, 0] * 12 + idx[:, 1]) * 12 + idx[:, 2]
+        for name in fields:
+            if name == "Coordinates":
+                continue
+            assert np.array_equal(again["/PartType0/" + name].data,
+                                  ref["/PartType0/" + name].data[source]), \
+                (ncell, name)
+    # the hole of the benchmark survives
+    assert (ref["/PartType0/NumberDensity"].data == 0.).any()
+
+
+def test_snapshot_of_another_grid_type_is_refused(exe, tmp_path):
+    a = tmp_path / "a"
+    a.mkdir()
+    first = dry_run_snapshot(exe, a, lexington_params(8))
+    d = tmp_path / "b"
+    d.mkdir()
+    shutil.copy(os.path.join(BENCH, "lexingtonHII40.yml"), d)
+    p = d / "run.param"
+    p.write_text(snapshot_params(8, str(tmp_path / "nothing.hdf5")))
+    r = subprocess.run([exe, "--params", str(p), "--dry-run"],
+                       capture_output=True, text=True, cwd=str(d))
+    assert r.returncode != 0 and "Could not open file" in r.stderr + r.stdout
+    assert os.path.exists(first)
+
+
+@pytest.mark.gpu
+def test_restart_from_the_last_snapshot(exe, tmp_path):
+    """A run continued from its own last snapshot starts from exactly that
+    state (neutral fractions included) and stays where it had converged."""
+    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = text.replace("[64, 64, 64]", "[16, 16, 16]")
+    text = text.replace("number of photons: 1e6", "number of photons: 50000")
+    text = text.replace("number of iterations: 20", "number of iterations: 8")
+    # (a snapshot without densities and temperatures cannot be a starting
+    # point, here as in the reference)
+    text = text.replace("NumberDensity: 0",
+                        "NumberDensity: 1\n  Temperature: 1")
+    a = tmp_path / "a"
+    a.mkdir()
+    (a / "run.param").write_text(text)
+    r = subprocess.run([exe, "--params", "run.param"], capture_output=True,
+                       text=True, cwd=str(a))
+    assert r.returncode == 0, r.stderr
+    last = hdf5_mini.read(str(a / "stromgren_008.hdf5"))
+    old = "DensityFunction:\n  type: Homogeneous"
+    assert old in text
+    restart = text.replace(old, "DensityFunction:\n  type: CMacIonizeSnapshot\n"
+                           "  filename: " + str(a / "stromgren_008.hdf5"))
+    restart = restart.replace("number of iterations: 8",
+                              "number of iterations: 2")
+    b = tmp_path / "b"
+    b.mkdir()
+    (b / "run.param").write_text(restart)
+    r = subprocess.run([exe, "--params", "run.param"], capture_output=True,
+                       text=True, cwd=str(b))
+    assert r.returncode == 0, r.stderr
+    first = hdf5_mini.read(str(b / "stromgren_000.hdf5"))
+    for name in ("NumberDensity", "NeutralFractionH", "Coordinates"):
+        assert np.array_equal(first["/PartType0/" + name].data,
+                              last["/PartType0/" + name].data), name
+    after = hdf5_mini.read(str(b / "stromgren_002.hdf5"))
+    x0 = last["/PartType0/NeutralFractionH"].data
+    x1 = after["/PartType0/NeutralFractionH"].data
+    assert abs((x1 < 0.5).mean() - (x0 < 0.5).mean()) < 0.02
+    assert 0.05 < (x0 < 0.5).mean() < 0.95

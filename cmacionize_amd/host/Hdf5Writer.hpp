@@ -33,7 +33,7 @@ namespace cmi {
 class Hdf5Writer {
   /* entries a symbol-table node can hold (2 x the group leaf node K of the
    * superblock): one node per group is enough for every group written here */
-  static constexpr int LEAF_K = 32;
+  static constexpr int LEAF_K = 128;
   static constexpr int INTERNAL_K = 16;
   static constexpr uint64_t UNDEF = ~(uint64_t)0;
 
@@ -279,6 +279,25 @@ public:
                   value.c_str(), value.size() + 1));
   }
   void create_group(const std::string &group_name) { (void)group(group_name); }
+  /* an attribute as another file held it: class 0 (integer), 1 (IEEE float)
+   * or 3 (fixed-length string), element size, dimensions, raw bytes */
+  void attribute_raw(const std::string &group_name, const std::string &name,
+                     int cls, uint32_t size, bool is_signed,
+                     const std::vector<uint64_t> &dims,
+                     const std::vector<uint8_t> &data) {
+    Bytes type;
+    if (cls == 1 && size == 8)
+      type = type_double();
+    else if (cls == 0 && size == 4)
+      type = type_int32(is_signed);
+    else if (cls == 3)
+      type = type_string(size);
+    else
+      throw std::runtime_error("HDF5 attribute \"" + name +
+                               "\": a type this writer does not write");
+    group(group_name).attributes.push_back(
+        attribute(name, type, dims, data.data(), data.size()));
+  }
 
   /* a dataset of doubles; `write` streams prod(dims) doubles when the file is
    * written */

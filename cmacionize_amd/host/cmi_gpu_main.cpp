@@ -5,8 +5,10 @@
  * Command line of the reference's driver for this path
  * (src/CMacIonize.cpp:113-179,306-377): --params/-p, --threads/-t,
  * --every-iteration-output/-e, --output-statistics/-s, --dry-run/-n,
- * --verbose/-v. Flags that select other code paths of the reference (--rhd,
- * --emission, --dusty-radiative-transfer, --task-based-rhd) are rejected.
+ * --verbose/-v, and the emission mode --emission/-m with --file/-f
+ * (EmissivityCalculationSimulation.hpp). Flags that select other code paths
+ * of the reference (--rhd, --dusty-radiative-transfer, --task-based-rhd) are
+ * rejected.
  * New: --device N (HIP device ordinal), --describe (print the lowered plugin
  * descriptors as JSON; with --dry-run no GPU is needed), --blocks BX,BY,BZ
  * (domain decomposition: one engine per block of the grid, the counterpart of
@@ -16,6 +18,7 @@
  * reference's TaskBasedIonizationSimulation:source copy level; default: one
  * per device, 2^level at most).
  */
+#include "EmissivityCalculationSimulation.hpp"
 #include "GpuIonizationSimulation.hpp"
 
 #include <cstring>
@@ -114,6 +117,8 @@ int main(int argc, char **argv) {
     return values;
   };
   bool dry_snapshot = false;
+  bool emission = false;
+  std::string input_file;
   bool every_iteration = false, statistics = false, dry_run = false,
        verbose = false, do_describe = false;
   for (int i = 1; i < argc; ++i) {
@@ -142,6 +147,10 @@ int main(int argc, char **argv) {
       devices = int_list(need("--devices"));
     else if (a == "--copies")
       copies = std::atoi(need("--copies").c_str());
+    else if (a == "--emission" || a == "-m")
+      emission = true;
+    else if (a == "--file" || a == "-f")
+      input_file = need("--file");
     else if (a == "--every-iteration-output" || a == "-e")
       every_iteration = true;
     else if (a == "--output-statistics" || a == "-s")
@@ -164,13 +173,25 @@ int main(int argc, char **argv) {
                 << "usage: cmi-gpu --params FILE [--threads N] [--device N] "
                    "[--blocks BX,BY,BZ] [--devices D0,D1,...] [--copies K] "
                    "[--every-iteration-output] [--output-statistics] "
-                   "[--dry-run] [--dry-run-snapshot] [--describe] [--verbose]\n";
+                   "[--dry-run] [--dry-run-snapshot] [--describe] [--verbose]\n"
+                   "       cmi-gpu --emission --params FILE --file "
+                   "SNAPSHOT.hdf5 [--device N]\n";
       return 1;
     }
   }
   if (params.empty()) {
     std::cerr << "Required option --params missing\n";
     return 1;
+  }
+  if (emission) {
+    /* src/CMacIonize.cpp: the emission mode */
+    try {
+      return EmissivityCalculationSimulation::do_simulation(
+          params, input_file, device, !dry_run, true);
+    } catch (std::exception &e) {
+      std::cerr << "Error: " << e.what() << std::endl;
+      return 1;
+    }
   }
   try {
     GpuIonizationSimulation simulation(!dry_run || dry_snapshot,

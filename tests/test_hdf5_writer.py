@@ -272,3 +272,88 @@ def test_emission_lines_in_the_final_snapshot(exe, tmp_path, oracle, blocks):
         for c in lit[::5]:
             ref = oracle.emissivities(sim.model, n[c], T[c], x[:, c])[k]
             assert abs(values[c] - ref) <= 1e-10 * ref, (name, c)
+
+
+@pytest.mark.gpu
+def test_emission_mode_on_a_snapshot(exe, tmp_path, oracle):
+    """`cmi-gpu --emission --params lines.param --file snapshot.hdf5` (the
+    reference's emission mode, src/EmissivityCalculationSimulation.cpp): the
+    flagged lines are added to the snapshot, everything else in it stays; the
+    values equal the oracle's and those the run itself writes with the same
+    switches in its parameter file."""
+    import shutil
+    text = open(os.path.join(BENCH, "lexingtonHII40.param")).read()
+    text = text.replace("[64, 64, 64]", "[14, 14, 14]")
+    text = text.replace("number of photons: 1e8", "number of photons: 30000")
+    text = text.replace("number of iterations: 20", "number of iterations: 6")
+    text = text.replace("NumberDensity: 0", "NumberDensity: 1")
+    switches = ("\nEmissivityValues:\n  Hbeta: true\n  OIII_5007: true\n"
+                "  NeIII_3869: true\n  avg_T: true\n  WFC2_F555W: true\n")
+    names = ["Hbeta", "OIII_5007", "NeIII_3869", "avg_T", "WFC2_F555W"]
+    results = {}
+    for label, extra in (("plain", ""), ("in_run", switches)):
+        d = tmp_path / label
+        d.mkdir()
+        shutil.copy(os.path.join(BENCH, "lexingtonHII40.yml"), d)
+        (d / "run.param").write_text(text + extra)
+        r = subprocess.run([exe, "--params", "run.param"], capture_output=True,
+                           text=True, cwd=str(d))
+        assert r.returncode == 0, r.stderr
+        results[label] = str(d / "lexingtonHII40_006.hdf5")
+    before = hdf5_mini.read(results["plain"])
+    lines = tmp_path / "lines.param"
+    lines.write_text(switches)
+    for repeat in range(2):
+        r = subprocess.run([exe, "--emission", "--params", str(lines),
+                            "--file", results["plain"]], capture_output=True,
+                           text=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr
+        assert ("already exists" in r.stdout) == (repeat == 1)
+    after = hdf5_mini.read(results["plain"])
+    in_run = hdf5_mini.read(results["in_run"])
+    # everything that was there still is
+    assert sorted(after.root.members) == sorted(before.root.members)
+    for g in before.root.members:
+        assert dict(after["/" + g].attrs).keys() == \
+            dict(before["/" + g].attrs).keys()
+        for k, v in before["/" + g].attrs.items():
+            assert np.array_equal(np.asarray(after["/" + g].attrs[k]),
+                                  np.asarray(v)), (g, k)
+    for name, node in before["/PartType0"].members.items():
+        assert np.array_equal(after["/PartType0/" + name].data, node.data)
+    assert sorted(after["/PartType0"].members) == \
+        sorted(list(before["/PartType0"].members) + names)
+    # the lines the run wrote itself (same switches in its parameter file)
+    # are what the emission mode computes from that snapshot
+    r = subprocess.run([exe, "--emission", "--params", str(lines), "--file",
+                        results["in_run"]], capture_output=True, text=True,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0 and "already exists" in r.stdout, r.stderr
+    redone = hdf5_mini.read(results["in_run"])
+    for name in names:
+        assert np.array_equal(redone["/PartType0/" + name].data,
+                              in_run["/PartType0/" + name].data), name
+        assert in_run["/PartType0/" + name].data.max() > 0.
+    # ... and the oracle's
+    ions = ["H", "He", "C+", "C++", "N", "N+", "N++", "O", "O+", "Ne", "Ne+",
+            "S+", "S++", "S+++"]
+    x = np.array([after["/PartType0/NeutralFraction" + i].data for i in ions])
+    n = after["/PartType0/NumberDensity"].data
+    T = after["/PartType0/Temperature"].data
+    sim = oracle.lexington_simulation(4)
+    index = {"Hbeta": "HBeta", "OIII_5007": "OIII_5007",
+             "NeIII_3869": "NeIII_3869", "avg_T": "avg_T",
+             "WFC2_F555W": "WFC2_F555W"}
+    lit = np.flatnonzero((x[0] < 0.2) & (T > 3000.))
+    assert len(lit) > 50
+    for name in names:
+        values = after["/PartType0/" + name].data
+        k = oracle.EMISSION_LINES.index(index[name])
+        for c in lit[::5]:
+            ref = oracle.emissivities(sim.model, n[c], T[c], x[:, c])[k]
+            assert abs(values[c] - ref) <= 1e-10 * ref, (name, c)
+    # a snapshot without the ionic fractions is refused
+    r = subprocess.run([exe, "--emission", "--params", str(lines), "--file",
+                        str(tmp_path / "nowhere.hdf5")], capture_output=True,
+                       text=True, cwd=str(tmp_path))
+    assert r.returncode != 0 and "Could not open" in r.stderr

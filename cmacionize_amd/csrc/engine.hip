@@ -110,6 +110,7 @@ struct cmi_gpu_engine {
   uint32_t *tile_begin = nullptr;      /* [ntiles + 2] */
   /* counting sort of the slots by tile (null: too many tiles, radix sort) */
   uint32_t *tile_blockhist = nullptr, *tile_total = nullptr;
+  uint32_t *tile_new_slots = nullptr; /* slots filled by a round's re-emissions */
   uint32_t *tile_ended_slot = nullptr; /* slot of each absorption record */
   unsigned int *tile_absorbed_count = nullptr; /* [units of work] */
   unsigned int *tile_absorbed_before = nullptr; /* their running totals */
@@ -141,6 +142,10 @@ struct cmi_gpu_engine {
     int tile_refill_threshold = 48;
     int tile_max_rounds = 1000;
     bool tile_counting_sort = true; /* false: rocPRIM radix sort of the slots */
+    /* multi-ion runs: the cross sections of re-emitted flights in a kernel of
+     * their own (flight_weights_kernel) instead of inside the interaction
+     * kernels */
+    bool defer_weights = true;
     /* the free slots are squeezed out once there are this many slots per
      * flight (measured: 2 beats 4, 8 and never by 1 % - rows in tile order
      * are read faster than rows scattered among free slots) */
@@ -1289,6 +1294,8 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
         (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
   else if (k == "tile_compact_ratio")
     e->tune.tile_compact_ratio = (int)(value < 1 ? 1 : value);
+  else if (k == "defer_weights")
+    e->tune.defer_weights = value != 0;
   else if (k == "tile_counting_sort")
     e->tune.tile_counting_sort = value != 0;
   else if (k == "tile_max_rounds")
@@ -1412,7 +1419,7 @@ static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
   const size_t hist_bytes =
       counting ? sizeof(uint32_t) * (size_t)t.ntiles * CMI_TILE_SORT_BLOCKS : 0;
   const size_t total = 2 * (row_bytes + weight_bytes + key_bytes) +
-                       2 * key_bytes + 2 * begin_bytes + 2 * count_bytes +
+                       3 * key_bytes + 2 * begin_bytes + 2 * count_bytes +
                        item_bytes + hist_bytes;
   HIP_TRY(hipMalloc(&e->tile_block, total));
   if (!e->tile_counts)
@@ -1432,6 +1439,8 @@ static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
   e->tile_iota = (uint32_t *)at;
   at += key_bytes;
   e->tile_ended_slot = (uint32_t *)at;
+  at += key_bytes;
+  e->tile_new_slots = (uint32_t *)at;
   at += key_bytes;
   e->tile_begin = (uint32_t *)at;
   at += begin_bytes;
@@ -1789,6 +1798,10 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       ia.ended_slot = e->tile_ended_slot;
       const uint32_t item_flights = e->full_ions ? CMI_TILE_ITEM_FLIGHTS_FULL
                                                  : CMI_TILE_ITEM_FLIGHTS_H;
+      const bool defer = e->full_ions && e->tune.defer_weights;
+      unsigned int *const d_new = e->tile_counts + 4;
+      ia.new_slots = e->tile_new_slots;
+      ia.new_count = d_new;
       unsigned int *const d_nrows = e->tile_counts;
       unsigned int *const d_nlive = e->tile_counts + 1;
       unsigned int *const d_nitems = e->tile_counts + 2;
@@ -1801,7 +1814,10 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       ia.rows.count = d_nrows;
       {
         const int iblocks = e->num_cu * 8;
-        if (e->full_ions)
+        if (e->full_ions && defer)
+          interaction_kernel<true, true, true>
+              <<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);
+        else if (e->full_ions)
           interaction_kernel<true, true>
               <<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);
         else
@@ -1820,6 +1836,17 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                     "tile rounds: %u flights, room for %u - flights were "
                     "lost, the iteration is invalid",
                     nslots, e->tile_rows[cur].capacity);
+      if (defer && nslots != 0) {
+        FlightWeightsArgs wa;
+        wa.model = e->model;
+        wa.rows = e->tile_rows[cur];
+        wa.slots = nullptr;
+        wa.count = nullptr;
+        wa.n = nslots;
+        flight_weights_kernel<<<grid_blocks(e, (int64_t)nslots, 8), CMI_BLOCK,
+                                0, e->stream>>>(wa);
+        HIP_TRY(hipGetLastError());
+      }
       for (int round = 0; nslots != 0; ++round) {
         /* sort the slots by tile (free slots last), cut the flights into
          * units of work */
@@ -1948,7 +1975,21 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         HIP_TRY(hipGetLastError());
         /* (about a quarter of a round's flights are absorbed) */
         const int sblocks = grid_blocks(e, (int64_t)nlive / 2 + 1, 8);
-        if (e->full_ions)
+        if (defer) {
+          HIP_TRY(hipMemsetAsync(d_new, 0, sizeof(unsigned int), e->stream));
+          interaction_slots_kernel<true, true>
+              <<<sblocks, CMI_BLOCK, 0, e->stream>>>(ia);
+          HIP_TRY(hipGetLastError());
+          FlightWeightsArgs wa;
+          wa.model = e->model;
+          wa.rows = e->tile_rows[cur];
+          wa.slots = e->tile_new_slots;
+          wa.count = d_new;
+          wa.n = 0;
+          /* (about a tenth of a round's flights are re-emitted) */
+          flight_weights_kernel<<<grid_blocks(e, (int64_t)nlive / 4 + 1, 8),
+                                  CMI_BLOCK, 0, e->stream>>>(wa);
+        } else if (e->full_ions)
           interaction_slots_kernel<true>
               <<<sblocks, CMI_BLOCK, 0, e->stream>>>(ia);
         else

@@ -1054,6 +1054,11 @@ struct InteractArgs {
   const unsigned int *nitems;
   const unsigned int *absorbed_before; /* running totals of the counts */
   const uint32_t *ended_slot;
+  /* DEFER: the accumulation weights (14 Verner cross sections) of the new
+   * flights are left to flight_weights_kernel; the slots kernel lists the
+   * slots it filled */
+  uint32_t *new_slots;
+  unsigned int *new_count;
 };
 
 /* the handler's decision for a packet of frequency nu absorbed in `cell`:
@@ -1089,7 +1094,7 @@ interaction_decide(const InteractArgs &a, double nu, int32_t cell,
  * in the order of reemit_launch(): the re-emitted packet as a flight of the
  * tile rounds, starting at p.pos. Returns false if the start lies outside the
  * box: the flight ends at once (CartesianDensityGrid::is_inside, :187-227). */
-template <bool FULL>
+template <bool FULL, bool DEFER = false>
 __device__ __forceinline__ bool
 interaction_new_flight(const InteractArgs &a, double new_frequency,
                        int32_t type, PacketRng &rng, Packet<FULL> &p,
@@ -1098,7 +1103,8 @@ interaction_new_flight(const InteractArgs &a, double new_frequency,
   constexpr int L = FULL ? CMI_TILE_LOG2_FULL : CMI_TILE_LOG2_H;
   p.nu = new_frequency;
   random_direction(p, rng);
-  set_cross_sections(a.model, p, weights);
+  if (!DEFER)
+    set_cross_sections(a.model, p, weights);
   p.tau = -log(rng.next());
   p.type = type;
   start_flight<FULL, false>(a.grid, p);
@@ -1143,8 +1149,9 @@ block_reserve(bool mine, unsigned int *counter, unsigned int *s_count,
 #ifndef CMI_INTERACT_WAVES_H
 #define CMI_INTERACT_WAVES_H 4
 #endif
-template <bool FULL, bool ROWS>
-__global__ void __launch_bounds__(CMI_BLOCK, FULL ? 1 : CMI_INTERACT_WAVES_H)
+template <bool FULL, bool ROWS, bool DEFER = false>
+__global__ void __launch_bounds__(CMI_BLOCK,
+                                  (FULL && !DEFER) ? 1 : CMI_INTERACT_WAVES_H)
     interaction_kernel(const InteractArgs a) {
   __shared__ unsigned int s_count[CMI_BLOCK / 64], s_base;
   const int lane = threadIdx.x & 63;
@@ -1182,8 +1189,8 @@ __global__ void __launch_bounds__(CMI_BLOCK, FULL ? 1 : CMI_INTERACT_WAVES_H)
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax)
           p.pos[ax] = a.qin.pos[ax][i];
-        fly = interaction_new_flight<FULL>(a, new_frequency, type, rng, p,
-                                           weights, plc, key);
+        fly = interaction_new_flight<FULL, DEFER>(a, new_frequency, type, rng,
+                                                  p, weights, plc, key);
         if (!fly) {
           tw += w;
           tc1 += (type == TYPE_DIFFUSE_HI) ? w : 0.;
@@ -1192,7 +1199,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, FULL ? 1 : CMI_INTERACT_WAVES_H)
       }
       const unsigned int q = block_reserve(fly, a.rows.count, s_count, &s_base);
       if (fly && q < a.rows.capacity)
-        write_flight_row<FULL>(
+        write_flight_row<FULL, DEFER>(
             a.rows, q, p, plc, key, id,
             cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin),
             weights);
@@ -1273,9 +1280,11 @@ __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
 /* ... then one lane per record, whatever unit it belongs to (the decision is
  * long and divergent - for multi-ion transport it ends with 14 Verner cross
  * sections - so every lane should have one) */
-template <bool FULL>
-__global__ void __launch_bounds__(CMI_BLOCK, FULL ? 1 : CMI_INTERACT_WAVES_H)
+template <bool FULL, bool DEFER = false>
+__global__ void __launch_bounds__(CMI_BLOCK,
+                                  (FULL && !DEFER) ? 1 : CMI_INTERACT_WAVES_H)
     interaction_slots_kernel(const InteractArgs a) {
+  __shared__ unsigned int s_count[CMI_BLOCK / 64], s_base;
   const int lane = threadIdx.x & 63;
   const uint32_t key_dead = CMI_TILE_KEY_DEAD(a.tiles);
   const uint32_t nitems = *a.nitems;
@@ -1295,50 +1304,60 @@ __global__ void __launch_bounds__(CMI_BLOCK, FULL ? 1 : CMI_INTERACT_WAVES_H)
         hi = mid;
     }
     const uint64_t j = base + threadIdx.x;
-    if (j >= total)
-      continue;
-    /* ... and this lane's, a few units further at most */
-    while (a.absorbed_before[lo + 1] <= (uint32_t)j)
-      ++lo;
-    const unsigned int i =
-        a.items[lo].begin + ((uint32_t)j - a.absorbed_before[lo]);
-    const uint32_t slot = a.ended_slot[i];
-    const uint32_t id = a.qin.id[i];
-    const uint32_t meta = a.qin.meta[i];
-    const uint32_t origin = cmi_meta_origin(meta);
-    const double w = a.model.photon_weight[origin]; /* the packet's weight */
-    PacketRng rng;
-    rng.resume(a.seed, a.iteration, a.first_packet + id, meta & 0xffffffu,
-               (meta >> 24) & 1u);
-    int32_t type;
-    const double new_frequency =
-        interaction_decide<FULL>(a, a.qin.nu[i], a.qin.cell[i], rng, type);
-    uint32_t key = key_dead;
-    if (new_frequency != 0.) {
-      Packet<FULL> p;
-      double weights[CMI_NACC];
-      uint32_t plc = 0;
+    const bool valid = j < total;
+    bool made = false; /* a new flight in this lane's slot */
+    uint32_t slot = 0;
+    if (valid) {
+      /* ... and this lane's, a few units further at most */
+      while (a.absorbed_before[lo + 1] <= (uint32_t)j)
+        ++lo;
+      const unsigned int i =
+          a.items[lo].begin + ((uint32_t)j - a.absorbed_before[lo]);
+      slot = a.ended_slot[i];
+      const uint32_t id = a.qin.id[i];
+      const uint32_t meta = a.qin.meta[i];
+      const uint32_t origin = cmi_meta_origin(meta);
+      const double w = a.model.photon_weight[origin]; /* the packet's weight */
+      PacketRng rng;
+      rng.resume(a.seed, a.iteration, a.first_packet + id, meta & 0xffffffu,
+                 (meta >> 24) & 1u);
+      int32_t type;
+      const double new_frequency =
+          interaction_decide<FULL>(a, a.qin.nu[i], a.qin.cell[i], rng, type);
+      uint32_t key = key_dead;
+      if (new_frequency != 0.) {
+        Packet<FULL> p;
+        double weights[CMI_NACC];
+        uint32_t plc = 0;
 #pragma unroll
-      for (int ax = 0; ax < 3; ++ax)
-        p.pos[ax] = a.qin.pos[ax][i];
-      if (interaction_new_flight<FULL>(a, new_frequency, type, rng, p, weights,
-                                       plc, key)) {
-        write_flight_row<FULL>(
-            a.rows, slot, p, plc, key, id,
-            cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin),
-            weights);
+        for (int ax = 0; ax < 3; ++ax)
+          p.pos[ax] = a.qin.pos[ax][i];
+        if (interaction_new_flight<FULL, DEFER>(a, new_frequency, type, rng, p,
+                                                weights, plc, key)) {
+          write_flight_row<FULL, DEFER>(
+              a.rows, slot, p, plc, key, id,
+              cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin),
+              weights);
+          made = true;
+        } else {
+          key = key_dead;
+          tw += w;
+          tc1 += (type == TYPE_DIFFUSE_HI) ? w : 0.;
+          tc2 += (type == TYPE_DIFFUSE_HeI) ? w : 0.;
+        }
       } else {
-        key = key_dead;
         tw += w;
-        tc1 += (type == TYPE_DIFFUSE_HI) ? w : 0.;
-        tc2 += (type == TYPE_DIFFUSE_HeI) ? w : 0.;
+        tc3 += w;
       }
-    } else {
-      tw += w;
-      tc3 += w;
+      if (key == key_dead)
+        a.rows.keys[slot] = key;
     }
-    if (key == key_dead)
-      a.rows.keys[slot] = key;
+    if (DEFER) {
+      /* (the trip count is the same for every thread of a workgroup) */
+      const unsigned int q = block_reserve(made, a.new_count, s_count, &s_base);
+      if (made)
+        a.new_slots[q] = slot;
+    }
   }
   tw = wave_sum(tw);
   tc1 = wave_sum(tc1);
@@ -1349,6 +1368,43 @@ __global__ void __launch_bounds__(CMI_BLOCK, FULL ? 1 : CMI_INTERACT_WAVES_H)
     atomic_add_f64(&counter_shard(a.counters)->typecount[1], tc1);
     atomic_add_f64(&counter_shard(a.counters)->typecount[2], tc2);
     atomic_add_f64(&counter_shard(a.counters)->typecount[3], tc3);
+  }
+}
+
+/* The accumulation weights of new flights (PhotonSource::set_cross_sections,
+ * src/PhotonSource.cpp:189-199: 14 Verner cross sections - ~30 pow() - and the
+ * two heating weights) from the frequency in their rows. On its own instead of
+ * inside the interaction kernels: there half the lanes idle through it (their
+ * packets were absorbed for good) at 2 waves/SIMD under the decision's
+ * registers; here every lane has a flight. slots == nullptr: the flights are
+ * the slots [0, n). */
+struct FlightWeightsArgs {
+  ModelDev model;
+  FlightRowsDev rows;
+  const uint32_t *slots;
+  const unsigned int *count; /* or */
+  uint64_t n;
+};
+
+__global__ void __launch_bounds__(CMI_BLOCK)
+    flight_weights_kernel(const FlightWeightsArgs a) {
+  uint64_t n = a.count ? (uint64_t)*a.count : a.n;
+  if (n > a.rows.capacity)
+    n = a.rows.capacity;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride) {
+    const uint32_t q = a.slots ? a.slots[i] : (uint32_t)i;
+    Packet<true> p;
+    p.nu = a.rows.rows[(size_t)CMI_FLIGHT_DOUBLES * q + 6];
+    double weights[CMI_NACC];
+    set_cross_sections<true>(a.model, p, weights);
+    double4 *w = reinterpret_cast<double4 *>(a.rows.weights +
+                                             (size_t)CMI_NACC * q);
+#pragma unroll
+    for (int k = 0; k < CMI_NACC; k += 4)
+      w[k >> 2] = make_double4(weights[k], weights[k + 1], weights[k + 2],
+                               weights[k + 3]);
   }
 }
 

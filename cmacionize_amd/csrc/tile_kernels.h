@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(CMI_BLOCK)
 }
 
 /* a new flight into slot q (interaction kernel) */
-template <bool FULL>
+template <bool FULL, bool DEFER = false>
 __device__ __forceinline__ void
 write_flight_row(const FlightRowsDev &out, unsigned int q,
                  const Packet<FULL> &p, uint32_t packed_lc, uint32_t key,
@@ -340,7 +340,7 @@ write_flight_row(const FlightRowsDev &out, unsigned int q,
                                        (uint32_t)p.cell)),
       0., 0.);
   out.keys[q] = key;
-  if (FULL) {
+  if (FULL && !DEFER) {
     double4 *w = reinterpret_cast<double4 *>(out.weights + (size_t)CMI_NACC * q);
 #pragma unroll
     for (int i = 0; i < CMI_NACC; i += 4)

@@ -400,6 +400,9 @@ int cmi_gpu_compute_emissivities(cmi_gpu_engine *engine, int32_t nlines,
  *                           in the tile kernel
  *   "tile_compact_ratio" (2)  free slots are squeezed out of the flight rows
  *                           once there are this many slots per flight
+ *   "defer_weights" (1)     multi-ion runs: the 14 cross sections of re-emitted
+ *                           flights are computed by a kernel of their own, not
+ *                           inside the re-emission kernels
  *   "tile_counting_sort" (1)  the slots are put in tile order by counting
  *                           (per-tile counters in LDS; up to 32768 tiles) -
  *                           0: by rocPRIM's radix sort

@@ -257,6 +257,39 @@ __device__ inline void emit_physics(const ModelDev &m, PacketRng &rng,
   p.tau = -log(rng.next());
 }
 
+/* the same from a row written by direction_key_kernel - {sigma[14], nu, tau}
+ * of this packet, computed there with the same functions: the random numbers
+ * the spectrum and the optical depth consumed are drawn and dropped */
+template <bool FULL>
+__device__ __forceinline__ void
+emit_physics_from_row(const ModelDev &m, PacketRng &rng, Packet<FULL> &p,
+                      double (&weights)[CMI_NACC], uint32_t origin,
+                      const double *row) {
+  const double4 *r4 = reinterpret_cast<const double4 *>(row);
+#pragma unroll
+  for (int k = 0; k < CMI_NACC; k += 4) {
+    const double4 v = r4[k >> 2];
+    weights[k] = v.x;
+    weights[k + 1] = v.y;
+    weights[k + 2] = v.z;
+    weights[k + 3] = v.w;
+  }
+  p.nu = weights[CMI_NION];
+  p.tau = weights[CMI_NION + 1];
+  p.sigma_H = weights[ION_H_n];
+  p.sigma_He = weights[ION_He_n];
+  p.sigma_He_corr = m.abundance[0] * p.sigma_He;
+  weights[CMI_NION] = p.sigma_H * (p.nu - m.nu_H);
+  weights[CMI_NION + 1] = p.sigma_He * (p.nu - m.nu_He);
+  /* sample_source_spectrum: one uniform for a Planck spectrum, none for a
+   * monochromatic one; then the optical depth's */
+  const bool draws = origin != 0 ? m.continuous_spectrum_type != 0
+                                 : m.spectrum_type != 0;
+  if (draws)
+    (void)rng.next();
+  (void)rng.next();
+}
+
 template <bool FULL, bool EXACT>
 __device__ inline uint32_t emit_packet(const GridDev &g, const ModelDev &m,
                                        PacketRng &rng, Packet<FULL> &p,

@@ -146,6 +146,10 @@ struct cmi_gpu_engine {
      * their own (flight_weights_kernel) instead of inside the interaction
      * kernels */
     bool defer_weights = true;
+    /* multi-ion runs: the emission physics of the new packets (spectrum,
+     * cross sections, optical depth) in the sort-key kernel, read back by the
+     * transport kernel (shoot_kernel<..., PRE>) */
+    bool pre_emission = true;
     /* the free slots are squeezed out once there are this many slots per
      * flight (measured: 2 beats 4, 8 and never by 1 % - rows in tile order
      * are read faster than rows scattered among free slots) */
@@ -1294,6 +1298,8 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
         (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
   else if (k == "tile_compact_ratio")
     e->tune.tile_compact_ratio = (int)(value < 1 ? 1 : value);
+  else if (k == "pre_emission")
+    e->tune.pre_emission = value != 0;
   else if (k == "defer_weights")
     e->tune.defer_weights = value != 0;
   else if (k == "tile_counting_sort")
@@ -1586,6 +1592,16 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       kernel_first = heat ? shoot_kernel<false, true, false, false, true>
                           : shoot_kernel<false, false, false, false, true>;
   }
+  /* ... and, for multi-ion runs whose packets are sorted anyway, with the
+   * emission physics done by the key kernel (the rows live in the second
+   * weights buffer of the tile rounds, idle during the first generation) */
+  void (*kernel_first_pre)(const ShootArgs) = nullptr;
+  if (kernel_first != kernel && e->full_ions && e->tune.pre_emission &&
+      e->tune.sort_packets && passes && e->tune.tile_rounds &&
+      !e->grid.decomposed && e->grid.copy_count <= 1)
+    kernel_first_pre =
+        heat ? shoot_kernel<true, true, false, false, true, true>
+             : shoot_kernel<true, false, false, false, true, true>;
 
   auto occupancy = [&](void (*k)(const ShootArgs), int &blocks_per_cu) -> int {
     blocks_per_cu = 0;
@@ -1689,6 +1705,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     a.batch_offset = done;
     a.n_packets = n;
     a.order = nullptr;
+    a.pre_rows = nullptr;
     a.xin = flights ? flights + (size_t)CMI_FLIGHT_DOUBLES * done : nullptr;
     a.xin_local = 0;
     a.xout.rows = e->export_rows;
@@ -1739,6 +1756,8 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       }
       k.keys = e->sort_keys[0];
       k.ids = e->sort_ids[0];
+      k.pre_rows = kernel_first_pre ? e->tile_rows[1].weights : nullptr;
+      a.pre_rows = k.pre_rows;
       direction_key_kernel<<<grid_blocks(e, (int64_t)n, 8), CMI_BLOCK, 0,
                              e->stream>>>(k);
       HIP_TRY(hipGetLastError());
@@ -1762,7 +1781,10 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       if (trc)
         return trc;
     }
-    kernel_first<<<(unsigned)blocks, CMI_BLOCK, 0, e->stream>>>(a);
+    if (sorted && kernel_first_pre)
+      kernel_first_pre<<<(unsigned)blocks, CMI_BLOCK, 0, e->stream>>>(a);
+    else
+      kernel_first<<<(unsigned)blocks, CMI_BLOCK, 0, e->stream>>>(a);
     HIP_TRY(hipGetLastError());
     {
       int trc = timer_end(e, e->kernel_events, kev, n);

@@ -77,6 +77,10 @@ struct ShootArgs {
   /* processing order: position i of the launch handles packet
    * first_packet + order[i] (direction-sorted); NULL = identity */
   const uint32_t *order;
+  /* PRE: row (packet id - batch_offset) holds what emit_physics would
+   * compute for that packet - 14 cross sections, the frequency, the optical
+   * depth - written by direction_key_kernel */
+  const double *pre_rows;
   uint32_t chunk; /* consecutive positions a wave consumes before it jumps */
   uint32_t seed;
   uint32_t iteration;
@@ -431,7 +435,8 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
  * non-periodic grid (the first generation of every benchmark config): those
  * choices are compile-time constants and the code of the other aggregation
  * modes and of the periodic wrap is not in the march loop at all. */
-template <bool FULL, bool HEAT, bool REEMIT, bool EXACT, bool TABLE = false>
+template <bool FULL, bool HEAT, bool REEMIT, bool EXACT, bool TABLE = false,
+          bool PRE = false>
 __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
     shoot_kernel(const ShootArgs a) {
   const int lane = threadIdx.x & 63;
@@ -628,7 +633,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
       if (!active && rank < avail) {
         const uint64_t i = pos + rank;
         bool mine = true;
-        if (a.xin != nullptr) {
+        if (!PRE && a.xin != nullptr) {
           /* a flight handed over by another block of the grid */
           const double *r = a.xin + (size_t)CMI_FLIGHT_DOUBLES * i;
           int64_t cell_global;
@@ -677,7 +682,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
             else
               resume_flight(a.grid, p, cell_global);
           }
-        } else if (a.qin.id != nullptr) {
+        } else if (!PRE && a.qin.id != nullptr) {
           /* a ready flight: re-emitted by the interaction kernel */
           packet_id = a.qin.id[i];
           lane_meta = a.qin.meta[i];
@@ -764,7 +769,13 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
             }
           }
           if (mine) {
-            emit_physics<FULL>(a.model, rng, p, weights, origin);
+            if (PRE)
+              emit_physics_from_row<FULL>(
+                  a.model, rng, p, weights, origin,
+                  a.pre_rows + (size_t)CMI_NACC *
+                                   (packet_id - (uint32_t)a.batch_offset));
+            else
+              emit_physics<FULL>(a.model, rng, p, weights, origin);
             lane_meta = cmi_pack_meta(rng.block, rng.have, 0, origin);
           }
         }
@@ -1440,6 +1451,9 @@ struct KeyArgs {
   uint32_t source_mask;
   uint32_t *keys;
   uint32_t *ids;
+  /* multi-ion transport: row i receives the emission physics of packet
+   * first_packet + i (emit_physics_from_row reads it back); NULL = none */
+  double *pre_rows;
 };
 
 __device__ __forceinline__ uint32_t spread_bits_11(uint32_t x) {
@@ -1518,7 +1532,30 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     const uint32_t ip = (uint32_t)(u_phi * 2048.);
     const uint32_t morton = spread_bits_11(ic) | (spread_bits_11(ip) << 1);
     uint32_t tau_class = 0;
-    if (a.tau_bits != 0) {
+    if (a.pre_rows != nullptr) {
+      /* the whole of emit_physics, here where every lane has a packet and the
+       * registers are free (the transport kernel runs it at 3 waves/SIMD
+       * between its refills) */
+      Packet<true> q;
+      double weights[CMI_NACC];
+      q.nu = sample_source_spectrum(a.model, rng, origin);
+      set_cross_sections<true>(a.model, q, weights);
+      const double tau = -log(rng.next());
+      weights[CMI_NION] = q.nu;
+      weights[CMI_NION + 1] = tau;
+      double4 *row = reinterpret_cast<double4 *>(a.pre_rows +
+                                                 (size_t)CMI_NACC * i);
+#pragma unroll
+      for (int k = 0; k < CMI_NACC; k += 4)
+        row[k >> 2] = make_double4(weights[k], weights[k + 1], weights[k + 2],
+                                   weights[k + 3]);
+      if (a.tau_bits != 0) {
+        const double range = tau * a.sigma_ref / (q.sigma_H + q.sigma_He_corr);
+        const int octave = (int)floor(log2(range)) + (1 << (a.tau_bits - 1));
+        const int top = (1 << a.tau_bits) - 1;
+        tau_class = (uint32_t)(octave < 0 ? 0 : (octave > top ? top : octave));
+      }
+    } else if (a.tau_bits != 0) {
       if (!a.full_ions) {
         (void)sample_source_spectrum(a.model, rng, origin); /* its draws */
         const double u_tau = rng.next();            /* tau = -ln u */

@@ -400,6 +400,11 @@ int cmi_gpu_compute_emissivities(cmi_gpu_engine *engine, int32_t nlines,
  *                           in the tile kernel
  *   "tile_compact_ratio" (2)  free slots are squeezed out of the flight rows
  *                           once there are this many slots per flight
+ *   "pre_emission" (1)      multi-ion runs with sorted packets: the spectrum
+ *                           sample, the 14 cross sections and the optical
+ *                           depth of every new packet are computed by the
+ *                           sort-key kernel and read back by the transport
+ *                           kernel
  *   "defer_weights" (1)     multi-ion runs: the 14 cross sections of re-emitted
  *                           flights are computed by a kernel of their own, not
  *                           inside the re-emission kernels

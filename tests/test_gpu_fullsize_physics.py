@@ -100,12 +100,15 @@ def test_fullsize_reemission_reordering_invariance(converged):
                    refill_threshold_reemit=32, sort_packets=1,
                    max_packets_per_launch=1 << 27, tile_rounds=1,
                    tile_min_flights=100000, tile_refill_threshold=16,
-                   tile_min_per_item=-1, tile_counting_sort=1)
+                   tile_min_per_item=-1, tile_counting_sort=1,
+                   pre_emission=1, defer_weights=1)
     results = []
     for kw in (dict(),
                dict(tile_rounds=0),
                dict(tile_min_flights=0, tile_min_per_item=0, tile_refill_threshold=40),
                dict(tile_counting_sort=0),
+               dict(pre_emission=0),
+               dict(defer_weights=0),
                dict(aggregate=0, sort_packets=0),
                dict(reemit_passes=0),
                dict(aggregate_reemit=2, refill_threshold_reemit=8,

@@ -192,6 +192,13 @@ def test_diffuse_stromgren_shoot_matches_oracle(oracle, tuning):
     dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0),
     dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0,
          tile_counting_sort=0),
+    # cross sections inside the transport / re-emission kernels instead of in
+    # the key kernel / a kernel of their own
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0,
+         pre_emission=0),
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0,
+         defer_weights=0),
+    dict(pre_emission=0, defer_weights=0),
     dict(tile_rounds=0),
 ])
 def test_lexington_iteration_matches_oracle(oracle, tuning):

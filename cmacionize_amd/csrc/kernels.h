@@ -1502,7 +1502,10 @@ __device__ inline float approximate_opacity_cross_section(const ModelDev &m,
   return sum;
 }
 
-__global__ void __launch_bounds__(CMI_BLOCK)
+#ifndef CMI_KEY_WAVES
+#define CMI_KEY_WAVES 3
+#endif
+__global__ void __launch_bounds__(CMI_BLOCK, CMI_KEY_WAVES)
     direction_key_kernel(const KeyArgs a) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint32_t lo_bits = 22u - a.dir_hi_bits;

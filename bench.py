@@ -53,15 +53,15 @@ CONFIGS = {
     "stromgren": dict(
         name="stromgren.param", bytes_per_step=16. + 16. * 1, diffuse=False,
         lexington=False, converge_iterations=20,
-        kernel="shoot_kernel<false, false, false, false, true>"),
+        kernel="shoot_kernel<false, false, false, false, true, false>"),
     "stromgren_diffuse": dict(
         name="stromgren_diffuse.param", bytes_per_step=16. + 16. * 1,
         diffuse=True, lexington=False, converge_iterations=20,
-        kernel="shoot_kernel<false, false, false, false, true>"),
+        kernel="shoot_kernel<false, false, false, false, true, false>"),
     "lexington": dict(
         name="lexingtonHII40.param", bytes_per_step=16. + 16. * 16,
         diffuse=True, lexington=True, converge_iterations=20,
-        kernel="shoot_kernel<true, true, false, false, true>"),
+        kernel="shoot_kernel<true, true, false, false, true, true>"),
 }
 
 # The CPU baseline (oracle/cmio_transport_fast.c) against the REFERENCE on the

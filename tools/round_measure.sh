@@ -14,12 +14,15 @@ OUT=$REPO/$1
 ROUND=${2:-r02}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-for CFG in stromgren stromgren_diffuse lexington; do
-  tools/pmc_profile.sh "$1/pmc_$CFG" -- bench.py --config $CFG --steps 3 --warmup 0 --no-cpu-baseline
-done
-python3 tools/pmc_rooflines.py "$OUT" 3 > "$OUT/counters.json"
-mkdir -p "$REPO/profiles/$ROUND"
-cp "$OUT/counters.json" "$REPO/profiles/$ROUND/counters.json"
+# (SKIP_PMC=1: keep profiles/rNN/counters.json as it is)
+if [ -z "${SKIP_PMC:-}" ]; then
+  for CFG in stromgren stromgren_diffuse lexington; do
+    tools/pmc_profile.sh "$1/pmc_$CFG" -- bench.py --config $CFG --steps 3 --warmup 0 --no-cpu-baseline
+  done
+  python3 tools/pmc_rooflines.py "$OUT" 3 > "$OUT/counters.json" || exit 1
+  mkdir -p "$REPO/profiles/$ROUND"
+  cp "$OUT/counters.json" "$REPO/profiles/$ROUND/counters.json"
+fi
 for CFG in stromgren stromgren_diffuse lexington; do
   python3 bench.py --config $CFG > "$OUT/bench_$CFG.json" 2> "$OUT/bench_$CFG.err"
   echo "bench $CFG rc=$?"

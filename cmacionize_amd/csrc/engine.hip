@@ -111,6 +111,10 @@ struct cmi_gpu_engine {
   /* counting sort of the slots by tile (null: too many tiles, radix sort) */
   uint32_t *tile_blockhist = nullptr, *tile_total = nullptr;
   uint32_t *tile_new_slots = nullptr; /* slots filled by a round's re-emissions */
+  /* the temperature solve as a pipeline (temperature_pipeline.h) */
+  char *temp_pipe_block = nullptr;
+  uint32_t temp_pipe_capacity = 0;
+  unsigned int *temp_pipe_counts = nullptr;
   uint32_t *tile_ended_slot = nullptr; /* slot of each absorption record */
   unsigned int *tile_absorbed_count = nullptr; /* [units of work] */
   unsigned int *tile_absorbed_before = nullptr; /* their running totals */
@@ -150,6 +154,8 @@ struct cmi_gpu_engine {
      * cross sections, optical depth) in the sort-key kernel, read back by the
      * transport kernel (shoot_kernel<..., PRE>) */
     bool pre_emission = true;
+    /* the temperature solve as a pipeline of kernels (0: one kernel) */
+    bool temperature_pipeline = true;
     /* the free slots are squeezed out once there are this many slots per
      * flight (measured: 2 beats 4, 8 and never by 1 % - rows in tile order
      * are read faster than rows scattered among free slots) */
@@ -864,6 +870,8 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
     (void)hipFree(e->acc_block);
   (void)hipFree(e->opacity);
   (void)hipFree(e->counters);
+  (void)hipFree(e->temp_pipe_block);
+  (void)hipFree(e->temp_pipe_counts);
   (void)hipFree(e->tables);
   (void)hipFree(e->spectra);
   delete e->host_tables;
@@ -1298,6 +1306,8 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
         (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
   else if (k == "tile_compact_ratio")
     e->tune.tile_compact_ratio = (int)(value < 1 ? 1 : value);
+  else if (k == "temperature_pipeline")
+    e->tune.temperature_pipeline = value != 0;
   else if (k == "pre_emission")
     e->tune.pre_emission = value != 0;
   else if (k == "defer_weights")
@@ -2319,6 +2329,80 @@ int cmi_gpu_get_wave_steps(cmi_gpu_engine *e, uint64_t *nwavesteps) {
   return CMI_GPU_OK;
 }
 
+/* the temperature solve of the cells [a.first, a.first + a.count) as the
+ * pipeline of temperature_pipeline.h, in passes of at most 2^23 cells (the
+ * solve state and a step's evaluations of a pass: 5 GB) */
+static int temperature_pipeline(cmi_gpu_engine *e, const UpdateArgs &a) {
+  const uint32_t want =
+      (uint32_t)(a.count < (1ll << 23) ? a.count : (1ll << 23));
+  const size_t state_doubles = (size_t)TS_NFIELD;
+  const size_t eval_doubles = 3 * (size_t)TE_NFIELD;
+  auto bytes_for = [&](uint32_t cap) {
+    return sizeof(double) * (state_doubles + eval_doubles) * cap +
+           sizeof(uint32_t) * 4 * (size_t)cap;
+  };
+  if (e->temp_pipe_capacity < want) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    (void)hipFree(e->temp_pipe_block);
+    e->temp_pipe_block = nullptr;
+    e->temp_pipe_capacity = 0;
+    HIP_TRY(hipMalloc(&e->temp_pipe_block, bytes_for(want)));
+    e->temp_pipe_capacity = want;
+  }
+  if (!e->temp_pipe_counts)
+    HIP_TRY(hipMalloc(&e->temp_pipe_counts, 4 * sizeof(unsigned int)));
+  const uint32_t cap = e->temp_pipe_capacity;
+  TempPipeArgs p;
+  p.u = a;
+  p.capacity = cap;
+  char *at = e->temp_pipe_block;
+  p.state = (double *)at;
+  at += sizeof(double) * state_doubles * cap;
+  p.eval = (double *)at;
+  at += sizeof(double) * eval_doubles * cap;
+  p.slot_cell = (uint32_t *)at;
+  at += sizeof(uint32_t) * (size_t)cap;
+  p.niter = (int32_t *)at;
+  at += sizeof(uint32_t) * (size_t)cap;
+  p.list[0] = (uint32_t *)at;
+  at += sizeof(uint32_t) * (size_t)cap;
+  p.list[1] = (uint32_t *)at;
+  p.counts = e->temp_pipe_counts;
+  for (int64_t done = 0; done < a.count; done += cap) {
+    p.chunk_first = a.first + done;
+    p.chunk_count = a.count - done < (int64_t)cap ? a.count - done : cap;
+    p.current = 0;
+    p.nactive = 0;
+    HIP_TRY(hipMemsetAsync(p.counts, 0, 4 * sizeof(unsigned int), e->stream));
+    temp_begin_kernel<<<grid_blocks(e, p.chunk_count, 8), CMI_BLOCK, 0,
+                        e->stream>>>(p);
+    HIP_TRY(hipGetLastError());
+    unsigned int nactive = 0;
+    {
+      int rrc = read_counters(e, p.counts, 1, &nactive);
+      if (rrc)
+        return rrc;
+    }
+    /* (a solve ends after t_max_iterations steps at the latest) */
+    while (nactive != 0) {
+      p.nactive = nactive;
+      const int eblocks = grid_blocks(e, 3ll * nactive, 8);
+      temp_eval_kernel<<<eblocks, CMI_BLOCK, 0, e->stream>>>(p);
+      temp_linecool_kernel<<<eblocks, CMI_BLOCK, 0, e->stream>>>(p);
+      unsigned int *next_count = p.counts + 1 + (1 - p.current);
+      HIP_TRY(hipMemsetAsync(next_count, 0, sizeof(unsigned int), e->stream));
+      temp_secant_kernel<<<grid_blocks(e, (int64_t)nactive, 8), CMI_BLOCK, 0,
+                           e->stream>>>(p);
+      HIP_TRY(hipGetLastError());
+      int rrc = read_counters(e, next_count, 1, &nactive);
+      if (rrc)
+        return rrc;
+      p.current = 1 - p.current;
+    }
+  }
+  return CMI_GPU_OK;
+}
+
 int cmi_gpu_update_cells(cmi_gpu_engine *e, uint32_t loop, double totweight) {
   if (!e)
     return fail(CMI_GPU_EINVAL, "null engine");
@@ -2368,7 +2452,11 @@ int cmi_gpu_update_cells_range(cmi_gpu_engine *e, uint32_t loop,
       return trc;
   }
   const int blocks = grid_blocks(e, ncell, 8);
-  if (solve_temperature)
+  if (solve_temperature && e->tune.temperature_pipeline) {
+    int prc = temperature_pipeline(e, a);
+    if (prc)
+      return prc;
+  } else if (solve_temperature)
     temperature_kernel<<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
   else if (e->full_ions)
     ionization_kernel<true><<<blocks, CMI_BLOCK, 0, e->stream>>>(a);

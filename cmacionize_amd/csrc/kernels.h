@@ -1775,6 +1775,8 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   }
 }
 
+#include "temperature_pipeline.h"
+
 /* probe: one balance evaluation / one temperature solve per input row */
 __global__ void thermal_probe_kernel(const ModelDev model, int64_t n,
                                      int32_t solve, const double *J,

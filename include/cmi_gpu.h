@@ -400,6 +400,10 @@ int cmi_gpu_compute_emissivities(cmi_gpu_engine *engine, int32_t nlines,
  *                           in the tile kernel
  *   "tile_compact_ratio" (2)  free slots are squeezed out of the flight rows
  *                           once there are this many slots per flight
+ *   "temperature_pipeline" (1)  the temperature solve as one kernel per stage
+ *                           of a secant step (ionization balance / line
+ *                           cooling / update), each dense in like work -
+ *                           0: one kernel holding the whole solve of a cell
  *   "pre_emission" (1)      multi-ion runs with sorted packets: the spectrum
  *                           sample, the 14 cross sections and the optical
  *                           depth of every new packet are computed by the

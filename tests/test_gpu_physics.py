@@ -422,3 +422,39 @@ def test_periodic_diffuse_shoot_matches_oracle(oracle, tuning):
         assert np.allclose(h, sim.heating[0], rtol=1e-9,
                            atol=1e-12 * np.abs(sim.heating[0]).max())
     eng.close()
+
+
+def test_temperature_pipeline_equals_single_kernel(oracle):
+    """The temperature solve as a pipeline of kernels (default) and as one
+    kernel run the same functions in the same order: identical results, bit
+    for bit, from the same accumulators - on a grid the engine brought to the
+    iteration where the solve starts."""
+    from cmacionize_amd import engine as E
+    ncell, npacket = 20, 60000
+    sim = oracle.lexington_simulation(ncell)
+    eng = lexington_engine(ncell, sim)
+    for loop in range(5):
+        eng.reset_grid()
+        eng.shoot(42, loop, 0, npacket)
+        tw, _, _ = eng.get_counters()
+        if loop < 4:
+            eng.update_cells(loop, tw)
+    fields = [E.FIELD_NUMBER_DENSITY, E.FIELD_TEMPERATURE] + \
+        [E.FIELD_IONIC_FRACTION + i for i in range(14)] + \
+        [E.FIELD_MEAN_INTENSITY + i for i in range(14)] + \
+        [E.FIELD_HEATING, E.FIELD_HEATING + 1]
+    before = {f: eng.download_field(f) for f in fields}
+    results = []
+    for pipeline in (1, 0, 1):
+        for f in fields:
+            eng.upload_field(f, before[f])
+        eng.set_tuning(temperature_pipeline=pipeline)
+        eng.update_cells(4, tw)
+        results.append({f: eng.download_field(f) for f in fields})
+    solved = results[0][E.FIELD_TEMPERATURE]
+    assert (solved != before[E.FIELD_TEMPERATURE]).sum() > 1000
+    assert 5000. < solved[solved > 600.].mean() < 15000.
+    for f in fields:
+        assert np.array_equal(results[0][f], results[1][f]), f
+        assert np.array_equal(results[0][f], results[2][f]), f
+    eng.close()

@@ -156,6 +156,8 @@ struct cmi_gpu_engine {
     bool pre_emission = true;
     /* the temperature solve as a pipeline of kernels (0: one kernel) */
     bool temperature_pipeline = true;
+    /* ... whose last slots one launch finishes (temp_finish_kernel) */
+    uint32_t temperature_finish_slots = 32768;
     /* the free slots are squeezed out once there are this many slots per
      * flight (measured: 2 beats 4, 8 and never by 1 % - rows in tile order
      * are read faster than rows scattered among free slots) */
@@ -1306,6 +1308,8 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
         (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
   else if (k == "tile_compact_ratio")
     e->tune.tile_compact_ratio = (int)(value < 1 ? 1 : value);
+  else if (k == "temperature_finish_slots")
+    e->tune.temperature_finish_slots = (uint32_t)(value < 0 ? 0 : value);
   else if (k == "temperature_pipeline")
     e->tune.temperature_pipeline = value != 0;
   else if (k == "pre_emission")
@@ -2330,11 +2334,11 @@ int cmi_gpu_get_wave_steps(cmi_gpu_engine *e, uint64_t *nwavesteps) {
 }
 
 /* the temperature solve of the cells [a.first, a.first + a.count) as the
- * pipeline of temperature_pipeline.h, in passes of at most 2^23 cells (the
- * solve state and a step's evaluations of a pass: 5 GB) */
+ * pipeline of temperature_pipeline.h, in passes of at most 2^24 cells (the
+ * solve state and a step's evaluations of a pass: 10 GB) */
 static int temperature_pipeline(cmi_gpu_engine *e, const UpdateArgs &a) {
   const uint32_t want =
-      (uint32_t)(a.count < (1ll << 23) ? a.count : (1ll << 23));
+      (uint32_t)(a.count < (1ll << 24) ? a.count : (1ll << 24));
   const size_t state_doubles = (size_t)TS_NFIELD;
   const size_t eval_doubles = 3 * (size_t)TE_NFIELD;
   auto bytes_for = [&](uint32_t cap) {
@@ -2386,6 +2390,14 @@ static int temperature_pipeline(cmi_gpu_engine *e, const UpdateArgs &a) {
     /* (a solve ends after t_max_iterations steps at the latest) */
     while (nactive != 0) {
       p.nactive = nactive;
+      if (nactive <= e->tune.temperature_finish_slots) {
+        /* the stragglers: one launch, four lanes per slot */
+        temp_finish_kernel<<<(unsigned)((4ull * nactive + CMI_BLOCK - 1) /
+                                        CMI_BLOCK),
+                             CMI_BLOCK, 0, e->stream>>>(p);
+        HIP_TRY(hipGetLastError());
+        break;
+      }
       const int eblocks = grid_blocks(e, 3ll * nactive, 8);
       temp_eval_kernel<<<eblocks, CMI_BLOCK, 0, e->stream>>>(p);
       temp_linecool_kernel<<<eblocks, CMI_BLOCK, 0, e->stream>>>(p);

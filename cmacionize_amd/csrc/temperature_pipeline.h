@@ -3,7 +3,7 @@
  * (src/TemperatureCalculator.cpp:567-931) over the grid as a pipeline of
  * small kernels instead of one: the same functions of device_thermal.h, the
  * same arithmetic in the same order - results equal those of
- * temperature_kernel bit for bit (tests/test_gpu_fixtures.py) - but
+ * temperature_kernel bit for bit (tests/test_gpu_physics.py) - but
  *
  *   temp_begin_kernel     every cell: cells that need no solve are stored,
  *                         the others get a slot (solve state in global memory)
@@ -16,6 +16,7 @@
  *     temp_secant_kernel    one lane per slot: the step's new temperature;
  *                           converged cells are finished and stored, the rest
  *                           is listed for the next step
+ *   temp_finish_kernel    the last few slots, all their remaining steps
  *
  * One kernel holding a whole solve keeps ~400 values alive (256 registers +
  * 137 spilled, 2 waves/SIMD) and its lanes take 1 to ~10 steps each; here
@@ -411,6 +412,77 @@ __global__ void __launch_bounds__(CMI_BLOCK)
         block_reserve(again, a.counts + 1 + next, s_count, &s_base);
     if (again)
       a.list[next][q] = slot;
+  }
+}
+
+/* The last slots - a handful of cells whose secant iteration wanders until
+ * t_max_iterations ends it; as pipeline steps they would cost a hundred rounds
+ * of three nearly empty launches each - are finished by one launch: four
+ * lanes per slot, three of which run the step's three balance evaluations
+ * side by side (cooling_and_heating_balance, whole); all of them then take
+ * the same secant step from the exchanged gains and losses. */
+__global__ void __launch_bounds__(CMI_BLOCK)
+    temp_finish_kernel(const TempPipeArgs a_in) {
+  __shared__ TablesDev lds_tables;
+  __shared__ double abund_s[13 * CMI_BLOCK];
+  TempPipeArgs a = a_in;
+  temp_stage_tables(a_in.u.model.tables, &lds_tables);
+  a.u.model.tables = &lds_tables;
+  double *const abund = abund_s + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 3;          /* evaluation of this lane (3: none) */
+  const int first = lane & ~3;       /* the slot's first lane */
+  const uint64_t group =
+      ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const bool valid = group < a.nactive;
+  uint32_t slot = 0;
+  TemperatureSolve s;
+  double ntot = 0., zmid = 0.;
+  CellIntegrals J = temp_integrals(a.u, a.chunk_first);
+  bool again = false;
+  if (valid) {
+    slot = a.list[a.current][group];
+    temp_load_state(a, slot, s);
+    ntot = a.state[(size_t)TS_NTOT * a.capacity + slot];
+    zmid = a.state[(size_t)TS_ZMID * a.capacity + slot];
+    J = temp_integrals(a.u, a.chunk_first + a.slot_cell[slot]);
+    again = true; /* listed: its last step left it unconverged */
+  }
+  while (__ballot(again) != 0ull) {
+    double gaink = 0., lossk = 0., h0k = 0., he0k = 0.;
+    const double T0 = s.T0;
+    if (again && sub < 3) {
+      const double T1 = 1.1 * T0;
+      const double Tk = (sub == 0) ? T1 : ((sub == 1) ? 0.9 * T0 : T0);
+      double x[CMI_NION];
+      cooling_and_heating_balance(a.u.model, h0k, he0k, gaink, lossk, Tk, ntot,
+                                  zmid, J, s.h, x, abund, CMI_BLOCK);
+    }
+    /* (every lane of the wave takes part in the exchange) */
+    const double gain1 = __shfl(gaink, first, 64);
+    const double loss1 = __shfl(lossk, first, 64);
+    const double gain2 = __shfl(gaink, first + 1, 64);
+    const double loss2 = __shfl(lossk, first + 1, 64);
+    const double gain0 = __shfl(gaink, first + 2, 64);
+    const double loss0 = __shfl(lossk, first + 2, 64);
+    const double h0 = __shfl(h0k, first + 2, 64);
+    const double he0 = __shfl(he0k, first + 2, 64);
+    if (again) {
+      ++s.niter;
+      s.Tlast = T0;
+      s.h0 = h0;
+      s.he0 = he0;
+      s.gain0 = gain0;
+      s.loss0 = loss0;
+      temperature_step_finish(a.u.model, s, T0, gain1, loss1, gain2, loss2);
+      again = temperature_goes_on(a.u.model, s);
+    }
+  }
+  if (valid && sub == 0) {
+    const int64_t c = a.chunk_first + a.slot_cell[slot];
+    double T, heating[2], x[CMI_NION];
+    temperature_end(a.u.model, ntot, J, s, T, heating, x);
+    temp_store_cell(a.u, c, ntot, T, x, heating);
   }
 }
 

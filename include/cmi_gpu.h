@@ -404,6 +404,8 @@ int cmi_gpu_compute_emissivities(cmi_gpu_engine *engine, int32_t nlines,
  *                           of a secant step (ionization balance / line
  *                           cooling / update), each dense in like work -
  *                           0: one kernel holding the whole solve of a cell
+ *   "temperature_finish_slots" (32768)  ... and once so few cells are still
+ *                           iterating, one launch takes them to their end
  *   "pre_emission" (1)      multi-ion runs with sorted packets: the spectrum
  *                           sample, the 14 cross sections and the optical
  *                           depth of every new packet are computed by the

@@ -337,6 +337,22 @@ __host__ __device__ inline uint32_t cmi_meta_origin(uint32_t meta) {
 }
 
 /* packet counters accumulated by the transport kernel */
+/* SpectrumTracker (src/SpectrumTracker.hpp:41-262) of up to
+ * CMI_MAX_TRACKERS cells: packets that cross a tracked cell are counted by
+ * frequency bin and photon type (primary, diffuse H, diffuse He), optionally
+ * only those flying within a cone around a reference direction. Counted by
+ * the kernels with the exact marcher (a run with trackers uses those). */
+#define CMI_MAX_TRACKERS 16
+struct TrackersDev {
+  int32_t n; /* 0: none */
+  int32_t nbins;
+  double minimum_frequency, inverse_frequency_width;
+  int64_t cell[CMI_MAX_TRACKERS]; /* index in this engine's grid, -1: not here */
+  double cos_opening_angle[CMI_MAX_TRACKERS];
+  double direction[CMI_MAX_TRACKERS][3]; /* normalised; all zero: any */
+  unsigned long long *counts;            /* [n][3][nbins] */
+};
+
 struct CountersDev {
   double totweight;
   double typecount[4];

@@ -111,6 +111,9 @@ struct cmi_gpu_engine {
   /* counting sort of the slots by tile (null: too many tiles, radix sort) */
   uint32_t *tile_blockhist = nullptr, *tile_total = nullptr;
   uint32_t *tile_new_slots = nullptr; /* slots filled by a round's re-emissions */
+  /* SpectrumTrackers: counted while enabled (the exact marcher then) */
+  TrackersDev trackers = {};
+  bool trackers_enabled = false;
   /* the temperature solve as a pipeline (temperature_pipeline.h) */
   char *temp_pipe_block = nullptr;
   uint32_t temp_pipe_capacity = 0;
@@ -872,6 +875,7 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
     (void)hipFree(e->acc_block);
   (void)hipFree(e->opacity);
   (void)hipFree(e->counters);
+  (void)hipFree(e->trackers.counts);
   (void)hipFree(e->temp_pipe_block);
   (void)hipFree(e->temp_pipe_counts);
   (void)hipFree(e->tables);
@@ -1570,7 +1574,8 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   const bool small_grid = e->ncell < CMI_FAST_MARCHER_MAX_CELLS;
   const int agg = small_grid ? e->tune.aggregate : CMI_AGG_NONE;
   const int agg_reemit = small_grid ? e->tune.aggregate_reemit : CMI_AGG_NONE;
-  const bool exact = e->tune.exact_dda || !small_grid;
+  const bool tracking = e->trackers_enabled && e->trackers.n != 0;
+  const bool exact = e->tune.exact_dda || !small_grid || tracking;
   /* with re-emission in passes the transport launches use the variant WITHOUT
    * the re-emission code (absorbed packets go to the interaction kernel); the
    * variant with it follows re-emissions in place */
@@ -1732,6 +1737,9 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     a.refill_threshold = flights ? e->tune.refill_threshold_reemit
                                  : e->tune.refill_threshold;
     a.exp_no_atomics = e->tune.exp_no_atomics;
+    a.trackers = e->trackers;
+    if (!tracking)
+      a.trackers.n = 0;
     a.aggregate = flights ? agg_reemit : agg;
     a.qin = no_queue;
     a.qout = no_queue;
@@ -2528,6 +2536,87 @@ int cmi_gpu_compute_emissivities(cmi_gpu_engine *e, int32_t nlines,
   if (err != hipSuccess)
     return fail(CMI_GPU_EDEVICE, "compute_emissivities: %s",
                 hipGetErrorString(err));
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *e, int32_t n,
+                                  const double *positions, int32_t nbins,
+                                  const double *opening_angles,
+                                  const double *reference_directions) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  if (n < 0 || n > CMI_MAX_TRACKERS)
+    return fail(CMI_GPU_EINVAL, "set_spectrum_trackers: %d trackers, at most "
+                "%d", (int)n, CMI_MAX_TRACKERS);
+  if (n > 0 && (!positions || nbins < 1))
+    return fail(CMI_GPU_EINVAL, "set_spectrum_trackers: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(e->trackers.counts);
+  e->trackers = TrackersDev();
+  if (n == 0)
+    return CMI_GPU_OK;
+  TrackersDev t = TrackersDev();
+  t.n = n;
+  t.nbins = nbins;
+  /* src/SpectrumTracker.hpp:88-90: nbins bins over three Rydberg frequencies */
+  t.minimum_frequency = 3.289e15;
+  t.inverse_frequency_width = 1. / (3. * 3.289e15 / nbins);
+  const GridDev &g = e->grid;
+  for (int32_t k = 0; k < n; ++k) {
+    /* the cell that holds the position (CartesianDensityGrid::get_cell_indices,
+     * src/CartesianDensityGrid.cpp:152-161); TrackerManager::add_trackers
+     * aborts for a position outside the box (src/TrackerManager.hpp:181-184) */
+    int64_t cell = 0;
+    bool here = true;
+    for (int a = 0; a < 3; ++a) {
+      const double x = positions[3 * k + a];
+      if (!(x >= g.anchor[a] && x <= g.anchor[a] + g.box_sides[a]))
+        return fail(CMI_GPU_EINVAL, "Tracker is not inside grid!");
+      int64_t i = (int64_t)((x - g.anchor[a]) * g.inv_cellside[a]);
+      if (i >= g.global_ncell[a])
+        i = g.global_ncell[a] - 1;
+      i -= g.offset[a];
+      here = here && i >= 0 && i < g.ncell[a];
+      cell = cell * g.ncell[a] + i;
+    }
+    t.cell[k] = here ? cell : -1;
+    t.cos_opening_angle[k] = opening_angles ? cos(opening_angles[k]) : -1.;
+    double norm2 = 0.;
+    for (int a = 0; a < 3; ++a) {
+      t.direction[k][a] =
+          reference_directions ? reference_directions[3 * k + a] : 0.;
+      norm2 += t.direction[k][a] * t.direction[k][a];
+    }
+    if (norm2 > 0.)
+      for (int a = 0; a < 3; ++a)
+        t.direction[k][a] /= sqrt(norm2);
+  }
+  const size_t bytes = sizeof(unsigned long long) * 3 * (size_t)n * nbins;
+  HIP_TRY(hipMalloc(&t.counts, bytes));
+  HIP_TRY(hipMemsetAsync(t.counts, 0, bytes, e->stream));
+  e->trackers = t;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_enable_trackers(cmi_gpu_engine *e, int32_t enable) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  e->trackers_enabled = enable != 0;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_get_tracker_counts(cmi_gpu_engine *e, uint64_t *counts) {
+  if (!e || !counts)
+    return fail(CMI_GPU_EINVAL, "get_tracker_counts: bad argument");
+  if (e->trackers.n == 0)
+    return fail(CMI_GPU_ESTATE, "get_tracker_counts: no trackers set");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(counts, e->trackers.counts,
+                         sizeof(unsigned long long) * 3 *
+                             (size_t)e->trackers.n * e->trackers.nbins,
+                         hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return CMI_GPU_OK;
 }
 

@@ -86,6 +86,7 @@ struct ShootArgs {
   uint32_t iteration;
   int32_t refill_threshold;
   int32_t exp_no_atomics; /* experiment: skip the accumulation */
+  TrackersDev trackers;   /* EXACT kernels only */
   int32_t aggregate;      /* CMI_AGG_* */
   /* qin.id != NULL: this launch flies the ready flights of qin instead of
    * emitting new packets. qout.id != NULL: a packet that is absorbed is parked
@@ -832,6 +833,28 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
         }
         ++nsteps;
         accumulate = (kappa.x >= 0.); /* number density > 0 */
+        /* DensityGrid::update_integrals' tracker hook,
+         * src/DensityGrid.hpp:188-191 (SpectrumTracker::count_photon) */
+        if (EXACT && a.trackers.n != 0 && accumulate) {
+          for (int k = 0; k < a.trackers.n; ++k) {
+            if (last_cell_wide != a.trackers.cell[k])
+              continue;
+            const double *d = a.trackers.direction[k];
+            if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] > 0. &&
+                p.dir[0] * d[0] + p.dir[1] * d[1] + p.dir[2] * d[2] <
+                    a.trackers.cos_opening_angle[k])
+              continue;
+            const uint32_t bin =
+                (uint32_t)((p.nu - a.trackers.minimum_frequency) *
+                           a.trackers.inverse_frequency_width);
+            if (bin < (uint32_t)a.trackers.nbins && p.type < TYPE_ABSORBED)
+              atomicAdd(a.trackers.counts +
+                            ((size_t)k * 3 + (size_t)p.type) *
+                                (size_t)a.trackers.nbins +
+                            bin,
+                        1ull);
+          }
+        }
       }
       if (!EXACT && any_periodic && stepping && p.tau >= 0.)
         fast_wrap(a.grid, p);

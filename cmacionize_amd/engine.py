@@ -84,6 +84,8 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_group_destroy", "cmi_gpu_group_reduce_accumulators",
     "cmi_gpu_group_update_cells",
     "cmi_gpu_group_exchange_flights", "cmi_gpu_compute_emissivities",
+    "cmi_gpu_set_spectrum_trackers", "cmi_gpu_enable_trackers",
+    "cmi_gpu_get_tracker_counts",
 ]
 
 # the emission lines of EmissivityValues (src/EmissivityValues.hpp:36-81), in
@@ -191,6 +193,10 @@ def load_library():
     L.cmi_gpu_compute_emissivities.argtypes = [
         vp, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_int64,
         C.POINTER(C.c_double)]
+    L.cmi_gpu_set_spectrum_trackers.argtypes = [vp, C.c_int32, _dp, C.c_int32,
+                                                _dp, _dp]
+    L.cmi_gpu_enable_trackers.argtypes = [vp, C.c_int32]
+    L.cmi_gpu_get_tracker_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.cmi_gpu_update_cells_range.argtypes = [vp, C.c_uint32, C.c_double,
                                              C.c_int64, C.c_int64]
     L.cmi_gpu_refresh_transport_records.argtypes = [vp]
@@ -518,6 +524,31 @@ class GpuEngine:
             self._h, len(names), idx.ctypes.data_as(C.POINTER(C.c_int32)),
             first_cell, ncell, out.ctypes.data_as(C.POINTER(C.c_double))))
         return dict(zip(names, out))
+
+    def set_spectrum_trackers(self, positions, nbins=100, opening_angles=None,
+                              reference_directions=None):
+        """SpectrumTrackers in the cells that hold `positions` ([n][3])."""
+        pos = _f64(positions).reshape(-1, 3)
+        n = len(pos)
+        ang = None if opening_angles is None else _f64(opening_angles)
+        ref = None if reference_directions is None else \
+            _f64(reference_directions).reshape(-1, 3)
+        self._check(self._lib.cmi_gpu_set_spectrum_trackers(
+            self._h, n, _p(pos) if n else None, nbins,
+            None if ang is None else _p(ang),
+            None if ref is None else _p(ref)))
+        self._trackers = (n, nbins)
+
+    def enable_trackers(self, on=True):
+        self._check(self._lib.cmi_gpu_enable_trackers(self._h, int(on)))
+
+    def get_tracker_counts(self):
+        """counts[tracker][type (primary, diffuse H, diffuse He)][bin]"""
+        n, nbins = self._trackers
+        out = np.zeros((n, 3, nbins), dtype=np.uint64)
+        self._check(self._lib.cmi_gpu_get_tracker_counts(
+            self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
 
     def set_tuning(self, **kw):
         for k, v in kw.items():

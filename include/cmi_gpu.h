@@ -351,6 +351,28 @@ int cmi_gpu_compute_emissivities(cmi_gpu_engine *engine, int32_t nlines,
                                  const int32_t *lines, int64_t first_cell,
                                  int64_t ncell, double *emissivities);
 
+/* replaces: TrackerManager::add_trackers with SpectrumTrackers
+ * (src/TrackerManager.hpp:178-205, src/SpectrumTracker.hpp:41-262) and the
+ * hook in DensityGrid::update_integrals (src/DensityGrid.hpp:188-191): every
+ * packet that crosses the cell holding positions[3 k ..] (with gas in it) is
+ * counted in tracker k by frequency bin (nbins bins over [1, 4) x 3.289e15 Hz,
+ * :88-90) and photon type (primary, diffuse H, diffuse He) - if
+ * reference_directions[3 k ..] is not the null vector only packets within
+ * opening_angles[k] (radians) of it (:178-186). At most 16 trackers; n = 0
+ * removes them; opening_angles / reference_directions may be NULL (all
+ * packets). Counting happens while enabled (the reference adds its trackers
+ * for the last iteration, src/IonizationSimulation.cpp:367-370) and makes the
+ * transport use the exact marcher without the combining table or tile
+ * rounds. A block of a decomposed grid counts the trackers that lie in it. */
+int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *engine, int32_t n,
+                                  const double *positions, int32_t nbins,
+                                  const double *opening_angles,
+                                  const double *reference_directions);
+int cmi_gpu_enable_trackers(cmi_gpu_engine *engine, int32_t enable);
+/* counts[(k * 3 + type) * nbins + bin] since the trackers were set
+ * (SpectrumTracker::output_tracker's three columns, :226-238). Synchronous. */
+int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);
+
 /* Performance knobs (no effect on what is computed, only on how):
  *   "sort_packets" (1)      process the packets of a launch in emission-
  *                           direction order, so that the lanes of a wave cross

@@ -231,6 +231,15 @@ double cmio_reemit_scripted(const cmio_model *model, double sigma_H,
                             double xHe, const double *uniforms,
                             int32_t *type, uint32_t *draws);
 
+/* SpectrumTrackers on cells (long indices) of the grid: while n != 0,
+ * cmio_interact counts the packets that cross them - by frequency bin (nbins
+ * over [1, 4) x 3.289e15 Hz) and photon type - into
+ * counts[(k * 3 + type) * nbins + bin] (src/SpectrumTracker.hpp:176-212,
+ * src/DensityGrid.hpp:188-191). The arrays stay the caller's. */
+void cmio_set_trackers(int32_t n, int32_t nbins, const int64_t *cell,
+                       const double *cos_opening_angle,
+                       const double *direction, uint64_t *counts);
+
 /* A photon packet: src/Photon.hpp:36-69 */
 typedef struct {
   double position[3];

@@ -221,6 +221,56 @@ static int is_inside(const cmio_grid *grid, int32_t index[3],
   return inside;
 }
 
+/* SpectrumTrackers (src/SpectrumTracker.hpp:41-262) on cells of the grid:
+ * DensityGrid::update_integrals counts every packet that crosses a cell with
+ * a tracker (src/DensityGrid.hpp:188-191). One set per process, installed by
+ * the test (cmio_set_trackers); counts[(k * 3 + type) * nbins + bin]. */
+static struct {
+  int32_t n, nbins;
+  const int64_t *cell;
+  const double *cos_opening_angle; /* [n] */
+  const double *direction;         /* [n][3], normalised or null vector */
+  uint64_t *counts;
+} trackers = {0, 0, NULL, NULL, NULL, NULL};
+
+void cmio_set_trackers(int32_t n, int32_t nbins, const int64_t *cell,
+                       const double *cos_opening_angle,
+                       const double *direction, uint64_t *counts) {
+  trackers.n = n;
+  trackers.nbins = nbins;
+  trackers.cell = cell;
+  trackers.cos_opening_angle = cos_opening_angle;
+  trackers.direction = direction;
+  trackers.counts = counts;
+}
+
+/* SpectrumTracker::count_photon, src/SpectrumTracker.hpp:176-212 */
+static void count_photon(int64_t cell, const cmio_photon *photon) {
+  const double minimum_frequency = 3.289e15;
+  const double inverse_frequency_width =
+      1. / (3. * 3.289e15 / trackers.nbins);
+  for (int32_t k = 0; k < trackers.n; ++k) {
+    if (trackers.cell[k] != cell)
+      continue;
+    const double *d = trackers.direction + 3 * k;
+    if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] > 0.) {
+      const double dot_product = photon->direction[0] * d[0] +
+                                 photon->direction[1] * d[1] +
+                                 photon->direction[2] * d[2];
+      if (dot_product < trackers.cos_opening_angle[k])
+        continue;
+    }
+    const uint32_t index = (uint32_t)((photon->energy - minimum_frequency) *
+                                      inverse_frequency_width);
+    if (index < (uint32_t)trackers.nbins && photon->type >= 0 &&
+        photon->type < 3) {
+#pragma omp atomic
+      trackers.counts[((size_t)k * 3 + (size_t)photon->type) * trackers.nbins +
+                      index] += 1;
+    }
+  }
+}
+
 int64_t cmio_interact(const cmio_grid *grid, const cmio_model *model,
                       cmio_cells *cells, cmio_photon *photon,
                       double optical_depth, int64_t *trace_cell,
@@ -299,6 +349,8 @@ int64_t cmio_interact(const cmio_grid *grid, const cmio_model *model,
       cells->heating[0][cell] += dhH;
 #pragma omp atomic
       cells->heating[1][cell] += dhHe;
+      if (trackers.n != 0)
+        count_photon(cell, photon);
     }
 
     if (trace_cell && nstep < trace_cap) {

@@ -519,3 +519,40 @@ def lexington_simulation(ncell=32, star_temperature=40000.):
     m.do_temperature = 1
     m.pahfac = 0.
     return sim
+
+
+class Trackers:
+    """SpectrumTrackers on cells of the oracle's grid (cmio_set_trackers):
+    installed while the object is used as a context manager."""
+
+    def __init__(self, cells, nbins=100, opening_angles=None,
+                 reference_directions=None):
+        self.cells = np.ascontiguousarray(cells, dtype=np.int64)
+        n = len(self.cells)
+        self.nbins = nbins
+        ang = np.full(n, np.pi) if opening_angles is None else \
+            np.asarray(opening_angles, dtype=np.float64)
+        self.cosang = np.ascontiguousarray(np.cos(ang))
+        d = np.zeros((n, 3)) if reference_directions is None else \
+            np.array(reference_directions, dtype=np.float64).reshape(n, 3)
+        norm = np.sqrt((d * d).sum(axis=1))
+        d[norm > 0.] /= norm[norm > 0., None]
+        self.directions = np.ascontiguousarray(d)
+        self.counts = np.zeros((n, 3, nbins), dtype=np.uint64)
+
+    def __enter__(self):
+        L = lib()
+        L.cmio_set_trackers.argtypes = [
+            C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+            C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.cmio_set_trackers.restype = None
+        L.cmio_set_trackers(
+            len(self.cells), self.nbins,
+            self.cells.ctypes.data_as(C.POINTER(C.c_int64)),
+            _ptr(self.cosang), _ptr(self.directions),
+            self.counts.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return self
+
+    def __exit__(self, *exc):
+        lib().cmio_set_trackers(0, 0, None, None, None, None)
+        return False

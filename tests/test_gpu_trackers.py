@@ -1,0 +1,79 @@
+"""GPU parity of the SpectrumTrackers (cmi_gpu_set_spectrum_trackers: the
+tracker hook of DensityGrid::update_integrals, src/DensityGrid.hpp:188-191,
+with SpectrumTracker::count_photon, src/SpectrumTracker.hpp:176-212): the same
+packets cross the same cells in engine and oracle, so the counts - integers -
+must be equal."""
+import numpy as np
+import pytest
+
+from test_gpu_physics import lexington_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def cell_of(position, anchor, side, ncell):
+    i = [int((position[a] - anchor) / side * ncell) for a in range(3)]
+    return (i[0] * ncell + i[1]) * ncell + i[2]
+
+
+@pytest.mark.parametrize("tuning", [dict(), dict(reemit_passes=0)])
+def test_tracker_counts_match_oracle(oracle, tuning):
+    ncell, npacket = 20, 40000
+    sim = oracle.lexington_simulation(ncell)
+    eng = lexington_engine(ncell, sim)
+    eng.set_tuning(**tuning)
+    pc = oracle.PC
+    anchor, side = -5. * pc, 10. * pc
+    positions = np.array([[1.3 * pc, 0.4 * pc, -0.7 * pc],
+                          [-2.1 * pc, 1.9 * pc, 0.2 * pc],
+                          [1.3 * pc, 0.4 * pc, -0.7 * pc],   # same cell, cone
+                          [0.01 * pc, 0.01 * pc, 0.01 * pc],  # in the hole
+                          [3.6 * pc, -3.2 * pc, 2.9 * pc]])
+    angles = np.array([np.pi, np.pi, 0.5, np.pi, 1.2])
+    directions = np.array([[0., 0., 0.], [0., 0., 0.], [1., 0.3, -0.5],
+                           [0., 0., 0.], [1., -1., 1.]])
+    nbins = 40
+    eng.set_spectrum_trackers(positions, nbins, angles, directions)
+    cells = [cell_of(p, anchor, side, ncell) for p in positions]
+    # a first iteration without trackers (they are added for the last one);
+    # then both go on from the oracle's state
+    eng.reset_grid()
+    eng.shoot(42, 0, 0, npacket)
+    sim.run(npacket, 1, seed=42)
+    assert not eng.get_tracker_counts().any()
+    eng.upload_cells(sim.number_density, sim.temperature,
+                     np.array([np.asarray(x) for x in sim.x]))
+    eng.enable_trackers(True)
+    eng.reset_grid()
+    eng.shoot(42, 1, 0, npacket)
+    tw, tc, ns = eng.get_counters()
+    got = eng.get_tracker_counts()
+    with oracle.Trackers(cells, nbins, angles, directions) as t:
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(42, 1, 0, npacket)
+    assert tw == sim.totweight and np.array_equal(tc, sim.typecount)
+    assert np.array_equal(got, t.counts)
+    # primaries and re-emitted hydrogen photons were seen; the cone sees a
+    # part of what the open tracker of the same cell sees; no gas, no count
+    assert got[0, 0].sum() > 50 and got[0, 1].sum() > 5
+    assert 0 < got[2].sum() < got[0].sum()
+    assert not got[3].any()
+    # switched off again: nothing more is counted, and the fast path is back
+    eng.enable_trackers(False)
+    eng.reset_grid()
+    eng.shoot(42, 2, 0, npacket)
+    assert np.array_equal(eng.get_tracker_counts(), got)
+    eng.set_spectrum_trackers(np.zeros((0, 3)))
+    eng.close()
+
+
+def test_tracker_arguments():
+    from cmacionize_amd import engine as E
+    eng = lexington_engine(4)
+    with pytest.raises(E.EngineError, match="not inside grid"):
+        eng.set_spectrum_trackers([[1.e30, 0., 0.]])
+    with pytest.raises(E.EngineError, match="at most"):
+        eng.set_spectrum_trackers(np.zeros((17, 3)))
+    eng.close()

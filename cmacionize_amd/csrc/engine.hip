@@ -2550,6 +2550,11 @@ int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *e, int32_t n,
                 "%d", (int)n, CMI_MAX_TRACKERS);
   if (n > 0 && (!positions || nbins < 1))
     return fail(CMI_GPU_EINVAL, "set_spectrum_trackers: bad argument");
+  /* (flights handed over between blocks carry the state of the incremental
+   * marcher; the trackers count in the exact one) */
+  if (n > 0 && e->grid.decomposed)
+    return fail(CMI_GPU_ESTATE, "set_spectrum_trackers: trackers need an "
+                "undivided grid (this engine holds a block of one)");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   (void)hipFree(e->trackers.counts);

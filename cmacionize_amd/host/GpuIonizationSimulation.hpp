@@ -347,6 +347,108 @@ inline DensityGridWriter *generate_writer(const std::string &output_folder,
   throw ParameterError("Unknown DensityGridWriter type: \"" + type + "\"");
 }
 
+/* TrackerManager with SpectrumTrackers (src/TrackerManager.hpp:41-380,
+ * src/SpectrumTracker.hpp:41-262): the trackers of a YAML block file, placed
+ * on the engines for the last iteration and written as the reference's text
+ * files afterwards. (Its HDF5 output and tracker types other than Spectrum
+ * are not provided.) */
+class TrackerManager {
+  std::vector<double> _positions, _opening_angles, _reference_directions;
+  std::vector<std::string> _output_names;
+  int32_t _number_of_bins = 0;
+  const uint_fast64_t _number_of_photons;
+  std::vector<uint64_t> _counts;
+
+public:
+  explicit TrackerManager(ParameterFile &params)
+      : _number_of_photons((uint_fast64_t)params.get_integer(
+            "TrackerManager:minimum number of photon packets", 0)) {
+    const std::string filename = params.get_filename("TrackerManager:filename");
+    if (params.get_bool("TrackerManager:HDF5 output", false))
+      throw ParameterError("TrackerManager:HDF5 output is not provided "
+                           "(text files are)");
+    ParameterFile blocks(filename);
+    const long long n = blocks.get_integer("number of trackers", -1);
+    if (n < 0)
+      throw ParameterError("\"number of trackers\" not found in \"" +
+                           filename + "\"");
+    if (n > 16)
+      throw ParameterError("at most 16 trackers");
+    for (long long i = 0; i < n; ++i) {
+      const std::string name = "tracker[" + std::to_string(i) + "]:";
+      const std::array<double, 3> x =
+          blocks.get_physical_vector(QUANTITY_LENGTH, name + "position", "");
+      const std::string type = blocks.get_string(name + "type", "Spectrum");
+      if (type != "Spectrum")
+        throw ParameterError("Tracker type \"" + type +
+                             "\" is not provided (Spectrum is)");
+      const int32_t bins =
+          (int32_t)blocks.get_integer(name + "number of bins", 100);
+      if (i > 0 && bins != _number_of_bins)
+        throw ParameterError("all trackers must have the same number of bins");
+      _number_of_bins = bins;
+      _opening_angles.push_back(blocks.get_physical_value(
+          QUANTITY_ANGLE, name + "opening angle", "180. degrees"));
+      /* (a vector of plain numbers) */
+      const std::string d =
+          blocks.get_string(name + "reference direction", "[0., 0., 0.]");
+      double v[3] = {0., 0., 0.};
+      if (std::sscanf(d.c_str(), " [ %lf , %lf , %lf ]", &v[0], &v[1],
+                      &v[2]) != 3)
+        throw ParameterError("bad reference direction \"" + d + "\"");
+      for (int a = 0; a < 3; ++a) {
+        _positions.push_back(x[a]);
+        _reference_directions.push_back(v[a]);
+      }
+      _output_names.push_back(blocks.get_string(
+          name + "output name", "Tracker" + std::to_string(i) + ".txt"));
+    }
+    std::ofstream ofile(filename + ".used-values");
+    blocks.print_contents(ofile);
+  }
+
+  uint_fast64_t get_number_of_photons() const { return _number_of_photons; }
+  size_t size() const { return _output_names.size(); }
+
+  /* TrackerManager::add_trackers */
+  int lower(cmi_gpu_engine *engine) const {
+    int rc = cmi_gpu_set_spectrum_trackers(
+        engine, (int32_t)size(), _positions.data(), _number_of_bins,
+        _opening_angles.data(), _reference_directions.data());
+    if (rc == CMI_GPU_OK)
+      rc = cmi_gpu_enable_trackers(engine, 1);
+    return rc;
+  }
+  /* the counts of one engine, added to the total (the copies of a tracker
+   * are merged, src/TrackerManager.hpp:321-332) */
+  int collect(cmi_gpu_engine *engine) {
+    std::vector<uint64_t> part(3 * size() * (size_t)_number_of_bins);
+    const int rc = cmi_gpu_get_tracker_counts(engine, part.data());
+    if (rc != CMI_GPU_OK)
+      return rc;
+    _counts.resize(part.size(), 0);
+    for (size_t k = 0; k < part.size(); ++k)
+      _counts[k] += part[k];
+    return CMI_GPU_OK;
+  }
+  /* SpectrumTracker::output_tracker, :226-238 */
+  void output_trackers() const {
+    const double minimum_frequency = 3.289e15;
+    const double frequency_width = 3. * 3.289e15 / _number_of_bins;
+    for (size_t t = 0; t < size(); ++t) {
+      std::ofstream ofile(_output_names[t]);
+      ofile << "# frequency (Hz)\tprimary count\tdiffuse H count\tdiffuse He "
+               "count\n";
+      const uint64_t *c = _counts.data() + 3 * t * (size_t)_number_of_bins;
+      for (int32_t i = 0; i < _number_of_bins; ++i) {
+        const double nu = minimum_frequency + (i + 0.5) * frequency_width;
+        ofile << nu << "\t" << c[i] << "\t" << c[_number_of_bins + i] << "\t"
+              << c[2 * _number_of_bins + i] << "\n";
+      }
+    }
+  }
+};
+
 class GpuIonizationSimulation {
   const bool _every_iteration_output;
   const bool _output_statistics;
@@ -620,6 +722,19 @@ class GpuIonizationSimulation {
    * computed there (cmi_gpu_compute_emissivities) and go into the last
    * snapshot as the same datasets. */
   std::vector<int32_t> _emission_lines;
+  std::unique_ptr<TrackerManager> _trackers;
+
+  template <typename F> void for_each_engine(F f) {
+    if (decomposed()) {
+      for (Block &b : _blocks)
+        f(b.engine);
+    } else if (!_replicas.empty()) {
+      for (cmi_gpu_engine *e : _replicas)
+        f(e);
+    } else if (_engine) {
+      f(_engine);
+    }
+  }
 
   void compute_emissivities() {
     DensityGrid &g = *_density_grid;
@@ -771,8 +886,9 @@ public:
 
     _random_seed =
         (int32_t)_parameter_file.get_integer("IonizationSimulation:random seed", 42);
+    /* src/IonizationSimulation.cpp:208-213 */
     if (_parameter_file.get_bool("IonizationSimulation:enable trackers", false))
-      throw ParameterError("Trackers are not on this path");
+      _trackers.reset(new TrackerManager(_parameter_file));
 
     /* all parameters read: dump them (src/IonizationSimulation.cpp:218-226) */
     if (write_output) {
@@ -1035,6 +1151,13 @@ public:
       uint_fast64_t lnumphoton = _number_of_photons;
       if (loop == 0)
         lnumphoton = _number_of_photons_init;
+      /* src/IonizationSimulation.cpp:367-370 */
+      if (_trackers && loop == _number_of_iterations - 1) {
+        for_each_engine([&](cmi_gpu_engine *e) {
+          check(_trackers->lower(e), "set_spectrum_trackers");
+        });
+        lnumphoton = std::max(lnumphoton, _trackers->get_number_of_photons());
+      }
 
       status("Start shooting " + std::to_string(lnumphoton) + " photons...");
       auto t0 = std::chrono::steady_clock::now();
@@ -1108,6 +1231,14 @@ public:
       status("Maximum number of iterations (" +
              std::to_string(_number_of_iterations) + ") reached, stopping.");
 
+    /* src/IonizationSimulation.cpp:651-653 */
+    if (_trackers && _number_of_iterations > 0) {
+      for_each_engine([&](cmi_gpu_engine *e) {
+        check(_trackers->collect(e), "get_tracker_counts");
+        check(cmi_gpu_enable_trackers(e, 0), "enable_trackers");
+      });
+      _trackers->output_trackers();
+    }
     download_state();
     compute_emissivities();
     if (_density_grid_writer)

@@ -35,7 +35,8 @@ enum Quantity {
   QUANTITY_FLUX,
   QUANTITY_TIME,
   QUANTITY_DENSITY,
-  QUANTITY_VELOCITY
+  QUANTITY_VELOCITY,
+  QUANTITY_ANGLE
 };
 
 /* value + exponents of (length, time, mass, temperature, current, angle) */
@@ -196,6 +197,8 @@ inline const char *SI_unit_name(Quantity q) {
     return "kg m^-3";
   case QUANTITY_VELOCITY:
     return "m s^-1";
+  case QUANTITY_ANGLE:
+    return "radians";
   }
   return "";
 }

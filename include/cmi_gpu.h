@@ -363,7 +363,8 @@ int cmi_gpu_compute_emissivities(cmi_gpu_engine *engine, int32_t nlines,
  * packets). Counting happens while enabled (the reference adds its trackers
  * for the last iteration, src/IonizationSimulation.cpp:367-370) and makes the
  * transport use the exact marcher without the combining table or tile
- * rounds. A block of a decomposed grid counts the trackers that lie in it. */
+ * rounds. Not for the blocks of a decomposed grid (CMI_GPU_ESTATE): flights
+ * handed over between blocks carry the incremental marcher's state. */
 int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *engine, int32_t n,
                                   const double *positions, int32_t nbins,
                                   const double *opening_angles,

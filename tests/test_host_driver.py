@@ -416,3 +416,64 @@ def test_ascii_file_source_distribution(exe, tmp_path):
     r = subprocess.run([exe, "--params", str(p), "--dry-run"],
                        capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 1 and "number of sources" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks", [None, "2,2,1"])
+def test_trackers_through_the_driver(exe, tmp_path, blocks):
+    """IonizationSimulation:enable trackers + a TrackerManager block file
+    (src/TrackerManager.hpp, src/SpectrumTracker.hpp): the trackers count in
+    the last iteration and are written as the reference's text files. A grid
+    in blocks refuses them."""
+    import shutil
+    text = open(os.path.join(BENCH, "lexingtonHII40.param")).read()
+    text = text.replace("[64, 64, 64]", "[16, 16, 16]")
+    text = text.replace("number of photons: 1e8", "number of photons: 30000")
+    text = text.replace("number of iterations: 20", "number of iterations: 4")
+    text = text.replace("type: Gadget", "type: AsciiFile")
+    text = text.replace("random seed: 42",
+                        "random seed: 42\n  enable trackers: true")
+    text += ("\nTrackerManager:\n  filename: trackers.yml\n"
+             "  minimum number of photon packets: 50000\n")
+    assert "enable trackers: true" in text
+    (tmp_path / "trackers.yml").write_text(
+        "number of trackers: 2\n"
+        "tracker[0]:\n"
+        "  position: [1.3 pc, 0.4 pc, -0.7 pc]\n"
+        "  type: Spectrum\n"
+        "  number of bins: 50\n"
+        "tracker[1]:\n"
+        "  position: [-2.1 pc, 1.9 pc, 0.2 pc]\n"
+        "  number of bins: 50\n"
+        "  opening angle: 60. degrees\n"
+        "  reference direction: [-1., 1., 0.]\n"
+        "  output name: second.txt\n")
+    shutil.copy(os.path.join(BENCH, "lexingtonHII40.yml"), tmp_path)
+    (tmp_path / "run.param").write_text(text)
+    r = subprocess.run([exe, "--params", "run.param"] +
+                       (["--blocks", blocks] if blocks else []),
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    if blocks:
+        assert r.returncode != 0 and "undivided grid" in r.stderr
+        return
+    assert r.returncode == 0, r.stderr
+    # the last iteration used the trackers' packet count
+    assert "Start shooting 50000 photons" in r.stdout
+    assert r.stdout.count("Start shooting 30000 photons") == 3
+    assert os.path.exists(tmp_path / "trackers.yml.used-values")
+    first = open(tmp_path / "Tracker0.txt").read().splitlines()
+    assert first[0] == ("# frequency (Hz)\tprimary count\tdiffuse H count\t"
+                        "diffuse He count")
+    a = np.loadtxt(tmp_path / "Tracker0.txt")
+    b = np.loadtxt(tmp_path / "second.txt")
+    assert a.shape == b.shape == (50, 4)
+    width = 3. * 3.289e15 / 50
+    assert np.allclose(a[:, 0], 3.289e15 + (np.arange(50) + 0.5) * width,
+                       rtol=1e-5)
+    # a 40 000 K star: primaries fall off with frequency; the diffuse hydrogen
+    # photons sit just above the threshold
+    assert a[:, 1].sum() > 100 and a[:5, 1].sum() > a[-20:, 1].sum()
+    assert a[:, 2].sum() > 10 and a[:3, 2].sum() >= 0.8 * a[:, 2].sum()
+    # the cone around the outward direction sees the star's light, not all of
+    # the diffuse field
+    assert 0 < b[:, 1:].sum() < a[:, 1:].sum() * 3

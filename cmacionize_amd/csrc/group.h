@@ -220,6 +220,30 @@ struct cmi_gpu_group {
   uint64_t rounds = 0, flights = 0;
 };
 
+/* fn(k), k < n, on one host thread each: the engines' cell updates block
+ * their callers (the temperature pipeline reads a count back per secant
+ * step), and engines on different devices should not wait for each other.
+ * The first error becomes the caller's. */
+template <typename F> static int group_in_parallel(int n, F fn) {
+  if (n == 1)
+    return fn(0);
+  std::vector<int> rc((size_t)n, 0);
+  std::vector<std::string> message((size_t)n);
+  std::vector<std::thread> threads;
+  for (int k = 0; k < n; ++k)
+    threads.emplace_back([&, k]() {
+      rc[k] = fn(k);
+      if (rc[k])
+        message[k] = cmi_gpu_last_error(); /* thread-local */
+    });
+  for (std::thread &t : threads)
+    t.join();
+  for (int k = 0; k < n; ++k)
+    if (rc[k])
+      return fail(rc[k], "%s", message[k].c_str());
+  return CMI_GPU_OK;
+}
+
 extern "C" {
 
 int cmi_gpu_group_create(int32_t n, cmi_gpu_engine *const *engines,
@@ -466,13 +490,18 @@ static int update_class(cmi_gpu_group *g, GroupClass &c, uint32_t loop,
   std::vector<int64_t> first(n + 1, 0);
   for (int r = 0; r < n; ++r)
     first[r + 1] = first[r] + ncell / n + (r < ncell % n ? 1 : 0);
-  for (int r = 0; r < n; ++r) {
-    cmi_gpu_engine *e = g->engine[c.member[r]];
-    const int rc = cmi_gpu_update_cells_range(e, loop, totweight, first[r],
-                                              first[r + 1] - first[r]);
+  {
+    const int rc = group_in_parallel(n, [&](int r) -> int {
+      cmi_gpu_engine *e = g->engine[c.member[r]];
+      const int urc = cmi_gpu_update_cells_range(e, loop, totweight, first[r],
+                                                 first[r + 1] - first[r]);
+      if (urc)
+        return urc;
+      HIP_TRY(hipEventRecord(g->solved[c.member[r]], e->stream));
+      return CMI_GPU_OK;
+    });
     if (rc)
       return rc;
-    HIP_TRY(hipEventRecord(g->solved[c.member[r]], e->stream));
   }
   if ((c.distinct_devices || force) && ncell % n == 0) {
     /* MPICommunicator::gather of the temperature and the ionic fractions
@@ -539,12 +568,9 @@ int cmi_gpu_group_update_cells(cmi_gpu_group *g, uint32_t loop,
                                double totweight) {
   if (!g)
     return fail(CMI_GPU_EINVAL, "null group");
-  for (GroupClass &c : g->classes) {
-    const int rc = update_class(g, c, loop, totweight);
-    if (rc)
-      return rc;
-  }
-  return CMI_GPU_OK;
+  return group_in_parallel((int)g->classes.size(), [&](int k) -> int {
+    return update_class(g, g->classes[(size_t)k], loop, totweight);
+  });
 }
 
 int cmi_gpu_group_exchange_flights(cmi_gpu_group *g, uint32_t seed,

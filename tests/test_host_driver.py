@@ -477,3 +477,39 @@ def test_trackers_through_the_driver(exe, tmp_path, blocks):
     # the cone around the outward direction sees the star's light, not all of
     # the diffuse field
     assert 0 < b[:, 1:].sum() < a[:, 1:].sum() * 3
+
+
+def test_tracker_block_file_is_parsed(exe, tmp_path):
+    """TrackerManager's block file (src/TrackerManager.hpp:98-170): parsed
+    with the parameter file grammar, used values written back, unknown types
+    and missing keys reported (no GPU needed: dry run)."""
+    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = text.replace("random seed: 42",
+                        "random seed: 42\n  enable trackers: true")
+    if "enable trackers" not in text:
+        text = text.replace("IonizationSimulation:",
+                            "IonizationSimulation:\n  enable trackers: true")
+    text += "\nTrackerManager:\n  filename: trackers.yml\n"
+    (tmp_path / "run.param").write_text(text)
+
+    def dry_run():
+        return subprocess.run([exe, "--params", "run.param", "--dry-run"],
+                              capture_output=True, text=True,
+                              cwd=str(tmp_path))
+    (tmp_path / "trackers.yml").write_text(
+        "number of trackers: 1\ntracker[0]:\n"
+        "  position: [1. pc, 0.5 pc, -2. pc]\n"
+        "  opening angle: 45. degrees\n")
+    r = dry_run()
+    assert r.returncode == 0, r.stderr
+    used = open(tmp_path / "trackers.yml.used-values").read()
+    assert "number of bins: 100" in used and "Tracker0.txt" in used
+    assert "0.785398" in used  # 45 degrees in radians
+    (tmp_path / "trackers.yml").write_text(
+        "number of trackers: 1\ntracker[0]:\n"
+        "  position: [1. pc, 0.5 pc, -2. pc]\n  type: Absorption\n")
+    r = dry_run()
+    assert r.returncode != 0 and "Absorption" in r.stderr
+    (tmp_path / "trackers.yml").write_text("tracker[0]:\n  type: Spectrum\n")
+    r = dry_run()
+    assert r.returncode != 0 and "number of trackers" in r.stderr

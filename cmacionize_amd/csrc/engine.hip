@@ -128,6 +128,9 @@ struct cmi_gpu_engine {
   struct Tuning {
     bool sort_packets = true;
     int sort_tau_bits = -1;  /* tau classes per direction bin; -1 = auto */
+    /* direction bits of the sort key (2 x 11 at most); -1 = auto: one or two
+     * fewer than 22 where that saves the radix sort a pass of 8 bits */
+    int sort_dir_bits = -1;
     int aggregate = CMI_AGG_BLOCK;      /* first generation (sorted bundles) */
     int aggregate_reemit = CMI_AGG_NONE; /* later generations (random flights) */
     int refill_threshold = CMI_REFILL_THRESHOLD;
@@ -1271,6 +1274,9 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
   const std::string k(key);
   if (k == "sort_packets")
     e->tune.sort_packets = value != 0;
+  else if (k == "sort_dir_bits")
+    e->tune.sort_dir_bits =
+        (int)(value < 0 ? -1 : (value < 2 ? 2 : (value > 22 ? 22 : value)));
   else if (k == "sort_tau_bits")
     e->tune.sort_tau_bits = (int)(value < 0 ? -1 : (value > 3 ? 3 : value));
   else if (k == "aggregate")
@@ -1710,7 +1716,17 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     ++source_bits;
   if (source_bits > 10u - tau_bits)
     source_bits = 10u - tau_bits;
-  const int key_bits = (int)(22u + tau_bits + source_bits);
+  uint32_t dir_bits = 22u;
+  if (e->tune.sort_dir_bits >= 0) {
+    dir_bits = (uint32_t)e->tune.sort_dir_bits;
+  } else {
+    /* measured on 256^3, 1e8 packets: 21 bits order the packets as well as
+     * 22 (20 nearly, 18 not), and 21 + 3 tau bits are three passes, not four */
+    const uint32_t over = (22u + tau_bits + source_bits) % 8u;
+    if (over == 1u || over == 2u)
+      dir_bits = 22u - over;
+  }
+  const int key_bits = (int)(dir_bits + tau_bits + source_bits);
 
   for (uint64_t done = 0; done < n_packets; done += max_launch) {
     const uint64_t n = n_packets - done < max_launch ? n_packets - done
@@ -1768,11 +1784,12 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       k.source_mask = (1u << source_bits) - 1u;
       /* coarse direction bins of ~64 x 2^tau_bits packets per source */
       k.dir_hi_bits = 0;
+      k.dir_bits = dir_bits;
       if (tau_bits != 0) {
         const uint64_t per_bin = 64ull << tau_bits;
         const uint64_t per_source =
             n / (uint64_t)(e->model.nsource > 0 ? e->model.nsource : 1);
-        while (k.dir_hi_bits < 22u &&
+        while (k.dir_hi_bits < dir_bits &&
                (per_source >> (k.dir_hi_bits + 1u)) >= per_bin)
           ++k.dir_hi_bits;
       }

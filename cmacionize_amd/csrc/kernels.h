@@ -1466,7 +1466,8 @@ struct KeyArgs {
   uint64_t n_packets;
   uint32_t seed;
   uint32_t iteration;
-  uint32_t dir_hi_bits; /* 0..22 */
+  uint32_t dir_hi_bits; /* 0..dir_bits */
+  uint32_t dir_bits;    /* direction bits kept in the key: <= 22 */
   uint32_t tau_bits;    /* 0..3 */
   /* multi-ion transport: a packet's range also depends on its frequency; the
    * class is then the octave of tau sigma_ref / (sigma_H + A_He sigma_He) */
@@ -1532,7 +1533,7 @@ __device__ inline float approximate_opacity_cross_section(const ModelDev &m,
 __global__ void __launch_bounds__(CMI_BLOCK, CMI_KEY_WAVES)
     direction_key_kernel(const KeyArgs a) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint32_t lo_bits = 22u - a.dir_hi_bits;
+  const uint32_t lo_bits = a.dir_bits - a.dir_hi_bits;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
        i < a.n_packets; i += stride) {
     PacketRng rng;
@@ -1557,7 +1558,8 @@ __global__ void __launch_bounds__(CMI_BLOCK, CMI_KEY_WAVES)
     const double u_phi = rng.next();  /* phi = 2 pi u */
     const uint32_t ic = (uint32_t)(u_cost * 2048.);
     const uint32_t ip = (uint32_t)(u_phi * 2048.);
-    const uint32_t morton = spread_bits_11(ic) | (spread_bits_11(ip) << 1);
+    const uint32_t morton =
+        (spread_bits_11(ic) | (spread_bits_11(ip) << 1)) >> (22u - a.dir_bits);
     uint32_t tau_class = 0;
     if (a.pre_rows != nullptr) {
       /* the whole of emit_physics, here where every lane has a packet and the
@@ -1600,7 +1602,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, CMI_KEY_WAVES)
     }
     const uint32_t hi = morton >> lo_bits;
     const uint32_t lo = morton & ((1u << lo_bits) - 1u);
-    a.keys[i] = ((src & a.source_mask) << (22u + a.tau_bits)) |
+    a.keys[i] = ((src & a.source_mask) << (a.dir_bits + a.tau_bits)) |
                 (hi << (a.tau_bits + lo_bits)) | (tau_class << lo_bits) | lo;
     a.ids[i] = (uint32_t)i;
   }

@@ -384,6 +384,10 @@ int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);
  *                           their flights at about the same step (0 = plain
  *                           direction order, -1 = chosen from the number of
  *                           packets per launch)
+ *   "sort_dir_bits" (-1)    direction bits of the sort key, 2 .. 22 (an equal-area
+ *                           2048 x 2048 lattice, Morton order); -1 = auto: 22,
+ *                           or one or two fewer where that saves the radix
+ *                           sort a pass
  *   "aggregate" (2)         what happens to a step's contributions before
  *                           HBM sees an atomic: 0 = one atomic per lane and
  *                           step; 1 = lanes of a wave in the same cell are

@@ -228,22 +228,61 @@ __global__ void snapshot_steps_kernel(const CountersDev *counters,
     *dst = sum;
 }
 
-/* all shards of the counters, added up */
-static int download_counters(cmi_gpu_engine *e, CountersDev &sum) {
-  std::vector<CountersDev> host(CMI_COUNTER_SHARDS);
-  HIP_TRY(hipMemcpyAsync(host.data(), e->counters,
-                         sizeof(CountersDev) * CMI_COUNTER_SHARDS,
-                         hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  sum = CountersDev();
-  for (const CountersDev &c : host) {
-    sum.totweight += c.totweight;
+/* all shards of the counters, added up (shard k by thread k % 256, then the
+ * 256 partial sums in a fixed order: the same result every time) into the
+ * engine's mailbox - pinned host memory the device writes directly; a staged
+ * copy of the 64 KB of shards into pageable memory cost 0.25 ms */
+__global__ void __launch_bounds__(256)
+    counters_sum_kernel(const CountersDev *shards, CountersDev *out) {
+  __shared__ CountersDev partial[256];
+  CountersDev mine = CountersDev();
+  for (int k = threadIdx.x; k < CMI_COUNTER_SHARDS; k += 256) {
+    const CountersDev c = shards[k];
+    mine.totweight += c.totweight;
     for (int i = 0; i < 4; ++i)
-      sum.typecount[i] += c.typecount[i];
-    sum.nsteps += c.nsteps;
-    sum.natomics += c.natomics;
-    sum.nwavesteps += c.nwavesteps;
+      mine.typecount[i] += c.typecount[i];
+    mine.nsteps += c.nsteps;
+    mine.natomics += c.natomics;
+    mine.nwavesteps += c.nwavesteps;
   }
+  partial[threadIdx.x] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    CountersDev sum = CountersDev();
+    for (int t = 0; t < 256; ++t) {
+      sum.totweight += partial[t].totweight;
+      for (int i = 0; i < 4; ++i)
+        sum.typecount[i] += partial[t].typecount[i];
+      sum.nsteps += partial[t].nsteps;
+      sum.natomics += partial[t].natomics;
+      sum.nwavesteps += partial[t].nwavesteps;
+    }
+    *out = sum;
+  }
+}
+
+static int ensure_mailbox(cmi_gpu_engine *e) {
+  if (!e->mailbox) {
+    HIP_TRY(hipHostMalloc(&e->mailbox, 16 * sizeof(unsigned int),
+                          hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&e->mailbox_dev, e->mailbox, 0));
+  }
+  return CMI_GPU_OK;
+}
+
+static int download_counters(cmi_gpu_engine *e, CountersDev &sum) {
+  {
+    int rc = ensure_mailbox(e);
+    if (rc)
+      return rc;
+  }
+  static_assert(sizeof(CountersDev) <= 16 * sizeof(unsigned int),
+                "the counters fit the mailbox");
+  counters_sum_kernel<<<1, 256, 0, e->stream>>>(
+      e->counters, reinterpret_cast<CountersDev *>(e->mailbox_dev));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  memcpy(&sum, (const void *)e->mailbox, sizeof sum);
   return CMI_GPU_OK;
 }
 
@@ -1503,10 +1542,10 @@ static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
  * run dry */
 static int read_counters(cmi_gpu_engine *e, const unsigned int *src, int n,
                          unsigned int *out) {
-  if (!e->mailbox) {
-    HIP_TRY(hipHostMalloc(&e->mailbox, 16 * sizeof(unsigned int),
-                          hipHostMallocMapped));
-    HIP_TRY(hipHostGetDevicePointer((void **)&e->mailbox_dev, e->mailbox, 0));
+  {
+    int rc = ensure_mailbox(e);
+    if (rc)
+      return rc;
   }
   mailbox_kernel<<<1, 16, 0, e->stream>>>(src, e->mailbox_dev, n);
   HIP_TRY(hipGetLastError());

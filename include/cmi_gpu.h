@@ -315,7 +315,9 @@ int cmi_gpu_get_wave_steps(cmi_gpu_engine *engine, uint64_t *nwavesteps);
  * (src/IonizationStateCalculator.cpp:70-272) or the temperature solve
  * (src/TemperatureCalculator.cpp:567-931). Reads the (reduced) accumulators,
  * writes ionic fractions (+temperature) and the transport opacities.
- * Asynchronous. */
+ * Asynchronous for the ionization balance; the temperature solve runs as a
+ * pipeline of kernels that reads one count back per secant step and returns
+ * with the last kernel enqueued (tuning "temperature_pipeline"). */
 int cmi_gpu_update_cells(cmi_gpu_engine *engine, uint32_t loop,
                          double totweight);
 /* Rebuild the transport records {n x_H, n x_He} of all cells from the state

@@ -48,9 +48,11 @@
 #define CMI_TILE_LOG2_FULL 3 /* 14 ions + heating: 8^3 cells */
 #define CMI_TILE_THREADS 512
 /* flights per unit of work: a tile with more is shared by several workgroups
- * (each with its own LDS copy, all written back with atomics) */
-#define CMI_TILE_ITEM_FLIGHTS_H 4096
-#define CMI_TILE_ITEM_FLIGHTS_FULL 2048
+ * (each with its own LDS copy, all written back with atomics); measured on
+ * 256^3: half as many cost 1 ms (H-only) / 3 ms (multi-ion) per iteration,
+ * twice as many gain nothing */
+#define CMI_TILE_ITEM_FLIGHTS_H 8192
+#define CMI_TILE_ITEM_FLIGHTS_FULL 4096
 #define CMI_TILE_PLAN_THREADS 1024
 
 /* key of a slot that holds no flight (tiles have keys < ntiles): sorts behind

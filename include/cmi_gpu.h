@@ -423,7 +423,7 @@ int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);
  *   "tile_min_flights" (100000), "tile_min_per_item" (-1 = auto: 200), "tile_max_rounds" (1000)
  *                           the rounds end - and passes of the transport
  *                           kernel take over - once fewer flights than this,
- *                           or fewer than this per unit of work (<= 4096
+ *                           or fewer than this per unit of work (<= 8192
  *                           flights of one tile), are left
  *   "tile_refill_threshold" (48)  idle lanes of a wave that trigger a refill
  *                           in the tile kernel

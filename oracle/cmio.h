@@ -96,6 +96,15 @@ double cmio_rng_uniform(uint32_t seed, uint32_t iteration, uint64_t packet,
 int cmio_num_threads(void);
 void cmio_set_num_threads(int n);
 
+/* Errors (cmio_error.c): the oracle never abort()s. Where the reference
+ * raises cmac_error the first message is recorded, the function returns a
+ * harmless value (NaN for a rate, nothing done for a loop) and the caller -
+ * tests/oracle_lib.py after every call - asks for it here. */
+void cmio_set_error(const char *fmt, ...)
+    __attribute__((format(printf, 1, 2)));
+const char *cmio_last_error(void); /* NULL: none since the last clear */
+void cmio_clear_error(void);
+
 /* -------------------------------------------------------------- model -- */
 
 /* Regular Cartesian grid: src/CartesianDensityGrid.cpp:40-95 */

@@ -63,12 +63,13 @@ static void lc_init(void) {
   g_lc.ready = 1;
 }
 
-static void lc_ensure(void) {
-  if (!g_lc.ready) {
-#pragma omp critical(cmio_lc_init)
-    if (!g_lc.ready)
-      lc_init();
-  }
+/* the tables are built when the library is loaded - before any thread of a
+ * parallel region can ask for them (a lazy "if (!ready) init" under a
+ * critical section is not enough: the compiler may store the flag before the
+ * last table entries) */
+__attribute__((constructor)) static void lc_ensure(void) {
+  if (!g_lc.ready)
+    lc_init();
 }
 
 double cmio_lc_energy_difference(int element, int transition) {
@@ -184,9 +185,9 @@ double cmio_line_cooling(double temperature, double electron_density,
   for (int e = 0; e < CMI_LC_NFIVE; ++e) {
     double pop[5];
     if (level_populations(e, prefactor, temperature, Tinv, logT, pop)) {
-      fprintf(stderr, "cmio: singular level matrix (element %d, T %g)\n", e,
-              temperature);
-      abort();
+      cmio_set_error("cmio: singular level matrix (element %d, T %g)", e,
+                     temperature);
+      return NAN;
     }
     const cmi_lc_five_level *d = &cmi_lc_five[e];
     double cl[5];
@@ -228,9 +229,9 @@ void cmio_line_strengths(double temperature, double electron_density,
   for (int e = 0; e < CMI_LC_NFIVE; ++e) {
     double pop[5];
     if (level_populations(e, prefactor, temperature, Tinv, logT, pop)) {
-      fprintf(stderr, "cmio: singular level matrix (element %d, T %g)\n", e,
-              temperature);
-      abort();
+      cmio_set_error("cmio: singular level matrix (element %d, T %g)", e,
+                     temperature);
+      return;
     }
     const cmi_lc_five_level *d = &cmi_lc_five[e];
     const double pre = abundances[e] * kb;

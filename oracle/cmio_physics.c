@@ -65,6 +65,11 @@ static void verner_init(void) {
   g_terms_ready = 1;
 }
 
+__attribute__((constructor)) static void verner_load(void) {
+  if (!g_terms_ready)
+    verner_init();
+}
+
 /* get_cross_section_verner for one (ion, shell) term. The reference's
  * special cases for Z = 15, 17, 19, > 20 and for neutral/singly ionized
  * Z > 18 cannot occur for the tracked ions (Z in {1,2,6,7,8,10,16}). */
@@ -99,11 +104,7 @@ static double verner_term_cross_section(const verner_term *t, double e) {
 }
 
 double cmio_verner_cross_section(int ion, double energy) {
-  if (!g_terms_ready) {
-#pragma omp critical(cmio_verner_init)
-    if (!g_terms_ready)
-      verner_init();
-  }
+  /* (g_terms is built when the library is loaded, verner_load below) */
   /* terms of one ion are adjacent and in the reference's summation order */
   double sigma = 0.;
   int first = 1;
@@ -143,8 +144,8 @@ static double verner_rec_fit(int ion, double T) {
       return r->p[0] * pow(tt, -r->p[1]);
     }
   }
-  fprintf(stderr, "cmio: no recombination fit for ion %d\n", ion);
-  abort();
+  cmio_set_error("cmio: no recombination fit for ion %d", ion);
+  return NAN;
 }
 
 /* dielectronic terms, Nussbaumer & Storey form:
@@ -265,8 +266,8 @@ double cmio_verner_recombination_rate(int ion, double temperature) {
     break;
   }
   default:
-    fprintf(stderr, "cmio: unknown ion %d\n", ion);
-    abort();
+    cmio_set_error("cmio: unknown ion %d", ion);
+    return NAN;
   }
   rate *= 1.e-6; /* cm^3 s^-1 -> m^3 s^-1 */
   return fmax(0., rate);
@@ -351,8 +352,8 @@ static double ct_eval(const ct_fit *f, double T4) {
     return f->a * t * t;
   }
   default:
-    fprintf(stderr, "cmio: charge transfer of an ion with itself\n");
-    abort();
+    cmio_set_error("cmio: charge transfer of an ion with itself");
+    return NAN;
   }
 }
 

@@ -197,8 +197,8 @@ double cmio_spectrum_sample(const cmio_model *model, cmio_rng *rng) {
     return model->mono_frequency; /* no random number drawn */
   }
   if (!model->tables) {
-    fprintf(stderr, "cmio: Planck spectrum needs cmio_tables_create\n");
-    abort();
+    cmio_set_error("cmio: Planck spectrum needs cmio_tables_create");
+    return NAN;
   }
   return sample_planck(model->tables, rng);
 }
@@ -210,8 +210,8 @@ double cmio_continuous_spectrum_sample(const cmio_model *model,
     return model->continuous_mono_frequency;
   }
   if (!model->tables) {
-    fprintf(stderr, "cmio: Planck spectrum needs cmio_tables_create\n");
-    abort();
+    cmio_set_error("cmio: Planck spectrum needs cmio_tables_create");
+    return NAN;
   }
   const cmio_tables *t = model->tables;
   return sample_planck_table(t->planck2_cdf, t->planck2_logcdf,
@@ -275,8 +275,9 @@ double cmio_reemit_frequency(const cmio_model *model, const cmio_photon *photon,
   }
   const cmio_tables *t = model->tables;
   if (!t) {
-    fprintf(stderr, "cmio: physical re-emission needs cmio_tables_create\n");
-    abort();
+    cmio_set_error("cmio: physical re-emission needs cmio_tables_create");
+    *type = CMIO_TYPE_ABSORBED;
+    return 0.;
   }
   /* the reference stores these per cell at the start of the iteration
    * (src/IonizationSimulation.cpp:380-383); T does not change while packets

@@ -249,9 +249,9 @@ void cmio_subgrid_shoot(const cmio_grid *grid, const int32_t nsub[3],
   for (int a = 0; a < 3; ++a) {
     if (nsub[a] < 1 || grid->ncell[a] % nsub[a] != 0) {
       /* src/DensitySubGridCreator.hpp:94-98 */
-      fprintf(stderr, "Number of subgrids not compatible with number of "
-                      "cells!\n");
-      abort();
+      cmio_set_error("Number of subgrids not compatible with number of "
+                     "cells!");
+      return;
     }
     L.nsub[a] = nsub[a];
     L.sub_ncell[a] = grid->ncell[a] / nsub[a];

@@ -364,12 +364,10 @@ int64_t cmio_interact(const cmio_grid *grid, const cmio_model *model,
 
   if (nstep == 0 && optical_depth > 0.) {
     /* cmac_error in the reference, :436-442 */
-    fprintf(stderr,
-            "cmio_interact: photon leaves the system immediately "
-            "(position: %g %g %g, direction: %g %g %g)!\n",
-            origin[0], origin[1], origin[2], photon->direction[0],
-            photon->direction[1], photon->direction[2]);
-    abort();
+    cmio_set_error("cmio_interact: photon leaves the system immediately "
+                   "(position: %g %g %g, direction: %g %g %g)!",
+                   origin[0], origin[1], origin[2], photon->direction[0],
+                   photon->direction[1], photon->direction[2]);
   }
 
   for (int a = 0; a < 3; ++a) {

@@ -156,8 +156,8 @@ void cmio_shoot_fast(const cmio_grid *grid, const cmio_model *model,
       (int64_t)grid->ncell[0] * grid->ncell[1] * grid->ncell[2];
   fast_cell *aos = (fast_cell *)malloc(sizeof(fast_cell) * (size_t)ncell);
   if (!aos) {
-    fprintf(stderr, "cmio_shoot_fast: out of memory\n");
-    abort();
+    cmio_set_error("cmio_shoot_fast: out of memory");
+    return;
   }
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < ncell; ++i) {

@@ -94,6 +94,34 @@ class Photon(C.Structure):
 _lib = None
 
 
+class OracleError(RuntimeError):
+    """An error the oracle recorded (oracle/cmio_error.c) where the reference
+    would have raised cmac_error."""
+
+
+def _errcheck(result, func, args):
+    msg = _raw_last_error()
+    if msg:
+        text = msg.decode()
+        _raw_clear_error()
+        raise OracleError(text)
+    return result
+
+
+class _CheckedCDLL(C.CDLL):
+    """Every function of the library reports the oracle's error flag as a
+    Python exception of the call that set it."""
+
+    def __getitem__(self, name):
+        f = super().__getitem__(name)
+        if name not in ("cmio_last_error", "cmio_clear_error"):
+            f.errcheck = _errcheck
+        return f
+
+
+_raw_last_error = _raw_clear_error = None
+
+
 def build():
     """(Re)build oracle/libcmio.so with gcc; cheap when up to date."""
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
@@ -106,7 +134,14 @@ def lib():
     path = os.path.join(ORACLE_DIR, "libcmio.so")
     if not os.path.exists(path):
         build()
-    L = C.CDLL(path)
+    global _raw_last_error, _raw_clear_error
+    L = _CheckedCDLL(path)
+    _raw_last_error = L.cmio_last_error
+    _raw_last_error.restype = C.c_char_p
+    _raw_last_error.argtypes = []
+    _raw_clear_error = L.cmio_clear_error
+    _raw_clear_error.restype = None
+    _raw_clear_error.argtypes = []
     L.cmio_rng_uniform.restype = C.c_double
     L.cmio_rng_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64,
                                    C.c_uint32]

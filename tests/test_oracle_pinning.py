@@ -302,3 +302,23 @@ def test_fast_shoot_equals_shoot(oracle):
             assert np.allclose(np.asarray(b.heating[k]), ref, rtol=1e-12,
                                atol=1e-15 * max(np.abs(ref).max(), 1e-300))
         assert np.asarray(a.J[0]).max() > 0.
+
+
+def test_oracle_errors_are_python_exceptions_not_aborts(oracle):
+    """Where the reference raises cmac_error the oracle records a message
+    (oracle/cmio_error.c) and oracle_lib raises it: an oracle-side error is
+    the failure of one test, not the death of the test run."""
+    oracle_lib = oracle
+    L = oracle_lib.lib()
+    # a NaN temperature makes every level matrix singular
+    # (src/LineCoolingData.cpp:1569-1701 -> cmac_error in the reference)
+    abund = np.full(13, 1e-4)
+    with pytest.raises(oracle_lib.OracleError, match="singular level matrix"):
+        L.cmio_line_cooling(float("nan"), 100.,
+                            abund.ctypes.data_as(oracle_lib.dp))
+    # the flag is cleared by the raise: the next call is clean
+    assert L.cmio_line_cooling(8000., 100.,
+                               abund.ctypes.data_as(oracle_lib.dp)) > 0.
+    with pytest.raises(oracle_lib.OracleError, match="unknown ion"):
+        L.cmio_verner_recombination_rate(99, 8000.)
+    assert L.cmio_verner_recombination_rate(0, 8000.) > 0.

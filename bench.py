@@ -235,6 +235,31 @@ def roofline(config, ncell, cfg, steps_per_launch, kernel_s, launches,
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: run this script as N
+    ranks under torch.distributed.run (one per GPU, RCCL over xGMI) and hand
+    through their output and exit code. Nothing here initialises a GPU
+    (device_count() does not)."""
+    import socket
+    import subprocess
+    import torch
+    if os.environ.get("CMI_BENCH_BACKEND", "nccl") == "nccl" and \
+            torch.cuda.device_count() < n:
+        print("bench.py: --gpus %d but only %d GPU(s) are visible" %
+              (n, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + \
+        sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,6 +293,13 @@ def main():
     if args.converge_packets is None:
         args.converge_packets = args.packets
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as
+        # child processes, before anything in this process touches a GPU
+        # (one process per GPU; the reference: one MPI rank per node,
+        # src/MPICommunicator.hpp:207-222)
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     from cmacionize_amd.simulation import GpuBackend, ReplicaIterationDriver
     from cmacionize_amd import STROMGREN as S
@@ -292,9 +324,13 @@ def main():
                                                            local_rank))
         else:
             dist.init_process_group(collective, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" %
-              (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d: start "
+                         "one rank per GPU (plain `python bench.py --gpus N` "
+                         "does that by itself)" % (args.gpus, world))
+    if collective == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks asked for, %d GPUs visible" %
+                         (world, torch.cuda.device_count()))
 
     ncell = args.ncell
     npk = int(args.packets)
@@ -441,6 +477,10 @@ def main():
             "value": value,
             "unit": "packets/s",
             "n_gpus": world,
+            "ranks_in_collective": (dist.get_world_size() if world > 1
+                                    else 1),
+            "packets_per_rank_per_step": (float(npk) / world if domain
+                                          else float(npk)),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,

@@ -39,6 +39,7 @@
 #include <stdlib.h>
 
 #include <string>
+#include <mutex>
 #include <thread>
 
 /* the handful of RCCL entry points used, by their rccl.h signatures */
@@ -55,17 +56,29 @@ struct RcclApi {
   int (*AllGather)(const void *, void *, size_t, int, comm_t,
                    hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  std::mutex mutex;
+  bool ready = false;
+  /* (callable from several host threads at once: the classes of a group are
+   * updated on a thread each) */
   bool load() {
-    if (handle)
+    std::lock_guard<std::mutex> lock(mutex);
+    if (ready)
       return true;
-    for (const char *name : {"librccl.so.1", "librccl.so",
-                             "/opt/rocm/lib/librccl.so.1"}) {
-      handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (handle)
-        break;
-    }
+    if (!handle)
+      for (const char *name : {"librccl.so.1", "librccl.so",
+                               "/opt/rocm/lib/librccl.so.1"}) {
+        handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (handle)
+          break;
+      }
     if (!handle)
       return false;
+    if (!resolve())
+      return false;
+    ready = true; /* only once every symbol is there */
+    return true;
+  }
+  bool resolve() {
 #define CMI_RCCL_SYM(member, symbol)                                           \
   member = reinterpret_cast<decltype(member)>(dlsym(handle, symbol));          \
   if (!member)                                                                 \
@@ -387,6 +400,10 @@ static int active_accumulators(cmi_gpu_engine *e, double *ptr[2],
 
 /* the RCCL communicator of a class (one rank per member), made on first use */
 static int class_comm(cmi_gpu_group *g, GroupClass &c) {
+  /* one communicator is made at a time (ncclCommInitAll of two classes from
+   * two host threads at once is not something RCCL promises) */
+  static std::mutex comm_mutex;
+  std::lock_guard<std::mutex> lock(comm_mutex);
   if (!c.comm.empty())
     return CMI_GPU_OK;
   const int n = (int)c.member.size();
@@ -443,14 +460,19 @@ static int reduce_class(cmi_gpu_group *g, GroupClass &c) {
   /* one grouped all-reduce per piece: every engine's call is enqueued on its
    * own stream, behind its transport kernels */
   for (int p = 0; p < pieces; ++p) {
+    /* (no return between GroupStart and GroupEnd: an open group would queue
+     * this thread's later collectives for ever) */
     int rc = g_rccl.GroupStart();
-    for (int i = 0; i < n && rc == 0; ++i) {
+    hipError_t herr = hipSuccess;
+    for (int i = 0; i < n && rc == 0 && herr == hipSuccess; ++i) {
       cmi_gpu_engine *e = g->engine[c.member[i]];
-      HIP_TRY(hipSetDevice(e->device));
-      rc = g_rccl.AllReduce(ptr[i][p], ptr[i][p], (size_t)count[p],
-                            kNcclDouble, kNcclSum, c.comm[i], e->stream);
+      herr = hipSetDevice(e->device);
+      if (herr == hipSuccess)
+        rc = g_rccl.AllReduce(ptr[i][p], ptr[i][p], (size_t)count[p],
+                              kNcclDouble, kNcclSum, c.comm[i], e->stream);
     }
     const int rc_end = g_rccl.GroupEnd();
+    HIP_TRY(herr);
     if (rc == 0)
       rc = rc_end;
     if (rc != 0)
@@ -493,6 +515,9 @@ static int update_class(cmi_gpu_group *g, GroupClass &c, uint32_t loop,
   {
     const int rc = group_in_parallel(n, [&](int r) -> int {
       cmi_gpu_engine *e = g->engine[c.member[r]];
+      /* (a fresh host thread has device 0 current, and update_cells_range
+       * returns before its own hipSetDevice for an empty slab) */
+      HIP_TRY(hipSetDevice(e->device));
       const int urc = cmi_gpu_update_cells_range(e, loop, totweight, first[r],
                                                  first[r + 1] - first[r]);
       if (urc)
@@ -512,9 +537,12 @@ static int update_class(cmi_gpu_group *g, GroupClass &c, uint32_t loop,
       return rc0;
     const int64_t count = ncell / n;
     int rc = g_rccl.GroupStart();
-    for (int r = 0; r < n && rc == 0; ++r) {
+    hipError_t herr = hipSuccess;
+    for (int r = 0; r < n && rc == 0 && herr == hipSuccess; ++r) {
       cmi_gpu_engine *e = g->engine[c.member[r]];
-      HIP_TRY(hipSetDevice(e->device));
+      herr = hipSetDevice(e->device);
+      if (herr != hipSuccess)
+        break;
       for (int f = 1; f < 16 && rc == 0; ++f) {
         double *field = e->state_block + (int64_t)f * ncell;
         rc = g_rccl.AllGather(field + r * count, field, (size_t)count,
@@ -528,6 +556,7 @@ static int update_class(cmi_gpu_group *g, GroupClass &c, uint32_t loop,
       }
     }
     const int rc_end = g_rccl.GroupEnd();
+    HIP_TRY(herr);
     if (rc == 0)
       rc = rc_end;
     if (rc != 0)

@@ -333,9 +333,10 @@ public:
       m[1].data = type_double();
       m[2].type = 0x0005; /* fill value, version 2: none defined */
       m[2].data.u8(2);
-      m[2].data.u8(2); /* allocate early */
-      m[2].data.u8(0);
-      m[2].data.u8(0);
+      m[2].data.u8(2); /* space allocation time: late (1 is early) - what
+                        * libhdf5 itself writes for contiguous data */
+      m[2].data.u8(0); /* fill value written on allocation */
+      m[2].data.u8(0); /* no fill value defined */
       m[3].type = 0x0008; /* layout version 3, contiguous */
       m[3].data.u8(3);
       m[3].data.u8(1);

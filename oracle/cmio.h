@@ -104,6 +104,9 @@ void cmio_set_error(const char *fmt, ...)
     __attribute__((format(printf, 1, 2)));
 const char *cmio_last_error(void); /* NULL: none since the last clear */
 void cmio_clear_error(void);
+/* test processes: the native backtrace of a thread that abort()s (a GPU
+ * fault inside the HSA runtime, a heap check of glibc) goes to fd */
+void cmio_install_abort_backtrace(int fd);
 
 /* -------------------------------------------------------------- model -- */
 

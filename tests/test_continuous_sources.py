@@ -187,6 +187,7 @@ def test_weighted_tallies_match_oracle(oracle, discrete, tuning):
                            atol=1e-12 * np.abs(sim.heating[0]).max())
         eng.upload_field(E.FIELD_MEAN_INTENSITY, sim.J[0])
         eng.update_cells(loop, sim.totweight)
+        eng.synchronize()  # device errors surface here, not in the oracle
         sim.update(loop, sim.totweight)
         assert np.array_equal(eng.download_field(E.FIELD_IONIC_FRACTION),
                               sim.x[0])
@@ -421,6 +422,7 @@ def test_weighted_tallies_multi_ion(oracle, tiles):
                              np.asarray(sim.J[f]) if f < 14
                              else np.asarray(sim.heating[f - 14]))
         eng.update_cells(loop, sim.totweight)
+        eng.synchronize()  # device errors surface here, not in the oracle
         sim.update(loop, sim.totweight)
         x = eng.download_field(E.FIELD_IONIC_FRACTION)
         assert np.allclose(x, sim.x[0], rtol=1e-6)

@@ -23,11 +23,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_bench(ranks, extra):
+def run_bench(ranks, extra, launcher=False):
     env = dict(os.environ, CMI_BENCH_BACKEND="gloo")
-    if ranks == 1:
-        cmd = [sys.executable, "bench.py", "--gpus", "1"]
+    if ranks == 1 or not launcher:
+        # plain `python bench.py --gpus N`: bench.py starts its N ranks itself
+        cmd = [sys.executable, "bench.py", "--gpus", str(ranks)]
     else:
+        # the driver's own command line
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                "--master-port", str(free_port()), "bench.py", "--gpus",
@@ -47,9 +49,16 @@ def test_two_ranks_replica_and_domain_reach_the_one_rank_state():
         assert key in one
     replica = run_bench(2, [])
     assert replica["n_gpus"] == 2 and replica["scaling"] == "weak"
+    assert replica["ranks_in_collective"] == 2
+    assert replica["packets_per_rank_per_step"] == 4e5
+    launched = run_bench(2, [], launcher=True)
+    assert launched["n_gpus"] == 2 and launched["ranks_in_collective"] == 2
+    assert launched["ionized_volume_fraction"] == \
+        replica["ionized_volume_fraction"]
     assert "replica x2" in replica["config"]["parallelism"]
     domain = run_bench(2, ["--decomposition", "domain"])
     assert domain["n_gpus"] == 2 and domain["scaling"] == "strong"
+    assert domain["packets_per_rank_per_step"] == 2e5
     assert domain["flights_exchanged_last_step"] >= 0
     # replica: twice the packets per iteration - the same physical state up to
     # Monte Carlo noise; domain: the same packets as the one-rank run
@@ -60,3 +69,19 @@ def test_two_ranks_replica_and_domain_reach_the_one_rank_state():
     assert abs(domain["dda_steps_per_packet"] -
                one["dda_steps_per_packet"]) < 1e-6 * one["dda_steps_per_packet"]
     assert replica["value"] > 0. and domain["value"] > 0.
+
+
+def test_more_ranks_than_gpus_is_refused():
+    """`--gpus N` with fewer than N devices fails loudly instead of running
+    fewer ranks and printing an N-GPU line."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = dict(os.environ)
+    env.pop("CMI_BENCH_BACKEND", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n)] + COMMON,
+                       cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0
+    assert "GPU(s) are visible" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

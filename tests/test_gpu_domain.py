@@ -332,6 +332,10 @@ def test_decomposed_diffuse_matches_oracle(oracle, blocks, tiles):
             sl = tuple(slice(off[a], off[a] + size[a]) for a in range(3))
             b.engine.upload_field(E.FIELD_MEAN_INTENSITY, Jo[sl].ravel())
             b.update_cells(loop, driver.totweight)
+        # (a device fault is reported by the device call, not inside the
+        # oracle's long CPU section)
+        for b in backends:
+            b.engine.synchronize()
         sim.update(loop, sim.totweight)
         x = assemble(dec, backends, E.FIELD_IONIC_FRACTION)
         assert np.array_equal(x, sim.x[0])
@@ -462,6 +466,10 @@ def test_decomposed_lexington_matches_oracle(oracle, tiles):
                     E.FIELD_HEATING + k,
                     np.asarray(sim.heating[k]).reshape(shape)[sl].ravel())
             b.update_cells(loop, driver.totweight)
+        # (a device fault is reported by the device call, not inside the
+        # oracle's long CPU section)
+        for b in backends:
+            b.engine.synchronize()
         sim.update(loop, sim.totweight)
         T = assemble(dec, backends, E.FIELD_TEMPERATURE)
         assert np.allclose(T, sim.temperature, rtol=1e-6, atol=0.), loop
@@ -676,6 +684,10 @@ def test_group_with_copies_of_the_source_block_matches_oracle(oracle):
                 c.engine.download_field(E.FIELD_MEAN_INTENSITY), J0)
         for b in backends:
             b.update_cells(loop, tw)
+        # (a device fault is reported by the device call, not inside the
+        # oracle's long CPU section)
+        for b in backends:
+            b.engine.synchronize()
         sim.update(loop, sim.totweight)
         x = assemble(dec, backends[:dec.world], E.FIELD_IONIC_FRACTION)
         assert np.allclose(x, sim.x[0], rtol=1e-8)

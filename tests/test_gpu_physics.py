@@ -181,6 +181,7 @@ def test_diffuse_stromgren_shoot_matches_oracle(oracle, tuning):
         eng.upload_field(E.FIELD_MEAN_INTENSITY, sim.J[0])
         eng.upload_field(E.FIELD_HEATING, sim.heating[0])
         eng.update_cells(loop, tw)
+        eng.synchronize()  # device errors surface here, not in the oracle
         sim.update(loop, sim.totweight)
         assert np.array_equal(eng.download_field(E.FIELD_IONIC_FRACTION),
                               sim.x[0])
@@ -241,6 +242,7 @@ def test_lexington_iteration_matches_oracle(oracle, tuning):
         for k in range(2):
             eng.upload_field(E.FIELD_HEATING + k, sim.heating[k])
         eng.update_cells(loop, tw)
+        eng.synchronize()  # device errors surface here, not in the oracle
         sim.update(loop, sim.totweight)
         T = eng.download_field(E.FIELD_TEMPERATURE)
         assert np.allclose(T, sim.temperature, rtol=1e-6, atol=0.), loop
@@ -255,6 +257,74 @@ def test_lexington_iteration_matches_oracle(oracle, tuning):
                          np.array([np.asarray(x) for x in sim.x]))
     assert sim.temperature.max() > 6000. and sim.temperature.min() == 500.
     eng.close()
+
+
+@pytest.mark.parametrize("tuning", [
+    dict(),                              # begin -> finish, no pipeline step
+    dict(temperature_finish_slots=0),    # every step as pipeline kernels
+    dict(temperature_finish_slots=100),  # pipeline steps, then the finish
+    dict(temperature_pipeline=0),        # the solve as one kernel
+])
+def test_temperature_solve_on_eight_small_engines_at_once(oracle, tuning):
+    """TemperatureCalculator::calculate_temperature
+    (src/TemperatureCalculator.cpp:567-931) of eight 12^3 engines enqueued
+    back to back on eight streams of one device - for a grid this small the
+    pipeline is temp_begin_kernel -> read-back -> temp_finish_kernel with no
+    step in between, and cmi_gpu_update_cells returns with the last kernel in
+    flight - while the oracle solves the same cells on the host's cores. Every
+    engine must then hold the oracle's temperatures and fractions; the
+    engines' results are equal bit for bit."""
+    from cmacionize_amd import engine as E
+    ncell, npacket, nengine = 12, 20000, 8
+    sim = oracle.lexington_simulation(ncell)
+    for loop in range(4):
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(42, loop, 0, npacket)
+        sim.update(loop, sim.totweight)
+    engines = [lexington_engine(ncell, sim) for _ in range(nengine)]
+    for eng in engines:
+        if tuning:
+            eng.set_tuning(**tuning)
+    for loop in (4, 5):
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(42, loop, 0, npacket)
+        for eng in engines:
+            for ion in range(14):
+                eng.upload_field(E.FIELD_MEAN_INTENSITY + ion, sim.J[ion])
+            for k in range(2):
+                eng.upload_field(E.FIELD_HEATING + k, sim.heating[k])
+        # all eight solves in flight at once, the oracle beside them
+        for eng in engines:
+            eng.update_cells(loop, sim.totweight)
+        sim.update(loop, sim.totweight)
+        for eng in engines:
+            eng.synchronize()
+        T0 = engines[0].download_field(E.FIELD_TEMPERATURE)
+        assert np.allclose(T0, sim.temperature, rtol=1e-6, atol=0.), loop
+        x0 = []
+        for ion in range(14):
+            x = engines[0].download_field(E.FIELD_IONIC_FRACTION + ion)
+            ref = np.asarray(sim.x[ion])
+            ok = np.isclose(x, ref, rtol=1e-5, atol=1e-300) | \
+                (np.isnan(x) & np.isnan(ref))
+            assert ok.all(), (loop, ion)
+            x0.append(x)
+        for eng in engines[1:]:
+            assert np.array_equal(eng.download_field(E.FIELD_TEMPERATURE), T0)
+            for ion in range(14):
+                assert np.array_equal(
+                    eng.download_field(E.FIELD_IONIC_FRACTION + ion),
+                    x0[ion], equal_nan=True), (loop, ion)
+        for eng in engines:
+            eng.upload_cells(sim.number_density, sim.temperature,
+                             np.array([np.asarray(x) for x in sim.x]))
+    assert sim.temperature.max() > 6000.
+    for eng in engines:
+        eng.close()
 
 
 def test_lexington_converged_state_within_one_percent_of_oracle(oracle):
@@ -322,6 +392,7 @@ def test_fixed_value_reemission_matches_oracle(oracle, passes):
         assert np.allclose(J, sim.J[0], rtol=1e-9, atol=1e-12 * sim.J[0].max())
         eng.upload_field(E.FIELD_MEAN_INTENSITY, sim.J[0])
         eng.update_cells(loop, tw)
+        eng.synchronize()  # device errors surface here, not in the oracle
         sim.update(loop, sim.totweight)
         assert np.array_equal(eng.download_field(E.FIELD_IONIC_FRACTION),
                               sim.x[0])

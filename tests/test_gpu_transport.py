@@ -258,6 +258,7 @@ def test_shoot_matches_oracle(oracle, ncell, npacket):
         eng.upload_field(E.FIELD_MEAN_INTENSITY, sim.J[0])
         eng.upload_field(E.FIELD_HEATING, sim.heating[0])
         eng.update_cells(loop, tw)
+        eng.synchronize()  # device errors surface here, not in the oracle
         sim.update(loop, sim.totweight)
         xH = eng.download_field(E.FIELD_IONIC_FRACTION)
         assert np.array_equal(xH, sim.x[0])
@@ -405,6 +406,7 @@ def test_multiple_weighted_sources_match_oracle(oracle):
         assert np.allclose(J, sim.J[0], rtol=1e-9, atol=1e-12 * sim.J[0].max())
         eng.upload_field(E.FIELD_MEAN_INTENSITY, sim.J[0])
         eng.update_cells(loop, tw)
+        eng.synchronize()  # device errors surface here, not in the oracle
         sim.update(loop, sim.totweight)
         assert np.array_equal(eng.download_field(E.FIELD_IONIC_FRACTION),
                               sim.x[0])

@@ -94,6 +94,7 @@ double cmio_rng_uniform(uint32_t seed, uint32_t iteration, uint64_t packet,
                         uint32_t draw);
 
 int cmio_num_threads(void);
+int cmio_thread_index(void);
 void cmio_set_num_threads(int n);
 
 /* Errors (cmio_error.c): the oracle never abort()s. Where the reference

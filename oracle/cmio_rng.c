@@ -73,3 +73,12 @@ int cmio_num_threads(void) {
   return 1;
 #endif
 }
+
+/* index of the calling thread inside a parallel region (0 outside one) */
+int cmio_thread_index(void) {
+#ifdef _OPENMP
+  return omp_get_thread_num();
+#else
+  return 0;
+#endif
+}

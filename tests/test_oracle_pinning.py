@@ -278,11 +278,19 @@ def test_stromgren_oracle_physics(oracle):
     assert abs(recombinations / 4.26e49 - 1.) < 0.02
 
 
-def test_fast_shoot_equals_shoot(oracle):
+@pytest.mark.parametrize("hot_radius", [None, "0", "3"])
+def test_fast_shoot_equals_shoot(oracle, hot_radius, monkeypatch):
     """The CPU-baseline organisation of the transport loop (cmio_shoot_fast:
     array-of-structures cells, one lock per cell, single lock-free adds for
-    hydrogen-only runs) flies the same packets with the same arithmetic: equal
-    tallies up to the order of the additions, for all three benchmark models."""
+    hydrogen-only runs, per-thread copies of the accumulators of the cells
+    around a source) flies the same packets with the same arithmetic: equal
+    tallies up to the order of the additions, for all three benchmark models,
+    with the default cube of private cells (here: the whole grid), without
+    one and with a small one."""
+    if hot_radius is None:
+        monkeypatch.delenv("CMIO_FAST_HOT_RADIUS", raising=False)
+    else:
+        monkeypatch.setenv("CMIO_FAST_HOT_RADIUS", hot_radius)
     for make, n in ((lambda: oracle.stromgren_simulation(16), 20000),
                     (lambda: oracle.stromgren_simulation(16, diffuse=True),
                      20000),

@@ -114,6 +114,8 @@ struct cmi_gpu_engine {
   /* SpectrumTrackers: counted while enabled (the exact marcher then) */
   TrackersDev trackers = {};
   bool trackers_enabled = false;
+  /* PAD transport kernels: n x_H inside a layer of ghost cells */
+  double *pad_H = nullptr;
   /* the temperature solve as a pipeline (temperature_pipeline.h) */
   char *temp_pipe_block = nullptr;
   uint32_t temp_pipe_capacity = 0;
@@ -160,6 +162,12 @@ struct cmi_gpu_engine {
      * cross sections, optical depth) in the sort-key kernel, read back by the
      * transport kernel (shoot_kernel<..., PRE>) */
     bool pre_emission = true;
+    /* hydrogen-only first generation on a whole non-periodic grid: march
+     * through the padded records (shoot_kernel<..., PAD>) */
+    bool pad_march = true;
+    /* sorted first generation: the blocks of an XCD take neighbouring
+     * positions of the packet order */
+    bool xcd_remap = false;
     /* the temperature solve as a pipeline of kernels (0: one kernel) */
     bool temperature_pipeline = true;
     /* ... whose last slots one launch finishes (temp_finish_kernel) */
@@ -919,6 +927,7 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->counters);
   (void)hipFree(e->trackers.counts);
   (void)hipFree(e->temp_pipe_block);
+  (void)hipFree(e->pad_H);
   (void)hipFree(e->temp_pipe_counts);
   (void)hipFree(e->tables);
   (void)hipFree(e->spectra);
@@ -1361,6 +1370,10 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
     e->tune.temperature_finish_slots = (uint32_t)(value < 0 ? 0 : value);
   else if (k == "temperature_pipeline")
     e->tune.temperature_pipeline = value != 0;
+  else if (k == "pad_march")
+    e->tune.pad_march = value != 0;
+  else if (k == "xcd_remap")
+    e->tune.xcd_remap = value != 0;
   else if (k == "pre_emission")
     e->tune.pre_emission = value != 0;
   else if (k == "defer_weights")
@@ -1656,6 +1669,14 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       kernel_first = heat ? shoot_kernel<false, true, false, false, true>
                           : shoot_kernel<false, false, false, false, true>;
   }
+  /* ... and, hydrogen only on a whole grid, marching through padded records */
+  const bool pad = kernel_first != kernel && !e->full_ions &&
+                   e->tune.pad_march && !e->grid.decomposed &&
+                   e->grid.copy_count <= 1;
+  if (pad)
+    kernel_first =
+        heat ? shoot_kernel<false, true, false, false, true, false, true>
+             : shoot_kernel<false, false, false, false, true, false, true>;
   /* ... and, for multi-ion runs whose packets are sorted anyway, with the
    * emission physics done by the key kernel (the rows live in the second
    * weights buffer of the tile rounds, idle during the first generation) */
@@ -1687,6 +1708,14 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       return rc;
   }
 
+  /* (the specialised first-generation kernels may fit more blocks per CU) */
+  int blocks_per_cu_first = blocks_per_cu;
+  if (kernel_first != kernel) {
+    int rc = occupancy(kernel_first_pre ? kernel_first_pre : kernel_first,
+                       blocks_per_cu_first);
+    if (rc)
+      return rc;
+  }
   const bool sorted = e->tune.sort_packets && !flights;
   const uint64_t max_launch = e->tune.max_packets_per_launch;
   if (sorted) {
@@ -1767,6 +1796,19 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   }
   const int key_bits = (int)(dir_bits + tau_bits + source_bits);
 
+  if (pad) {
+    /* the padded records of this call's cell state (0.1 ms at 256^3) */
+    const GridDev &g = e->grid;
+    const int64_t padded = (int64_t)(g.ncell[0] + 2 * CMI_PAD_LAYERS) *
+                           (g.ncell[1] + 2 * CMI_PAD_LAYERS) *
+                           (g.ncell[2] + 2 * CMI_PAD_LAYERS);
+    if (!e->pad_H)
+      HIP_TRY(hipMalloc(&e->pad_H, sizeof(double) * (size_t)padded));
+    pad_record_kernel<<<grid_blocks(e, padded, 8), CMI_BLOCK, 0, e->stream>>>(
+        e->cells.opacity, e->pad_H, g.ncell[0], g.ncell[1], g.ncell[2]);
+    HIP_TRY(hipGetLastError());
+  }
+
   for (uint64_t done = 0; done < n_packets; done += max_launch) {
     const uint64_t n = n_packets - done < max_launch ? n_packets - done
                                                      : max_launch;
@@ -1785,6 +1827,12 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     a.xout.rows = e->export_rows;
     a.xout.count = e->export_count;
     a.xout.capacity = (unsigned int)e->export_capacity;
+    a.pad_H = pad ? e->pad_H : nullptr;
+    a.xcd_remap = (sorted && e->tune.xcd_remap) ? 1 : 0;
+    a.pad_ny = e->grid.ncell[1] + 2 * CMI_PAD_LAYERS;
+    a.pad_nz = e->grid.ncell[2] + 2 * CMI_PAD_LAYERS;
+    a.pad_inv_yz = 1. / ((double)a.pad_ny * (double)a.pad_nz);
+    a.pad_inv_z = 1. / (double)a.pad_nz;
     a.chunk = e->tune.chunk;
     a.seed = seed;
     a.iteration = iteration;
@@ -1846,7 +1894,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     }
     /* enough chunks for every wave of a full grid, else fewer blocks */
     const uint64_t nchunks = (n + a.chunk - 1) / a.chunk;
-    int64_t blocks = (int64_t)e->num_cu * blocks_per_cu;
+    int64_t blocks = (int64_t)e->num_cu * blocks_per_cu_first;
     const int64_t need = (int64_t)((nchunks + (CMI_BLOCK / 64) - 1) /
                                    (CMI_BLOCK / 64));
     if (blocks > need)

@@ -102,7 +102,51 @@ struct ShootArgs {
    * (flights left over by the tile rounds) instead of the whole grid's */
   int32_t xin_local;
   ExchangeDev xout;
+  /* PAD kernels: n x_H of every cell of the grid with CMI_PAD_LAYERS layers
+   * of ghost cells around it (pad_record_kernel): -1 marks a vacuum cell, -2
+   * a ghost cell - the march learns from the record it loads anyway that the
+   * packet has left the box */
+  const double *pad_H;
+  int32_t xcd_remap;
+  /* padded extents ny + 2 L, nz + 2 L (L = CMI_PAD_LAYERS) and the
+   * reciprocals of (ny + 2 L)(nz + 2 L) and nz + 2 L */
+  int32_t pad_ny, pad_nz;
+  double pad_inv_yz, pad_inv_z;
 };
+
+/* waves per SIMD the PAD kernel is built for (64 VGPRs; measured 46.5 -> 44.0
+ * ms per iteration of 1e8 packets against 6; the variant with the heating
+ * term does not fit 64 registers and stays at 6) */
+#ifndef CMI_PAD_WAVES
+#define CMI_PAD_WAVES 8
+#endif
+/* ghost layers around the grid */
+#define CMI_PAD_LAYERS 1
+#define CMI_PAD_VACUUM (-1.)
+#define CMI_PAD_GHOST (-2.)
+/* long index in the grid of the padded long index c of a cell inside it
+ * (c < 2^29; (c + 0.5) / d is never within 0.5 / d of an integer, far more
+ * than the rounding of the product) */
+__device__ __forceinline__ int32_t cmi_unpad_cell(const ShootArgs &a,
+                                                  const GridDev &g,
+                                                  int32_t c) {
+  const double cc = (double)c + 0.5;
+  const int32_t ix = (int32_t)(cc * a.pad_inv_yz);
+  const int32_t r = c - ix * (a.pad_ny * a.pad_nz);
+  const int32_t iy = (int32_t)(((double)r + 0.5) * a.pad_inv_z);
+  const int32_t iz = r - iy * a.pad_nz;
+  return ((ix - CMI_PAD_LAYERS) * g.ncell[1] + (iy - CMI_PAD_LAYERS)) *
+             g.ncell[2] +
+         (iz - CMI_PAD_LAYERS);
+}
+
+/* quad_perm DPP controls: lane j of every group of 4 reads lane j - 1 / j - 2
+ * / j - 3 / j + 1 of its group (lanes without such a neighbour read some lane
+ * of the group; the caller masks them) */
+#define CMI_DPP_QUAD_SHR1 0x90 /* [0,0,1,2] */
+#define CMI_DPP_QUAD_SHR2 0x40 /* [0,0,0,1] */
+#define CMI_DPP_QUAD_SHR3 0x00 /* [0,0,0,0] */
+#define CMI_DPP_QUAD_SHL1 0xF9 /* [1,2,3,3] */
 
 /* update_integrals, src/DensityGrid.hpp:150-197, hydrogen-only form without
  * cross-lane aggregation: the crossed non-vacuum cell receives ds * w *
@@ -183,6 +227,50 @@ __device__ __forceinline__ void run_sums(int32_t key, double (&v)[N],
   if (rounds > 5)
     CMI_SCAN_ROUND(CMI_DPP_ROW_BCAST31, 0xc)
 #undef CMI_SCAN_ROUND
+}
+
+/* The same sums over runs of equal keys inside every group of 4 lanes, without
+ * the rounds of a scan: a lane reads the keys and values of the (up to) three
+ * lanes below it in its group with quad_perm DPP moves and adds those that
+ * belong to its run.
+ * The LAST lane of every run (inside its group) holds the run's total and is
+ * flagged in `tail`. Must be called by all 64 lanes. */
+template <int CTRL> __device__ __forceinline__ int quad_read_i32(int v) {
+  /* (every lane of a group has a source lane: no "old" value to keep, so no
+   * copy of one in front of the move) */
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ double quad_read_f64(double v) {
+  const int lo = quad_read_i32<CTRL>(__double2loint(v));
+  const int hi = quad_read_i32<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ void quad_run_sums(int32_t key, double (&v)[N],
+                                              bool &tail) {
+  const int q = threadIdx.x & 3;
+  const int32_t k1 = quad_read_i32<CMI_DPP_QUAD_SHR1>(key);
+  const int32_t k2 = quad_read_i32<CMI_DPP_QUAD_SHR2>(key);
+  const int32_t k3 = quad_read_i32<CMI_DPP_QUAD_SHR3>(key);
+  const int32_t kn = quad_read_i32<CMI_DPP_QUAD_SHL1>(key);
+  double v1[N], v2[N], v3[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    v1[k] = quad_read_f64<CMI_DPP_QUAD_SHR1>(v[k]);
+    v2[k] = quad_read_f64<CMI_DPP_QUAD_SHR2>(v[k]);
+    v3[k] = quad_read_f64<CMI_DPP_QUAD_SHR3>(v[k]);
+  }
+  const bool e1 = (q >= 1) && key == k1;
+  const bool e2 = e1 && (q >= 2) && key == k2;
+  const bool e3 = e2 && (q == 3) && key == k3;
+  tail = (q == 3) || key != kn;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    /* (selects: a value that is not part of the run adds as +0.) */
+    v[k] += e1 ? v1[k] : 0.;
+    v[k] += e2 ? v2[k] : 0.;
+    v[k] += e3 ? v3[k] : 0.;
+  }
 }
 
 /* FULL mode (all 14 ions + 2 heating terms per step): update_integrals as a
@@ -438,12 +526,29 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
  * choices are compile-time constants and the code of the other aggregation
  * modes and of the periodic wrap is not in the march loop at all. */
 template <bool FULL, bool HEAT, bool REEMIT, bool EXACT, bool TABLE = false,
-          bool PRE = false>
-__global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
-    shoot_kernel(const ShootArgs a) {
+          bool PRE = false, bool PAD = false>
+__global__ void
+    __launch_bounds__(CMI_BLOCK,
+                      REEMIT ? 1
+                             : (FULL ? 3 : ((PAD && !HEAT) ? CMI_PAD_WAVES : 6)))
+        shoot_kernel(const ShootArgs a) {
+  /* PAD: the hydrogen-only first generation on a whole, non-periodic grid,
+   * marching through the padded records (ShootArgs::pad_H) */
+  static_assert(!PAD || (TABLE && !FULL && !REEMIT && !EXACT && !PRE),
+                "PAD is a specialisation of the hydrogen-only TABLE kernel");
   const int lane = threadIdx.x & 63;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
-  const uint64_t wave = (uint64_t)blockIdx.x * (CMI_BLOCK / 64) +
+  /* Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
+   * one - speed only, nothing depends on it): with xcd_remap the blocks of an
+   * XCD take neighbouring positions of the sorted packet order, so that the
+   * ray bundles flying through the same cells share one L2 */
+  uint32_t block = blockIdx.x;
+  if (a.xcd_remap) {
+    const uint32_t xcd = block & 7u, q = gridDim.x >> 3, r = gridDim.x & 7u;
+    block = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) +
+            (block >> 3);
+  }
+  const uint64_t wave = (uint64_t)block * (CMI_BLOCK / 64) +
                         (threadIdx.x >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * (CMI_BLOCK / 64);
   const uint64_t chunk = a.chunk;
@@ -481,6 +586,11 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
     s_continuous[threadIdx.x >> 6][lane] = 0;
   unsigned int nsteps = 0, natomics = 0; /* per lane and launch: < 2^32 */
   unsigned int nwavesteps = 0;
+  /* PAD: the steps of the whole wave (wave-uniform: scalar arithmetic), and
+   * the record of the cell the lane's packet is about to cross - it lives
+   * across refills of other lanes, and says "outside" by itself */
+  unsigned long long nsteps_wave = 0;
+  double pad_next = CMI_PAD_GHOST;
   const bool any_periodic =
       !TABLE &&
       (a.grid.periodic[0] | a.grid.periodic[1] | a.grid.periodic[2]) != 0;
@@ -566,10 +676,11 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
       for (int k = threadIdx.x; k < lds_slots; k += CMI_BLOCK) {
         const int32_t t = lds_tag[k];
         if (t >= 0) {
-          atomic_add_f64(acc_at(a.cells, ION_H_n, t), lds_val[k]);
+          const int32_t c = PAD ? cmi_unpad_cell(a, a.grid, t) : t;
+          atomic_add_f64(acc_at(a.cells, ION_H_n, c), lds_val[k]);
           lds_val[k] = 0.;
           if (HEAT) {
-            atomic_add_f64(acc_at(a.cells, CMI_NION, t),
+            atomic_add_f64(acc_at(a.cells, CMI_NION, c),
                            lds_val[lds_slots + k]);
             lds_val[lds_slots + k] = 0.;
           }
@@ -587,7 +698,19 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
   };
   /* add (v0[, v1]) to `cell` through the block table; called by all 64 lanes */
   auto table_add = [&](bool add, int32_t cell, double v0, double v1) {
-    uint32_t slot = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_TABLE_BITS);
+    /* (PAD: a full-rate 24-bit multiply - the cells of a bundle differ in
+     * their low bits) */
+    uint32_t slot;
+    if (PAD) {
+      /* (asm: the compiler widens __umul24 to the quarter-rate v_mul_lo_u32) */
+      uint32_t product;
+      asm("v_mul_u32_u24 %0, %1, %2"
+          : "=v"(product)
+          : "v"(cell), "v"(0x9E3779u));
+      slot = (product >> (24 - CMI_TABLE_BITS)) & (CMI_TABLE_SLOTS - 1);
+    } else {
+      slot = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_TABLE_BITS);
+    }
     bool pending = add;
     for (int probe = 0; probe < CMI_TABLE_PROBES; ++probe) {
       if (pending) {
@@ -605,9 +728,10 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
         break;
     }
     if (pending) {
-      atomic_add_f64(acc_at(a.cells, ION_H_n, cell), v0);
+      const int32_t c = PAD ? cmi_unpad_cell(a, a.grid, cell) : cell;
+      atomic_add_f64(acc_at(a.cells, ION_H_n, c), v0);
       if (HEAT)
-        atomic_add_f64(acc_at(a.cells, CMI_NION, cell), v1);
+        atomic_add_f64(acc_at(a.cells, CMI_NION, c), v1);
       natomics += HEAT ? 2 : 1;
     }
   };
@@ -770,6 +894,21 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
                        p.index[2];
             }
           }
+          if (PAD) {
+            /* the padded long index and its strides (start_flight has set
+             * index[], the signs and rem[0] < 0 for a start outside the box) */
+            const int32_t sy = a.pad_nz, sx = a.pad_ny * a.pad_nz;
+            p.cstep[0] = (p.dir[0] > 0.) ? sx : -sx;
+            p.cstep[1] = (p.dir[1] > 0.) ? sy : -sy;
+            p.cstep[2] = (p.dir[2] > 0.) ? 1 : -1;
+            const bool outside = fast_outside(p);
+            p.cell = outside ? 0
+                             : ((p.index[0] + CMI_PAD_LAYERS) * a.pad_ny +
+                                (p.index[1] + CMI_PAD_LAYERS)) *
+                                       a.pad_nz +
+                                   (p.index[2] + CMI_PAD_LAYERS);
+            pad_next = outside ? CMI_PAD_GHOST : a.pad_H[p.cell];
+          }
           if (mine) {
             if (PRE)
               emit_physics_from_row<FULL>(
@@ -806,10 +945,96 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
     int window = 0;
     if (FULL)
       load_quarter_weights(stage, wq);
+    if constexpr (PAD) {
+      /* The same loop on the padded records. What bounds it is instruction
+       * issue - a SIMD issues one vector AND one scalar instruction per four
+       * cycles, so the loop is as long as the larger of its two counts
+       * (measured: trading vector selects for execution-mask arithmetic, 2
+       * scalar instructions per vector one saved, gained nothing; neither did
+       * a software pipeline with two record loads in flight, nor 8 waves per
+       * SIMD - the loads are not what it waits for). So: no cell counters per
+       * axis (the ghost record says "outside"), every tied axis advances by
+       * selects, run sums by quad_perm reads, a 24-bit multiply for the hash. */
+      const double sigma = p.sigma_H;
+      double wsig = p.weight * p.sigma_H;
+      double hw = HEAT ? wsig * (p.nu - a.model.nu_H) : 0.;
+      /* (kept in registers: recomputing them costs a multiplication a step) */
+      asm volatile("" : "+v"(wsig), "+v"(hw));
+      for (;;) {
+        const bool stepping = active && p.tau > 0. && pad_next > -1.5;
+        const unsigned long long flying = __ballot(stepping);
+        if (flying == 0ull ||
+            (avail_after != 0 && (int)__popcll(~flying) >= a.refill_threshold))
+          break;
+        ++nwavesteps;
+        nsteps_wave += (unsigned long long)__popcll(flying);
+        double ds = 0.;
+        bool accumulate = false;
+        if (stepping) {
+          const double k = pad_next;
+          const double tmin =
+              min_f64(p.tmax[0], min_f64(p.tmax[1], p.tmax[2]));
+          const double t_old = p.t;
+          ds = tmin - t_old;
+          const double sk = sigma * max_f64(k, 0.);
+          p.tau -= ds * sk;
+          last_cell = p.cell;
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            /* every tied axis advances */
+            const bool hit = (p.tmax[ax] == tmin);
+            p.tmax[ax] += hit ? p.tdelta[ax] : 0.;
+            p.cell += hit ? p.cstep[ax] : 0;
+          }
+          p.t = tmin;
+          if (p.tau < 0.) {
+            /* Scorr = ds tau / tau_cell = tau / (sigma n x_H): reciprocal, one
+             * Newton step, the quotient and its correction (~1e-16) */
+            double r = __builtin_amdgcn_rcp(sk);
+            r = __fma_rn(__fma_rn(-sk, r, 1.), r, r);
+            double corr = p.tau * r;
+            corr = __fma_rn(__fma_rn(-corr, sk, p.tau), r, corr);
+            ds += corr;
+            p.t = t_old + ds;
+          }
+          accumulate = (k >= 0.); /* number density > 0 */
+        }
+        if (stepping && p.tau >= 0.)
+          pad_next = *reinterpret_cast<const double *>(
+              reinterpret_cast<const char *>(a.pad_H) +
+              ((uint32_t)p.cell << 3));
+        if (CMI_EXP(a) == 12) {
+          /* experiment: the march alone (results are wrong) */
+          asm volatile("" ::"v"(ds), "v"(accumulate ? 1 : 0));
+          continue;
+        }
+        const int32_t key = accumulate ? last_cell : ~lane;
+        double v[2] = {ds * wsig, HEAT ? ds * hw : 0.};
+        bool tail;
+        if (HEAT)
+          quad_run_sums<2>(key, v, tail);
+        else
+          quad_run_sums<1>(key, reinterpret_cast<double(&)[1]>(v), tail);
+        if (CMI_EXP(a) == 11) {
+          /* experiment: no table (results are wrong) */
+          asm volatile("" ::"v"(v[0]), "v"(tail ? 1 : 0));
+          continue;
+        }
+        table_add(tail && accumulate, last_cell, v[0], v[1]);
+      }
+      /* the rest of the kernel reads the flight's end the usual way */
+      if (active && !(p.tau > 0. && pad_next > -1.5)) {
+        p.rem[0] = (p.tau >= 0. && !(pad_next > -1.5)) ? -1 : 0;
+        p.rem[1] = 0;
+        p.rem[2] = 0;
+        if (last_cell >= 0)
+          last_cell = cmi_unpad_cell(a, a.grid, last_cell);
+      }
+    }
     double2 kappa_next = make_double2(0., 0.);
-    if (!EXACT && active && p.tau > 0. && !fast_outside(p))
+    if (!PAD && !EXACT && active && p.tau > 0. && !fast_outside(p))
       kappa_next = fast_load_record(a.cells.opacity, p);
-    for (;;) {
+    for (; !PAD;) {
       bool stepping = active && p.tau > 0.;
       if (EXACT)
         stepping = stepping && is_inside(a.grid, p);
@@ -1049,7 +1274,8 @@ __global__ void __launch_bounds__(CMI_BLOCK, REEMIT ? 1 : (FULL ? 3 : 6))
     atomic_add_f64(&counter_shard(a.counters)->typecount[1], s1);
     atomic_add_f64(&counter_shard(a.counters)->typecount[2], s2);
     atomic_add_f64(&counter_shard(a.counters)->typecount[3], s3);
-    atomicAdd(&counter_shard(a.counters)->nsteps, (unsigned long long)ns);
+    atomicAdd(&counter_shard(a.counters)->nsteps,
+              (unsigned long long)ns + nsteps_wave);
     atomicAdd(&counter_shard(a.counters)->natomics, (unsigned long long)na);
     atomicAdd(&counter_shard(a.counters)->nwavesteps, (unsigned long long)nwavesteps);
   }
@@ -1921,6 +2147,29 @@ __global__ void __launch_bounds__(CMI_BLOCK)
         (ntot > 0.) ? make_double2(ntot * cells.x[ION_H_n][c],
                                    ntot * cells.x[ION_He_n][c])
                     : make_double2(-1., 0.);
+  }
+}
+
+/* PAD kernels: n x_H of every cell inside one layer of ghost cells
+ * (ShootArgs::pad_H), from the transport records */
+__global__ void __launch_bounds__(CMI_BLOCK)
+    pad_record_kernel(const double2 *__restrict__ opacity, double *pad,
+                      int32_t nx, int32_t ny, int32_t nz) {
+  const int64_t total = (int64_t)(nx + 2 * CMI_PAD_LAYERS) *
+                        (ny + 2 * CMI_PAD_LAYERS) * (nz + 2 * CMI_PAD_LAYERS);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+       c += stride) {
+    constexpr int L = CMI_PAD_LAYERS;
+    const int32_t pz = (int32_t)(c % (nz + 2 * L)) - L;
+    const int32_t py = (int32_t)((c / (nz + 2 * L)) % (ny + 2 * L)) - L;
+    const int32_t px = (int32_t)(c / ((int64_t)(nz + 2 * L) * (ny + 2 * L))) - L;
+    double v = CMI_PAD_GHOST;
+    if (px >= 0 && px < nx && py >= 0 && py < ny && pz >= 0 && pz < nz) {
+      const double k = opacity[((int64_t)px * ny + py) * nz + pz].x;
+      v = (k >= 0.) ? k : CMI_PAD_VACUUM;
+    }
+    pad[c] = v;
   }
 }
 

@@ -435,6 +435,11 @@ int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);
  *                           0: one kernel holding the whole solve of a cell
  *   "temperature_finish_slots" (32768)  ... and once so few cells are still
  *                           iterating, one launch takes them to their end
+ *   "pad_march" (1)         hydrogen-only runs on a whole, non-periodic grid:
+ *                           the first generation marches through a copy of
+ *                           n x_H with one layer of ghost cells, whose record
+ *                           says that the packet has left the box (no cell
+ *                           counters per axis in the march)
  *   "pre_emission" (1)      multi-ion runs with sorted packets: the spectrum
  *                           sample, the 14 cross sections and the optical
  *                           depth of every new packet are computed by the

@@ -306,10 +306,15 @@ def test_tuning_does_not_change_results():
                dict(sort_packets=0, aggregate=2, refill_threshold=7,
                     chunk=100, max_blocks_per_cu=2,
                     max_packets_per_launch=33333),
+               # the block table without the march through padded records
+               dict(sort_packets=1, aggregate=2, refill_threshold=64,
+                    pad_march=0),
+               dict(sort_packets=0, aggregate=2, refill_threshold=9,
+                    chunk=100, pad_march=0, max_packets_per_launch=33333),
                dict(exact_dda=1)):
         base = dict(sort_packets=1, aggregate=2, refill_threshold=64,
                     sort_tau_bits=2, chunk=64, max_blocks_per_cu=8, exact_dda=0,
-                    max_packets_per_launch=1 << 27)
+                    max_packets_per_launch=1 << 27, pad_march=1)
         base.update(kw)
         eng.set_tuning(**base)
         eng.reset_grid()

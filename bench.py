@@ -53,15 +53,15 @@ CONFIGS = {
     "stromgren": dict(
         name="stromgren.param", bytes_per_step=16. + 16. * 1, diffuse=False,
         lexington=False, converge_iterations=20,
-        kernel="shoot_kernel<false, false, false, false, true, false>"),
+        kernel="shoot_kernel<false, false, false, false, true, false, true>"),
     "stromgren_diffuse": dict(
         name="stromgren_diffuse.param", bytes_per_step=16. + 16. * 1,
         diffuse=True, lexington=False, converge_iterations=20,
-        kernel="shoot_kernel<false, false, false, false, true, false>"),
+        kernel="shoot_kernel<false, false, false, false, true, false, true>"),
     "lexington": dict(
         name="lexingtonHII40.param", bytes_per_step=16. + 16. * 16,
         diffuse=True, lexington=True, converge_iterations=20,
-        kernel="shoot_kernel<true, true, false, false, true, true>"),
+        kernel="shoot_kernel<true, true, false, false, true, true, false>"),
 }
 
 # The CPU baseline (oracle/cmio_transport_fast.c) against the REFERENCE on the
@@ -119,6 +119,18 @@ def setup_engine(backend, ncell, cfg, block=None):
                      x)
 
 
+def cpu_quota():
+    """CPUs the cgroup grants this process (cpu.max: quota / period), or None
+    when unlimited / unknown."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(ncell, config, cfg, engine, seconds=12.):
     """The CPU form of the transport loop (oracle/cmio_transport_fast.c:
     the reference's classic organisation - cells as structures, one lock per
@@ -138,22 +150,34 @@ def cpu_baseline(ncell, config, cfg, engine, seconds=12.):
                                               compact=True)
         sim.x[0][:] = engine.download_field(E.FIELD_IONIC_FRACTION)
     # every packet starts in the 8 cells around the star: with many threads
-    # the first steps contend for their cache lines (the reference's classic
-    # path has the same hot spot; its task-based path replicates the source
-    # subgrid instead). Take the thread count that serves the CPU best.
+    # the first steps contend for their cache lines. The reference's
+    # task-based path replicates the source subgrid
+    # (src/DensitySubGridCreator.hpp:437-531); the port keeps private
+    # accumulators per thread for a cube around each source
+    # (CMIO_FAST_HOT_RADIUS). How many cores the process really gets is the
+    # cgroup's CPU quota, not the number of hardware threads it can see (the
+    # GPU boxes: 256 threads visible, cpu.max = 16 CPUs; measured with
+    # tools/host_cores_probe.c): probe thread counts around the quota.
     all_cores = oracle_lib.num_threads()
+    quota = cpu_quota()
+    budget = min(all_cores, int(round(quota))) if quota else all_cores
+    candidates = sorted(set(max(1, min(all_cores, t)) for t in
+                            (budget, 2 * budget, max(budget // 2, 1))),
+                        reverse=True)
     best = None
-    for threads in sorted(set([all_cores, max(all_cores // 2, 1),
-                               max(all_cores // 4, 1)]), reverse=True):
-        oracle_lib.set_num_threads(threads)
-        n = 10000 * threads
-        sim.reset()
-        t0 = time.perf_counter()
-        sim.shoot_fast(42, 1000, 0, n)
-        rate = n / (time.perf_counter() - t0)
-        if best is None or rate > best[0]:
-            best = (rate, threads)
-    rate, cores = best
+    for threads in candidates:
+        for radius in (16, 32):
+            os.environ["CMIO_FAST_HOT_RADIUS"] = str(radius)
+            oracle_lib.set_num_threads(threads)
+            n = 20000 * threads
+            sim.reset()
+            t0 = time.perf_counter()
+            sim.shoot_fast(42, 1000, 0, n)
+            rate = n / (time.perf_counter() - t0)
+            if best is None or rate > best[0]:
+                best = (rate, threads, radius)
+    rate, cores, radius = best
+    os.environ["CMIO_FAST_HOT_RADIUS"] = str(radius)
     oracle_lib.set_num_threads(cores)
     n2 = int(max(20000 * cores, min(rate * seconds, 2e8)))
     sim.reset()
@@ -165,10 +189,14 @@ def cpu_baseline(ncell, config, cfg, engine, seconds=12.):
     return {"value": n2 / dt, "unit": "packets/s", "cores": cores,
             "kind": "port",
             "host_threads_available": all_cores,
+            "host_cpu_quota": quota,
+            "private_accumulator_radius_cells": radius,
             "sample": "%d packets on the converged %d^3 %s state, transport "
-                      "only, %.1f s, at the best of {all, 1/2, 1/4} of the "
-                      "host's threads; the reference's classic loop restated "
-                      "in C (cells as structures, one lock per cell, OpenMP). "
+                      "only, %.1f s, at the best of {1/2, 1, 2} x the CPUs "
+                      "the cgroup grants this process; the reference's "
+                      "classic loop restated in C (cells as structures, one "
+                      "lock per cell, per-thread copies of the accumulators "
+                      "around the source as in the task-based path, OpenMP). "
                       "Calibration against the reference itself, 8 threads, "
                       "64^3, whole 20-iteration run: this port %.3g, reference "
                       "classic %.3g, reference task-based %.3g packets/s "
@@ -179,57 +207,85 @@ def cpu_baseline(ncell, config, cfg, engine, seconds=12.):
             "calibration": cal}
 
 
-def roofline(config, ncell, cfg, steps_per_launch, kernel_s, launches,
+PROFILE = os.path.join("profiles", "r03", "counters.json")
+
+
+def roofline(config, ncell, cfg, steps_per_launch, lanes_per_wave_step,
              first_generation_ms):
-    """What bounds the dominant kernel, from this run's clocks and the PMC
-    counters of the same kernels (profiles/r02/counters.json, made by
-    tools/pmc_rooflines.py from separate rocprofv3 --pmc passes of this very
-    command; instruction counts per launch are deterministic - same packets)."""
+    """The dominant kernel against the HBM roofline as SURVEY.md 8(d) defines
+    it - algorithmic bytes per DDA step x the steps one launch executes / the
+    launch's duration (HIP events of this run) / 8 TB/s - and, from the PMC
+    counters of the same kernel (profiles/r03/counters.json: separate
+    rocprofv3 --pmc passes of this very command, tools/pmc_profile.sh +
+    tools/pmc_rooflines.py; counts per launch are deterministic - same
+    packets), the bytes the fabric really moved and how busy each unit of the
+    chip was. Counter-based ratios use the PROFILED launch's own duration, and
+    the line says when that differs from this run's by more than 10 %."""
+    t = first_generation_ms * 1e-3 if first_generation_ms else None
+    algorithmic = (steps_per_launch * cfg["bytes_per_step"]
+                   if steps_per_launch else None)
     out = {
         "kernel": cfg["kernel"],
-        "bound": None, "achieved": None, "peak": None, "unit": None,
-        "frac": None, "traffic": None,
+        "bound": "hbm",
+        "achieved": algorithmic / t / 1e9 if t and algorithmic else None,
+        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": (algorithmic / t / 1e9 / HBM_PEAK_GBS
+                 if t and algorithmic else None),
+        "traffic": None,
         "kernel_avg_ms": first_generation_ms,
         "dda_steps_per_launch": steps_per_launch,
+        "bytes_per_dda_step_algorithmic": cfg["bytes_per_step"],
+        "note": "frac > 1 is possible and expected: `achieved` counts the "
+                "ALGORITHMIC bytes of a step (record read + accumulator "
+                "read-modify-write per lane); direction-sorted packets, "
+                "cross-lane run sums and the LDS combining table keep most "
+                "of them on chip - `traffic` is what the fabric moved",
     }
-    path = os.path.join(ROOT, "profiles", "r02", "counters.json")
+    path = os.path.join(ROOT, PROFILE)
     if not os.path.exists(path):
         return out
     c = json.load(open(path)).get(config)
     if not c or c.get("ncell") != ncell:
         return out
     k = c["dominant"]
-    t = first_generation_ms * 1e-3
-    # candidates: fraction of the unit's capacity the kernel uses
-    cand = {
+    if k.get("kernel") != cfg["kernel"]:
+        return out
+    tp = k["kernel_ms"] * 1e-3   # the profiled launch's own duration
+    util = {
         # VALU issue: busy SIMD cycles / (1024 SIMDs x cycles at max clock)
-        "valu-issue": (k["valu_busy_cycles"] / t / 1e9,
-                       N_SIMD * MAX_CLOCK_GHZ, "G SIMD-cycles/s"),
+        "valu-issue": k["valu_busy_cycles"] / tp / 1e9 /
+        (N_SIMD * MAX_CLOCK_GHZ),
         # LDS: busy LDS cycles / (256 CUs x cycles)
-        "lds": (k["lds_busy_cycles"] / t / 1e9, N_CU * MAX_CLOCK_GHZ,
-                "G LDS-cycles/s"),
-        # memory-side atomic requests (64-B) against the measured chip rate
-        "atomic-requests": (k["atomic_requests"] / t / 1e9, 23.5,
-                            "G requests/s"),
+        "lds": k["lds_busy_cycles"] / tp / 1e9 / (N_CU * MAX_CLOCK_GHZ),
+        # memory-side atomic requests (64 B) against the measured chip rate
+        # (profiles/r01/atomic_rates.txt: 23.5 G requests/s whatever the
+        # footprint, tools/microbench/atomic_scope.hip)
+        "atomic-requests": k["atomic_requests"] / tp / 1e9 / 23.5,
         # fabric traffic against HBM peak
-        "hbm": (k["hbm_bytes"] / t / 1e9, HBM_PEAK_GBS, "GB/s"),
+        "hbm": k["hbm_bytes"] / tp / 1e9 / HBM_PEAK_GBS,
     }
-    bound = max(cand, key=lambda n: cand[n][0] / cand[n][1])
-    achieved, peak, unit = cand[bound]
     out.update({
-        "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-        "frac": achieved / peak, "traffic": k["hbm_bytes"],
-        "utilization": dict((n, v[0] / v[1]) for n, v in cand.items()),
-        "profiled_kernel_ms": k["kernel_ms"],
-        "profile": "profiles/r02/counters.json",
-        # the algorithmic-byte model of SURVEY 8d, for reference: it exceeds
-        # what the fabric moves because the on-chip aggregation works
-        "algorithmic_GBps": (steps_per_launch * cfg["bytes_per_step"] / t /
-                             1e9),
-        "bytes_per_dda_step_algorithmic": cfg["bytes_per_step"],
+        "traffic": k["hbm_bytes"],
+        "traffic_frac_of_peak": util["hbm"],
         "bytes_per_dda_step_measured": k["hbm_bytes"] /
-        max(steps_per_launch, 1.),
+        max(steps_per_launch or 1., 1.),
+        "utilization": util,
+        "highest_utilization": max(util, key=util.get),
+        "profiled_kernel_ms": k["kernel_ms"],
+        "profile": PROFILE,
+        "profile_commit": c.get("commit"),
+        "profile_stale": bool(first_generation_ms) and
+        abs(k["kernel_ms"] - first_generation_ms) > 0.1 * first_generation_ms,
     })
+    if steps_per_launch and lanes_per_wave_step:
+        # instructions executed per 64-lane iteration of the march loop (all
+        # of the kernel's instructions over its loop iterations)
+        wave_steps = steps_per_launch / lanes_per_wave_step
+        out["lanes_stepping_per_wave_iteration"] = lanes_per_wave_step
+        if "valu_insts" in k:
+            out["valu_insts_per_wave_iteration"] = k["valu_insts"] / wave_steps
+        if "salu_insts" in k:
+            out["salu_insts_per_wave_iteration"] = k["salu_insts"] / wave_steps
     if "other_kernels" in c:
         out["other_kernels"] = c["other_kernels"]
     return out
@@ -406,6 +462,8 @@ def main():
         if last_big + 1 < len(volume):
             converged_at = last_big + 2  # 1-based count of iterations run
 
+    lanes_per_wave_step = None
+
     def timed(global_packets, steps):
         nonlocal loop
         barrier()
@@ -418,6 +476,11 @@ def main():
             loop += 1
         barrier()
         elapsed = time.perf_counter() - t0
+        # (the last iteration's counters: lanes that step per wave iteration)
+        nonlocal lanes_per_wave_step
+        wave_steps = backend.engine.get_wave_steps()
+        if wave_steps:
+            lanes_per_wave_step = backend.engine.get_counters()[2] / wave_steps
         launches = backend.engine.get_launch_times()
         lsteps = backend.engine.get_launch_steps()
         # (the step counter after each launch; it restarts with every
@@ -461,9 +524,17 @@ def main():
         shoot_s = timing["shoot_ms"] * 1e-3
         # the first-generation transport launch of every iteration: the
         # launches that started this rank's full packet count
-        mine = npk if not domain else None
-        first_gen = [(ms, st) for ms, n, st in launches
-                     if mine is None or n == mine]
+        if not domain:
+            first_gen = [(ms, st) for ms, n, st in launches if n == npk]
+        else:
+            # a block flies what starts in it: the first launch of an
+            # iteration is the one after which the step counter (it restarts
+            # with reset_grid) is not larger than after the launch before
+            first_gen, before = [], None
+            for ms, n, st in launches:
+                if before is None or st <= before:
+                    first_gen.append((ms, st))
+                before = st
         first_gen_ms = float(np.mean([f[0] for f in first_gen])) \
             if first_gen else None
         first_gen_steps = float(np.mean([f[1] for f in first_gen])) \
@@ -532,7 +603,7 @@ def main():
                 "ionized_volume_fraction_by_iteration": volume,
             },
             "roofline": roofline(args.config, ncell, cfg, first_gen_steps,
-                                 kernel_s, len(launches), first_gen_ms),
+                                 lanes_per_wave_step, first_gen_ms),
         }
         if strong is not None:
             out["strong_scaling"] = strong

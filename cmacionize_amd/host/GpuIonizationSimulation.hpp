@@ -491,6 +491,7 @@ class GpuIonizationSimulation {
    * the copies */
   std::vector<Block> _blocks;
   size_t _number_of_copies = 0;
+  size_t _number_of_neighbour_copies = 0;
   /* replica mode (the reference's MPI path,
    * src/IonizationSimulation.cpp:394-397,458-529): one engine per device,
    * each holding the whole grid and flying its share of the packets */
@@ -971,8 +972,9 @@ public:
          * (TaskBasedIonizationSimulation:source copy level, default 4,
          * src/TaskBasedIonizationSimulation.cpp:199,514-560); here a block
          * is 1/P of the grid, so: one copy per device at most, 2^level at
-         * most, and no copies of the neighbours. --copies K asks for exactly
-         * K engines per source block (also on one device: tests). */
+         * most. --copies K asks for exactly K engines per source block (also
+         * on one device: tests). The neighbours of a block with copies get
+         * half as many, as in the reference (below). */
         {
           const int level = (int)_parameter_file.get_integer(
               "TaskBasedIonizationSimulation:source copy level", 4);
@@ -1004,14 +1006,53 @@ public:
                                          c[2])] = 1;
             }
           }
+          /* engines per block: `want` for a block with a source; the blocks
+           * next to a block with 2^l engines get 2^(l-1) at least, and so on
+           * outwards (the reference's restriction of the copy levels,
+           * src/TaskBasedIonizationSimulation.cpp:533-556: a packet that
+           * leaves a block with many copies must not find all of them queueing
+           * for one neighbour) - capped by the device pool like `want` */
+          std::vector<size_t> engines_of(originals, 1);
+          int top_level = 0;
+          for (size_t o = 0; o < originals; ++o)
+            if (has_source[o]) {
+              engines_of[o] = want;
+              while (((size_t)2 << top_level) <= want)
+                ++top_level;
+            }
+          for (int level = top_level; level > 1; --level) {
+            const size_t here = (size_t)1 << level;
+            for (size_t o = 0; o < originals; ++o) {
+              if (engines_of[o] < here || engines_of[o] >= 2 * here)
+                continue;
+              const int bx = (int)(o / ((size_t)_nblock[1] * _nblock[2]));
+              const int by = (int)((o / _nblock[2]) % _nblock[1]);
+              const int bz = (int)(o % _nblock[2]);
+              const int at[3] = {bx, by, bz};
+              for (int axis = 0; axis < 3; ++axis)
+                for (int side = -1; side <= 1; side += 2) {
+                  int nb[3] = {at[0], at[1], at[2]};
+                  nb[axis] += side;
+                  if (nb[axis] < 0 || nb[axis] >= _nblock[axis]) {
+                    if (!config.periodic[axis] || _nblock[axis] < 2)
+                      continue;
+                    nb[axis] = (nb[axis] + _nblock[axis]) % _nblock[axis];
+                  }
+                  const size_t n =
+                      ((size_t)nb[0] * _nblock[1] + nb[1]) * _nblock[2] + nb[2];
+                  engines_of[n] = std::max(engines_of[n], here / 2);
+                }
+            }
+          }
           for (size_t o = 0; o < originals; ++o) {
-            if (!has_source[o])
+            const size_t want_here = engines_of[o];
+            if (want_here < 2)
               continue;
             /* on the devices after the original's, round-robin */
             size_t at = 0;
             while (at < pool.size() && pool[at] != _blocks[o].device)
               ++at;
-            for (size_t k = 1; k < want; ++k) {
+            for (size_t k = 1; k < want_here; ++k) {
               Block b = _blocks[o];
               b.original = (int)o;
               b.device = pool[(at + k) % pool.size()];
@@ -1029,6 +1070,8 @@ public:
                             1024),
                     "set_export_buffer");
               ++_number_of_copies;
+              if (!has_source[o])
+                ++_number_of_neighbour_copies;
             }
           }
           if (_number_of_copies + originals > 64)
@@ -1046,8 +1089,12 @@ public:
         status("Domain decomposition: " +
                std::to_string(_blocks.size() - _number_of_copies) +
                " blocks and " + std::to_string(_number_of_copies) +
-               " copies of source blocks, flights handed over device to "
-               "device.");
+               " copies of source blocks" +
+               (_number_of_neighbour_copies
+                    ? " (" + std::to_string(_number_of_neighbour_copies) +
+                          " of them of their neighbours)"
+                    : std::string()) +
+               ", flights handed over device to device.");
       }
     }
   }

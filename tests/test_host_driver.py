@@ -339,6 +339,61 @@ def test_cmi_gpu_executable_with_copies_of_the_source_block(exe, tmp_path,
 
 
 @pytest.mark.gpu
+def test_copies_cascade_to_the_neighbours_of_the_source_block(exe, tmp_path,
+                                                              oracle):
+    """An off-centre star on a grid of 4 x 1 x 1 blocks with --copies 4: the
+    block with the star gets 4 engines, the blocks next to it 2 each (the
+    reference's restriction of the copy levels to one level per neighbour,
+    src/TaskBasedIonizationSimulation.cpp:533-556 and
+    src/DensitySubGridCreator.hpp:437-531), the far block 1: nine engines,
+    flights routed to the copies of the block they enter by packet id.
+    Against the oracle on the undivided grid, same seed."""
+    text = open(os.path.join(BENCH, "stromgren_diffuse.param")).read()
+    text = text.replace("[64, 64, 64]", "[24, 12, 12]")
+    text = text.replace("number of photons: 1e6", "number of photons: 30000")
+    text = text.replace("number of iterations: 20", "number of iterations: 4")
+    text = text.replace("type: Gadget", "type: AsciiFile")
+    assert "position: [0. pc, 0. pc, 0. pc]" in text
+    # in the second of the four blocks along x
+    text = text.replace("position: [0. pc, 0. pc, 0. pc]",
+                        "position: [-1.1 pc, 0.3 pc, -0.2 pc]")
+    p = tmp_path / "run.param"
+    p.write_text(text)
+    r = subprocess.run([exe, "--params", str(p), "--output-statistics",
+                        "--blocks", "4,1,1", "--copies", "4"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert ("4 blocks and 5 copies of source blocks (2 of them of their "
+            "neighbours)") in r.stdout, r.stdout
+    snapshots = sorted(f for f in os.listdir(tmp_path) if f.endswith("004.txt"))
+    assert len(snapshots) == 1, os.listdir(tmp_path)
+    last = np.loadtxt(tmp_path / snapshots[0])
+    d = describe(exe, str(p), str(tmp_path))
+    sim = oracle.OracleSimulation((24, 12, 12), d["anchor"], d["sides"])
+    sim.set_sources([d["sources"][0]["position"]], [1.],
+                    d["total_luminosity"])
+    sim.set_homogeneous(100. * (1. / 0.01 / 0.01 / 0.01), 8000.)
+    m = sim.model
+    m.spectrum_type = oracle.SPECTRUM_MONOCHROMATIC
+    m.mono_frequency = d["spectrum"]["frequency"]
+    m.xsec_type = oracle.XSEC_FIXED
+    m.recomb_type = oracle.RECOMB_FIXED
+    m.reemit_type = oracle.REEMIT_PHYSICAL
+    m.do_temperature = 0
+    for i in range(14):
+        m.xsec_fixed[i] = d["cross_sections"][i]
+        m.recomb_fixed[i] = d["recombination_rates"][i]
+    sim.run(30000, 4, seed=42)
+    x = np.asarray(sim.x[0])
+    assert 0.02 < (x < 0.5).mean() < 0.98
+    # (equal seeds: the differences are rounding, amplified through four
+    # iterations of the ionization balance)
+    rel = np.abs(last[:, 5] - x) / x
+    assert np.median(rel) < 1e-5
+    assert (rel < 1e-2).mean() > 0.97, (rel > 1e-2).sum()
+
+
+@pytest.mark.gpu
 def test_cmi_gpu_executable_with_a_continuous_source(exe, tmp_path, oracle):
     """stromgren.param plus `ContinuousPhotonSource: type: Isotropic` with a
     monochromatic ContinuousPhotonSourceSpectrum of given total flux: the host

@@ -4,7 +4,8 @@
 per-launch figures bench.py's roofline uses and a per-kernel table of the
 timed phase:
 
-    python tools/pmc_rooflines.py OUTDIR K > profiles/r02/counters.json
+    CMI_PROFILE_COMMIT=$(git rev-parse --short HEAD) \
+        python tools/pmc_rooflines.py OUTDIR K > profiles/r03/counters.json
     (OUTDIR/pmc_<config>/pass*/**/*counter_collection.csv)
 
 Units (MI355X_MICROARCH.md): SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count
@@ -23,12 +24,14 @@ import sys
 from collections import defaultdict
 
 root, steps = sys.argv[1], int(sys.argv[2])
-# (template arguments: FULL, HEAT, REEMIT, EXACT, TABLE - the first
+# (template arguments: FULL, HEAT, REEMIT, EXACT, TABLE, PRE, PAD - the first
 # generation of an iteration runs the TABLE variant)
-DOMINANT = {"stromgren": "shoot_kernel<false, false, false, false, true, false>",
+DOMINANT = {"stromgren":
+                "shoot_kernel<false, false, false, false, true, false, true>",
             "stromgren_diffuse":
-                "shoot_kernel<false, false, false, false, true, false>",
-            "lexington": "shoot_kernel<true, true, false, false, true, true>"}
+                "shoot_kernel<false, false, false, false, true, false, true>",
+            "lexington":
+                "shoot_kernel<true, true, false, false, true, true, false>"}
 N_SIMD, N_CU, MAXCLK = 1024, 256, 2.4e9
 
 
@@ -86,7 +89,9 @@ for config, dominant in DOMINANT.items():
     if not passes:
         continue
     entry = {"ncell": 256, "steps_profiled": steps, "dominant": {},
-             "other_kernels": []}
+             "other_kernels": [],
+             # the source the profiled library was built from
+             "commit": os.environ.get("CMI_PROFILE_COMMIT")}
     merged = {}   # counter -> per-launch mean over the first-gen launches
     table = defaultdict(dict)
     for pname, rows in sorted(passes.items()):

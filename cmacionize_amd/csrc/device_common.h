@@ -351,7 +351,13 @@ struct TrackersDev {
   double cos_opening_angle[CMI_MAX_TRACKERS];
   double direction[CMI_MAX_TRACKERS][3]; /* normalised; all zero: any */
   unsigned long long *counts;            /* [n][3][nbins] */
+  /* AbsorptionTrackers (src/AbsorptionTracker.hpp:49-235) among them: sums
+   * of path length x cross section x weight per photon type and ion */
+  int32_t kind[CMI_MAX_TRACKERS]; /* CMI_TRACKER_* */
+  double *absorption;             /* [n][4][CMI_NION] */
 };
+#define CMI_TRACKER_SPECTRUM 0
+#define CMI_TRACKER_ABSORPTION 1
 
 struct CountersDev {
   double totweight;

@@ -926,6 +926,7 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->opacity);
   (void)hipFree(e->counters);
   (void)hipFree(e->trackers.counts);
+  (void)hipFree(e->trackers.absorption);
   (void)hipFree(e->temp_pipe_block);
   (void)hipFree(e->pad_H);
   (void)hipFree(e->temp_pipe_counts);
@@ -1633,7 +1634,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   const int agg = small_grid ? e->tune.aggregate : CMI_AGG_NONE;
   const int agg_reemit = small_grid ? e->tune.aggregate_reemit : CMI_AGG_NONE;
   const bool tracking = e->trackers_enabled && e->trackers.n != 0;
-  const bool exact = e->tune.exact_dda || !small_grid || tracking;
+  /* (trackers count in the exact marcher on an undivided grid - the counts
+   * equal the oracle's one by one - and in the incremental one on the blocks
+   * of a decomposed grid, whose hand-overs carry its state) */
+  const bool exact = e->tune.exact_dda || !small_grid ||
+                     (tracking && !e->grid.decomposed);
   /* with re-emission in passes the transport launches use the variant WITHOUT
    * the re-emission code (absorbed packets go to the interaction kernel); the
    * variant with it follows re-emissions in place */
@@ -1654,13 +1659,27 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   PICK(true, false, true)
   PICK(true, true, true)
 #undef PICK
+  if (tracking && !exact) {
+    /* (a block of a decomposed grid: the hook in the incremental marcher) */
+#define PICK_TRACK(F, H)                                                       \
+  if (e->full_ions == F && heat == H) {                                        \
+    kernel = shoot_kernel<F, H, false, false, false, false, false, true>;     \
+    kernel_inline = shoot_kernel<F, H, true, false, false, false, false, true>; \
+  }
+    PICK_TRACK(false, false)
+    PICK_TRACK(false, true)
+    PICK_TRACK(true, false)
+    PICK_TRACK(true, true)
+#undef PICK_TRACK
+  }
   if (reemit && !passes)
     kernel = kernel_inline;
   /* the first generation of new packets on a non-periodic grid with the
    * block combining table (every benchmark config): the specialised build of
    * the same kernel */
   void (*kernel_first)(const ShootArgs) = kernel;
-  if (!flights && !exact && agg == CMI_AGG_BLOCK && kernel != kernel_inline &&
+  if (!flights && !exact && !tracking && agg == CMI_AGG_BLOCK &&
+      kernel != kernel_inline &&
       !(e->grid.periodic[0] | e->grid.periodic[1] | e->grid.periodic[2])) {
     if (e->full_ions)
       kernel_first = heat ? shoot_kernel<true, true, false, false, true>
@@ -1730,7 +1749,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       return rc;
   }
   /* later generations in tile rounds: needs the incremental marcher */
-  const bool tiles = passes && e->tune.tile_rounds && !exact;
+  const bool tiles = passes && e->tune.tile_rounds && !exact && !tracking;
   void (*tkernel)(const TileArgs) = nullptr;
   int tile_threads = 0, tile_blocks_per_cu = 0;
   if (tiles) {
@@ -2647,21 +2666,29 @@ int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *e, int32_t n,
                                   const double *positions, int32_t nbins,
                                   const double *opening_angles,
                                   const double *reference_directions) {
+  return cmi_gpu_set_trackers(e, n, positions, nullptr, nbins, opening_angles,
+                              reference_directions);
+}
+
+int cmi_gpu_set_trackers(cmi_gpu_engine *e, int32_t n, const double *positions,
+                         const int32_t *kinds, int32_t nbins,
+                         const double *opening_angles,
+                         const double *reference_directions) {
   if (!e)
     return fail(CMI_GPU_EINVAL, "null engine");
   if (n < 0 || n > CMI_MAX_TRACKERS)
-    return fail(CMI_GPU_EINVAL, "set_spectrum_trackers: %d trackers, at most "
+    return fail(CMI_GPU_EINVAL, "set_trackers: %d trackers, at most "
                 "%d", (int)n, CMI_MAX_TRACKERS);
   if (n > 0 && (!positions || nbins < 1))
-    return fail(CMI_GPU_EINVAL, "set_spectrum_trackers: bad argument");
-  /* (flights handed over between blocks carry the state of the incremental
-   * marcher; the trackers count in the exact one) */
-  if (n > 0 && e->grid.decomposed)
-    return fail(CMI_GPU_ESTATE, "set_spectrum_trackers: trackers need an "
-                "undivided grid (this engine holds a block of one)");
+    return fail(CMI_GPU_EINVAL, "set_trackers: bad argument");
+  for (int32_t k = 0; kinds && k < n; ++k)
+    if (kinds[k] != CMI_TRACKER_SPECTRUM && kinds[k] != CMI_TRACKER_ABSORPTION)
+      return fail(CMI_GPU_EINVAL, "set_trackers: unknown kind %d of tracker "
+                  "%d", (int)kinds[k], (int)k);
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   (void)hipFree(e->trackers.counts);
+  (void)hipFree(e->trackers.absorption);
   e->trackers = TrackersDev();
   if (n == 0)
     return CMI_GPU_OK;
@@ -2690,6 +2717,7 @@ int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *e, int32_t n,
       cell = cell * g.ncell[a] + i;
     }
     t.cell[k] = here ? cell : -1;
+    t.kind[k] = kinds ? kinds[k] : CMI_TRACKER_SPECTRUM;
     t.cos_opening_angle[k] = opening_angles ? cos(opening_angles[k]) : -1.;
     double norm2 = 0.;
     for (int a = 0; a < 3; ++a) {
@@ -2704,7 +2732,23 @@ int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *e, int32_t n,
   const size_t bytes = sizeof(unsigned long long) * 3 * (size_t)n * nbins;
   HIP_TRY(hipMalloc(&t.counts, bytes));
   HIP_TRY(hipMemsetAsync(t.counts, 0, bytes, e->stream));
+  const size_t abytes = sizeof(double) * 4 * CMI_NION * (size_t)n;
+  HIP_TRY(hipMalloc(&t.absorption, abytes));
+  HIP_TRY(hipMemsetAsync(t.absorption, 0, abytes, e->stream));
   e->trackers = t;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_get_tracker_absorption(cmi_gpu_engine *e, double *absorption) {
+  if (!e || !absorption)
+    return fail(CMI_GPU_EINVAL, "get_tracker_absorption: bad argument");
+  if (e->trackers.n == 0)
+    return fail(CMI_GPU_ESTATE, "get_tracker_absorption: no trackers set");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(absorption, e->trackers.absorption,
+                    sizeof(double) * 4 * CMI_NION * (size_t)e->trackers.n,
+                    hipMemcpyDeviceToHost));
   return CMI_GPU_OK;
 }
 

@@ -526,7 +526,7 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
  * choices are compile-time constants and the code of the other aggregation
  * modes and of the periodic wrap is not in the march loop at all. */
 template <bool FULL, bool HEAT, bool REEMIT, bool EXACT, bool TABLE = false,
-          bool PRE = false, bool PAD = false>
+          bool PRE = false, bool PAD = false, bool TRACK = false>
 __global__ void
     __launch_bounds__(CMI_BLOCK,
                       REEMIT ? 1
@@ -536,6 +536,8 @@ __global__ void
    * marching through the padded records (ShootArgs::pad_H) */
   static_assert(!PAD || (TABLE && !FULL && !REEMIT && !EXACT && !PRE),
                 "PAD is a specialisation of the hydrogen-only TABLE kernel");
+  static_assert(!TRACK || (!TABLE && !EXACT && !PRE && !PAD),
+                "TRACK is the tracker hook in the plain incremental marcher");
   const int lane = threadIdx.x & 63;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
   /* Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
@@ -1059,11 +1061,33 @@ __global__ void
         ++nsteps;
         accumulate = (kappa.x >= 0.); /* number density > 0 */
         /* DensityGrid::update_integrals' tracker hook,
-         * src/DensityGrid.hpp:188-191 (SpectrumTracker::count_photon) */
-        if (EXACT && a.trackers.n != 0 && accumulate) {
+         * src/DensityGrid.hpp:188-191 (SpectrumTracker::count_photon), and
+         * DensitySubGrid::update_intensity_counters',
+         * src/DensitySubGrid.hpp:614-617 (AbsorptionTracker::count_photon).
+         * In the kernels of the exact marcher and in the TRACK builds of the
+         * incremental one (blocks of a decomposed grid while trackers count:
+         * in the other builds the hook's registers would spill the march
+         * loop). */
+        if ((EXACT || TRACK) && a.trackers.n != 0 && accumulate) {
+          const int64_t tracked_cell =
+              EXACT ? last_cell_wide : (int64_t)last_cell;
           for (int k = 0; k < a.trackers.n; ++k) {
-            if (last_cell_wide != a.trackers.cell[k])
+            if (tracked_cell != a.trackers.cell[k])
               continue;
+            if (a.trackers.kind[k] == CMI_TRACKER_ABSORPTION) {
+              /* src/AbsorptionTracker.hpp:133-138: the step's contribution
+               * to every mean intensity, by photon type */
+              double *bins = a.trackers.absorption +
+                             ((size_t)k * 4 + (size_t)p.type) * CMI_NION;
+              const double dsw = ds * p.weight;
+              if (FULL) {
+                for (int ion = 0; ion < CMI_NION; ++ion)
+                  atomic_add_f64(bins + ion, dsw * stage.weight[lane][ion]);
+              } else {
+                atomic_add_f64(bins + ION_H_n, dsw * p.sigma_H);
+              }
+              continue;
+            }
             const double *d = a.trackers.direction[k];
             if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] > 0. &&
                 p.dir[0] * d[0] + p.dir[1] * d[1] + p.dir[2] * d[2] <

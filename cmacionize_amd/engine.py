@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("CMI_GPU_LIBRARY",
                           os.path.join(_HERE, "libcmi_gpu.so"))
 
 NION = 14
+TRACKER_SPECTRUM, TRACKER_ABSORPTION = 0, 1
 NACC = 16
 NTYPE = 4
 
@@ -85,7 +86,8 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_group_update_cells",
     "cmi_gpu_group_exchange_flights", "cmi_gpu_compute_emissivities",
     "cmi_gpu_set_spectrum_trackers", "cmi_gpu_enable_trackers",
-    "cmi_gpu_get_tracker_counts",
+    "cmi_gpu_get_tracker_counts", "cmi_gpu_set_trackers",
+    "cmi_gpu_get_tracker_absorption",
 ]
 
 # the emission lines of EmissivityValues (src/EmissivityValues.hpp:36-81), in
@@ -195,6 +197,10 @@ def load_library():
         C.POINTER(C.c_double)]
     L.cmi_gpu_set_spectrum_trackers.argtypes = [vp, C.c_int32, _dp, C.c_int32,
                                                 _dp, _dp]
+    L.cmi_gpu_set_trackers.argtypes = [vp, C.c_int32, _dp,
+                                       C.POINTER(C.c_int32), C.c_int32, _dp,
+                                       _dp]
+    L.cmi_gpu_get_tracker_absorption.argtypes = [vp, _dp]
     L.cmi_gpu_enable_trackers.argtypes = [vp, C.c_int32]
     L.cmi_gpu_get_tracker_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.cmi_gpu_update_cells_range.argtypes = [vp, C.c_uint32, C.c_double,
@@ -538,6 +544,32 @@ class GpuEngine:
             None if ang is None else _p(ang),
             None if ref is None else _p(ref)))
         self._trackers = (n, nbins)
+
+    def set_trackers(self, positions, kinds, nbins=100, opening_angles=None,
+                     reference_directions=None):
+        """Trackers of the given kinds (TRACKER_SPECTRUM / TRACKER_ABSORPTION)
+        in the cells that hold `positions` ([n][3])."""
+        pos = _f64(positions).reshape(-1, 3)
+        n = len(pos)
+        kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        assert kinds.size == n
+        ang = None if opening_angles is None else _f64(opening_angles)
+        ref = None if reference_directions is None else \
+            _f64(reference_directions).reshape(-1, 3)
+        self._check(self._lib.cmi_gpu_set_trackers(
+            self._h, n, _p(pos) if n else None,
+            kinds.ctypes.data_as(C.POINTER(C.c_int32)), nbins,
+            None if ang is None else _p(ang),
+            None if ref is None else _p(ref)))
+        self._trackers = (n, nbins)
+
+    def get_tracker_absorption(self):
+        """absorption[tracker][photon type (4)][ion (14)]: the sums of an
+        AbsorptionTracker (zero rows for spectrum trackers)"""
+        n, _ = self._trackers
+        out = np.zeros((n, 4, NION))
+        self._check(self._lib.cmi_gpu_get_tracker_absorption(self._h, _p(out)))
+        return out
 
     def enable_trackers(self, on=True):
         self._check(self._lib.cmi_gpu_enable_trackers(self._h, int(on)))

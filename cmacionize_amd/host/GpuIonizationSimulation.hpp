@@ -347,26 +347,48 @@ inline DensityGridWriter *generate_writer(const std::string &output_folder,
   throw ParameterError("Unknown DensityGridWriter type: \"" + type + "\"");
 }
 
-/* TrackerManager with SpectrumTrackers (src/TrackerManager.hpp:41-380,
- * src/SpectrumTracker.hpp:41-262): the trackers of a YAML block file, placed
- * on the engines for the last iteration and written as the reference's text
- * files afterwards. (Its HDF5 output and tracker types other than Spectrum
- * are not provided.) */
+/* TrackerManager (src/TrackerManager.hpp:41-380) with SpectrumTrackers
+ * (src/SpectrumTracker.hpp:41-262) and AbsorptionTrackers
+ * (src/AbsorptionTracker.hpp:49-235): the trackers of a YAML block file,
+ * placed on the engines for the last iteration (every block of a decomposed
+ * grid gets all of them and counts those in its own cells; the counts of
+ * blocks and copies are merged, :307-318), normalised and written as the
+ * reference's text files - or, with "HDF5 output", as one HDF5 file of tracker
+ * groups (:330-367; like the reference's, for AbsorptionTrackers only: its
+ * SpectrumTracker has no HDF5 form, src/Tracker.hpp:112-130). */
 class TrackerManager {
   std::vector<double> _positions, _opening_angles, _reference_directions;
+  std::vector<int32_t> _kinds;
   std::vector<std::string> _output_names;
   int32_t _number_of_bins = 0;
   const uint_fast64_t _number_of_photons;
+  const bool _hdf5_output;
+  const std::string _hdf5_name;
   std::vector<uint64_t> _counts;
+  std::vector<double> _absorption; /* [tracker][4 types][14 ions] */
+
+  static const char *photontype_name(int type) {
+    /* get_photontype_name, src/PhotonType.hpp:64-85 */
+    switch (type) {
+    case 0:
+      return "source photon";
+    case 1:
+      return "diffuse H photon";
+    case 2:
+      return "diffuse He photon";
+    default:
+      return "absorbed photon";
+    }
+  }
 
 public:
   explicit TrackerManager(ParameterFile &params)
       : _number_of_photons((uint_fast64_t)params.get_integer(
-            "TrackerManager:minimum number of photon packets", 0)) {
+            "TrackerManager:minimum number of photon packets", 0)),
+        _hdf5_output(params.get_bool("TrackerManager:HDF5 output", false)),
+        _hdf5_name(params.get_string("TrackerManager:HDF5 output name",
+                                     "trackers.hdf5")) {
     const std::string filename = params.get_filename("TrackerManager:filename");
-    if (params.get_bool("TrackerManager:HDF5 output", false))
-      throw ParameterError("TrackerManager:HDF5 output is not provided "
-                           "(text files are)");
     ParameterFile blocks(filename);
     const long long n = blocks.get_integer("number of trackers", -1);
     if (n < 0)
@@ -374,35 +396,55 @@ public:
                            filename + "\"");
     if (n > 16)
       throw ParameterError("at most 16 trackers");
+    _number_of_bins = 100;
+    bool bins_set = false;
     for (long long i = 0; i < n; ++i) {
       const std::string name = "tracker[" + std::to_string(i) + "]:";
       const std::array<double, 3> x =
           blocks.get_physical_vector(QUANTITY_LENGTH, name + "position", "");
+      /* TrackerFactory::generate, src/TrackerFactory.hpp:60-72 */
       const std::string type = blocks.get_string(name + "type", "Spectrum");
-      if (type != "Spectrum")
-        throw ParameterError("Tracker type \"" + type +
-                             "\" is not provided (Spectrum is)");
-      const int32_t bins =
-          (int32_t)blocks.get_integer(name + "number of bins", 100);
-      if (i > 0 && bins != _number_of_bins)
-        throw ParameterError("all trackers must have the same number of bins");
-      _number_of_bins = bins;
-      _opening_angles.push_back(blocks.get_physical_value(
-          QUANTITY_ANGLE, name + "opening angle", "180. degrees"));
-      /* (a vector of plain numbers) */
-      const std::string d =
-          blocks.get_string(name + "reference direction", "[0., 0., 0.]");
+      if (type != "Spectrum" && type != "Absorption")
+        throw ParameterError("Unknown Tracker type: \"" + type + "\"");
+      const bool absorption = type == "Absorption";
+      _kinds.push_back(absorption ? CMI_GPU_TRACKER_ABSORPTION
+                                  : CMI_GPU_TRACKER_SPECTRUM);
+      double angle = 3.141592653589793;
       double v[3] = {0., 0., 0.};
-      if (std::sscanf(d.c_str(), " [ %lf , %lf , %lf ]", &v[0], &v[1],
-                      &v[2]) != 3)
-        throw ParameterError("bad reference direction \"" + d + "\"");
+      if (!absorption) {
+        const int32_t bins =
+            (int32_t)blocks.get_integer(name + "number of bins", 100);
+        if (bins_set && bins != _number_of_bins)
+          throw ParameterError(
+              "all spectrum trackers must have the same number of bins");
+        _number_of_bins = bins;
+        bins_set = true;
+        angle = blocks.get_physical_value(QUANTITY_ANGLE,
+                                          name + "opening angle",
+                                          "180. degrees");
+        /* (a vector of plain numbers) */
+        const std::string d =
+            blocks.get_string(name + "reference direction", "[0., 0., 0.]");
+        if (std::sscanf(d.c_str(), " [ %lf , %lf , %lf ]", &v[0], &v[1],
+                        &v[2]) != 3)
+          throw ParameterError("bad reference direction \"" + d + "\"");
+      }
+      _opening_angles.push_back(angle);
       for (int a = 0; a < 3; ++a) {
         _positions.push_back(x[a]);
         _reference_directions.push_back(v[a]);
       }
+      /* src/TrackerManager.hpp:132-138 */
       _output_names.push_back(blocks.get_string(
-          name + "output name", "Tracker" + std::to_string(i) + ".txt"));
+          name + "output name",
+          "Tracker" + std::to_string(i) + (_hdf5_output ? "" : ".txt")));
     }
+    if (_hdf5_output)
+      for (int32_t kind : _kinds)
+        if (kind != CMI_GPU_TRACKER_ABSORPTION)
+          throw ParameterError(
+              "TrackerManager:HDF5 output: only Absorption trackers have an "
+              "HDF5 form (as in the reference, src/Tracker.hpp:112-130)");
     std::ofstream ofile(filename + ".used-values");
     blocks.print_contents(ofile);
   }
@@ -412,31 +454,98 @@ public:
 
   /* TrackerManager::add_trackers */
   int lower(cmi_gpu_engine *engine) const {
-    int rc = cmi_gpu_set_spectrum_trackers(
-        engine, (int32_t)size(), _positions.data(), _number_of_bins,
-        _opening_angles.data(), _reference_directions.data());
+    int rc = cmi_gpu_set_trackers(engine, (int32_t)size(), _positions.data(),
+                                  _kinds.data(), _number_of_bins,
+                                  _opening_angles.data(),
+                                  _reference_directions.data());
     if (rc == CMI_GPU_OK)
       rc = cmi_gpu_enable_trackers(engine, 1);
     return rc;
   }
   /* the counts of one engine, added to the total (the copies of a tracker
-   * are merged, src/TrackerManager.hpp:321-332) */
+   * are merged, src/TrackerManager.hpp:307-318) */
   int collect(cmi_gpu_engine *engine) {
     std::vector<uint64_t> part(3 * size() * (size_t)_number_of_bins);
-    const int rc = cmi_gpu_get_tracker_counts(engine, part.data());
+    int rc = cmi_gpu_get_tracker_counts(engine, part.data());
     if (rc != CMI_GPU_OK)
       return rc;
     _counts.resize(part.size(), 0);
     for (size_t k = 0; k < part.size(); ++k)
       _counts[k] += part[k];
+    std::vector<double> sums(4 * NUMBER_OF_IONNAMES * size());
+    rc = cmi_gpu_get_tracker_absorption(engine, sums.data());
+    if (rc != CMI_GPU_OK)
+      return rc;
+    _absorption.resize(sums.size(), 0.);
+    for (size_t k = 0; k < sums.size(); ++k)
+      _absorption[k] += sums[k];
     return CMI_GPU_OK;
   }
-  /* SpectrumTracker::output_tracker, :226-238 */
+  /* TrackerManager::normalize -> AbsorptionTracker::normalize
+   * (src/AbsorptionTracker.hpp:87-93; a SpectrumTracker keeps its counts) */
+  void normalize(const double luminosity_per_weight) {
+    for (double &v : _absorption)
+      v *= luminosity_per_weight;
+  }
+  /* TrackerManager::output_trackers, :323-375 */
   void output_trackers() const {
+    if (_hdf5_output) {
+      /* one group: all trackers are AbsorptionTrackers
+       * (AbsorptionTracker::same_group / create_group / append_to_group,
+       * src/AbsorptionTracker.hpp:170-223) */
+      Hdf5Writer file;
+      const std::string group = "Group0";
+      file.attribute(group, "type", std::string("Absorption"));
+      std::vector<std::string> ion_names;
+      for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+        ion_names.push_back(ion_name(ion));
+      file.dataset(group, "ion name", ion_names);
+      const size_t n = size();
+      for (int type = 0; type < 4; ++type) {
+        std::vector<double> table(n * NUMBER_OF_IONNAMES);
+        for (size_t t = 0; t < n; ++t)
+          for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+            table[t * NUMBER_OF_IONNAMES + ion] =
+                _absorption[(t * 4 + (size_t)type) * NUMBER_OF_IONNAMES + ion];
+        file.dataset(group, std::string(photontype_name(type)) + " absorption",
+                     {(uint64_t)n, (uint64_t)NUMBER_OF_IONNAMES},
+                     [table](std::ostream &os) {
+                       os.write(reinterpret_cast<const char *>(table.data()),
+                                8 * table.size());
+                     });
+      }
+      const std::vector<double> positions = _positions;
+      file.dataset(group, "positions", {(uint64_t)n, 3},
+                   [positions](std::ostream &os) {
+                     os.write(reinterpret_cast<const char *>(positions.data()),
+                              8 * positions.size());
+                   });
+      file.dataset(group, "tracker labels", _output_names);
+      file.attribute(group, "position unit", std::string("m"));
+      file.write(_hdf5_name);
+      return;
+    }
     const double minimum_frequency = 3.289e15;
     const double frequency_width = 3. * 3.289e15 / _number_of_bins;
     for (size_t t = 0; t < size(); ++t) {
       std::ofstream ofile(_output_names[t]);
+      if (_kinds[t] == CMI_GPU_TRACKER_ABSORPTION) {
+        /* AbsorptionTracker::output_tracker, :145-160 */
+        ofile << "# Ion ";
+        for (int type = 0; type < 4; ++type)
+          ofile << "\t" << photontype_name(type);
+        ofile << "\n";
+        for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion) {
+          ofile << ion_name(ion);
+          for (int type = 0; type < 4; ++type)
+            ofile << "\t"
+                  << _absorption[(t * 4 + (size_t)type) * NUMBER_OF_IONNAMES +
+                                 ion];
+          ofile << "\n";
+        }
+        continue;
+      }
+      /* SpectrumTracker::output_tracker, :226-238 */
       ofile << "# frequency (Hz)\tprimary count\tdiffuse H count\tdiffuse He "
                "count\n";
       const uint64_t *c = _counts.data() + 3 * t * (size_t)_number_of_bins;
@@ -540,6 +649,20 @@ class GpuIonizationSimulation {
     for (size_t k = 0; k < n; ++k)
       if (errors[k])
         std::rethrow_exception(errors[k]);
+  }
+
+  /* PhotonSource::get_total_luminosity, src/PhotonSource.cpp:95-111 */
+  double total_luminosity() const {
+    double luminosity = 0.;
+    if (_photon_source_distribution)
+      luminosity += _photon_source_distribution->get_total_luminosity();
+    if (_continuous_photon_source)
+      luminosity +=
+          _continuous_photon_source->has_total_luminosity()
+              ? _continuous_photon_source->get_total_luminosity()
+              : _continuous_photon_source->get_total_surface_area() *
+                    _continuous_photon_source_spectrum->get_total_flux();
+    return luminosity;
   }
 
   void lower_model(cmi_gpu_engine *engine) {
@@ -1284,6 +1407,8 @@ public:
         check(_trackers->collect(e), "get_tracker_counts");
         check(cmi_gpu_enable_trackers(e, 0), "enable_trackers");
       });
+      /* src/IonizationSimulation.cpp:621-624 */
+      _trackers->normalize(total_luminosity() / _last_totweight);
       _trackers->output_trackers();
     }
     download_state();

@@ -106,9 +106,10 @@ class Hdf5Writer {
   struct Dataset {
     std::string name;
     std::vector<uint64_t> dims;
-    /* writes the raw data (dims product doubles) to the stream */
+    /* writes the raw data (dims product elements) to the stream */
     std::function<void(std::ostream &)> write;
     uint64_t bytes;
+    Bytes type; /* datatype message of an element; empty: IEEE double */
   };
   struct Group {
     std::string name;
@@ -321,6 +322,26 @@ public:
     });
   }
 
+  /* a 1-D dataset of fixed-length, null-padded strings (the reference writes
+   * variable-length ones, HDF5Tools::write_dataset for std::string: readers
+   * see the same strings) */
+  void dataset(const std::string &group_name, const std::string &name,
+               const std::vector<std::string> &values) {
+    size_t width = 1;
+    for (const std::string &v : values)
+      width = std::max(width, v.size() + 1);
+    std::string raw(width * values.size(), '\0');
+    for (size_t i = 0; i < values.size(); ++i)
+      raw.replace(i * width, values[i].size(), values[i]);
+    Dataset d;
+    d.name = name;
+    d.dims = {values.size()};
+    d.type = type_string((uint32_t)width);
+    d.bytes = raw.size();
+    d.write = [raw](std::ostream &os) { os.write(raw.data(), raw.size()); };
+    group(group_name).datasets.push_back(d);
+  }
+
   void write(const std::string &filename) const {
     /* pass 1: sizes -> addresses. Layout: superblock, root header, root
      * tables, then per group {header, tables, dataset headers}, raw data. */
@@ -330,7 +351,7 @@ public:
       m[0].type = 0x0001;
       m[0].data = space(d.dims);
       m[1].type = 0x0003;
-      m[1].data = type_double();
+      m[1].data = d.type.empty() ? type_double() : d.type;
       m[2].type = 0x0005; /* fill value, version 2: none defined */
       m[2].data.u8(2);
       m[2].data.u8(2); /* space allocation time: late (1 is early) - what

@@ -364,14 +364,40 @@ int cmi_gpu_compute_emissivities(cmi_gpu_engine *engine, int32_t nlines,
  * removes them; opening_angles / reference_directions may be NULL (all
  * packets). Counting happens while enabled (the reference adds its trackers
  * for the last iteration, src/IonizationSimulation.cpp:367-370) and makes the
- * transport use the exact marcher without the combining table or tile
- * rounds. Not for the blocks of a decomposed grid (CMI_GPU_ESTATE): flights
- * handed over between blocks carry the incremental marcher's state. */
+ * transport run without the combining table and without tile rounds - in the
+ * exact marcher on an undivided grid, in the incremental one on a block of a
+ * decomposed grid (flights handed over between blocks carry its state). */
 int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *engine, int32_t n,
                                   const double *positions, int32_t nbins,
                                   const double *opening_angles,
                                   const double *reference_directions);
+/* The same with a kind per tracker (NULL: all spectrum trackers):
+ * CMI_GPU_TRACKER_SPECTRUM as above, CMI_GPU_TRACKER_ABSORPTION an
+ * AbsorptionTracker (src/AbsorptionTracker.hpp:49-235, the hook of
+ * DensitySubGrid::update_intensity_counters, src/DensitySubGrid.hpp:592-617):
+ * for every packet crossing the cell, path length x cross section x weight
+ * per ion, summed by photon type - the cell's mean-intensity sums split by
+ * type (m^3; cmi_gpu_get_tracker_absorption). The engine's cross sections
+ * are the classic path's (no element abundance in them: the reference's
+ * task-based packets carry A_element sigma, src/SourceDiscretePhotonTask
+ * Context.hpp:172-180 - multiply the ion's column by its element's abundance
+ * for that convention). On a block of a decomposed grid a tracker outside
+ * the block counts nothing; the caller adds the blocks' (and copies') counts
+ * (TrackerManager::normalize merges copies, src/TrackerManager.hpp:307-318). */
+#define CMI_GPU_TRACKER_SPECTRUM 0
+#define CMI_GPU_TRACKER_ABSORPTION 1
+int cmi_gpu_set_trackers(cmi_gpu_engine *engine, int32_t n,
+                         const double *positions, const int32_t *kinds,
+                         int32_t nbins, const double *opening_angles,
+                         const double *reference_directions);
 int cmi_gpu_enable_trackers(cmi_gpu_engine *engine, int32_t enable);
+/* absorption[(k * 4 + type) * 14 + ion] since the trackers were set, type in
+ * the order of src/PhotonType.hpp:36-50 (the row of PHOTONTYPE_ABSORBED stays
+ * zero: no packet flies with that type). Not normalised
+ * (AbsorptionTracker::normalize multiplies by luminosity / total weight).
+ * Synchronous. */
+int cmi_gpu_get_tracker_absorption(cmi_gpu_engine *engine,
+                                   double *absorption);
 /* counts[(k * 3 + type) * nbins + bin] since the trackers were set
  * (SpectrumTracker::output_tracker's three columns, :226-238). Synchronous. */
 int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);

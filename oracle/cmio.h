@@ -252,6 +252,11 @@ double cmio_reemit_scripted(const cmio_model *model, double sigma_H,
 void cmio_set_trackers(int32_t n, int32_t nbins, const int64_t *cell,
                        const double *cos_opening_angle,
                        const double *direction, uint64_t *counts);
+/* ... some of which (kind[k] != 0) are AbsorptionTrackers
+ * (src/AbsorptionTracker.hpp:49-235): path length x cross section x weight of
+ * every crossing packet into absorption[(k * 4 + type) * 14 + ion]. Call
+ * after cmio_set_trackers (which resets the kinds). */
+void cmio_set_tracker_kinds(const int32_t *kind, double *absorption);
 
 /* A photon packet: src/Photon.hpp:36-69 */
 typedef struct {

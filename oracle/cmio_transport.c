@@ -231,7 +231,11 @@ static struct {
   const double *cos_opening_angle; /* [n] */
   const double *direction;         /* [n][3], normalised or null vector */
   uint64_t *counts;
-} trackers = {0, 0, NULL, NULL, NULL, NULL};
+  /* AbsorptionTrackers among them (src/AbsorptionTracker.hpp:49-235): kind[k]
+   * != 0, sums in absorption[(k * 4 + type) * CMIO_NION + ion] */
+  const int32_t *kind;
+  double *absorption;
+} trackers = {0, 0, NULL, NULL, NULL, NULL, NULL, NULL};
 
 void cmio_set_trackers(int32_t n, int32_t nbins, const int64_t *cell,
                        const double *cos_opening_angle,
@@ -242,16 +246,38 @@ void cmio_set_trackers(int32_t n, int32_t nbins, const int64_t *cell,
   trackers.cos_opening_angle = cos_opening_angle;
   trackers.direction = direction;
   trackers.counts = counts;
+  trackers.kind = NULL;
+  trackers.absorption = NULL;
 }
 
-/* SpectrumTracker::count_photon, src/SpectrumTracker.hpp:176-212 */
-static void count_photon(int64_t cell, const cmio_photon *photon) {
+void cmio_set_tracker_kinds(const int32_t *kind, double *absorption) {
+  trackers.kind = kind;
+  trackers.absorption = absorption;
+}
+
+/* SpectrumTracker::count_photon, src/SpectrumTracker.hpp:176-212, and
+ * AbsorptionTracker::count_photon, src/AbsorptionTracker.hpp:133-138, with the
+ * dmean_intensity of DensitySubGrid::update_intensity_counters
+ * (src/DensitySubGrid.hpp:596-603): distance x cross section x weight */
+static void count_photon(int64_t cell, const cmio_photon *photon, double ds) {
   const double minimum_frequency = 3.289e15;
   const double inverse_frequency_width =
       1. / (3. * 3.289e15 / trackers.nbins);
   for (int32_t k = 0; k < trackers.n; ++k) {
     if (trackers.cell[k] != cell)
       continue;
+    if (trackers.kind && trackers.kind[k] != 0) {
+      if (photon->type >= 0 && photon->type < 4) {
+        double *bins = trackers.absorption +
+                       ((size_t)k * 4 + (size_t)photon->type) * CMIO_NION;
+        for (int ion = 0; ion < CMIO_NION; ++ion) {
+          const double d = ds * photon->weight * photon->cross_section[ion];
+#pragma omp atomic
+          bins[ion] += d;
+        }
+      }
+      continue;
+    }
     const double *d = trackers.direction + 3 * k;
     if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] > 0.) {
       const double dot_product = photon->direction[0] * d[0] +
@@ -350,7 +376,7 @@ int64_t cmio_interact(const cmio_grid *grid, const cmio_model *model,
 #pragma omp atomic
       cells->heating[1][cell] += dhHe;
       if (trackers.n != 0)
-        count_photon(cell, photon);
+        count_photon(cell, photon, ds);
     }
 
     if (trace_cell && nstep < trace_cap) {

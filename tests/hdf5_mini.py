@@ -157,9 +157,16 @@ class File:
         if layout is not None:
             address, size = layout
             n = int(np.prod(dims))
-            assert size == n * dtype.itemsize
-            node.data = np.frombuffer(self.b, dtype=dtype, count=n,
-                                      offset=address).reshape(dims)
+            if isinstance(dtype, tuple):   # fixed-length strings
+                width = dtype[1]
+                assert size == n * width
+                raw = self.b[address:address + size]
+                node.data = [raw[i * width:(i + 1) * width].split(b"\0")[0]
+                             .decode() for i in range(n)]
+            else:
+                assert size == n * dtype.itemsize
+                node.data = np.frombuffer(self.b, dtype=dtype, count=n,
+                                          offset=address).reshape(dims)
         return node
 
     def __getitem__(self, path):

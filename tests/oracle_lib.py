@@ -561,9 +561,13 @@ class Trackers:
     installed while the object is used as a context manager."""
 
     def __init__(self, cells, nbins=100, opening_angles=None,
-                 reference_directions=None):
+                 reference_directions=None, kinds=None):
         self.cells = np.ascontiguousarray(cells, dtype=np.int64)
         n = len(self.cells)
+        # kinds[k] != 0: an AbsorptionTracker, sums in absorption[k][type][ion]
+        self.kinds = None if kinds is None else \
+            np.ascontiguousarray(kinds, dtype=np.int32)
+        self.absorption = np.zeros((n, 4, NION))
         self.nbins = nbins
         ang = np.full(n, np.pi) if opening_angles is None else \
             np.asarray(opening_angles, dtype=np.float64)
@@ -586,6 +590,12 @@ class Trackers:
             self.cells.ctypes.data_as(C.POINTER(C.c_int64)),
             _ptr(self.cosang), _ptr(self.directions),
             self.counts.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if self.kinds is not None:
+            L.cmio_set_tracker_kinds.argtypes = [C.POINTER(C.c_int32), dp]
+            L.cmio_set_tracker_kinds.restype = None
+            L.cmio_set_tracker_kinds(
+                self.kinds.ctypes.data_as(C.POINTER(C.c_int32)),
+                _ptr(self.absorption))
         return self
 
     def __exit__(self, *exc):

@@ -1,4 +1,5 @@
-"""GPU parity of the SpectrumTrackers (cmi_gpu_set_spectrum_trackers: the
+"""GPU parity of the trackers (cmi_gpu_set_spectrum_trackers /
+cmi_gpu_set_trackers: the
 tracker hook of DensityGrid::update_integrals, src/DensityGrid.hpp:188-191,
 with SpectrumTracker::count_photon, src/SpectrumTracker.hpp:176-212): the same
 packets cross the same cells in engine and oracle, so the counts - integers -
@@ -77,3 +78,107 @@ def test_tracker_arguments():
     with pytest.raises(E.EngineError, match="at most"):
         eng.set_spectrum_trackers(np.zeros((17, 3)))
     eng.close()
+
+
+@pytest.mark.parametrize("tuning", [dict(), dict(reemit_passes=0)])
+def test_absorption_trackers_match_oracle(oracle, tuning):
+    """AbsorptionTrackers (src/AbsorptionTracker.hpp:49-235, the hook of
+    DensitySubGrid::update_intensity_counters, src/DensitySubGrid.hpp:592-617)
+    beside a SpectrumTracker: path length x cross section x weight per ion and
+    photon type for every packet that crosses the cell. Summed over the types
+    a tracker holds the cell's own mean-intensity sums."""
+    from cmacionize_amd import engine as E
+    ncell, npacket = 20, 40000
+    sim = oracle.lexington_simulation(ncell)
+    eng = lexington_engine(ncell, sim)
+    eng.set_tuning(**tuning)
+    pc = oracle.PC
+    anchor, side = -5. * pc, 10. * pc
+    positions = np.array([[1.3 * pc, 0.4 * pc, -0.7 * pc],
+                          [-2.1 * pc, 1.9 * pc, 0.2 * pc],
+                          [1.3 * pc, 0.4 * pc, -0.7 * pc],   # same cell
+                          [0.01 * pc, 0.01 * pc, 0.01 * pc]])  # in the hole
+    kinds = [E.TRACKER_ABSORPTION, E.TRACKER_ABSORPTION, E.TRACKER_SPECTRUM,
+             E.TRACKER_ABSORPTION]
+    nbins = 30
+    eng.set_trackers(positions, kinds, nbins)
+    cells = [cell_of(p, anchor, side, ncell) for p in positions]
+    sim.run(npacket, 1, seed=42)
+    eng.upload_cells(sim.number_density, sim.temperature,
+                     np.array([np.asarray(x) for x in sim.x]))
+    eng.enable_trackers(True)
+    eng.reset_grid()
+    eng.shoot(42, 1, 0, npacket)
+    got_counts = eng.get_tracker_counts()
+    got = eng.get_tracker_absorption()
+    with oracle.Trackers(cells, nbins, kinds=kinds) as t:
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(42, 1, 0, npacket)
+    assert np.array_equal(got_counts, t.counts)
+    assert got_counts[2].sum() > 50 and not got_counts[[0, 1, 3]].any()
+    assert np.allclose(got, t.absorption, rtol=1e-9,
+                       atol=1e-12 * t.absorption.max())
+    # source photons and re-emitted hydrogen photons were absorbed; nothing
+    # flies with the type "absorbed"; no gas, no absorption
+    assert got[0, 0, 0] > 0. and got[0, 1, 0] > 0.
+    assert not got[:, 3].any() and not got[3].any() and not got[2].any()
+    # all types together: the cell's mean-intensity sums of this iteration
+    for k in (0, 1):
+        for ion in range(14):
+            J = eng.download_field(E.FIELD_MEAN_INTENSITY + ion)[cells[k]]
+            assert abs(got[k, :, ion].sum() - J) <= 1e-9 * J + 1e-300, ion
+    eng.close()
+
+
+def test_trackers_on_a_decomposed_grid(oracle):
+    """Trackers on the blocks of a decomposed grid (TrackerManager::
+    add_trackers for a DensitySubGridCreator, src/TrackerManager.hpp:243-297):
+    every block is given all trackers and counts those in its own cells - in
+    the incremental marcher, whose state the hand-overs carry; the caller adds
+    the blocks' counts (TrackerManager::normalize, :307-318). Against the
+    oracle on the undivided grid."""
+    from cmacionize_amd import engine as E
+    from test_gpu_domain import decomposed_backends, upload_state
+    ncell, npacket = 24, 40000
+    sim = oracle.lexington_simulation(ncell)
+    sim.run(npacket, 1, seed=42)
+    dec, backends, driver = decomposed_backends("lexington", ncell, (2, 2, 2),
+                                                npacket, sim)
+    upload_state(dec, backends, sim, ncell)
+    pc = oracle.PC
+    anchor, side = -5. * pc, 10. * pc
+    positions = np.array([[1.3 * pc, 0.4 * pc, -0.7 * pc],
+                          [-2.1 * pc, 1.9 * pc, 0.2 * pc],
+                          [-2.1 * pc, 1.9 * pc, 0.2 * pc],
+                          [3.6 * pc, -3.2 * pc, 2.9 * pc]])
+    kinds = [E.TRACKER_SPECTRUM, E.TRACKER_SPECTRUM, E.TRACKER_ABSORPTION,
+             E.TRACKER_ABSORPTION]
+    angles = np.array([np.pi, 0.9, np.pi, np.pi])
+    directions = np.array([[0., 0., 0.], [-1., 1., 0.2], [0., 0., 0.],
+                           [0., 0., 0.]])
+    nbins = 25
+    for b in backends:
+        b.engine.set_trackers(positions, kinds, nbins, angles, directions)
+        b.engine.enable_trackers(True)
+    driver.iteration(1, npacket, 42, update=False)
+    counts = sum(b.engine.get_tracker_counts().astype(np.int64)
+                 for b in backends)
+    absorption = sum(b.engine.get_tracker_absorption() for b in backends)
+    cells = [cell_of(p, anchor, side, ncell) for p in positions]
+    with oracle.Trackers(cells, nbins, angles, directions, kinds=kinds) as t:
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(42, 1, 0, npacket)
+    assert driver.totweight == sim.totweight
+    # (the incremental marcher crosses the same cells as the exact one except
+    # on exact corner ties: a count may differ once in a long while)
+    assert np.abs(counts - t.counts.astype(np.int64)).max() <= 1
+    assert counts[0].sum() > 50 and counts[1].sum() > 0
+    assert np.allclose(absorption, t.absorption, rtol=1e-6,
+                       atol=1e-9 * t.absorption.max())
+    assert absorption[2, 0, 0] > 0. and absorption[3, 0, 0] > 0.
+    for b in backends:
+        b.engine.close()

@@ -473,13 +473,8 @@ def test_ascii_file_source_distribution(exe, tmp_path):
     assert r.returncode == 1 and "number of sources" in r.stderr
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("blocks", [None, "2,2,1"])
-def test_trackers_through_the_driver(exe, tmp_path, blocks):
-    """IonizationSimulation:enable trackers + a TrackerManager block file
-    (src/TrackerManager.hpp, src/SpectrumTracker.hpp): the trackers count in
-    the last iteration and are written as the reference's text files. A grid
-    in blocks refuses them."""
+def tracker_run(exe, tmp_path, label, blocks, hdf5=False):
+    """lexingtonHII40.param at 16^3 with trackers in the last iteration"""
     import shutil
     text = open(os.path.join(BENCH, "lexingtonHII40.param")).read()
     text = text.replace("[64, 64, 64]", "[16, 16, 16]")
@@ -490,37 +485,74 @@ def test_trackers_through_the_driver(exe, tmp_path, blocks):
                         "random seed: 42\n  enable trackers: true")
     text += ("\nTrackerManager:\n  filename: trackers.yml\n"
              "  minimum number of photon packets: 50000\n")
+    if hdf5:
+        text += "  HDF5 output: true\n  HDF5 output name: absorbed.hdf5\n"
     assert "enable trackers: true" in text
-    (tmp_path / "trackers.yml").write_text(
-        "number of trackers: 2\n"
-        "tracker[0]:\n"
-        "  position: [1.3 pc, 0.4 pc, -0.7 pc]\n"
-        "  type: Spectrum\n"
-        "  number of bins: 50\n"
-        "tracker[1]:\n"
-        "  position: [-2.1 pc, 1.9 pc, 0.2 pc]\n"
-        "  number of bins: 50\n"
-        "  opening angle: 60. degrees\n"
-        "  reference direction: [-1., 1., 0.]\n"
-        "  output name: second.txt\n")
-    shutil.copy(os.path.join(BENCH, "lexingtonHII40.yml"), tmp_path)
-    (tmp_path / "run.param").write_text(text)
+    d = tmp_path / label
+    d.mkdir()
+    if hdf5:
+        (d / "trackers.yml").write_text(
+            "number of trackers: 2\n"
+            "tracker[0]:\n"
+            "  position: [1.3 pc, 0.4 pc, -0.7 pc]\n"
+            "  type: Absorption\n"
+            "tracker[1]:\n"
+            "  position: [-2.1 pc, 1.9 pc, 0.2 pc]\n"
+            "  type: Absorption\n"
+            "  output name: far side\n")
+    else:
+        (d / "trackers.yml").write_text(
+            "number of trackers: 3\n"
+            "tracker[0]:\n"
+            "  position: [1.3 pc, 0.4 pc, -0.7 pc]\n"
+            "  type: Spectrum\n"
+            "  number of bins: 50\n"
+            "tracker[1]:\n"
+            "  position: [-2.1 pc, 1.9 pc, 0.2 pc]\n"
+            "  number of bins: 50\n"
+            "  opening angle: 60. degrees\n"
+            "  reference direction: [-1., 1., 0.]\n"
+            "  output name: second.txt\n"
+            "tracker[2]:\n"
+            "  position: [1.3 pc, 0.4 pc, -0.7 pc]\n"
+            "  type: Absorption\n")
+    shutil.copy(os.path.join(BENCH, "lexingtonHII40.yml"), d)
+    (d / "run.param").write_text(text)
     r = subprocess.run([exe, "--params", "run.param"] +
                        (["--blocks", blocks] if blocks else []),
-                       capture_output=True, text=True, cwd=str(tmp_path))
-    if blocks:
-        assert r.returncode != 0 and "undivided grid" in r.stderr
-        return
+                       capture_output=True, text=True, cwd=str(d))
     assert r.returncode == 0, r.stderr
     # the last iteration used the trackers' packet count
     assert "Start shooting 50000 photons" in r.stdout
     assert r.stdout.count("Start shooting 30000 photons") == 3
-    assert os.path.exists(tmp_path / "trackers.yml.used-values")
-    first = open(tmp_path / "Tracker0.txt").read().splitlines()
+    assert os.path.exists(d / "trackers.yml.used-values")
+    return d
+
+
+def read_absorption(path):
+    lines = open(path).read().splitlines()
+    assert lines[0] == ("# Ion \tsource photon\tdiffuse H photon\t"
+                        "diffuse He photon\tabsorbed photon")
+    names = [l.split("\t")[0] for l in lines[1:]]
+    values = np.array([[float(v) for v in l.split("\t")[1:]]
+                       for l in lines[1:]])
+    return names, values
+
+
+@pytest.mark.gpu
+def test_trackers_through_the_driver(exe, tmp_path):
+    """IonizationSimulation:enable trackers + a TrackerManager block file
+    (src/TrackerManager.hpp, src/SpectrumTracker.hpp,
+    src/AbsorptionTracker.hpp): the trackers count in the last iteration and
+    are written as the reference's text files - on the undivided grid and on a
+    grid in blocks (every block counts the trackers in its cells, the driver
+    merges them)."""
+    whole = tracker_run(exe, tmp_path, "whole", None)
+    first = open(whole / "Tracker0.txt").read().splitlines()
     assert first[0] == ("# frequency (Hz)\tprimary count\tdiffuse H count\t"
                         "diffuse He count")
-    a = np.loadtxt(tmp_path / "Tracker0.txt")
-    b = np.loadtxt(tmp_path / "second.txt")
+    a = np.loadtxt(whole / "Tracker0.txt")
+    b = np.loadtxt(whole / "second.txt")
     assert a.shape == b.shape == (50, 4)
     width = 3. * 3.289e15 / 50
     assert np.allclose(a[:, 0], 3.289e15 + (np.arange(50) + 0.5) * width,
@@ -532,6 +564,60 @@ def test_trackers_through_the_driver(exe, tmp_path, blocks):
     # the cone around the outward direction sees the star's light, not all of
     # the diffuse field
     assert 0 < b[:, 1:].sum() < a[:, 1:].sum() * 3
+    # the AbsorptionTracker of the first tracker's cell (normalised: x
+    # luminosity / total weight): ion names down, photon types across
+    names, absorbed = read_absorption(whole / "Tracker2.txt")
+    # (get_ion_name, src/ElementNames.hpp:208-258)
+    assert names[:4] == ["H", "He", "C+", "C++"] and len(names) == 14
+    assert absorbed.shape == (14, 4)
+    assert absorbed[0, 0] > 0. and absorbed[0, 1] > 0.
+    assert not absorbed[:, 3].any()
+    # hydrogen absorbs source photons over more of the spectrum than He does
+    assert absorbed[0, 0] > absorbed[1, 0] > 0.
+    # the same run on 2 x 2 x 1 blocks
+    blocks = tracker_run(exe, tmp_path, "blocks", "2,2,1")
+    a2 = np.loadtxt(blocks / "Tracker0.txt")
+    b2 = np.loadtxt(blocks / "second.txt")
+    # (the blocks fly in the incremental marcher, the undivided grid in the
+    # exact one while trackers count: the same cells except on corner ties,
+    # and the states the two runs reached in three iterations differ by
+    # rounding)
+    assert np.abs(a2[:, 1:] - a[:, 1:]).max() <= 2
+    assert np.abs(b2[:, 1:] - b[:, 1:]).max() <= 2
+    names2, absorbed2 = read_absorption(blocks / "Tracker2.txt")
+    assert names2 == names
+    assert np.allclose(absorbed2, absorbed, rtol=1e-3,
+                       atol=1e-6 * absorbed.max())
+
+
+@pytest.mark.gpu
+def test_absorption_trackers_as_one_hdf5_file(exe, tmp_path):
+    """TrackerManager:HDF5 output (src/TrackerManager.hpp:330-367 with
+    AbsorptionTracker::create_group / append_to_group,
+    src/AbsorptionTracker.hpp:182-223): one group per tracker type with its
+    shared datasets; equal to the text files of the same run."""
+    import hdf5_mini
+    d = tracker_run(exe, tmp_path, "hdf5", None, hdf5=True)
+    f = hdf5_mini.read(str(d / "absorbed.hdf5"))
+    g = f["/Group0"]
+    assert g.attrs["type"] == "Absorption"
+    assert g.attrs["position unit"] == "m"
+    assert f["/Group0/ion name"].data[:3] == ["H", "He", "C+"]
+    assert len(f["/Group0/ion name"].data) == 14
+    assert f["/Group0/tracker labels"].data == ["Tracker0", "far side"]
+    pc = 3.086e16
+    assert np.allclose(f["/Group0/positions"].data,
+                       [[1.3 * pc, 0.4 * pc, -0.7 * pc],
+                        [-2.1 * pc, 1.9 * pc, 0.2 * pc]], rtol=1e-12)
+    t = tracker_run(exe, tmp_path, "text", None)
+    _, absorbed = read_absorption(t / "Tracker2.txt")
+    for column, name in enumerate(("source photon", "diffuse H photon",
+                                   "diffuse He photon", "absorbed photon")):
+        table = np.asarray(f["/Group0/" + name + " absorption"].data)
+        assert table.shape == (2, 14)
+        # (text files hold 6 significant digits)
+        assert np.allclose(table[0], absorbed[:, column], rtol=1e-5, atol=0.)
+    assert not os.path.exists(d / "Tracker0.txt")
 
 
 def test_tracker_block_file_is_parsed(exe, tmp_path):
@@ -564,7 +650,20 @@ def test_tracker_block_file_is_parsed(exe, tmp_path):
         "number of trackers: 1\ntracker[0]:\n"
         "  position: [1. pc, 0.5 pc, -2. pc]\n  type: Absorption\n")
     r = dry_run()
+    assert r.returncode == 0, r.stderr
+    (tmp_path / "trackers.yml").write_text(
+        "number of trackers: 1\ntracker[0]:\n"
+        "  position: [1. pc, 0.5 pc, -2. pc]\n  type: Polarization\n")
+    r = dry_run()
+    assert r.returncode != 0 and "Polarization" in r.stderr
+    # HDF5 output exists for Absorption trackers only (src/Tracker.hpp:112-130)
+    (tmp_path / "trackers.yml").write_text(
+        "number of trackers: 1\ntracker[0]:\n"
+        "  position: [1. pc, 0.5 pc, -2. pc]\n")
+    (tmp_path / "run.param").write_text(text + "  HDF5 output: true\n")
+    r = dry_run()
     assert r.returncode != 0 and "Absorption" in r.stderr
+    (tmp_path / "run.param").write_text(text)
     (tmp_path / "trackers.yml").write_text("tracker[0]:\n  type: Spectrum\n")
     r = dry_run()
     assert r.returncode != 0 and "number of trackers" in r.stderr

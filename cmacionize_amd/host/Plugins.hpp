@@ -30,6 +30,7 @@
 #include "ParameterFile.hpp"
 
 #include <array>
+#include <cfloat>
 #include <cmath>
 #include <memory>
 #include <string>
@@ -379,6 +380,262 @@ public:
   }
 };
 
+/* src/GadgetSnapshotDensityFunction.cpp:60-372: the gas particles of a Gadget
+ * / SWIFT HDF5 snapshot (PartType0: Coordinates, Masses, SmoothingLength,
+ * Density, optionally Temperature and NeutralFractionH) mapped onto the
+ * cells with the cubic spline kernel at the cell midpoints - density = sum of
+ * m W(r / h, h) over the particles whose kernel covers the midpoint,
+ * temperature and neutral fraction as kernel-weighted means. The reference
+ * finds those particles with an Octree; here a uniform grid of bins (side =
+ * the largest smoothing length) does: the same set, hence the same sums up to
+ * their order. */
+class GadgetSnapshotDensityFunction : public DensityFunction {
+  std::vector<double> _positions; /* [n][3], m */
+  std::vector<double> _masses, _smoothing_lengths, _densities, _temperatures,
+      _neutral_fractions;
+  bool _periodic = false;
+  std::array<double, 3> _box_sides = {0., 0., 0.}; /* periodic boxes, m */
+  /* bins over the particles */
+  std::array<double, 3> _bin_anchor = {0., 0., 0.}, _bin_side = {1., 1., 1.};
+  std::array<int, 3> _nbin = {1, 1, 1};
+  std::vector<uint32_t> _bin_start, _bin_particles;
+
+  /* src/CubicSplineKernel.hpp:36-59 */
+  static double kernel(double u, double h) {
+    const double KC1 = 2.546479089470, KC2 = 15.278874536822,
+                 KC5 = 5.092958178941;
+    if (u < 1.) {
+      if (u < 0.5)
+        return (KC1 + KC2 * (u - 1.) * u * u) / (h * h * h);
+      return KC5 * (1. - u) * (1. - u) * (1. - u) / (h * h * h);
+    }
+    return 0.;
+  }
+  int bin_of(double x, int a) const {
+    int i = (int)std::floor((x - _bin_anchor[a]) / _bin_side[a]);
+    if (_periodic)
+      return ((i % _nbin[a]) + _nbin[a]) % _nbin[a];
+    return i < 0 ? 0 : (i >= _nbin[a] ? _nbin[a] - 1 : i);
+  }
+  void build_bins() {
+    const size_t n = _masses.size();
+    double hmax = 0.;
+    std::array<double, 3> lo = {DBL_MAX, DBL_MAX, DBL_MAX},
+                          hi = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (size_t i = 0; i < n; ++i) {
+      hmax = std::max(hmax, _smoothing_lengths[i]);
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = std::min(lo[a], _positions[3 * i + a]);
+        hi[a] = std::max(hi[a], _positions[3 * i + a]);
+      }
+    }
+    size_t total = 1;
+    for (int a = 0; a < 3; ++a) {
+      const double extent = _periodic ? _box_sides[a] : hi[a] - lo[a];
+      _bin_anchor[a] = _periodic ? 0. : lo[a];
+      int nb = hmax > 0. ? (int)std::floor(extent / hmax) : 1;
+      nb = std::max(1, std::min(nb, 256));
+      _nbin[a] = nb;
+      _bin_side[a] = extent > 0. ? extent / nb : 1.;
+      total *= (size_t)nb;
+    }
+    std::vector<uint32_t> count(total + 1, 0);
+    std::vector<size_t> bin(n);
+    for (size_t i = 0; i < n; ++i) {
+      bin[i] = ((size_t)bin_of(_positions[3 * i], 0) * _nbin[1] +
+                bin_of(_positions[3 * i + 1], 1)) *
+                   _nbin[2] +
+               bin_of(_positions[3 * i + 2], 2);
+      ++count[bin[i] + 1];
+    }
+    for (size_t b = 0; b < total; ++b)
+      count[b + 1] += count[b];
+    _bin_start = count;
+    _bin_particles.resize(n);
+    std::vector<uint32_t> cursor(count.begin(), count.end() - 1);
+    for (size_t i = 0; i < n; ++i)
+      _bin_particles[cursor[bin[i]]++] = (uint32_t)i;
+  }
+
+public:
+  GadgetSnapshotDensityFunction(const std::string &name, bool fallback_periodic,
+                                double fallback_unit_length_in_SI,
+                                double fallback_unit_mass_in_SI,
+                                double fallback_unit_temperature_in_SI,
+                                bool use_neutral_fraction,
+                                double fallback_temperature,
+                                bool comoving_integration,
+                                double hubble_parameter) {
+    Hdf5Reader file(name);
+    auto number = [](const Hdf5Reader::Object &o, const char *attribute) {
+      const auto it = o.attributes.find(attribute);
+      if (it == o.attributes.end())
+        throw ParameterError(std::string("snapshot without \"") + attribute +
+                             "\"");
+      return Hdf5Reader::as_doubles(it->second);
+    };
+    /* :75-102 */
+    _periodic = fallback_periodic;
+    if (file.exists("/RuntimePars"))
+      _periodic =
+          number(file.open("/RuntimePars"), "PeriodicBoundariesOn").at(0) != 0.;
+    std::array<double, 3> sides = {0., 0., 0.};
+    if (_periodic) {
+      const std::vector<double> box = number(file.open("/Header"), "BoxSize");
+      for (int a = 0; a < 3; ++a)
+        sides[a] = box.size() >= 3 ? box[a] : box.at(0);
+    }
+    /* :104-160 */
+    double unit_length_in_SI = fallback_unit_length_in_SI,
+           unit_mass_in_SI = fallback_unit_mass_in_SI,
+           unit_temperature_in_SI = fallback_unit_temperature_in_SI;
+    if (file.exists("/Units")) {
+      const Hdf5Reader::Object units = file.open("/Units");
+      unit_length_in_SI = 0.01 * number(units, "Unit length in cgs (U_L)").at(0);
+      unit_mass_in_SI = 0.001 * number(units, "Unit mass in cgs (U_M)").at(0);
+      unit_temperature_in_SI =
+          number(units, "Unit temperature in cgs (U_T)").at(0);
+    } else {
+      if (unit_length_in_SI == 0.)
+        unit_length_in_SI = 1.;
+      if (unit_mass_in_SI == 0.)
+        unit_mass_in_SI = 1.;
+      if (unit_temperature_in_SI == 0.)
+        unit_temperature_in_SI = 1.;
+    }
+    if (comoving_integration) {
+      unit_length_in_SI /= hubble_parameter;
+      unit_mass_in_SI /= hubble_parameter;
+    }
+    const double unit_density_in_SI = unit_mass_in_SI / unit_length_in_SI /
+                                      (unit_length_in_SI * unit_length_in_SI);
+    /* :162-198 */
+    _positions = file.read_doubles("/PartType0/Coordinates");
+    _masses = file.read_doubles("/PartType0/Masses");
+    _smoothing_lengths = file.read_doubles("/PartType0/SmoothingLength");
+    _densities = file.read_doubles("/PartType0/Density");
+    const size_t n = _masses.size();
+    if (_positions.size() != 3 * n || _smoothing_lengths.size() != n ||
+        _densities.size() != n)
+      throw ParameterError("snapshot \"" + name +
+                           "\": particle datasets of different lengths");
+    if (file.exists("/PartType0/Temperature")) {
+      _temperatures = file.read_doubles("/PartType0/Temperature");
+    } else {
+      if (fallback_temperature == 0.)
+        fallback_temperature = 8000.;
+      /* (the fallback is a temperature in K already; the loop below scales
+       * every temperature by the unit, as the reference does) */
+      _temperatures.assign(n, fallback_temperature);
+    }
+    if (use_neutral_fraction && file.exists("/PartType0/NeutralFractionH"))
+      _neutral_fractions = file.read_doubles("/PartType0/NeutralFractionH");
+    /* :200-221 */
+    for (size_t i = 0; i < n; ++i) {
+      for (int a = 0; a < 3; ++a)
+        _positions[3 * i + a] *= unit_length_in_SI;
+      _masses[i] *= unit_mass_in_SI;
+      _smoothing_lengths[i] *= unit_length_in_SI;
+      _densities[i] *= unit_density_in_SI;
+      _temperatures[i] *= unit_temperature_in_SI;
+    }
+    for (int a = 0; a < 3; ++a)
+      _box_sides[a] = sides[a] * unit_length_in_SI;
+    build_bins();
+  }
+  explicit GadgetSnapshotDensityFunction(ParameterFile &params)
+      : GadgetSnapshotDensityFunction(
+            params.get_filename("DensityFunction:filename"),
+            params.get_bool("DensityFunction:fallback periodic flag", false),
+            params.get_physical_value(QUANTITY_LENGTH,
+                                      "DensityFunction:fallback unit length",
+                                      "0. m"),
+            params.get_physical_value(QUANTITY_MASS,
+                                      "DensityFunction:fallback unit mass",
+                                      "0. kg"),
+            params.get_physical_value(
+                QUANTITY_TEMPERATURE,
+                "DensityFunction:fallback unit temperature", "0. K"),
+            params.get_bool("DensityFunction:use neutral fraction", false),
+            params.get_physical_value(
+                QUANTITY_TEMPERATURE,
+                "DensityFunction:fallback initial temperature", "0. K"),
+            params.get_bool("DensityFunction:comoving integration flag", false),
+            params.get_double("DensityFunction:hubble parameter", 0.7)) {}
+
+  /* :313-359 */
+  DensityValues operator()(const Cell &cell) override {
+    const CoordinateVector position = cell.get_cell_midpoint();
+    double density = 0., temperature = 0.;
+    double neutral_fraction = _neutral_fractions.empty() ? -1. : 0.;
+    int visited[3][3], nvisit[3];
+    for (int a = 0; a < 3; ++a) {
+      nvisit[a] = 0;
+      const int c = bin_of(position[a], a);
+      for (int o = -1; o <= 1; ++o) {
+        int i = c + o;
+        if (_periodic)
+          i = ((i % _nbin[a]) + _nbin[a]) % _nbin[a];
+        else if (i < 0 || i >= _nbin[a])
+          continue;
+        bool seen = false;
+        for (int k = 0; k < nvisit[a]; ++k)
+          seen |= visited[a][k] == i;
+        if (!seen)
+          visited[a][nvisit[a]++] = i;
+      }
+    }
+    for (int ix = 0; ix < nvisit[0]; ++ix)
+      for (int iy = 0; iy < nvisit[1]; ++iy)
+        for (int iz = 0; iz < nvisit[2]; ++iz) {
+          const size_t bin =
+              ((size_t)visited[0][ix] * _nbin[1] + visited[1][iy]) * _nbin[2] +
+              visited[2][iz];
+          for (uint32_t k = _bin_start[bin]; k < _bin_start[bin + 1]; ++k) {
+            const size_t index = _bin_particles[k];
+            double r2 = 0.;
+            for (int a = 0; a < 3; ++a) {
+              double d = position[a] - _positions[3 * index + a];
+              if (_periodic) {
+                /* Box::periodic_distance, src/Box.hpp */
+                if (d < -0.5 * _box_sides[a])
+                  d += _box_sides[a];
+                if (d >= 0.5 * _box_sides[a])
+                  d -= _box_sides[a];
+              }
+              r2 += d * d;
+            }
+            const double h = _smoothing_lengths[index];
+            const double u = std::sqrt(r2) / h;
+            if (!(u < 1.))
+              continue;
+            const double splineval = _masses[index] * kernel(u, h);
+            density += splineval;
+            temperature +=
+                splineval * _temperatures[index] / _densities[index];
+            if (neutral_fraction >= 0.)
+              neutral_fraction += splineval * _neutral_fractions[index];
+          }
+        }
+    DensityValues values;
+    values.set_number_density(density / 1.6737236e-27);
+    values.set_temperature(temperature);
+    values.set_ionic_fraction(ION_H_n, neutral_fraction >= 0.
+                                           ? neutral_fraction / density
+                                           : 1.e-6);
+    values.set_ionic_fraction(ION_He_n, 1.e-6);
+    return values;
+  }
+
+  /* :366-372 */
+  double get_total_hydrogen_number() const {
+    double mtot = 0.;
+    for (double m : _masses)
+      mtot += m;
+    return mtot / 1.6737236e-27;
+  }
+};
+
 inline DensityFunction *generate_density_function(ParameterFile &params) {
   const std::string type =
       params.get_string("DensityFunction:type", "Homogeneous");
@@ -388,10 +645,12 @@ inline DensityFunction *generate_density_function(ParameterFile &params) {
     return new BlockSyntaxDensityFunction(params);
   if (type == "CMacIonizeSnapshot")
     return new CMacIonizeSnapshotDensityFunction(params);
+  if (type == "GadgetSnapshot")
+    return new GadgetSnapshotDensityFunction(params);
   throw ParameterError("Unknown DensityFunction type: \"" + type +
-                       "\" (this engine provides Homogeneous, BlockSyntax and "
-                       "CMacIonizeSnapshot; pass your own DensityFunction to "
-                       "initialize())");
+                       "\" (this engine provides Homogeneous, BlockSyntax, "
+                       "CMacIonizeSnapshot and GadgetSnapshot; pass your own "
+                       "DensityFunction to initialize())");
 }
 
 /* ---------------------------------------------- PhotonSourceDistribution */

@@ -36,7 +36,8 @@ enum Quantity {
   QUANTITY_TIME,
   QUANTITY_DENSITY,
   QUANTITY_VELOCITY,
-  QUANTITY_ANGLE
+  QUANTITY_ANGLE,
+  QUANTITY_MASS
 };
 
 /* value + exponents of (length, time, mass, temperature, current, angle) */
@@ -199,6 +200,8 @@ inline const char *SI_unit_name(Quantity q) {
     return "m s^-1";
   case QUANTITY_ANGLE:
     return "radians";
+  case QUANTITY_MASS:
+    return "kg";
   }
   return "";
 }

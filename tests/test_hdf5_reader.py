@@ -378,3 +378,99 @@ def test_restart_from_the_last_snapshot(exe, tmp_path):
     x1 = after["/PartType0/NeutralFractionH"].data
     assert abs((x1 < 0.5).mean() - (x0 < 0.5).mean()) < 0.02
     assert 0.05 < (x0 < 0.5).mean() < 0.95
+
+
+@pytest.fixture(scope="module")
+def sph_writer(tmp_path_factory):
+    out = tmp_path_factory.mktemp("sphcli") / "make_sph_snapshot"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror",
+                    "-I", os.path.join(ROOT, "cmacionize_amd", "host"),
+                    "-o", str(out),
+                    os.path.join(ROOT, "tests", "support",
+                                 "make_sph_snapshot.cpp"), "-lz"], check=True)
+    return str(out)
+
+
+def cubic_spline(u, h):
+    """src/CubicSplineKernel.hpp:36-59"""
+    w = np.where(u < 0.5, 2.546479089470 + 15.278874536822 * (u - 1.) * u * u,
+                 5.092958178941 * (1. - u) ** 3)
+    return np.where(u < 1., w, 0.) / h ** 3
+
+
+@pytest.mark.parametrize("periodic", [0, 1])
+def test_gadget_snapshot_density_function(exe, sph_writer, tmp_path, periodic):
+    """DensityFunction type GadgetSnapshot
+    (src/GadgetSnapshotDensityFunction.cpp:60-372): SPH particles of a Gadget /
+    SWIFT snapshot onto the cells - density as the sum of m W(r / h, h) over
+    the particles whose kernel covers the cell midpoint, temperature and
+    neutral fraction as kernel-weighted means; units from the snapshot's
+    /Units group, periodic distances in a periodic box. Against the same sums
+    in numpy."""
+    rng = np.random.default_rng(5 + periodic)
+    n, ncell = 4000, 10
+    ul_cgs, um_cgs, ut = 3.086e18, 1.989e33, 2.5     # pc, Msol, odd K unit
+    box = 10.                                        # in pc
+    x = rng.uniform(0., box, (n, 3))
+    m = rng.uniform(0.5, 1.5, n) * 1e-3
+    h = rng.uniform(0.6, 1.4, n)
+    rho = rng.uniform(0.5, 2., n) * 1e-3
+    T = rng.uniform(2000., 4000., n)
+    xH = rng.uniform(0., 1., n)
+    raw = tmp_path / "particles.bin"
+    with open(raw, "wb") as f:
+        f.write(struct.pack("<Q", n))
+        for a in (x, m, h, rho, T, xH):
+            f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
+    snap = tmp_path / "sph.hdf5"
+    subprocess.run([sph_writer, str(snap), str(raw), str(periodic), str(box),
+                    repr(ul_cgs), repr(um_cgs), repr(ut), str(1 | 2 | 4 | 8)],
+                   check=True)
+    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = text.replace("[64, 64, 64]", "[%d, %d, %d]" % ((ncell,) * 3))
+    text = text.replace("anchor: [-5. pc, -5. pc, -5. pc]",
+                        "anchor: [0. pc, 0. pc, 0. pc]")
+    old = text[text.index("DensityFunction:"):]
+    old = old[:old.index("\n\n") if "\n\n" in old else len(old)]
+    text = text.replace(old, "DensityFunction:\n  type: GadgetSnapshot\n"
+                        "  filename: sph.hdf5\n  use neutral fraction: true")
+    text = text.replace("type: Gadget\n", "type: Binary\n")
+    assert "GadgetSnapshot" in text and "anchor: [0. pc" in text
+    (tmp_path / "run.param").write_text(text)
+    r = subprocess.run([exe, "--params", "run.param", "--dry-run",
+                        "--dry-run-snapshot"], capture_output=True, text=True,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr + r.stdout
+    # (BinaryDensityGridWriter: int64 ncell[3], then n, T and the 14
+    # fractions as arrays of doubles)
+    blob = open(tmp_path / "stromgren_000.bin", "rb").read()
+    assert struct.unpack_from("<3q", blob) == (ncell,) * 3
+    fields = np.frombuffer(blob, dtype="<f8", offset=24).reshape(16, -1)
+    out = np.zeros((ncell ** 3, 6))
+    out[:, 3], out[:, 4], out[:, 5] = fields[0], fields[1], fields[2]
+    # the same sums in numpy (SI)
+    ul, um = ul_cgs * 0.01, um_cgs * 0.001
+    ax = (np.arange(ncell) + 0.5) * (box * ul / ncell)
+    mid = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"),
+                   axis=-1).reshape(-1, 3)
+    xs, hs, ms = x * ul, h * ul, m * um
+    rhos = rho * um / ul ** 3
+    d = mid[:, None, :] - xs[None, :, :]
+    if periodic:
+        side = box * ul
+        d = (d + 0.5 * side) % side - 0.5 * side
+    u = np.sqrt((d * d).sum(axis=2)) / hs[None, :]
+    w = ms[None, :] * cubic_spline(u, hs[None, :])
+    density = w.sum(axis=1)
+    assert (density > 0.).all()
+    assert np.allclose(out[:, 3], density / 1.6737236e-27, rtol=1e-5)
+    assert np.allclose(out[:, 4], (w * (T * ut / rhos)[None, :]).sum(axis=1),
+                       rtol=1e-5)
+    assert np.allclose(out[:, 5], (w * xH[None, :]).sum(axis=1) / density,
+                       rtol=1e-5)
+    if periodic:
+        # the cells at the faces of the box see particles across them
+        plain = np.sqrt(((mid[:, None, :] - xs[None, :, :]) ** 2).sum(axis=2))
+        alone = (ms[None, :] * cubic_spline(plain / hs[None, :],
+                                            hs[None, :])).sum(axis=1)
+        assert (density > 1.05 * alone).any()

@@ -69,6 +69,10 @@ def run_rank(rank, world, port, out_dir, shard=False):
     import torch.distributed as dist
     from cmacionize_amd.simulation import ReplicaIterationDriver
     os.environ["OMP_NUM_THREADS"] = "1"
+    # (the oracle's sums in a fixed order: one thread, whatever the
+    # environment was when libgomp started)
+    import oracle_lib
+    oracle_lib.set_num_threads(1)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
                             rank=rank, world_size=world)
     backend = OracleBackend(NCELL)
@@ -123,8 +127,13 @@ def test_replica_mode_matches_single_process(world, shard, tmp_path, oracle):
     port = free_port()
     mp.spawn(run_rank, args=(world, port, str(tmp_path), shard), nprocs=world,
              join=True)
-    # single process reference
-    os.environ["OMP_NUM_THREADS"] = "1"
+    # single process reference (one thread: the oracle library is loaded
+    # already, the environment variable would come too late - and with the
+    # order of its sums left to chance this comparison of a chaotic system
+    # fails once in a long while)
+    threads = oracle.num_threads()
+    oracle.set_num_threads(1)
+    request_threads_back = lambda: oracle.set_num_threads(threads)
     backend = OracleBackend(NCELL)
     driver = ReplicaIterationDriver(backend, 0, 1, None)
     first = None
@@ -152,3 +161,4 @@ def test_replica_mode_matches_single_process(world, shard, tmp_path, oracle):
         # Monte Carlo code is chaotic at the ulp level - so only loosely equal
         assert np.allclose(r["J"], ref_J, rtol=1e-3, atol=1e-6 * ref_J.max())
         assert np.allclose(r["xH"], ref_x, rtol=1e-3, atol=0.)
+    request_threads_back()

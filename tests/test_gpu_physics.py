@@ -201,6 +201,9 @@ def test_diffuse_stromgren_shoot_matches_oracle(oracle, tuning):
          defer_weights=0),
     dict(pre_emission=0, defer_weights=0),
     dict(tile_rounds=0),
+    # range classes in the sort key, as at 1e8 packets
+    dict(sort_tau_bits=3),
+    dict(sort_tau_bits=2, tile_rounds=0),
 ])
 def test_lexington_iteration_matches_oracle(oracle, tuning):
     """benchmarks/lexingtonHII40.param at 24^3: Planck source, Verner cross

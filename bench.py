@@ -53,15 +53,15 @@ CONFIGS = {
     "stromgren": dict(
         name="stromgren.param", bytes_per_step=16. + 16. * 1, diffuse=False,
         lexington=False, converge_iterations=20,
-        kernel="shoot_kernel<false, false, false, false, true, false, true>"),
+        kernel="shoot_kernel<false, false, false, false, true, false, true, false>"),
     "stromgren_diffuse": dict(
         name="stromgren_diffuse.param", bytes_per_step=16. + 16. * 1,
         diffuse=True, lexington=False, converge_iterations=20,
-        kernel="shoot_kernel<false, false, false, false, true, false, true>"),
+        kernel="shoot_kernel<false, false, false, false, true, false, true, false>"),
     "lexington": dict(
         name="lexingtonHII40.param", bytes_per_step=16. + 16. * 16,
         diffuse=True, lexington=True, converge_iterations=20,
-        kernel="shoot_kernel<true, true, false, false, true, true, false>"),
+        kernel="shoot_kernel<true, true, false, false, true, true, false, false>"),
 }
 
 # The CPU baseline (oracle/cmio_transport_fast.c) against the REFERENCE on the
@@ -609,8 +609,8 @@ def main():
             out["strong_scaling"] = strong
         if args.config != "stromgren":
             out["metric"] = "photon packets/sec, 256^3 " + args.config
-        if not args.no_cpu_baseline and not (domain and world > 1):
-            # (needs the whole grid's state on this rank)
+        if not args.no_cpu_baseline and world == 1:
+            # (rank 0 at N = 1 only: the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline(ncell, args.config, cfg,
                                                backend.engine)
         if domain:

@@ -1013,10 +1013,19 @@ __global__ void
         const int32_t key = accumulate ? last_cell : ~lane;
         double v[2] = {ds * wsig, HEAT ? ds * hw : 0.};
         bool tail;
+#if defined(CMI_PAD_SCAN_ROUNDS)
+        /* experiment: the scan over groups of 2^rounds lanes instead */
+        if (HEAT)
+          run_sums<2, CMI_PAD_SCAN_ROUNDS>(key, v, tail);
+        else
+          run_sums<1, CMI_PAD_SCAN_ROUNDS>(
+              key, reinterpret_cast<double(&)[1]>(v), tail);
+#else
         if (HEAT)
           quad_run_sums<2>(key, v, tail);
         else
           quad_run_sums<1>(key, reinterpret_cast<double(&)[1]>(v), tail);
+#endif
         if (CMI_EXP(a) == 11) {
           /* experiment: no table (results are wrong) */
           asm volatile("" ::"v"(v[0]), "v"(tail ? 1 : 0));

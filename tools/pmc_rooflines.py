@@ -24,14 +24,14 @@ import sys
 from collections import defaultdict
 
 root, steps = sys.argv[1], int(sys.argv[2])
-# (template arguments: FULL, HEAT, REEMIT, EXACT, TABLE, PRE, PAD - the first
+# (template arguments: FULL, HEAT, REEMIT, EXACT, TABLE, PRE, PAD, TRACK - the first
 # generation of an iteration runs the TABLE variant)
 DOMINANT = {"stromgren":
-                "shoot_kernel<false, false, false, false, true, false, true>",
+                "shoot_kernel<false, false, false, false, true, false, true, false>",
             "stromgren_diffuse":
-                "shoot_kernel<false, false, false, false, true, false, true>",
+                "shoot_kernel<false, false, false, false, true, false, true, false>",
             "lexington":
-                "shoot_kernel<true, true, false, false, true, true, false>"}
+                "shoot_kernel<true, true, false, false, true, true, false, false>"}
 N_SIMD, N_CU, MAXCLK = 1024, 256, 2.4e9
 
 

@@ -120,6 +120,11 @@ struct ShootArgs {
 #ifndef CMI_PAD_WAVES
 #define CMI_PAD_WAVES 8
 #endif
+/* rounds of the run-sum scan in front of the PAD kernel's table (0: groups of
+ * four lanes by quad_perm reads) */
+#ifndef CMI_PAD_SCAN_ROUNDS
+#define CMI_PAD_SCAN_ROUNDS 3
+#endif
 /* ghost layers around the grid */
 #define CMI_PAD_LAYERS 1
 #define CMI_PAD_VACUUM (-1.)
@@ -956,7 +961,8 @@ __global__ void
        * a software pipeline with two record loads in flight, nor 8 waves per
        * SIMD - the loads are not what it waits for). So: no cell counters per
        * axis (the ghost record says "outside"), every tied axis advances by
-       * selects, run sums by quad_perm reads, a 24-bit multiply for the hash. */
+       * selects, run sums over groups of 8 lanes, a 24-bit multiply for the
+       * hash. */
       const double sigma = p.sigma_H;
       double wsig = p.weight * p.sigma_H;
       double hw = HEAT ? wsig * (p.nu - a.model.nu_H) : 0.;
@@ -1013,8 +1019,10 @@ __global__ void
         const int32_t key = accumulate ? last_cell : ~lane;
         double v[2] = {ds * wsig, HEAT ? ds * hw : 0.};
         bool tail;
-#if defined(CMI_PAD_SCAN_ROUNDS)
-        /* experiment: the scan over groups of 2^rounds lanes instead */
+#if CMI_PAD_SCAN_ROUNDS > 0
+        /* run sums over groups of 2^rounds lanes (measured at 8 waves/SIMD,
+         * ms per iteration of 1e8 packets: groups of 4 by quad_perm reads
+         * 44.2, groups of 8 by three scan rounds 43.0, groups of 16 44.6) */
         if (HEAT)
           run_sums<2, CMI_PAD_SCAN_ROUNDS>(key, v, tail);
         else

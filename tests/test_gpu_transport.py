@@ -267,6 +267,78 @@ def test_shoot_matches_oracle(oracle, ncell, npacket):
     eng.close()
 
 
+@pytest.mark.parametrize("heat", [True, False])
+@pytest.mark.parametrize("pad", [1, 0])
+def test_noncubic_grid_with_vacuum_and_an_off_centre_star(oracle, pad, heat):
+    """A box of 20 x 12 x 16 cells of different sides, a star off its centre
+    and off the cell walls, a slab of vacuum and a neutral clump: the march
+    through the padded records (three different padded strides, ghost cells
+    behind every face, vacuum records) and the plain one against the oracle:
+    tallies and counters."""
+    from cmacionize_amd import GpuEngine, STROMGREN as S
+    from cmacionize_amd import engine as E
+    shape = (20, 12, 16)
+    pc = oracle.PC
+    anchor = (-4. * pc, -2. * pc, -3. * pc)
+    sides = (9. * pc, 5. * pc, 7. * pc)
+    star = [[0.37 * pc, 0.21 * pc, -0.43 * pc]]
+    n = int(np.prod(shape))
+    ix, iy, iz = np.meshgrid(*[np.arange(k) for k in shape], indexing="ij")
+    dens = np.full(shape, S["density"])
+    dens[14:16] = 0.                      # a slab of vacuum
+    xH = np.full(shape, 1.e-4)
+    xH[3:6, 2:5, 9:13] = 1.               # a neutral clump
+    eng = GpuEngine(shape, anchor, sides, (0, 0, 0), device=0,
+                    track_heating=heat)
+    eng.set_sources(star, [1.], S["luminosity"])
+    eng.set_spectrum_monochromatic(1.2 * S["frequency"])
+    sigma = np.zeros(14)
+    sigma[0] = S["sigma_H"]
+    alpha = np.zeros(14)
+    alpha[0] = S["alpha_H"]
+    eng.set_cross_sections_fixed(sigma)
+    eng.set_recombination_rates_fixed(alpha)
+    x = np.zeros((14, n))
+    x[0] = xH.ravel()
+    x[1] = S["xHe"]
+    eng.upload_cells(dens.ravel(), np.full(n, S["temperature"]), x)
+    eng.set_tuning(pad_march=pad, sort_tau_bits=2)
+    sim = oracle.OracleSimulation(shape, anchor, sides)
+    sim.set_sources(star, [1.], S["luminosity"])
+    sim.set_homogeneous(S["density"], S["temperature"])
+    sim.number_density[:] = dens.ravel()
+    sim.x[0][:] = xH.ravel()
+    m = sim.model
+    m.spectrum_type = oracle.SPECTRUM_MONOCHROMATIC
+    m.mono_frequency = 1.2 * S["frequency"]
+    m.xsec_type = oracle.XSEC_FIXED
+    m.xsec_fixed[0] = S["sigma_H"]
+    m.recomb_type = oracle.RECOMB_FIXED
+    m.recomb_fixed[0] = S["alpha_H"]
+    npacket = 60000
+    for loop in range(2):
+        eng.reset_grid()
+        eng.shoot(5, loop, 0, npacket)
+        tw, tc, ns = eng.get_counters()
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(5, loop, 0, npacket)
+        assert tw == sim.totweight == npacket
+        assert np.array_equal(tc, sim.typecount)
+        assert tc[0] > 0 and tc[3] > 0   # some packets escape, most do not
+        J = eng.download_field(E.FIELD_MEAN_INTENSITY)
+        ref = np.asarray(sim.J[0])
+        assert np.allclose(J, ref, rtol=1e-9, atol=1e-12 * ref.max())
+        assert not J.reshape(shape)[14:16].any()   # nothing tallied in vacuum
+        assert J.reshape(shape)[16:].any()         # but packets cross it
+        if heat:
+            h = eng.download_field(E.FIELD_HEATING)
+            assert np.allclose(h, sim.heating[0], rtol=1e-9,
+                               atol=1e-12 * np.abs(sim.heating[0]).max())
+    eng.close()
+
+
 def test_packet_range_partition_is_additive(oracle):
     """Shooting [0,N) in one call or in pieces gives the same tallies: the
     property the multi-GPU replica mode relies on."""

@@ -990,9 +990,21 @@ __global__ void
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax) {
             /* every tied axis advances */
+#if defined(CMI_PAD_MASKED_AXES)
+            /* experiment: adds under the execution mask instead of selects */
+            if (p.tmax[ax] == tmin) {
+              asm volatile("v_add_f64 %0, %0, %1"
+                           : "+v"(p.tmax[ax])
+                           : "v"(p.tdelta[ax]));
+              asm volatile("v_add_u32 %0, %0, %1"
+                           : "+v"(p.cell)
+                           : "v"(p.cstep[ax]));
+            }
+#else
             const bool hit = (p.tmax[ax] == tmin);
             p.tmax[ax] += hit ? p.tdelta[ax] : 0.;
             p.cell += hit ? p.cstep[ax] : 0;
+#endif
           }
           p.t = tmin;
           if (p.tau < 0.) {

@@ -466,6 +466,11 @@ int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);
  *                           n x_H with one layer of ghost cells, whose record
  *                           says that the packet has left the box (no cell
  *                           counters per axis in the march)
+ *   "xcd_remap" (0)         sorted first generation: the blocks that share an
+ *                           XCD (block index mod 8) take neighbouring
+ *                           positions of the packet order, so that bundles
+ *                           crossing the same cells share one L2 (measured:
+ *                           no difference on the benchmark grids)
  *   "pre_emission" (1)      multi-ion runs with sorted packets: the spectrum
  *                           sample, the 14 cross sections and the optical
  *                           depth of every new packet are computed by the

@@ -474,3 +474,45 @@ def test_gadget_snapshot_density_function(exe, sph_writer, tmp_path, periodic):
         alone = (ms[None, :] * cubic_spline(plain / hs[None, :],
                                             hs[None, :])).sum(axis=1)
         assert (density > 1.05 * alone).any()
+
+
+def test_gadget_snapshot_fixture_of_the_reference(exe, cli, tmp_path):
+    """test/testGadgetSnapshotDensityFunction.cpp:37-62 on the reference's own
+    fixture (tests/golden/gadget_test.hdf5 = the reference's test/test.hdf5,
+    a Gadget2 snapshot of 100 particles written by libhdf5): a 32^3 grid over
+    the unit box filled from it holds the snapshot's hydrogen atoms
+    (`assert_values_equal`: 1e-4) and, the file's temperatures being zero, an
+    average temperature of zero."""
+    fixture = os.path.join(ROOT, "tests", "golden", "gadget_test.hdf5")
+    masses = np.array(read(cli, fixture, "/PartType0/Masses")["data"])
+    units = read(cli, fixture, "/Units")["attributes"]
+    assert len(masses) == 100
+    assert units["Unit length in cgs (U_L)"] == [100]
+    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = text.replace("[64, 64, 64]", "[32, 32, 32]")
+    text = text.replace("anchor: [-5. pc, -5. pc, -5. pc]",
+                        "anchor: [0. m, 0. m, 0. m]")
+    text = text.replace("sides: [10. pc, 10. pc, 10. pc]",
+                        "sides: [1. m, 1. m, 1. m]")
+    old = text[text.index("DensityFunction:"):]
+    old = old[:old.index("\n\n")]
+    text = text.replace(old, "DensityFunction:\n  type: GadgetSnapshot\n"
+                        "  filename: " + fixture)
+    text = text.replace("type: Gadget\n", "type: Binary\n")
+    assert "sides: [1. m" in text and "GadgetSnapshot" in text
+    (tmp_path / "run.param").write_text(text)
+    r = subprocess.run([exe, "--params", "run.param", "--dry-run",
+                        "--dry-run-snapshot"], capture_output=True, text=True,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr + r.stdout
+    blob = open(tmp_path / "stromgren_000.bin", "rb").read()
+    assert struct.unpack_from("<3q", blob) == (32, 32, 32)
+    fields = np.frombuffer(blob, dtype="<f8", offset=24).reshape(16, -1)
+    cell_volume = (1. / 32) ** 3
+    in_grid = fields[0].sum() * cell_volume
+    unit_mass_in_SI = units["Unit mass in cgs (U_M)"][0] * 0.001
+    in_snapshot = masses.sum() * unit_mass_in_SI / 1.6737236e-27
+    # assert_values_equal_tol(a, b, 1e-4), test/Assert.hpp:54-58
+    assert abs(in_grid - in_snapshot) <= 1e-4 * abs(in_grid + in_snapshot)
+    assert in_snapshot > 0.
+    assert fields[1].mean() == 0.

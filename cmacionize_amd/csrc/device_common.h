@@ -345,12 +345,16 @@ __host__ __device__ inline uint32_t cmi_meta_origin(uint32_t meta) {
 #define CMI_MAX_TRACKERS 16
 struct TrackersDev {
   int32_t n; /* 0: none */
-  int32_t nbins;
-  double minimum_frequency, inverse_frequency_width;
+  /* bins of tracker k over [1, 4) x 3.289e15 Hz: nbins[k], its counts at
+   * counts[3 first_bin[k] + type nbins[k] + bin] */
+  int32_t nbins[CMI_MAX_TRACKERS];
+  int32_t first_bin[CMI_MAX_TRACKERS + 1];
+  double inverse_frequency_width[CMI_MAX_TRACKERS];
+  double minimum_frequency;
   int64_t cell[CMI_MAX_TRACKERS]; /* index in this engine's grid, -1: not here */
   double cos_opening_angle[CMI_MAX_TRACKERS];
   double direction[CMI_MAX_TRACKERS][3]; /* normalised; all zero: any */
-  unsigned long long *counts;            /* [n][3][nbins] */
+  unsigned long long *counts;            /* [n][3][nbins[k]] */
   /* AbsorptionTrackers (src/AbsorptionTracker.hpp:49-235) among them: sums
    * of path length x cross section x weight per photon type and ion */
   int32_t kind[CMI_MAX_TRACKERS]; /* CMI_TRACKER_* */

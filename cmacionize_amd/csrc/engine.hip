@@ -2666,12 +2666,18 @@ int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *e, int32_t n,
                                   const double *positions, int32_t nbins,
                                   const double *opening_angles,
                                   const double *reference_directions) {
-  return cmi_gpu_set_trackers(e, n, positions, nullptr, nbins, opening_angles,
+  if (n > CMI_MAX_TRACKERS)
+    return fail(CMI_GPU_EINVAL, "set_spectrum_trackers: %d trackers, at most "
+                "%d", (int)n, CMI_MAX_TRACKERS);
+  int32_t bins[CMI_MAX_TRACKERS];
+  for (int32_t k = 0; k < n && k < CMI_MAX_TRACKERS; ++k)
+    bins[k] = nbins;
+  return cmi_gpu_set_trackers(e, n, positions, nullptr, bins, opening_angles,
                               reference_directions);
 }
 
 int cmi_gpu_set_trackers(cmi_gpu_engine *e, int32_t n, const double *positions,
-                         const int32_t *kinds, int32_t nbins,
+                         const int32_t *kinds, const int32_t *nbins,
                          const double *opening_angles,
                          const double *reference_directions) {
   if (!e)
@@ -2679,8 +2685,12 @@ int cmi_gpu_set_trackers(cmi_gpu_engine *e, int32_t n, const double *positions,
   if (n < 0 || n > CMI_MAX_TRACKERS)
     return fail(CMI_GPU_EINVAL, "set_trackers: %d trackers, at most "
                 "%d", (int)n, CMI_MAX_TRACKERS);
-  if (n > 0 && (!positions || nbins < 1))
+  if (n > 0 && (!positions || !nbins))
     return fail(CMI_GPU_EINVAL, "set_trackers: bad argument");
+  for (int32_t k = 0; k < n; ++k)
+    if (nbins[k] < 1)
+      return fail(CMI_GPU_EINVAL, "set_trackers: tracker %d with %d bins",
+                  (int)k, (int)nbins[k]);
   for (int32_t k = 0; kinds && k < n; ++k)
     if (kinds[k] != CMI_TRACKER_SPECTRUM && kinds[k] != CMI_TRACKER_ABSORPTION)
       return fail(CMI_GPU_EINVAL, "set_trackers: unknown kind %d of tracker "
@@ -2694,10 +2704,14 @@ int cmi_gpu_set_trackers(cmi_gpu_engine *e, int32_t n, const double *positions,
     return CMI_GPU_OK;
   TrackersDev t = TrackersDev();
   t.n = n;
-  t.nbins = nbins;
   /* src/SpectrumTracker.hpp:88-90: nbins bins over three Rydberg frequencies */
   t.minimum_frequency = 3.289e15;
-  t.inverse_frequency_width = 1. / (3. * 3.289e15 / nbins);
+  t.first_bin[0] = 0;
+  for (int32_t k = 0; k < n; ++k) {
+    t.nbins[k] = nbins[k];
+    t.first_bin[k + 1] = t.first_bin[k] + nbins[k];
+    t.inverse_frequency_width[k] = 1. / (3. * 3.289e15 / nbins[k]);
+  }
   const GridDev &g = e->grid;
   for (int32_t k = 0; k < n; ++k) {
     /* the cell that holds the position (CartesianDensityGrid::get_cell_indices,
@@ -2729,7 +2743,8 @@ int cmi_gpu_set_trackers(cmi_gpu_engine *e, int32_t n, const double *positions,
       for (int a = 0; a < 3; ++a)
         t.direction[k][a] /= sqrt(norm2);
   }
-  const size_t bytes = sizeof(unsigned long long) * 3 * (size_t)n * nbins;
+  const size_t bytes =
+      sizeof(unsigned long long) * 3 * (size_t)t.first_bin[n];
   HIP_TRY(hipMalloc(&t.counts, bytes));
   HIP_TRY(hipMemsetAsync(t.counts, 0, bytes, e->stream));
   const size_t abytes = sizeof(double) * 4 * CMI_NION * (size_t)n;
@@ -2767,7 +2782,7 @@ int cmi_gpu_get_tracker_counts(cmi_gpu_engine *e, uint64_t *counts) {
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipMemcpyAsync(counts, e->trackers.counts,
                          sizeof(unsigned long long) * 3 *
-                             (size_t)e->trackers.n * e->trackers.nbins,
+                             (size_t)e->trackers.first_bin[e->trackers.n],
                          hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return CMI_GPU_OK;

@@ -1124,12 +1124,11 @@ __global__ void
               continue;
             const uint32_t bin =
                 (uint32_t)((p.nu - a.trackers.minimum_frequency) *
-                           a.trackers.inverse_frequency_width);
-            if (bin < (uint32_t)a.trackers.nbins && p.type < TYPE_ABSORBED)
+                           a.trackers.inverse_frequency_width[k]);
+            if (bin < (uint32_t)a.trackers.nbins[k] && p.type < TYPE_ABSORBED)
               atomicAdd(a.trackers.counts +
-                            ((size_t)k * 3 + (size_t)p.type) *
-                                (size_t)a.trackers.nbins +
-                            bin,
+                            3 * (size_t)a.trackers.first_bin[k] +
+                            (size_t)p.type * (size_t)a.trackers.nbins[k] + bin,
                         1ull);
           }
         }

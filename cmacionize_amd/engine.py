@@ -198,8 +198,8 @@ def load_library():
     L.cmi_gpu_set_spectrum_trackers.argtypes = [vp, C.c_int32, _dp, C.c_int32,
                                                 _dp, _dp]
     L.cmi_gpu_set_trackers.argtypes = [vp, C.c_int32, _dp,
-                                       C.POINTER(C.c_int32), C.c_int32, _dp,
-                                       _dp]
+                                       C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_int32), _dp, _dp]
     L.cmi_gpu_get_tracker_absorption.argtypes = [vp, _dp]
     L.cmi_gpu_enable_trackers.argtypes = [vp, C.c_int32]
     L.cmi_gpu_get_tracker_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -548,20 +548,24 @@ class GpuEngine:
     def set_trackers(self, positions, kinds, nbins=100, opening_angles=None,
                      reference_directions=None):
         """Trackers of the given kinds (TRACKER_SPECTRUM / TRACKER_ABSORPTION)
-        in the cells that hold `positions` ([n][3])."""
+        in the cells that hold `positions` ([n][3]); nbins: one number for
+        all, or one per tracker."""
         pos = _f64(positions).reshape(-1, 3)
         n = len(pos)
         kinds = np.ascontiguousarray(kinds, dtype=np.int32)
         assert kinds.size == n
+        bins = np.ascontiguousarray(
+            np.broadcast_to(np.asarray(nbins, dtype=np.int32), (n,)))
         ang = None if opening_angles is None else _f64(opening_angles)
         ref = None if reference_directions is None else \
             _f64(reference_directions).reshape(-1, 3)
         self._check(self._lib.cmi_gpu_set_trackers(
             self._h, n, _p(pos) if n else None,
-            kinds.ctypes.data_as(C.POINTER(C.c_int32)), nbins,
+            kinds.ctypes.data_as(C.POINTER(C.c_int32)),
+            bins.ctypes.data_as(C.POINTER(C.c_int32)),
             None if ang is None else _p(ang),
             None if ref is None else _p(ref)))
-        self._trackers = (n, nbins)
+        self._trackers = (n, bins.tolist())
 
     def get_tracker_absorption(self):
         """absorption[tracker][photon type (4)][ion (14)]: the sums of an
@@ -575,11 +579,20 @@ class GpuEngine:
         self._check(self._lib.cmi_gpu_enable_trackers(self._h, int(on)))
 
     def get_tracker_counts(self):
-        """counts[tracker][type (primary, diffuse H, diffuse He)][bin]"""
+        """counts[tracker][type (primary, diffuse H, diffuse He)][bin]: one
+        array when all trackers have the same number of bins, else a list of
+        [3][bins] arrays."""
         n, nbins = self._trackers
-        out = np.zeros((n, 3, nbins), dtype=np.uint64)
+        bins = [nbins] * n if np.isscalar(nbins) else list(nbins)
+        flat = np.zeros(3 * max(sum(bins), 1), dtype=np.uint64)
         self._check(self._lib.cmi_gpu_get_tracker_counts(
-            self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+            self._h, flat.ctypes.data_as(C.POINTER(C.c_uint64))))
+        out, at = [], 0
+        for b in bins:
+            out.append(flat[at:at + 3 * b].reshape(3, b))
+            at += 3 * b
+        if len(set(bins)) <= 1:
+            return np.array(out).reshape(n, 3, bins[0] if bins else 0)
         return out
 
     def set_tuning(self, **kw):

@@ -360,7 +360,7 @@ class TrackerManager {
   std::vector<double> _positions, _opening_angles, _reference_directions;
   std::vector<int32_t> _kinds;
   std::vector<std::string> _output_names;
-  int32_t _number_of_bins = 0;
+  std::vector<int32_t> _number_of_bins; /* per tracker */
   const uint_fast64_t _number_of_photons;
   const bool _hdf5_output;
   const std::string _hdf5_name;
@@ -396,8 +396,6 @@ public:
                            filename + "\"");
     if (n > 16)
       throw ParameterError("at most 16 trackers");
-    _number_of_bins = 100;
-    bool bins_set = false;
     for (long long i = 0; i < n; ++i) {
       const std::string name = "tracker[" + std::to_string(i) + "]:";
       const std::array<double, 3> x =
@@ -411,14 +409,11 @@ public:
                                   : CMI_GPU_TRACKER_SPECTRUM);
       double angle = 3.141592653589793;
       double v[3] = {0., 0., 0.};
+      int32_t bins = 1; /* (an absorption tracker has no spectrum) */
       if (!absorption) {
-        const int32_t bins =
-            (int32_t)blocks.get_integer(name + "number of bins", 100);
-        if (bins_set && bins != _number_of_bins)
-          throw ParameterError(
-              "all spectrum trackers must have the same number of bins");
-        _number_of_bins = bins;
-        bins_set = true;
+        bins = (int32_t)blocks.get_integer(name + "number of bins", 100);
+        if (bins < 1)
+          throw ParameterError("a tracker needs at least one bin");
         angle = blocks.get_physical_value(QUANTITY_ANGLE,
                                           name + "opening angle",
                                           "180. degrees");
@@ -430,6 +425,7 @@ public:
           throw ParameterError("bad reference direction \"" + d + "\"");
       }
       _opening_angles.push_back(angle);
+      _number_of_bins.push_back(bins);
       for (int a = 0; a < 3; ++a) {
         _positions.push_back(x[a]);
         _reference_directions.push_back(v[a]);
@@ -455,7 +451,7 @@ public:
   /* TrackerManager::add_trackers */
   int lower(cmi_gpu_engine *engine) const {
     int rc = cmi_gpu_set_trackers(engine, (int32_t)size(), _positions.data(),
-                                  _kinds.data(), _number_of_bins,
+                                  _kinds.data(), _number_of_bins.data(),
                                   _opening_angles.data(),
                                   _reference_directions.data());
     if (rc == CMI_GPU_OK)
@@ -465,7 +461,10 @@ public:
   /* the counts of one engine, added to the total (the copies of a tracker
    * are merged, src/TrackerManager.hpp:307-318) */
   int collect(cmi_gpu_engine *engine) {
-    std::vector<uint64_t> part(3 * size() * (size_t)_number_of_bins);
+    size_t total_bins = 0;
+    for (int32_t b : _number_of_bins)
+      total_bins += (size_t)b;
+    std::vector<uint64_t> part(3 * total_bins);
     int rc = cmi_gpu_get_tracker_counts(engine, part.data());
     if (rc != CMI_GPU_OK)
       return rc;
@@ -526,8 +525,12 @@ public:
       return;
     }
     const double minimum_frequency = 3.289e15;
-    const double frequency_width = 3. * 3.289e15 / _number_of_bins;
+    size_t first_bin = 0; /* bins of the trackers before t */
     for (size_t t = 0; t < size(); ++t) {
+      const int32_t nbins = _number_of_bins[t];
+      const double frequency_width = 3. * 3.289e15 / nbins;
+      const uint64_t *c = _counts.data() + 3 * first_bin;
+      first_bin += (size_t)nbins;
       std::ofstream ofile(_output_names[t]);
       if (_kinds[t] == CMI_GPU_TRACKER_ABSORPTION) {
         /* AbsorptionTracker::output_tracker, :145-160 */
@@ -548,11 +551,10 @@ public:
       /* SpectrumTracker::output_tracker, :226-238 */
       ofile << "# frequency (Hz)\tprimary count\tdiffuse H count\tdiffuse He "
                "count\n";
-      const uint64_t *c = _counts.data() + 3 * t * (size_t)_number_of_bins;
-      for (int32_t i = 0; i < _number_of_bins; ++i) {
+      for (int32_t i = 0; i < nbins; ++i) {
         const double nu = minimum_frequency + (i + 0.5) * frequency_width;
-        ofile << nu << "\t" << c[i] << "\t" << c[_number_of_bins + i] << "\t"
-              << c[2 * _number_of_bins + i] << "\n";
+        ofile << nu << "\t" << c[i] << "\t" << c[nbins + i] << "\t"
+              << c[2 * nbins + i] << "\n";
       }
     }
   }

@@ -371,7 +371,9 @@ int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *engine, int32_t n,
                                   const double *positions, int32_t nbins,
                                   const double *opening_angles,
                                   const double *reference_directions);
-/* The same with a kind per tracker (NULL: all spectrum trackers):
+/* The same with a number of bins per tracker (nbins[n]: the reference's
+ * trackers each have their own, `number of bins` in the block file) and a
+ * kind per tracker (NULL: all spectrum trackers):
  * CMI_GPU_TRACKER_SPECTRUM as above, CMI_GPU_TRACKER_ABSORPTION an
  * AbsorptionTracker (src/AbsorptionTracker.hpp:49-235, the hook of
  * DensitySubGrid::update_intensity_counters, src/DensitySubGrid.hpp:592-617):
@@ -388,7 +390,7 @@ int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *engine, int32_t n,
 #define CMI_GPU_TRACKER_ABSORPTION 1
 int cmi_gpu_set_trackers(cmi_gpu_engine *engine, int32_t n,
                          const double *positions, const int32_t *kinds,
-                         int32_t nbins, const double *opening_angles,
+                         const int32_t *nbins, const double *opening_angles,
                          const double *reference_directions);
 int cmi_gpu_enable_trackers(cmi_gpu_engine *engine, int32_t enable);
 /* absorption[(k * 4 + type) * 14 + ion] since the trackers were set, type in
@@ -398,8 +400,11 @@ int cmi_gpu_enable_trackers(cmi_gpu_engine *engine, int32_t enable);
  * Synchronous. */
 int cmi_gpu_get_tracker_absorption(cmi_gpu_engine *engine,
                                    double *absorption);
-/* counts[(k * 3 + type) * nbins + bin] since the trackers were set
- * (SpectrumTracker::output_tracker's three columns, :226-238). Synchronous. */
+/* The counts since the trackers were set, tracker after tracker: tracker k's
+ * at counts[3 first_k + type nbins_k + bin], first_k = the bins of the
+ * trackers before it (with one bin count for all: counts[(k * 3 + type) *
+ * nbins + bin]; SpectrumTracker::output_tracker's three columns, :226-238).
+ * Synchronous. */
 int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);
 
 /* Performance knobs (no effect on what is computed, only on how):

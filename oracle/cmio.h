@@ -257,6 +257,9 @@ void cmio_set_trackers(int32_t n, int32_t nbins, const int64_t *cell,
  * every crossing packet into absorption[(k * 4 + type) * 14 + ion]. Call
  * after cmio_set_trackers (which resets the kinds). */
 void cmio_set_tracker_kinds(const int32_t *kind, double *absorption);
+/* ... each with its own number of bins (bins[n]; counts then tracker after
+ * tracker, [3][bins[k]] each). Call after cmio_set_trackers. */
+void cmio_set_tracker_bins(const int32_t *bins);
 
 /* A photon packet: src/Photon.hpp:36-69 */
 typedef struct {

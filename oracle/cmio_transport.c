@@ -235,7 +235,10 @@ static struct {
    * != 0, sums in absorption[(k * 4 + type) * CMIO_NION + ion] */
   const int32_t *kind;
   double *absorption;
-} trackers = {0, 0, NULL, NULL, NULL, NULL, NULL, NULL};
+  /* a number of bins per tracker (NULL: nbins for all): tracker k's counts
+   * then start at 3 x (the bins of the trackers before it) */
+  const int32_t *bins;
+} trackers = {0, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL};
 
 void cmio_set_trackers(int32_t n, int32_t nbins, const int64_t *cell,
                        const double *cos_opening_angle,
@@ -248,7 +251,10 @@ void cmio_set_trackers(int32_t n, int32_t nbins, const int64_t *cell,
   trackers.counts = counts;
   trackers.kind = NULL;
   trackers.absorption = NULL;
+  trackers.bins = NULL;
 }
+
+void cmio_set_tracker_bins(const int32_t *bins) { trackers.bins = bins; }
 
 void cmio_set_tracker_kinds(const int32_t *kind, double *absorption) {
   trackers.kind = kind;
@@ -261,9 +267,12 @@ void cmio_set_tracker_kinds(const int32_t *kind, double *absorption) {
  * (src/DensitySubGrid.hpp:596-603): distance x cross section x weight */
 static void count_photon(int64_t cell, const cmio_photon *photon, double ds) {
   const double minimum_frequency = 3.289e15;
-  const double inverse_frequency_width =
-      1. / (3. * 3.289e15 / trackers.nbins);
+  size_t first = 0; /* bins of the trackers before k */
   for (int32_t k = 0; k < trackers.n; ++k) {
+    const int32_t nbins = trackers.bins ? trackers.bins[k] : trackers.nbins;
+    const size_t base = 3 * first;
+    first += (size_t)nbins;
+    const double inverse_frequency_width = 1. / (3. * 3.289e15 / nbins);
     if (trackers.cell[k] != cell)
       continue;
     if (trackers.kind && trackers.kind[k] != 0) {
@@ -288,11 +297,9 @@ static void count_photon(int64_t cell, const cmio_photon *photon, double ds) {
     }
     const uint32_t index = (uint32_t)((photon->energy - minimum_frequency) *
                                       inverse_frequency_width);
-    if (index < (uint32_t)trackers.nbins && photon->type >= 0 &&
-        photon->type < 3) {
+    if (index < (uint32_t)nbins && photon->type >= 0 && photon->type < 3) {
 #pragma omp atomic
-      trackers.counts[((size_t)k * 3 + (size_t)photon->type) * trackers.nbins +
-                      index] += 1;
+      trackers.counts[base + (size_t)photon->type * (size_t)nbins + index] += 1;
     }
   }
 }

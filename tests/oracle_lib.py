@@ -564,6 +564,12 @@ class Trackers:
                  reference_directions=None, kinds=None):
         self.cells = np.ascontiguousarray(cells, dtype=np.int64)
         n = len(self.cells)
+        # nbins: one number for all trackers, or one per tracker (counts is
+        # then a list of [3][bins] views)
+        self.bins = None
+        if not np.isscalar(nbins):
+            self.bins = np.ascontiguousarray(nbins, dtype=np.int32)
+            nbins = int(self.bins.max())
         # kinds[k] != 0: an AbsorptionTracker, sums in absorption[k][type][ion]
         self.kinds = None if kinds is None else \
             np.ascontiguousarray(kinds, dtype=np.int32)
@@ -577,7 +583,15 @@ class Trackers:
         norm = np.sqrt((d * d).sum(axis=1))
         d[norm > 0.] /= norm[norm > 0., None]
         self.directions = np.ascontiguousarray(d)
-        self.counts = np.zeros((n, 3, nbins), dtype=np.uint64)
+        if self.bins is None:
+            self.counts = np.zeros((n, 3, nbins), dtype=np.uint64)
+            self._flat = self.counts
+        else:
+            self._flat = np.zeros(3 * int(self.bins.sum()), dtype=np.uint64)
+            self.counts, at = [], 0
+            for b in self.bins:
+                self.counts.append(self._flat[at:at + 3 * b].reshape(3, b))
+                at += 3 * int(b)
 
     def __enter__(self):
         L = lib()
@@ -589,7 +603,12 @@ class Trackers:
             len(self.cells), self.nbins,
             self.cells.ctypes.data_as(C.POINTER(C.c_int64)),
             _ptr(self.cosang), _ptr(self.directions),
-            self.counts.ctypes.data_as(C.POINTER(C.c_uint64)))
+            self._flat.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if self.bins is not None:
+            L.cmio_set_tracker_bins.argtypes = [C.POINTER(C.c_int32)]
+            L.cmio_set_tracker_bins.restype = None
+            L.cmio_set_tracker_bins(
+                self.bins.ctypes.data_as(C.POINTER(C.c_int32)))
         if self.kinds is not None:
             L.cmio_set_tracker_kinds.argtypes = [C.POINTER(C.c_int32), dp]
             L.cmio_set_tracker_kinds.restype = None

@@ -182,3 +182,41 @@ def test_trackers_on_a_decomposed_grid(oracle):
     assert absorption[2, 0, 0] > 0. and absorption[3, 0, 0] > 0.
     for b in backends:
         b.engine.close()
+
+
+def test_trackers_with_their_own_numbers_of_bins(oracle):
+    """The reference's trackers each have their own `number of bins`
+    (test/test_tracker_manager.yml: 100, 1000, 100): counts tracker after
+    tracker, equal to the oracle's."""
+    from cmacionize_amd import engine as E
+    ncell, npacket = 20, 40000
+    sim = oracle.lexington_simulation(ncell)
+    eng = lexington_engine(ncell, sim)
+    pc = oracle.PC
+    anchor, side = -5. * pc, 10. * pc
+    positions = np.array([[1.3 * pc, 0.4 * pc, -0.7 * pc],
+                          [-2.1 * pc, 1.9 * pc, 0.2 * pc],
+                          [1.3 * pc, 0.4 * pc, -0.7 * pc],
+                          [3.6 * pc, -3.2 * pc, 2.9 * pc]])
+    bins = [40, 1000, 7, 100]
+    eng.set_trackers(positions, [E.TRACKER_SPECTRUM] * 4, bins)
+    cells = [cell_of(p, anchor, side, ncell) for p in positions]
+    sim.run(npacket, 1, seed=42)
+    eng.upload_cells(sim.number_density, sim.temperature,
+                     np.array([np.asarray(x) for x in sim.x]))
+    eng.enable_trackers(True)
+    eng.reset_grid()
+    eng.shoot(42, 1, 0, npacket)
+    got = eng.get_tracker_counts()
+    with oracle.Trackers(cells, bins) as t:
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(42, 1, 0, npacket)
+    assert [g.shape for g in got] == [(3, b) for b in bins]
+    for g, want in zip(got, t.counts):
+        assert np.array_equal(g, want)
+    # the same packets in coarser and finer bins
+    assert got[0].sum() == got[2].sum() > 50
+    assert got[1].sum() > 0 and got[3].sum() > 0
+    eng.close()

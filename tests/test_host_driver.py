@@ -620,6 +620,44 @@ def test_absorption_trackers_as_one_hdf5_file(exe, tmp_path):
     assert not os.path.exists(d / "Tracker0.txt")
 
 
+@pytest.mark.gpu
+def test_tracker_manager_fixture_of_the_reference(exe, tmp_path):
+    """test/testTrackerManager.cpp:30-56 with the reference's own block file
+    (tests/golden/test_tracker_manager.yml = test/test_tracker_manager.yml:
+    three Spectrum trackers with 100, 1000 and 100 bins, one with its own
+    output name) on the box of that test (10 pc around the origin, 64^3):
+    all three are placed and written, each with its own number of bins."""
+    import shutil
+    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = text.replace("number of photons: 1e6", "number of photons: 100000")
+    text = text.replace("number of iterations: 20", "number of iterations: 2")
+    text = text.replace("type: Gadget", "type: AsciiFile")
+    assert "IonizationSimulation:" in text
+    text = text.replace("IonizationSimulation:",
+                        "IonizationSimulation:\n  enable trackers: true")
+    text += ("\nTrackerManager:\n  filename: test_tracker_manager.yml\n"
+             "  minimum number of photon packets: 99\n")
+    shutil.copy(os.path.join(ROOT, "tests", "golden",
+                             "test_tracker_manager.yml"), tmp_path)
+    (tmp_path / "run.param").write_text(text)
+    r = subprocess.run([exe, "--params", "run.param"], capture_output=True,
+                       text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    a = np.loadtxt(tmp_path / "Tracker0.txt")
+    b = np.loadtxt(tmp_path / "Tracker1.txt")
+    c = np.loadtxt(tmp_path / "special_position.txt")
+    assert a.shape == (100, 4) and b.shape == (1000, 4) and c.shape == (100, 4)
+    # a monochromatic 13.6 eV source: every count sits in the bin of that
+    # frequency; the star's own cell sees every packet, 4 pc away fewer
+    nu = 13.6 * 1.6021766208e-19 / 6.626070040e-34
+    for table, nbins in ((a, 100), (b, 1000), (c, 100)):
+        k = int((nu - 3.289e15) / (3. * 3.289e15 / nbins))
+        assert table[:, 1].sum() == table[k, 1] > 0
+        assert not table[:, 2:].any()
+    assert a[:, 1].sum() >= 100000 > b[:, 1].sum() > 0
+    assert abs(b[:, 1].sum() - c[:, 1].sum()) < 0.5 * b[:, 1].sum()
+
+
 def test_tracker_block_file_is_parsed(exe, tmp_path):
     """TrackerManager's block file (src/TrackerManager.hpp:98-170): parsed
     with the parameter file grammar, used values written back, unknown types

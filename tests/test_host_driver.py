@@ -289,6 +289,97 @@ def test_cmi_gpu_executable_with_replicas(exe, tmp_path, bench):
     assert stats[0] == stats[1]
 
 
+def test_parameter_file_fixture_of_the_reference(tmp_path):
+    """test/testParameterFile.cpp:78-150 on the reference's own test.param
+    (tests/golden/test.param): integers in decimal, hexadecimal and exponent
+    notation, the eight spellings of a boolean, units, vectors of numbers with
+    and without units, groups in groups, inline comments, defaults."""
+    out = tmp_path / "parameter_file_cli"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror",
+                    "-I", os.path.join(ROOT, "cmacionize_amd", "host"),
+                    "-o", str(out),
+                    os.path.join(ROOT, "tests", "support",
+                                 "parameter_file_cli.cpp"), "-lz"], check=True)
+    r = subprocess.run([str(out), os.path.join(ROOT, "tests", "golden",
+                                               "test.param")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    v = json.loads(r.stdout)
+    assert [v["test_integer%d" % i] for i in range(1, 6)] == \
+        [42, 42, 42, 1000000, 1000000]
+    assert v["test_float"] == 3.14 and v["test_unit"] == 3.086e16
+    assert [v["test_bool%d" % i] for i in range(1, 9)] == \
+        [True] * 4 + [False] * 4
+    assert v["test_string"] == "This is a test string."
+    assert v["group_member"] == 42 and v["group_group_member"] == 42
+    assert v["comments_value"] == "test comments string"
+    assert v["vector_unit"] == [3.086e16, 2., 2.4e19]
+    assert v["vector_int"] == [42, 42, 40]
+    assert v["vector_bool"] == [False, True, True]
+    assert v["not_in_file1"] == 42 and v["not_in_file2"] == 3.14
+    assert v["unit_not_in_file"] == 3.086e16 and v["not_in"] == "file?"
+    assert v["not_in_file3"] is True
+
+
+def test_block_syntax_fixture_of_the_reference(exe, tmp_path):
+    """test/testBlockSyntaxDensityFunction.cpp:30-50 with the reference's own
+    block file (tests/golden/blocksyntaxtest.yml = test/blocksyntaxtest.yml: a
+    cube, two spheres and a rhombus): a 64^3 grid over the unit box holds the
+    analytic number of hydrogen atoms within 0.003 (assert_values_equal_rel)."""
+    import struct
+    text = open(os.path.join(BENCH, "lexingtonHII40.param")).read()
+    text = text.replace("anchor: [-5. pc, -5. pc, -5. pc]",
+                        "anchor: [0. m, 0. m, 0. m]")
+    text = text.replace("sides: [10. pc, 10. pc, 10. pc]",
+                        "sides: [1. m, 1. m, 1. m]")
+    text = text.replace("filename: lexingtonHII40.yml",
+                        "filename: " + os.path.join(ROOT, "tests", "golden",
+                                                    "blocksyntaxtest.yml"))
+    text = text.replace("type: Gadget\n", "type: Binary\n")
+    assert "[64, 64, 64]" in text and "anchor: [0. m" in text
+    assert "blocksyntaxtest.yml" in text and "type: Binary" in text
+    (tmp_path / "run.param").write_text(text)
+    r = subprocess.run([exe, "--params", "run.param", "--dry-run",
+                        "--dry-run-snapshot"], capture_output=True, text=True,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr + r.stdout
+    blob = open(tmp_path / "lexingtonHII40_000.bin", "rb").read()
+    assert struct.unpack_from("<3q", blob) == (64, 64, 64)
+    fields = np.frombuffer(blob, dtype="<f8", offset=24).reshape(16, -1)
+    total = fields[0].sum() / 64. ** 3
+    expect = (4. * np.pi * 0.25 ** 3 / 3 + 4. * np.pi * 0.125 ** 3 / 3. +
+              4. * 0.125 ** 3 / 3.)
+    # assert_values_equal_rel(a, b, 0.003), test/Assert.hpp:63-68
+    assert abs(total - expect) <= 0.003 * abs(total + expect)
+    # the blocks' temperatures: 0 K outside, 100 K in the big sphere and the
+    # rhombus, 200 K in the inner sphere
+    assert set(np.unique(fields[1])) == {0., 100., 200.}
+
+
+def test_ascii_file_source_fixture_of_the_reference(exe, tmp_path):
+    """test/testAsciiFilePhotonSourceDistribution.cpp:30-49 with the
+    reference's own file (tests/golden/
+    test_asciifilephotonsourcedistribution.yml): three sources, 2.4e49 s^-1
+    in total, weights that sum to one, the first source at the origin."""
+    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    old = ("PhotonSourceDistribution:\n  type: SingleStar\n"
+           "  position: [0. pc, 0. pc, 0. pc]\n  luminosity: 4.26e49 s^-1\n")
+    assert old in text
+    text = text.replace(
+        old, "PhotonSourceDistribution:\n  type: AsciiFile\n  filename: " +
+        os.path.join(ROOT, "tests", "golden",
+                     "test_asciifilephotonsourcedistribution.yml") + "\n")
+    (tmp_path / "run.param").write_text(text)
+    d = describe(exe, str(tmp_path / "run.param"), str(tmp_path))
+    assert len(d["sources"]) == 3
+    assert d["total_luminosity"] == 2.4e49
+    assert abs(sum(s["weight"] for s in d["sources"]) - 1.) <= 1e-14
+    assert d["sources"][0]["position"] == [0., 0., 0.]
+    kpc = 3.086e19
+    assert np.allclose(d["sources"][1]["position"],
+                       [0.5 * kpc, 0.2 * kpc, 0.4 * kpc], rtol=1e-12)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("bench", ["stromgren_diffuse.param",
                                    "lexingtonHII40.param"])

@@ -450,6 +450,8 @@ public:
 
   /* TrackerManager::add_trackers */
   int lower(cmi_gpu_engine *engine) const {
+    if (size() == 0)
+      return CMI_GPU_OK;
     int rc = cmi_gpu_set_trackers(engine, (int32_t)size(), _positions.data(),
                                   _kinds.data(), _number_of_bins.data(),
                                   _opening_angles.data(),
@@ -461,6 +463,8 @@ public:
   /* the counts of one engine, added to the total (the copies of a tracker
    * are merged, src/TrackerManager.hpp:307-318) */
   int collect(cmi_gpu_engine *engine) {
+    if (size() == 0)
+      return CMI_GPU_OK; /* a block file without trackers */
     size_t total_bins = 0;
     for (int32_t b : _number_of_bins)
       total_bins += (size_t)b;

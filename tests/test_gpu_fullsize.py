@@ -64,8 +64,11 @@ def test_fullsize_reordering_invariance(converged):
     results = []
     default = dict(sort_packets=1, aggregate=2, refill_threshold=64, chunk=64,
                    sort_tau_bits=-1, max_packets_per_launch=1 << 27,
-                   exact_dda=0)
+                   exact_dda=0, pad_march=1)
     for kw in (dict(),
+               # the march on the plain records instead of the padded ones
+               dict(pad_march=0),
+               dict(pad_march=0, sort_tau_bits=3, chunk=128),
                dict(sort_packets=0, aggregate=0),
                dict(sort_tau_bits=3, max_packets_per_launch=700001),
                dict(aggregate=1, refill_threshold=16, chunk=256),

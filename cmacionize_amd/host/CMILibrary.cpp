@@ -6,9 +6,14 @@
  * bindings of the reference's fortran/ directory) links this instead.
  *
  *   cmi_init(parameter_file, num_thread, unit_length_in_SI, unit_mass_in_SI,
- *            mapping_type)            (+ the periodic dp / sp variants)
- *   cmi_compute_neutral_fraction_dp / _mp / _sp (x, y, z, h, m, nH, N)
+ *            mapping_type, talk)      (+ the periodic dp / sp variants)
+ *   cmi_compute_neutral_fraction_dp (double x y z h m -> double nH)
+ *   cmi_compute_neutral_fraction_mp (double x y z, float h m -> FLOAT nH)
+ *   cmi_compute_neutral_fraction_sp (float x y z h m -> float nH)
  *   cmi_destroy()
+ * typed exactly as src/CMILibrary.hpp:46-72 declares them
+ * (tests/support/cmi_library_caller.c is a C program compiled against those
+ * prototypes).
  *
  * cmi_compute_neutral_fraction_*: SPHArrayInterface::reset with the caller's
  * particle arrays, IonizationSimulation::initialize(interface) - the
@@ -22,6 +27,8 @@
  * CMI_GPU_DEVICE in the environment selects the HIP device (default 0).
  */
 #include "SPHArrayInterface.hpp"
+
+#include "../../include/cmi_library.h"
 
 #include <cstdlib>
 #include <iostream>
@@ -81,11 +88,13 @@ void compute(const TX *x, const TX *y, const TX *z, const TH *h, const TH *m,
 
 extern "C" {
 
+/* (declared in include/cmi_library.h: a definition that does not match its
+ * declaration there does not compile) */
 /* src/CMILibrary.cpp:48-62 */
 void cmi_init(const char *parameter_file, const int num_thread,
               const double unit_length_in_SI, const double unit_mass_in_SI,
-              const char *mapping_type) {
-  init(parameter_file, num_thread, false, [&]() {
+              const char *mapping_type, const int talk) {
+  init(parameter_file, num_thread, talk != 0, [&]() {
     return new SPHArrayInterface(unit_length_in_SI, unit_mass_in_SI,
                                  mapping_type);
   });
@@ -132,7 +141,7 @@ void cmi_compute_neutral_fraction_dp(const double *x, const double *y,
 /* :174-183 */
 void cmi_compute_neutral_fraction_mp(const double *x, const double *y,
                                      const double *z, const float *h,
-                                     const float *m, double *nH,
+                                     const float *m, float *nH,
                                      const size_t N) {
   compute(x, y, z, h, m, nH, N);
 }
@@ -147,5 +156,106 @@ void cmi_compute_neutral_fraction_sp(const float *x, const float *y,
 
 /* not in the reference (it aborts on errors): 0 = the last call succeeded */
 int cmi_gpu_library_status() { return global_status; }
+
+/* Not in the reference either: the two mappings of the coupling object on
+ * their own, host side only (no engine, no GPU), for the tests that pin them
+ * - the known answers of test/testSPHArrayInterface.cpp:70-155 are total
+ * hydrogen numbers of exactly this call sequence (reset, initialize,
+ * DensityGrid::initialize). precision: 0 = all arrays double, 1 = double
+ * positions with float h and m, 2 = all float (the three reset overloads).
+ * periodic_box: NULL or {anchor[3], sides[3]} in the caller's length unit.
+ * Returns 0, or 1 with a message on stderr. */
+namespace {
+SPHArrayInterface *make_interface(const char *mapping_type, double ul,
+                                  double um, const double *periodic_box) {
+  if (periodic_box)
+    return new SPHArrayInterface(ul, um, periodic_box, periodic_box + 3,
+                                 mapping_type);
+  return new SPHArrayInterface(ul, um, mapping_type);
+}
+void reset_interface(SPHArrayInterface &interface, int precision,
+                     const void *x, const void *y, const void *z,
+                     const void *h, const void *m, size_t N) {
+  if (precision == 0)
+    interface.reset((const double *)x, (const double *)y, (const double *)z,
+                    (const double *)h, (const double *)m, N);
+  else if (precision == 1)
+    interface.reset((const double *)x, (const double *)y, (const double *)z,
+                    (const float *)h, (const float *)m, N);
+  else
+    interface.reset((const float *)x, (const float *)y, (const float *)z,
+                    (const float *)h, (const float *)m, N);
+  interface.initialize();
+}
+DensityGrid *make_grid(const double *grid_anchor, const double *grid_sides,
+                       const int *ncell) {
+  const SimulationBox box({grid_anchor[0], grid_anchor[1], grid_anchor[2]},
+                          {grid_sides[0], grid_sides[1], grid_sides[2]},
+                          {false, false, false});
+  return new DensityGrid(box, {ncell[0], ncell[1], ncell[2]});
+}
+} // namespace
+
+int cmi_gpu_library_map_to_cells(const char *mapping_type, int precision,
+                                 const void *x, const void *y, const void *z,
+                                 const void *h, const void *m, size_t N,
+                                 double unit_length_in_SI,
+                                 double unit_mass_in_SI,
+                                 const double *periodic_box,
+                                 const double *grid_anchor,
+                                 const double *grid_sides, const int *ncell,
+                                 double *number_density) {
+  try {
+    std::unique_ptr<SPHArrayInterface> interface(make_interface(
+        mapping_type, unit_length_in_SI, unit_mass_in_SI, periodic_box));
+    reset_interface(*interface, precision, x, y, z, h, m, N);
+    std::unique_ptr<DensityGrid> grid(
+        make_grid(grid_anchor, grid_sides, ncell));
+    const int64_t n = grid->get_number_of_cells();
+    std::string error;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < n; ++i) {
+      try {
+        DensityGrid::iterator cell(grid.get(), i);
+        number_density[i] = (*interface)(cell).get_number_density();
+      } catch (const std::exception &e) {
+#pragma omp critical(cmi_library_probe_error)
+        error = e.what();
+      }
+    }
+    if (!error.empty())
+      throw std::runtime_error(error);
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << "cmi_gpu_library_map_to_cells: " << e.what() << std::endl;
+    return 1;
+  }
+}
+
+int cmi_gpu_library_map_to_particles(
+    const char *mapping_type, int precision, const void *x, const void *y,
+    const void *z, const void *h, const void *m, size_t N,
+    double unit_length_in_SI, double unit_mass_in_SI,
+    const double *periodic_box, const double *grid_anchor,
+    const double *grid_sides, const int *ncell,
+    const double *neutral_fraction_of_cells, double *nH) {
+  try {
+    std::unique_ptr<SPHArrayInterface> interface(make_interface(
+        mapping_type, unit_length_in_SI, unit_mass_in_SI, periodic_box));
+    reset_interface(*interface, precision, x, y, z, h, m, N);
+    std::unique_ptr<DensityGrid> grid(
+        make_grid(grid_anchor, grid_sides, ncell));
+    const int64_t n = grid->get_number_of_cells();
+    grid->_ionic_fraction[ION_H_n].assign(neutral_fraction_of_cells,
+                                          neutral_fraction_of_cells + n);
+    ParameterFile no_parameters;
+    interface->write(*grid, 0, no_parameters);
+    interface->fill_array(nH);
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << "cmi_gpu_library_map_to_particles: " << e.what() << std::endl;
+    return 1;
+  }
+}
 
 } // extern "C"

@@ -57,6 +57,9 @@ public:
       return _grid->get_cell_midpoint(_index);
     }
     double get_volume() const override { return _grid->get_cell_volume(); }
+    std::vector<Face> get_faces() const override {
+      return _grid->get_faces(_index);
+    }
     IonizationVariables get_ionization_variables() const {
       return IonizationVariables{_grid, _index};
     }
@@ -101,6 +104,32 @@ public:
   }
   double get_cell_volume() const {
     return _cellside[0] * _cellside[1] * _cellside[2];
+  }
+  /* CartesianDensityGrid::get_faces, src/CartesianDensityGrid.cpp:611-733:
+   * faces -x, +x, -y, +y, -z, +z; the vertices of a face go round it starting
+   * at its corner with the smallest coordinates, first along the lower of its
+   * two axes */
+  std::vector<Face> get_faces(int64_t index) const {
+    static const int ring[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+    const CoordinateVector mid = get_cell_midpoint(index);
+    std::vector<Face> faces(6);
+    for (int axis = 0; axis < 3; ++axis) {
+      const int u = axis == 0 ? 1 : 0; /* the face's own two axes */
+      const int w = axis == 2 ? 1 : 2;
+      for (int sign = 0; sign < 2; ++sign) {
+        Face &face = faces[2 * axis + sign];
+        face.midpoint = mid;
+        face.midpoint[axis] += (sign ? 0.5 : -0.5) * _cellside[axis];
+        face.vertices.resize(4);
+        for (int v = 0; v < 4; ++v) {
+          CoordinateVector &p = face.vertices[v];
+          p[axis] = mid[axis] + (sign ? 0.5 : -0.5) * _cellside[axis];
+          p[u] = mid[u] + 0.5 * ring[v][0] * _cellside[u];
+          p[w] = mid[w] + 0.5 * ring[v][1] * _cellside[w];
+        }
+      }
+    }
+    return faces;
   }
   iterator begin() const { return iterator(this, 0); }
   iterator end() const { return iterator(this, get_number_of_cells()); }

@@ -63,11 +63,20 @@ struct CoordinateVector {
   double &operator[](int i) { return v[i]; }
 };
 
+/* src/Face.hpp:37-127: a planar face of a cell, its vertices in order round
+ * the face */
+struct Face {
+  CoordinateVector midpoint;
+  std::vector<CoordinateVector> vertices;
+};
+
+/* src/Cell.hpp:36-57 */
 class Cell {
 public:
   virtual ~Cell() {}
   virtual CoordinateVector get_cell_midpoint() const = 0;
   virtual double get_volume() const = 0;
+  virtual std::vector<Face> get_faces() const { return std::vector<Face>(); }
 };
 
 class DensityValues {
@@ -1159,6 +1168,10 @@ struct SimulationBox {
                                          "[1. m, 1. m, 1. m]")),
         periodicity(params.get_bool_vector("SimulationBox:periodicity",
                                            {false, false, false})) {}
+  SimulationBox(const std::array<double, 3> &box_anchor,
+                const std::array<double, 3> &box_sides,
+                const std::array<bool, 3> &box_periodicity)
+      : anchor(box_anchor), sides(box_sides), periodicity(box_periodicity) {}
 };
 
 } // namespace cmi

@@ -17,9 +17,18 @@
  *               (src/CubicSplineKernel.hpp:36-59); back: every such particle
  *               loses W-weighted share of the cell's ionized fraction
  *               (src/SPHArrayInterface.cpp:943-959, .hpp:156-200)
- *   "Petkova"   the exact cell-particle volume integrals of Petkova et al.
- *               (2018) - NOT built here (600 lines of geometry that never
- *               touch the GPU path); asking for it is an error.
+ *   "Petkova"   the exact volume integral of every particle's kernel over
+ *               the cell (Petkova, Laibe & Bonnell 2018; PetkovaMapping.hpp:
+ *               src/SPHArrayInterface.cpp:208-925), for all particles whose
+ *               kernel can reach the cell (within smoothing length + half the
+ *               cell's diagonal of its midpoint); back: every such particle
+ *               loses its mass-weighted share of the cell's ionized fraction
+ *               (src/SPHArrayInterface.cpp:960-1003, .hpp:201-251). On a
+ *               Cartesian grid the reference's sum of vertex integrals is NOT
+ *               that volume integral (PetkovaMapping::mass_fraction says
+ *               why); "Petkova" reproduces the reference's numbers - pinned
+ *               by its known answers -, "Petkova_oriented" (not in the
+ *               reference) is the integral.
  *
  * The reference finds a cell's neighbours with an Octree; here a uniform bin
  * grid over the particles does (bin side = the largest smoothing length): the
@@ -30,9 +39,11 @@
 #define CMI_HOST_SPHARRAYINTERFACE_HPP
 
 #include "GpuIonizationSimulation.hpp"
+#include "PetkovaMapping.hpp"
 
 #include <cfloat>
 #include <cmath>
+#include <memory>
 #include <vector>
 
 namespace cmi {
@@ -53,7 +64,10 @@ inline double cubic_spline_kernel(double u, double h) {
 enum SPHArrayMappingType {
   SPHARRAY_MAPPING_M_OVER_V = 0,
   SPHARRAY_MAPPING_CENTROID,
-  SPHARRAY_MAPPING_PETKOVA
+  SPHARRAY_MAPPING_PETKOVA,
+  /* not in the reference: "Petkova" with every face's normal turned into the
+   * cell, see PetkovaMapping::mass_fraction */
+  SPHARRAY_MAPPING_PETKOVA_ORIENTED
 };
 
 class SPHArrayInterface : public DensityFunction, public DensityGridWriter {
@@ -70,23 +84,30 @@ class SPHArrayInterface : public DensityFunction, public DensityGridWriter {
   double _bin_side[3] = {1., 1., 1.};
   std::vector<uint32_t> _bin_start, _bin_particles;
 
+  /* the pre-computed vertex integrals, built by the constructors like the
+   * reference's gridding() (182 MB, a few seconds) */
+  std::unique_ptr<PetkovaMapping> _petkova;
+
   static SPHArrayMappingType get_mapping_type(const std::string &name) {
     if (name == "M_over_V")
       return SPHARRAY_MAPPING_M_OVER_V;
     if (name == "centroid")
       return SPHARRAY_MAPPING_CENTROID;
     if (name == "Petkova")
-      throw ParameterError(
-          "SPHArrayMappingType \"Petkova\" is not built on this path (use "
-          "\"centroid\" or \"M_over_V\")");
+      return SPHARRAY_MAPPING_PETKOVA;
+    if (name == "Petkova_oriented")
+      return SPHARRAY_MAPPING_PETKOVA_ORIENTED;
     throw ParameterError("Unknown SPHArrayMappingType: \"" + name + "\"!");
   }
 
   /* Box::periodic_distance, src/Box.hpp:113-128 (or the plain difference) */
-  void separation(const double p[3], size_t index, double d[3]) const {
+  void separation(const double p[3], size_t index, double d[3],
+                  bool only_if_periodic = false) const {
     for (int a = 0; a < 3; ++a) {
       d[a] = p[a] - _positions[3 * index + a];
-      if (_box_sides[0] != 0.) { /* as the reference: whenever a box is set */
+      /* as the reference: its own kernel sums wrap whenever a box is set, its
+       * Octree searches only in a periodic box */
+      if (only_if_periodic ? _is_periodic : _box_sides[0] != 0.) {
         if (2. * d[a] < -_box_sides[a])
           d[a] += _box_sides[a];
         if (2. * d[a] >= _box_sides[a])
@@ -102,42 +123,88 @@ class SPHArrayInterface : public DensityFunction, public DensityGridWriter {
       i = i < 0 ? 0 : (i >= _nbin[a] ? _nbin[a] - 1 : i);
     return i;
   }
-  /* calls f(index, r) for every particle within its own smoothing length of
-   * p (Octree::get_ngbs, src/Octree.hpp) */
-  template <typename F> void for_neighbours(const double p[3], F f) const {
-    const int c[3] = {bin_of(p[0], 0), bin_of(p[1], 1), bin_of(p[2], 2)};
-    /* a bin side is at least the largest smoothing length: 27 bins do */
-    int visited[3][3], nvisit[3];
-    for (int a = 0; a < 3; ++a) {
-      nvisit[a] = 0;
-      for (int o = -1; o <= 1; ++o) {
-        int i = c[a] + o;
+  /* the distinct bins along axis a within `reach` bins of bin c */
+  int bins_in_reach(int a, int c, int reach, std::vector<int> &out) const {
+    out.clear();
+    if (2 * reach + 1 >= _nbin[a]) {
+      for (int i = 0; i < _nbin[a]; ++i)
+        out.push_back(i);
+    } else {
+      for (int o = -reach; o <= reach; ++o) {
+        int i = c + o;
         if (_is_periodic)
           i = ((i % _nbin[a]) + _nbin[a]) % _nbin[a];
         else if (i < 0 || i >= _nbin[a])
           continue;
-        bool seen = false;
-        for (int k = 0; k < nvisit[a]; ++k)
-          seen |= visited[a][k] == i;
-        if (!seen)
-          visited[a][nvisit[a]++] = i;
+        out.push_back(i);
       }
     }
-    for (int ix = 0; ix < nvisit[0]; ++ix)
-      for (int iy = 0; iy < nvisit[1]; ++iy)
-        for (int iz = 0; iz < nvisit[2]; ++iz) {
-          const size_t bin =
-              ((size_t)visited[0][ix] * _nbin[1] + visited[1][iy]) * _nbin[2] +
-              visited[2][iz];
+    return (int)out.size();
+  }
+  /* calls f(index, r) for every particle i within margin + h_i of p:
+   * Octree::get_ngbs (margin 0, src/Octree.hpp:128-161) and
+   * Octree::get_ngbs_sphere (src/Octree.hpp:177-211) */
+  template <typename F>
+  void for_neighbours_within(const double p[3], double margin, F f) const {
+    const int c[3] = {bin_of(p[0], 0), bin_of(p[1], 1), bin_of(p[2], 2)};
+    /* a bin side is at least the largest smoothing length */
+    std::vector<int> bins[3];
+    for (int a = 0; a < 3; ++a) {
+      const int reach =
+          1 + (margin > 0. ? (int)std::ceil(margin / _bin_side[a]) : 0);
+      bins_in_reach(a, c[a], reach, bins[a]);
+    }
+    for (int ix : bins[0])
+      for (int iy : bins[1])
+        for (int iz : bins[2]) {
+          const size_t bin = ((size_t)ix * _nbin[1] + iy) * _nbin[2] + iz;
           for (uint32_t k = _bin_start[bin]; k < _bin_start[bin + 1]; ++k) {
             const size_t index = _bin_particles[k];
             double d[3];
-            separation(p, index, d);
-            const double r = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-            if (r < _smoothing_lengths[index])
-              f(index, r);
+            separation(p, index, d, true);
+            double r = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            if (r > _smoothing_lengths[index] + margin)
+              continue;
+            if (!_is_periodic) { /* the distance the kernel sums use */
+              separation(p, index, d);
+              r = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            }
+            f(index, r);
           }
         }
+  }
+  template <typename F> void for_neighbours(const double p[3], F f) const {
+    for_neighbours_within(p, 0., f);
+  }
+  /* the particles the Petkova mapping sums over for a cell, with the mass
+   * each of them has inside the cell (src/SPHArrayInterface.cpp:960-1003,
+   * src/SPHArrayInterface.hpp:201-240) */
+  template <typename F> void for_cell_masses(const Cell &cell, F f) const {
+    const CoordinateVector mid = cell.get_cell_midpoint();
+    const std::vector<Face> faces = cell.get_faces();
+    if (faces.empty())
+      throw ParameterError(
+          "the Petkova mapping needs the faces of the grid's cells");
+    /* the vertex furthest from the midpoint */
+    double radius = 0.;
+    for (const Face &face : faces)
+      for (const CoordinateVector &v : face.vertices) {
+        const double d[3] = {v[0] - mid[0], v[1] - mid[1], v[2] - mid[2]};
+        radius = std::max(radius,
+                          std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]));
+      }
+    const double p[3] = {mid[0], mid[1], mid[2]};
+    for_neighbours_within(p, radius, [&](size_t index, double) {
+      /* the kernel's h is half the SPH smoothing length; the particle's own
+       * position, also across a periodic face - as the reference */
+      const double h = 0.5 * _smoothing_lengths[index];
+      f(index, _petkova->mass_fraction(
+                   faces, &_positions[3 * index], h,
+                   _mapping_type == SPHARRAY_MAPPING_PETKOVA_ORIENTED
+                       ? p
+                       : nullptr) *
+                   _masses[index]);
+    });
   }
   /* Octree::get_closest_ngb */
   size_t closest_particle(const double p[3]) const {
@@ -232,7 +299,11 @@ public:
       : DensityGridWriter(""), _unit_length_in_SI(unit_length_in_SI),
         _unit_mass_in_SI(unit_mass_in_SI), _is_periodic(false),
         _box_anchor{0., 0., 0.}, _box_sides{0., 0., 0.},
-        _mapping_type(get_mapping_type(mapping_type)) {}
+        _mapping_type(get_mapping_type(mapping_type)) {
+    if (_mapping_type == SPHARRAY_MAPPING_PETKOVA ||
+        _mapping_type == SPHARRAY_MAPPING_PETKOVA_ORIENTED)
+      _petkova.reset(new PetkovaMapping());
+  }
   /* periodic versions, :69-130 (box in the caller's length unit) */
   template <typename T>
   SPHArrayInterface(double unit_length_in_SI, double unit_mass_in_SI,
@@ -246,7 +317,11 @@ public:
         _box_sides{box_sides[0] * unit_length_in_SI,
                    box_sides[1] * unit_length_in_SI,
                    box_sides[2] * unit_length_in_SI},
-        _mapping_type(get_mapping_type(mapping_type)) {}
+        _mapping_type(get_mapping_type(mapping_type)) {
+    if (_mapping_type == SPHARRAY_MAPPING_PETKOVA ||
+        _mapping_type == SPHARRAY_MAPPING_PETKOVA_ORIENTED)
+      _petkova.reset(new PetkovaMapping());
+  }
 
   void reset(const double *x, const double *y, const double *z,
              const double *h, const double *m, size_t npart) {
@@ -302,11 +377,14 @@ public:
     double density = 0.;
     if (_mapping_type == SPHARRAY_MAPPING_M_OVER_V) {
       density = _masses[0] / cell.get_volume();
-    } else {
+    } else if (_mapping_type == SPHARRAY_MAPPING_CENTROID) {
       for_neighbours(p, [&](size_t index, double r) {
         const double h = _smoothing_lengths[index];
         density += _masses[index] * cubic_spline_kernel(r / h, h);
       });
+    } else {
+      for_cell_masses(cell, [&](size_t, double mass) { density += mass; });
+      density = density / cell.get_volume();
     }
     /* "Ensure that the density > 0" */
     if (density <= 0.)
@@ -325,27 +403,56 @@ public:
     for (double &nf : _neutral_fractions)
       nf = 1.;
     const int64_t ncell = grid.get_number_of_cells();
+    if (_mapping_type == SPHARRAY_MAPPING_M_OVER_V) {
+      /* the last cell that names a particle wins: in cell order */
+      for (int64_t c = 0; c < ncell; ++c) {
+        DensityGrid::iterator cell(&grid, c);
+        const CoordinateVector mid = cell.get_cell_midpoint();
+        const double p[3] = {mid[0], mid[1], mid[2]};
+        _neutral_fractions[closest_particle(p)] =
+            cell.get_ionization_variables().get_ionic_fraction(ION_H_n);
+      }
+      return;
+    }
+    /* the reference runs the cells on its worker threads with one lock per
+     * particle; atomic subtractions here */
+    std::string error;
+#pragma omp parallel for schedule(dynamic, 64)
     for (int64_t c = 0; c < ncell; ++c) {
       DensityGrid::iterator cell(&grid, c);
       const CoordinateVector mid = cell.get_cell_midpoint();
       const double p[3] = {mid[0], mid[1], mid[2]};
-      const double xH = cell.get_ionization_variables().get_ionic_fraction(ION_H_n);
-      if (_mapping_type == SPHARRAY_MAPPING_M_OVER_V) {
-        _neutral_fractions[closest_particle(p)] = xH;
-      } else {
-        double cell_mass = 0.;
-        for_neighbours(p, [&](size_t index, double r) {
-          const double h = _smoothing_lengths[index];
-          cell_mass += _masses[index] * cubic_spline_kernel(r / h, h);
-        });
-        for_neighbours(p, [&](size_t index, double r) {
-          const double h = _smoothing_lengths[index];
-          const double splineval =
-              _masses[index] * cubic_spline_kernel(r / h, h);
-          _neutral_fractions[index] -= splineval / cell_mass * (1. - xH);
-        });
+      const double xH =
+          cell.get_ionization_variables().get_ionic_fraction(ION_H_n);
+      std::vector<std::pair<size_t, double>> inside;
+      double cell_mass = 0.;
+      try {
+        if (_mapping_type != SPHARRAY_MAPPING_CENTROID) {
+          for_cell_masses(cell, [&](size_t index, double mass) {
+            inside.emplace_back(index, mass);
+            cell_mass += mass;
+          });
+        } else {
+          for_neighbours(p, [&](size_t index, double r) {
+            const double h = _smoothing_lengths[index];
+            const double mass = _masses[index] * cubic_spline_kernel(r / h, h);
+            inside.emplace_back(index, mass);
+            cell_mass += mass;
+          });
+        }
+      } catch (const std::exception &e) {
+#pragma omp critical(sph_array_interface_error)
+        error = e.what();
+        continue;
+      }
+      for (const auto &part : inside) {
+        const double share = part.second / cell_mass * (1. - xH);
+#pragma omp atomic
+        _neutral_fractions[part.first] -= share;
       }
     }
+    if (!error.empty())
+      throw std::runtime_error(error);
   }
 
   /* SPHArrayInterface::fill_array, :1018-1035 */

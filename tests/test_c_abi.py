@@ -33,6 +33,37 @@ def test_header_binding_and_library_agree():
     assert text.count("src/") >= 40
 
 
+def test_library_mode_header_and_library_agree():
+    """include/cmi_library.h: the reference's seven entry points
+    (src/CMILibrary.hpp:46-72) with the reference's argument types, plus the
+    status and mapping probes; libcmi_gpu_library.so exports all of them and
+    is compiled against this header."""
+    text = open(os.path.join(ROOT, "include", "cmi_library.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(cmi_[a-z_0-9]+)\s*\(", code)))
+    assert declared == sorted([
+        "cmi_init", "cmi_init_periodic_dp", "cmi_init_periodic_sp",
+        "cmi_destroy", "cmi_compute_neutral_fraction_dp",
+        "cmi_compute_neutral_fraction_mp", "cmi_compute_neutral_fraction_sp",
+        "cmi_gpu_library_status", "cmi_gpu_library_map_to_cells",
+        "cmi_gpu_library_map_to_particles"])
+    lib = C.CDLL(os.path.join(ROOT, "cmacionize_amd",
+                              "libcmi_gpu_library.so"))
+    for name in declared:
+        assert hasattr(lib, name), name
+    flat = " ".join(code.split())
+    # the two places round 3 got wrong
+    assert ("void cmi_init(const char *parameter_file, const int num_thread, "
+            "const double unit_length_in_SI, const double unit_mass_in_SI, "
+            "const char *mapping_type, const int talk);") in flat
+    assert ("void cmi_compute_neutral_fraction_mp(const double *x, "
+            "const double *y, const double *z, const float *h, "
+            "const float *m, float *nH, const size_t N);") in flat
+    source = open(os.path.join(ROOT, "cmacionize_amd", "host",
+                               "CMILibrary.cpp")).read()
+    assert '#include "../../include/cmi_library.h"' in source
+
+
 def test_no_cpu_fallback():
     """Without a HIP device cmi_gpu_create returns an error and a message;
     with one, an impossible device ordinal does."""

@@ -8,7 +8,15 @@ particles).
 Checked against the oracle: the same mapping formulas in numpy (the
 reference's "centroid" mapping, src/SPHArrayInterface.cpp:943-959 and
 .hpp:156-200, with the cubic spline kernel of src/CubicSplineKernel.hpp),
-the oracle's run on the mapped density field, the inverse mapping in numpy."""
+the oracle's run on the mapped density field, the inverse mapping in numpy.
+
+The "Petkova" mapping (src/SPHArrayInterface.cpp:208-925,960-1003) is pinned
+by the reference's own known answers: the three total hydrogen numbers of
+test/testSPHArrayInterface.cpp:95,123,151 (1000 particles at positions drawn
+from glibc's unseeded rand(), mapped onto a 16^3 grid) at that test's
+tolerances. The C ABI itself is exercised by a C program typed from the
+reference's header (tests/support/cmi_library_caller.c) with guard words
+round every output buffer."""
 import ctypes as C
 import os
 import subprocess
@@ -33,12 +41,19 @@ def library():
     dp = C.POINTER(C.c_double)
     fp = C.POINTER(C.c_float)
     L.cmi_init.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_double,
-                           C.c_char_p]
+                           C.c_char_p, C.c_int]
     L.cmi_init_periodic_dp.argtypes = [C.c_char_p, C.c_int, C.c_double,
                                        C.c_double, dp, dp, C.c_char_p, C.c_int]
     L.cmi_compute_neutral_fraction_dp.argtypes = [dp] * 6 + [C.c_size_t]
-    L.cmi_compute_neutral_fraction_mp.argtypes = [dp] * 3 + [fp] * 2 + [
-        dp, C.c_size_t]
+    L.cmi_compute_neutral_fraction_mp.argtypes = [dp] * 3 + [fp] * 3 + [
+        C.c_size_t]
+    vp = C.c_void_p
+    L.cmi_gpu_library_map_to_cells.argtypes = [
+        C.c_char_p, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.c_double,
+        C.c_double, vp, vp, vp, vp, vp]
+    L.cmi_gpu_library_map_to_particles.argtypes = [
+        C.c_char_p, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.c_double,
+        C.c_double, vp, vp, vp, vp, vp, vp]
     L.cmi_compute_neutral_fraction_sp.argtypes = [fp] * 6 + [C.c_size_t]
     return L
 
@@ -53,9 +68,139 @@ def test_library_exports_the_reference_entry_points(library, tmp_path):
     # a wrong mapping type is reported, not fatal
     p = tmp_path / "lib.param"
     p.write_text(open(os.path.join(BENCH, "stromgren.param")).read())
-    library.cmi_init(str(p).encode(), 1, 1., 1., b"Petkova")
+    library.cmi_init(str(p).encode(), 1, 1., 1., b"Voronoi", 0)
     assert library.cmi_gpu_library_status() == 1
     library.cmi_destroy()
+
+
+def map_to_cells(library, mapping, precision, x, y, z, h, m, ncell,
+                 anchor=(0., 0., 0.), sides=(1., 1., 1.), periodic_box=None):
+    """SPHArrayInterface as a DensityFunction, host only: reset, initialize,
+    one evaluation per cell of a Cartesian grid."""
+    anchor = np.array(anchor, dtype=np.float64)
+    sides = np.array(sides, dtype=np.float64)
+    nc = np.array([ncell] * 3, dtype=np.int32)
+    out = np.zeros(ncell ** 3)
+    box = None if periodic_box is None else np.array(periodic_box,
+                                                      dtype=np.float64)
+    rc = library.cmi_gpu_library_map_to_cells(
+        mapping, precision, x.ctypes.data, y.ctypes.data, z.ctypes.data,
+        h.ctypes.data, m.ctypes.data, len(x), 1., 1.,
+        None if box is None else box.ctypes.data, anchor.ctypes.data,
+        sides.ctypes.data, nc.ctypes.data, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def test_petkova_mapping_known_answers(library):
+    """test/testSPHArrayInterface.cpp:70-155: 1000 particles (h = 0.2, m =
+    0.001) at Utilities::random_double() positions - rand() / RAND_MAX of the
+    C library, never seeded, so the default seed 1; the three blocks draw from
+    the one stream one after the other - on a 16^3 grid over the unit box:
+    total hydrogen numbers 8.89848e26 (double arrays, 1e-6), 8.76356e26 (float
+    h and m, 1e-5), 8.90243e26 (all float, 1e-6)."""
+    libc = C.CDLL("libc.so.6")
+    libc.rand.restype = C.c_int
+    rand_max = 2147483647
+    libc.srand(1)
+    for precision, known, tolerance in ((0, 8.89848e26, 1.e-6),
+                                        (1, 8.76356e26, 1.e-5),
+                                        (2, 8.90243e26, 1.e-6)):
+        r = np.array([libc.rand() / rand_max for _ in range(3000)])
+        r = r.reshape(1000, 3)
+        x, y, z = (np.ascontiguousarray(r[:, a]) for a in range(3))
+        h = np.full(1000, 0.2)
+        m = np.full(1000, 0.001)
+        if precision >= 1:
+            h, m = h.astype(np.float32), m.astype(np.float32)
+        if precision == 2:
+            x, y, z = (a.astype(np.float32) for a in (x, y, z))
+        n = map_to_cells(library, b"Petkova", precision, x, y, z, h, m, 16)
+        total = n.sum() / 16 ** 3   # get_total_hydrogen_number: sum n V
+        assert abs(total - known) <= tolerance * (total + known), \
+            (precision, total, known)
+
+
+def test_petkova_mapping_conserves_mass(library):
+    """"Petkova_oriented" (every face's normal into the cell - on a Cartesian
+    grid the reference's own sum is not the integral, see
+    PetkovaMapping::mass_fraction) integrates every kernel over every cell
+    exactly: particles whose kernels lie inside the grid put all their mass on
+    it (the interpolated vertex integrals are good to ~1e-3), and the mapping
+    back hands every cell's ionized fraction out in shares that add up to
+    one. Same vertex integrals, table and neighbour search as "Petkova"."""
+    rng = np.random.default_rng(5)
+    n = 400
+    # (which side of an edge the projected particle lies on comes from
+    # determinants of position vectors - src/SPHArrayInterface.cpp:789-795,
+    # 831-837 - and is lost for a face in a plane through the origin: the
+    # reference's behaviour, kept. Here the box is kept off those planes.)
+    origin = np.array([1.03, 2.07, 3.01])
+    x, y, z = (np.ascontiguousarray(rng.uniform(0.25, 0.75, n) + origin[a])
+               for a in range(3))
+    h = rng.uniform(0.1, 0.2, n)
+    m = rng.uniform(0.5, 1.5, n)
+    ncell = 12
+    dens = map_to_cells(library, b"Petkova_oriented", 0, x, y, z, h, m, ncell,
+                        anchor=origin)
+    mass = dens.sum() * M_H / ncell ** 3
+    # cells no kernel reaches get the reference's floor m[0] / V * 1e-6
+    floor = (dens * M_H / ncell ** 3 < 2.e-6 * m[0]).sum() * 1.e-6 * m[0]
+    assert abs(mass - floor - m.sum()) < 2.e-3 * m.sum(), (mass, m.sum())
+
+    xH = rng.uniform(0., 1., ncell ** 3)
+    nH = np.zeros(n)
+    anchor, sides = origin.copy(), np.ones(3)
+    nc = np.array([ncell] * 3, dtype=np.int32)
+    rc = library.cmi_gpu_library_map_to_particles(
+        b"Petkova_oriented", 0, x.ctypes.data, y.ctypes.data, z.ctypes.data,
+        h.ctypes.data, m.ctypes.data, n, 1., 1., None, anchor.ctypes.data,
+        sides.ctypes.data, nc.ctypes.data, xH.ctypes.data, nH.ctypes.data)
+    assert rc == 0
+    # sum over particles of what they lost = sum over the cells that have a
+    # neighbour of their ionized fraction
+    mid = (np.arange(ncell) + 0.5) / ncell
+    CX, CY, CZ = np.meshgrid(mid + origin[0], mid + origin[1],
+                             mid + origin[2], indexing="ij")
+    cells = np.stack([CX.ravel(), CY.ravel(), CZ.ravel()], axis=1)
+    pos = np.stack([x, y, z], axis=1)
+    radius = 0.5 * np.sqrt(3.) / ncell
+    r = np.linalg.norm(cells[:, None, :] - pos[None, :, :], axis=2)
+    has_neighbour = (r <= h[None, :] + radius).any(axis=1)
+    assert np.isclose((1. - nH).sum(), (1. - xH)[has_neighbour].sum(),
+                      rtol=1e-10)
+    # a neutral grid leaves the particles neutral
+    xH[:] = 1.
+    library.cmi_gpu_library_map_to_particles(
+        b"Petkova_oriented", 0, x.ctypes.data, y.ctypes.data, z.ctypes.data,
+        h.ctypes.data, m.ctypes.data, n, 1., 1., None, anchor.ctypes.data,
+        sides.ctypes.data, nc.ctypes.data, xH.ctypes.data, nH.ctypes.data)
+    assert np.array_equal(nH, np.ones(n))
+
+
+def test_vertex_integrals_add_up_to_the_kernel(library):
+    """One particle in the middle of one big cell: the sum of the 48 signed
+    vertex integrals is the whole kernel, 1; moved so that a face cuts the
+    kernel in half: 1/2 (symmetry); a corner at the particle: 1/8."""
+    h = np.array([0.4])
+    m = np.array([M_H])   # number density x volume = fraction inside
+    origin = (1., 2., 3.)   # (no face in a plane through the origin)
+    for pos, expect in (((0.5, 0.5, 0.5), 1.), ((1., 0.5, 0.5), 0.5),
+                        ((0.3, 0.6, 0.45), 1.), ((0.9, 0.5, 0.5), None),
+                        ((1., 1., 0.5), 0.25), ((1., 1., 1.), 0.125)):
+        x, y, z = (np.array([c + o]) for c, o in zip(pos, origin))
+        got = map_to_cells(library, b"Petkova_oriented", 0, x, y, z, h, m, 1,
+                           anchor=origin)[0]
+        if expect is None:
+            # a kernel cut by one face 0.1 from its centre: shells of radius
+            # r > 0.1 have the fraction (1 + 0.1 / r) / 2 of their area inside
+            r = np.linspace(0., 0.4, 400001)[1:]
+            shell = kernel(r / 0.4, 0.4) * 4. * np.pi * r * r
+            inside = np.where(r > 0.1, 0.5 * (1. + 0.1 / r), 1.)
+            expect = np.trapezoid(shell * inside, r) / np.trapezoid(shell, r)
+            assert 0.6 < expect < 0.9
+        # (trilinear interpolation of the vertex integrals: ~1e-3)
+        assert abs(got - expect) < 3.e-3, (pos, got)
 
 
 def kernel(u, h):
@@ -99,19 +244,22 @@ def test_library_mode_matches_the_oracle(library, oracle, tmp_path):
     cwd = os.getcwd()
     os.chdir(tmp_path)
     try:
-        library.cmi_init(str(p).encode(), 1, ul, um, b"centroid")
+        library.cmi_init(str(p).encode(), 1, ul, um, b"centroid", 0)
         assert library.cmi_gpu_library_status() == 0
         ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
         library.cmi_compute_neutral_fraction_dp(ptr(x), ptr(y), ptr(z),
                                                 ptr(hh), ptr(mm), ptr(nH), n)
         assert library.cmi_gpu_library_status() == 0
         # the mixed precision entry point: same particles, float h and m
-        nH_mp = np.full(n, -1.)
+        # (src/CMILibrary.hpp:66-68: its nH is FLOAT; n elements and a guard)
+        nH_mp = np.full(n + 16, -1., dtype=np.float32)
         h32, m32 = hh.astype(np.float32), mm.astype(np.float32)
         fptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
         library.cmi_compute_neutral_fraction_mp(ptr(x), ptr(y), ptr(z),
                                                 fptr(h32), fptr(m32),
-                                                ptr(nH_mp), n)
+                                                fptr(nH_mp), n)
+        assert np.all(nH_mp[n:] == -1.)
+        nH_mp = nH_mp[:n].astype(np.float64)
         library.cmi_destroy()
     finally:
         os.chdir(cwd)
@@ -139,3 +287,43 @@ def test_library_mode_matches_the_oracle(library, oracle, tmp_path):
     assert nH[rp < 1.5 * PC].max() < 0.3
     assert nH[rp > 6. * PC].min() > 0.9
     assert np.allclose(nH_mp, nH, rtol=0, atol=5e-3)
+
+
+@pytest.mark.gpu
+def test_c_caller_typed_from_the_reference_header(library, tmp_path):
+    """tests/support/cmi_library_caller.c: gcc-compiled C, prototypes typed
+    from src/CMILibrary.hpp:46-72, the call sequence of the reference's own C
+    caller (cmi_init_periodic_dp(..., "Petkova", 0) then _dp) and the other
+    two precisions, every nH buffer exactly N elements between guard words."""
+    exe = tmp_path / "cmi_library_caller"
+    subprocess.run(["gcc", "-O1", "-Wall", "-Wextra", "-o", str(exe),
+                    os.path.join(ROOT, "tests", "support",
+                                 "cmi_library_caller.c"),
+                    "-L" + os.path.join(ROOT, "cmacionize_amd"),
+                    "-lcmi_gpu_library", "-lcmi_gpu",
+                    "-Wl,-rpath," + os.path.join(ROOT, "cmacionize_amd"),
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = text.replace("[64, 64, 64]", "[16, 16, 16]")
+    text = text.replace("number of photons: 1e6", "number of photons: 40000")
+    text = text.replace("number of iterations: 20", "number of iterations: 6")
+    text = text.replace("type: Gadget", "type: AsciiFile")
+    p = tmp_path / "caller.param"
+    p.write_text(text)
+    out = tmp_path / "caller.txt"
+    for mapping in ("Petkova", "centroid"):
+        run = subprocess.run([str(exe), str(p), mapping, str(out)],
+                             cwd=tmp_path, capture_output=True, text=True,
+                             timeout=600)
+        assert run.returncode == 0, (mapping, run.returncode, run.stderr)
+        data = np.loadtxt(out)
+        pos, nH = data[:, :3], data[:, 3:]
+        assert np.all(np.isfinite(nH))
+        radius = np.linalg.norm(pos, axis=1)
+        # a Stromgren sphere of ~3 pc (stromgren.param in a 10 pc box)
+        assert nH[radius < 1.5].max() < 0.5, mapping
+        assert nH[radius > 4.5].min() > 0.9, mapping
+        # float h and m / all float against all double; the non-periodic
+        # middle call sees the same particles through a box of their extent
+        assert np.abs(nH[:, 2] - nH[:, 0]).max() < 0.02, mapping
+        assert np.abs(nH[:, 1] - nH[:, 0]).max() < 0.1, mapping

@@ -47,8 +47,11 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the 157.3 TFLOP/s fp32 vector rate
 PC = 3.086e16
 LEXINGTON_ABUNDANCES = [0.1, 2.2e-4, 4.e-5, 3.3e-4, 5.e-5, 9.e-6]
 
-# algorithmic HBM bytes per DDA step: one 16 B
-# cell record {n x_H, n x_He} read + 8 B read + 8 B write per accumulator
+# algorithmic HBM bytes per DDA step, SURVEY.md 8(d)'s figures: H-only =
+# n, x_H read (16) + J_H read-modify-write (16) = 32; 14 ions = n, x_H, x_He
+# read (24) + 16 accumulators read-modify-write (256) = 280. (The engine's
+# own record is 8 / 16 B - the pre-multiplied n x_H [, n x_He] - i.e. 24 /
+# 272 B; the figures quoted are the survey's, the larger ones.)
 CONFIGS = {
     "stromgren": dict(
         name="stromgren.param", bytes_per_step=16. + 16. * 1, diffuse=False,
@@ -59,7 +62,7 @@ CONFIGS = {
         diffuse=True, lexington=False, converge_iterations=20,
         kernel="shoot_kernel<false, false, false, false, true, false, true, false>"),
     "lexington": dict(
-        name="lexingtonHII40.param", bytes_per_step=16. + 16. * 16,
+        name="lexingtonHII40.param", bytes_per_step=24. + 16. * 16,
         diffuse=True, lexington=True, converge_iterations=20,
         kernel="shoot_kernel<true, true, false, false, true, true, false, false>"),
 }
@@ -207,72 +210,102 @@ def cpu_baseline(ncell, config, cfg, engine, seconds=12.):
             "calibration": cal}
 
 
-PROFILE = os.path.join("profiles", "r03", "counters.json")
+# PMC profiles of this very command, newest first (tools/round_measure.sh)
+PROFILES = [os.path.join("profiles", r, "counters.json")
+            for r in ("r04", "r03")]
+
+# what each unit of the chip can do per second (MI355X_MICROARCH.md; the
+# atomic-request rate is measured: profiles/r01/atomic_rates.txt)
+UNIT_PEAKS = {
+    "valu-issue": (N_SIMD * MAX_CLOCK_GHZ, "G busy SIMD-cycles/s"),
+    "lds": (N_CU * MAX_CLOCK_GHZ, "G busy LDS-cycles/s"),
+    "atomic-requests": (23.5, "G 64-B requests/s"),
+    "hbm": (HBM_PEAK_GBS, "GB/s"),
+}
+
+
+def load_profile(config, ncell, kernel):
+    for rel in PROFILES:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        c = json.load(open(path)).get(config)
+        if c and c.get("ncell") == ncell and \
+                c["dominant"].get("kernel") == kernel:
+            return rel, c
+    return None, None
 
 
 def roofline(config, ncell, cfg, steps_per_launch, lanes_per_wave_step,
              first_generation_ms):
-    """The dominant kernel against the HBM roofline as SURVEY.md 8(d) defines
-    it - algorithmic bytes per DDA step x the steps one launch executes / the
-    launch's duration (HIP events of this run) / 8 TB/s - and, from the PMC
-    counters of the same kernel (profiles/r03/counters.json: separate
-    rocprofv3 --pmc passes of this very command, tools/pmc_profile.sh +
-    tools/pmc_rooflines.py; counts per launch are deterministic - same
-    packets), the bytes the fabric really moved and how busy each unit of the
-    chip was. Counter-based ratios use the PROFILED launch's own duration, and
-    the line says when that differs from this run's by more than 10 %."""
+    """The dominant kernel (the first generation's transport launch) against
+    the unit of the chip that bounds it.
+
+    `bound` / `achieved` / `peak` / `frac` name the unit with the HIGHEST
+    measured utilisation in the PMC profile of this very command
+    (profiles/rNN/counters.json: separate rocprofv3 --pmc passes,
+    tools/pmc_profile.sh + tools/pmc_rooflines.py; numerator and denominator
+    of a ratio from the same pass, so frac <= 1 by construction) - for this
+    path that is never HBM: direction-sorted packets, cross-lane run sums and
+    the LDS combining table keep 85-97 % of a step's algorithmic bytes on
+    chip. SURVEY.md 8(d)'s HBM figures are all here too: `algorithmic_GBps`
+    (algorithmic bytes per DDA step x the steps one launch executes / the
+    launch's duration from the HIP events of THIS run), `traffic` (bytes the
+    fabric moved per launch: PMC, 2 x FETCH_SIZE + WRITE_SIZE),
+    `traffic_over_algorithmic`, and `hbm` (traffic against the 8 TB/s peak).
+    Without a profile of this kernel the bound is unknown and says so."""
     t = first_generation_ms * 1e-3 if first_generation_ms else None
     algorithmic = (steps_per_launch * cfg["bytes_per_step"]
                    if steps_per_launch else None)
     out = {
         "kernel": cfg["kernel"],
-        "bound": "hbm",
-        "achieved": algorithmic / t / 1e9 if t and algorithmic else None,
-        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": (algorithmic / t / 1e9 / HBM_PEAK_GBS
-                 if t and algorithmic else None),
-        "traffic": None,
+        "bound": None, "achieved": None, "peak": None, "unit": None,
+        "frac": None, "traffic": None,
         "kernel_avg_ms": first_generation_ms,
         "dda_steps_per_launch": steps_per_launch,
         "bytes_per_dda_step_algorithmic": cfg["bytes_per_step"],
-        "note": "frac > 1 is possible and expected: `achieved` counts the "
-                "ALGORITHMIC bytes of a step (record read + accumulator "
-                "read-modify-write per lane); direction-sorted packets, "
-                "cross-lane run sums and the LDS combining table keep most "
-                "of them on chip - `traffic` is what the fabric moved",
+        "algorithmic_bytes_per_launch": algorithmic,
+        "algorithmic_GBps": algorithmic / t / 1e9 if t and algorithmic
+        else None,
+        "algorithmic_over_hbm_peak": (algorithmic / t / 1e9 / HBM_PEAK_GBS
+                                      if t and algorithmic else None),
     }
-    path = os.path.join(ROOT, PROFILE)
-    if not os.path.exists(path):
-        return out
-    c = json.load(open(path)).get(config)
-    if not c or c.get("ncell") != ncell:
+    rel, c = load_profile(config, ncell, cfg["kernel"])
+    if c is None:
+        out["note"] = ("no PMC profile of this kernel at this grid size under "
+                       "profiles/: the bounding unit is unmeasured")
         return out
     k = c["dominant"]
-    if k.get("kernel") != cfg["kernel"]:
-        return out
     tp = k["kernel_ms"] * 1e-3   # the profiled launch's own duration
-    util = {
-        # VALU issue: busy SIMD cycles / (1024 SIMDs x cycles at max clock)
-        "valu-issue": k["valu_busy_cycles"] / tp / 1e9 /
-        (N_SIMD * MAX_CLOCK_GHZ),
-        # LDS: busy LDS cycles / (256 CUs x cycles)
-        "lds": k["lds_busy_cycles"] / tp / 1e9 / (N_CU * MAX_CLOCK_GHZ),
-        # memory-side atomic requests (64 B) against the measured chip rate
-        # (profiles/r01/atomic_rates.txt: 23.5 G requests/s whatever the
-        # footprint, tools/microbench/atomic_scope.hip)
-        "atomic-requests": k["atomic_requests"] / tp / 1e9 / 23.5,
-        # fabric traffic against HBM peak
-        "hbm": k["hbm_bytes"] / tp / 1e9 / HBM_PEAK_GBS,
+    rate = {
+        # busy SIMD cycles (4 x SQ_ACTIVE_INST_VALU) per second
+        "valu-issue": k["valu_busy_cycles"] / tp / 1e9,
+        # busy LDS cycles (SQ_LDS_IDX_ACTIVE) per second
+        "lds": k["lds_busy_cycles"] / tp / 1e9,
+        # memory-side atomic requests of 64 B (TCC_EA0_ATOMIC) per second
+        "atomic-requests": k["atomic_requests"] / tp / 1e9,
+        # fabric traffic
+        "hbm": k["hbm_bytes"] / tp / 1e9,
     }
+    util = {u: rate[u] / UNIT_PEAKS[u][0] for u in rate}
+    bound = max(util, key=util.get)
     out.update({
+        "bound": bound,
+        "achieved": rate[bound],
+        "peak": UNIT_PEAKS[bound][0],
+        "unit": UNIT_PEAKS[bound][1],
+        "frac": util[bound],
         "traffic": k["hbm_bytes"],
-        "traffic_frac_of_peak": util["hbm"],
+        "traffic_over_algorithmic": (k["hbm_bytes"] / algorithmic
+                                     if algorithmic else None),
+        "hbm": {"achieved": rate["hbm"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": util["hbm"]},
         "bytes_per_dda_step_measured": k["hbm_bytes"] /
         max(steps_per_launch or 1., 1.),
         "utilization": util,
-        "highest_utilization": max(util, key=util.get),
+        "waves_waiting_frac": k.get("wave_wait_frac"),
         "profiled_kernel_ms": k["kernel_ms"],
-        "profile": PROFILE,
+        "profile": rel,
         "profile_commit": c.get("commit"),
         "profile_stale": bool(first_generation_ms) and
         abs(k["kernel_ms"] - first_generation_ms) > 0.1 * first_generation_ms,
@@ -289,6 +322,41 @@ def roofline(config, ncell, cfg, steps_per_launch, lanes_per_wave_step,
     if "other_kernels" in c:
         out["other_kernels"] = c["other_kernels"]
     return out
+
+
+def roofline_cell_update(config, ncell, cfg, update_ms):
+    """the cell update of the multi-ion config (ionization
+    balance + temperature solve, the `temp_*` pipeline kernels) is fp64
+    vector-ALU / transcendental bound - reported separately as vector lane
+    operations per second (wave instructions x 64 lanes, PMC SQ_INSTS_VALU of
+    the same profile) against the vector fp64 rate (78.6 TFLOP/s = 3.93e13
+    fused multiply-adds per second)."""
+    rel, c = load_profile(config, ncell, cfg["kernel"])
+    if c is None:
+        return None
+    ks = [k for k in c.get("other_kernels", [])
+          if k["kernel"].startswith(("temp_", "temperature_kernel",
+                                     "ionization_kernel"))]
+    if not ks:
+        return None
+    ms = sum(k["ms_per_iteration"] for k in ks)
+    insts = sum(k["valu_insts_per_iteration"] for k in ks)
+    peak = FP64_VECTOR_PEAK_TFLOPS * 1e12 / 2.
+    busy = sum(k["valu_busy"] * k["ms_per_iteration"] for k in ks) / ms
+    return {
+        "kernels": [k["kernel"] for k in ks],
+        "bound": "fp64-valu",
+        "achieved": insts * 64. / (ms * 1e-3),
+        "peak": peak,
+        "unit": "vector lane operations/s",
+        "frac": insts * 64. / (ms * 1e-3) / peak,
+        "valu_issue_busy": busy,
+        "profiled_ms_per_update": ms,
+        "this_run_ms_per_update": update_ms,
+        "traffic": sum(k["hbm_GBps"] * k["ms_per_iteration"] * 1e6
+                       for k in ks),
+        "profile": rel,
+    }
 
 
 def launch_ranks(n):
@@ -544,7 +612,7 @@ def main():
         conv_packets = float(args.converge_packets) * \
             (1 if domain else world) * args.converge_iterations
         out = {
-            "metric": "photon packets/sec, 256^3 stromgren",
+            "metric": "photon packets/sec, %d^3 %s" % (ncell, args.config),
             "value": value,
             "unit": "packets/s",
             "n_gpus": world,
@@ -607,8 +675,14 @@ def main():
         }
         if strong is not None:
             out["strong_scaling"] = strong
-        if args.config != "stromgren":
-            out["metric"] = "photon packets/sec, 256^3 " + args.config
+        if cfg["lexington"]:
+            out["roofline_cell_update"] = roofline_cell_update(
+                args.config, ncell, cfg, out["cell_update_ms_per_step"])
+        if lanes_per_wave_step:
+            # 64-lane iterations of the march loops per packet (all
+            # generations of the last timed step)
+            out["wave_iterations_per_packet"] = (
+                nsteps_total / total_packets / lanes_per_wave_step)
         if not args.no_cpu_baseline and world == 1:
             # (rank 0 at N = 1 only: the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline(ncell, args.config, cfg,

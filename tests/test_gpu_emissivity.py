@@ -158,3 +158,25 @@ def test_bad_arguments_are_refused():
     assert lib.cmi_gpu_compute_emissivities(eng._h, 0, line, 0, 64, out) != 0
     assert lib.cmi_gpu_compute_emissivities(eng._h, 1, line, 0, 64, out) == 0
     eng.close()
+
+
+def test_hiilines_fixture_on_device():
+    """hiilines_testdata.txt (test/testEmissivityCalculator.cpp:88-260): the
+    100 HII-region cells of Kenny Wood's code as the cells of a 5 x 5 x 4
+    grid, 28 line sums at the reference's tolerances (1e-6; Balmer jump
+    1e-3) - `emissivity_kernel` end to end against reference numbers."""
+    from cmacionize_amd import GpuEngine
+    from test_oracle_emissivity import check_hiilines
+    data = load("hiilines_testdata.txt")
+    assert data.shape == (100, 46)
+    eng = GpuEngine((5, 5, 4), (0., 0., 0.), (5., 5., 4.), device=0)
+    eng.set_cross_sections_verner()
+    eng.set_recombination_rates_verner()
+    eng.set_abundances([0.1, 2.2e-4, 4.e-5, 3.3e-4, 5.e-5, 9.e-6])
+    eng.upload_cells(data[:, 0] * 1.e6, data[:, 1],
+                     np.ascontiguousarray(data[:, 2:16].T))
+    got = eng.compute_emissivities()
+    for c in range(100):
+        check_hiilines(data[c], {name: got[name][c] for name in got})
+    assert (got["HAlpha"] > 0.).sum() > 50
+    eng.close()

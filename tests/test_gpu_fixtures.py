@@ -1,7 +1,7 @@
 """The reference's known-answer fixtures for the atomic data, checked directly
-on the DEVICE functions through cmi_gpu_physics_probe (the other fixtures -
-h0, ioneng, tbal - run on the device in test_gpu_physics.py and
-test_gpu_transport.py). Same data files, same tolerances as the reference's
+on the DEVICE functions through cmi_gpu_physics_probe, and h0 through the
+cell update itself (the other fixtures - ioneng, tbal - run on the device in
+test_gpu_physics.py, hiilines and bjump in test_gpu_emissivity.py). Same data files, same tolerances as the reference's
 tests; the device's pow/exp/log differ from libm by ulps only."""
 import numpy as np
 import pytest
@@ -95,3 +95,56 @@ def test_reemission_probabilities_on_device(engine):
     for row, got in zip(data, p):
         for k in range(5):
             assert rel_ok(got[k], row[1 + k], 1.e-14), (row[0], k)
+
+
+def test_ionization_state_calculator_on_device(oracle):
+    """h0_testdata.txt (testIonizationStateCalculator.cpp:68-204) through the
+    engine's own cell update (`ionization_kernel<FULL>`): the file's 100
+    states are the 100 cells of a 5 x 5 x 4 grid of unit cells, their 14 mean
+    intensities uploaded as the accumulators; one source photon per second and
+    a total weight of 1 make the normalisation factor
+    luminosity / (weight x cell volume) the 1 of the reference test.
+    Tolerance 1e-9, the reference's."""
+    from cmacionize_amd import GpuEngine
+    from cmacionize_amd import engine as E
+    data = load("h0_testdata.txt")
+    assert data.shape == (100, 30)
+    eng = GpuEngine((5, 5, 4), (0., 0., 0.), (5., 5., 4.), device=0,
+                    track_heating=True)
+    eng.set_sources([[2.5, 2.5, 2.]], [1.], 1.)
+    eng.set_spectrum_planck(40000.)
+    eng.set_cross_sections_verner()
+    eng.set_recombination_rates_verner()
+    eng.set_abundances([0.1, 0., 0., 0., 0., 0.])
+    eng.set_temperature_params(do_temperature_calculation=0)
+    x0 = np.full((14, 100), 0.5)
+    eng.upload_cells(data[:, 15] * 1.e6, data[:, 14], x0)
+    eng.reset_grid()
+    for ion in range(14):
+        eng.upload_field(E.FIELD_MEAN_INTENSITY + ion, data[:, ion])
+    eng.update_cells(0, 1.)
+    worst = 0.
+    for ion in range(14):
+        got = eng.download_field(E.FIELD_IONIC_FRACTION + ion)
+        for c in range(100):
+            assert rel_ok(got[c], data[c, 16 + ion], 1.e-9), \
+                (c, ion, got[c], data[c, 16 + ion])
+        nz = data[:, 16 + ion] != 0.
+        worst = max(worst, np.abs(got[nz] / data[nz, 16 + ion] - 1.).max())
+    assert worst < 1.e-9
+    # the oracle from the same inputs, much closer than the fixture's digits
+    L = oracle.lib()
+    from test_oracle_pinning import verner_model
+    import ctypes as C
+    m = verner_model(oracle, 0.1)
+    for c in (0, 17, 99):
+        J = np.ascontiguousarray(data[c, :14])
+        heating, x = np.zeros(2), np.zeros(14)
+        L.cmio_ionization_state_cell(C.byref(m), 1., 1., data[c, 15] * 1.e6,
+                                     data[c, 14], J.ctypes.data_as(oracle.dp),
+                                     heating.ctypes.data_as(oracle.dp),
+                                     x.ctypes.data_as(oracle.dp))
+        got = np.array([eng.download_field(E.FIELD_IONIC_FRACTION + ion)[c]
+                        for ion in range(14)])
+        assert np.allclose(got, x, rtol=1e-11, atol=0.)
+    eng.close()

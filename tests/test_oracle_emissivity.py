@@ -102,3 +102,56 @@ def test_emissivities_of_a_cell(oracle):
                   ls[five(OIII, T23)] / ls[five(OIII, T13)], 1e-13)
     assert all(v >= 0. for v in e.values())
     assert e["WFC2_F675W"] > e["HAlpha"] and e["WFC2_F555W"] > e["HBeta"]
+
+
+# the line sums of test/testEmissivityCalculator.cpp:139-258: (column of
+# hiilines_testdata.txt, the emission lines summed, tolerance); columns 18 and
+# 27 are not checked by the reference, column 19 and 21 both against NeII 12mu
+HIILINES = [
+    (0, ("HAlpha",), 1.e-6), (1, ("HBeta",), 1.e-6), (2, ("HII",), 1.e-6),
+    (3, ("BALMER_JUMP_LOW",), 1.e-3), (4, ("BALMER_JUMP_HIGH",), 1.e-3),
+    (5, ("OI_6300", "OI_6364"), 1.e-6), (6, ("OII_3727",), 1.e-6),
+    (7, ("OIII_5007",), 1.e-6), (8, ("OIII_4363",), 1.e-6),
+    (9, ("OIII_88mu",), 1.e-6), (10, ("NII_5755",), 1.e-6),
+    (11, ("NII_6584",), 1.e-6), (12, ("NeIII_3869",), 1.e-6),
+    (13, ("SII_6725",), 1.e-6), (14, ("SII_4072",), 1.e-6),
+    (15, ("SIII_9405",), 1.e-6), (16, ("SIII_6312",), 1.e-6),
+    (17, ("SIII_19mu",), 1.e-6), (19, ("NeII_12mu",), 1.e-6),
+    (20, ("NIII_57mu",), 1.e-6), (21, ("NeII_12mu",), 1.e-6),
+    (22, ("NeIII_15mu",), 1.e-6), (23, ("NII_122mu",), 1.e-6),
+    (24, ("CII_2325",), 1.e-6), (25, ("CIII_1908",), 1.e-6),
+    (26, ("OII_7325",), 1.e-6), (28, ("HeI_5876",), 1.e-6),
+    (29, ("Hrec_s",), 1.e-6)]
+
+
+def check_hiilines(row, emissivity_of):
+    """one line of hiilines_testdata.txt: n (cm^-3), T, 14 ionic fractions,
+    30 emissivities of Kenny Wood's code in 1e-20 erg cm^-3 s^-1 (the last one,
+    Hrec_s, as it is); emissivity_of: name -> value in J m^-3 s^-1"""
+    em = row[16:]
+    for column, names, tolerance in HIILINES:
+        got = sum(emissivity_of[name] for name in names)
+        # erg cm^-3 s^-1 (angstrom^-1) -> J m^-3 s^-1 (angstrom^-1): 0.1
+        expect = em[column] if column == 29 else em[column] * 1.e-20 * 0.1
+        assert rel_ok(got, expect, tolerance), (column, names, got, expect)
+
+
+def hiilines_model(oracle):
+    """Abundances abundances(0.1, 2.2e-4, 4.e-5, 3.3e-4, 5.e-5, 9.e-6),
+    test/testEmissivityCalculator.cpp:42"""
+    sim = oracle.lexington_simulation(4)
+    for i, a in enumerate((0.1, 2.2e-4, 4.e-5, 3.3e-4, 5.e-5, 9.e-6)):
+        sim.model.abundance[1 + i] = a
+    return sim
+
+
+def test_hiilines(oracle):
+    """EmissivityCalculator::calculate_emissivities end to end against the
+    reference's third fixture (test/testEmissivityCalculator.cpp:88-260): 100
+    cells of an HII region model, 28 line sums at 1e-6 / 1e-3."""
+    data = load("hiilines_testdata.txt")
+    assert data.shape == (100, 46)
+    sim = hiilines_model(oracle)
+    for row in data:
+        e = oracle.emissivities(sim.model, row[0] * 1.e6, row[1], row[2:16])
+        check_hiilines(row, dict(zip(oracle.EMISSION_LINES, e)))

@@ -11,7 +11,7 @@
 set -u
 REPO=$(pwd)
 OUT=$REPO/$1
-ROUND=${2:-r03}
+ROUND=${2:-r04}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # (SKIP_PMC=1: keep profiles/rNN/counters.json as it is)

@@ -386,15 +386,27 @@ inline DensityGridWriter *generate_writer(const std::string &output_folder,
  * groups (:330-367; like the reference's, for AbsorptionTrackers only: its
  * SpectrumTracker has no HDF5 form, src/Tracker.hpp:112-130). */
 class TrackerManager {
+  /* one engine tracker per LEAF (Spectrum / Absorption); a "Multi" tracker
+   * (src/MultiTracker.hpp, src/MultiTracker.cpp:35-50) is a node whose leaves
+   * sit at the same position: the engine counts any number of trackers in
+   * one cell */
   std::vector<double> _positions, _opening_angles, _reference_directions;
   std::vector<int32_t> _kinds;
-  std::vector<std::string> _output_names;
-  std::vector<int32_t> _number_of_bins; /* per tracker */
+  std::vector<int32_t> _number_of_bins; /* per leaf */
+  struct Node {
+    int leaf = -1;                  /* >= 0: a leaf */
+    std::vector<Node> children;     /* a Multi tracker's trackers ... */
+    std::vector<std::string> names; /* ... and their "output name"s ("" = the
+                                       default, <file>.<i>.txt) */
+  };
+  std::vector<Node> _trackers;            /* the file's tracker[i] */
+  std::vector<std::string> _output_names; /* per tracker[i] */
+  std::vector<double> _tracker_positions; /* per tracker[i], [3] */
   const uint_fast64_t _number_of_photons;
   const bool _hdf5_output;
   const std::string _hdf5_name;
   std::vector<uint64_t> _counts;
-  std::vector<double> _absorption; /* [tracker][4 types][14 ions] */
+  std::vector<double> _absorption; /* [leaf][4 types][14 ions] */
 
   static const char *photontype_name(int type) {
     /* get_photontype_name, src/PhotonType.hpp:64-85 */
@@ -407,6 +419,138 @@ class TrackerManager {
       return "diffuse He photon";
     default:
       return "absorbed photon";
+    }
+  }
+
+  /* TrackerFactory::generate, src/TrackerFactory.hpp:60-72 */
+  Node generate(ParameterFile &blocks, const std::string &name,
+                const std::array<double, 3> &x) {
+    Node node;
+    const std::string type = blocks.get_string(name + "type", "Spectrum");
+    if (type == "Multi") {
+      /* MultiTracker::MultiTracker, src/MultiTracker.cpp:35-50 */
+      const long long n = blocks.get_integer(name + "number of trackers", -1);
+      if (n < 0)
+        throw ParameterError("\"" + name + "number of trackers\" not found");
+      for (long long i = 0; i < n; ++i) {
+        const std::string child = name + "tracker[" + std::to_string(i) + "]:";
+        node.children.push_back(generate(blocks, child, x));
+        node.names.push_back(blocks.get_string(child + "output name", ""));
+      }
+      return node;
+    }
+    if (type != "Spectrum" && type != "Absorption")
+      throw ParameterError("Unknown Tracker type: \"" + type + "\"");
+    if (_kinds.size() == 16)
+      throw ParameterError("at most 16 trackers");
+    const bool absorption = type == "Absorption";
+    node.leaf = (int)_kinds.size();
+    _kinds.push_back(absorption ? CMI_GPU_TRACKER_ABSORPTION
+                                : CMI_GPU_TRACKER_SPECTRUM);
+    double angle = 3.141592653589793;
+    double v[3] = {0., 0., 0.};
+    int32_t bins = 1; /* (an absorption tracker has no spectrum) */
+    if (!absorption) {
+      bins = (int32_t)blocks.get_integer(name + "number of bins", 100);
+      if (bins < 1)
+        throw ParameterError("a tracker needs at least one bin");
+      angle = blocks.get_physical_value(QUANTITY_ANGLE, name + "opening angle",
+                                        "180. degrees");
+      /* (a vector of plain numbers) */
+      const std::string d =
+          blocks.get_string(name + "reference direction", "[0., 0., 0.]");
+      if (std::sscanf(d.c_str(), " [ %lf , %lf , %lf ]", &v[0], &v[1],
+                      &v[2]) != 3)
+        throw ParameterError("bad reference direction \"" + d + "\"");
+    }
+    _opening_angles.push_back(angle);
+    _number_of_bins.push_back(bins);
+    for (int a = 0; a < 3; ++a) {
+      _positions.push_back(x[a]);
+      _reference_directions.push_back(v[a]);
+    }
+    return node;
+  }
+
+  size_t first_bin_of(int leaf) const {
+    size_t first = 0;
+    for (int t = 0; t < leaf; ++t)
+      first += (size_t)_number_of_bins[t];
+    return first;
+  }
+
+  /* SpectrumTracker::output_tracker, src/SpectrumTracker.hpp:226-238;
+   * AbsorptionTracker::output_tracker, src/AbsorptionTracker.hpp:145-160 */
+  void output_leaf(int t, const std::string &filename) const {
+    const double minimum_frequency = 3.289e15;
+    const int32_t nbins = _number_of_bins[t];
+    const double frequency_width = 3. * 3.289e15 / nbins;
+    const uint64_t *c = _counts.data() + 3 * first_bin_of(t);
+    std::ofstream ofile(filename);
+    if (_kinds[t] == CMI_GPU_TRACKER_ABSORPTION) {
+      ofile << "# Ion ";
+      for (int type = 0; type < 4; ++type)
+        ofile << "\t" << photontype_name(type);
+      ofile << "\n";
+      for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion) {
+        ofile << ion_name(ion);
+        for (int type = 0; type < 4; ++type)
+          ofile << "\t"
+                << _absorption[((size_t)t * 4 + (size_t)type) *
+                                   NUMBER_OF_IONNAMES +
+                               ion];
+        ofile << "\n";
+      }
+      return;
+    }
+    ofile << "# frequency (Hz)\tprimary count\tdiffuse H count\tdiffuse He "
+             "count\n";
+    for (int32_t i = 0; i < nbins; ++i) {
+      const double nu = minimum_frequency + (i + 0.5) * frequency_width;
+      ofile << nu << "\t" << c[i] << "\t" << c[nbins + i] << "\t"
+            << c[2 * nbins + i] << "\n";
+    }
+  }
+  /* Tracker::describe: SpectrumTracker.hpp:249-259, AbsorptionTracker.hpp:
+   * 230-232; a MultiTracker inside a MultiTracker describes nothing
+   * (src/Tracker.hpp:148) */
+  void describe(const Node &node, const std::string &prefix,
+                std::ostream &stream) const {
+    if (node.leaf < 0)
+      return;
+    const int t = node.leaf;
+    if (_kinds[t] == CMI_GPU_TRACKER_ABSORPTION) {
+      stream << prefix << "type: AbsorptionTracker\n";
+      return;
+    }
+    /* (the reference keeps the cosine and the normalised direction) */
+    const double *v = &_reference_directions[3 * (size_t)t];
+    const double norm2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const double scale = norm2 > 0. ? 1. / std::sqrt(norm2) : 1.;
+    stream << prefix << "type: Spectrum\n";
+    stream << prefix << "number of bins: " << _number_of_bins[t] << "\n";
+    stream << prefix << "opening angle: "
+           << std::acos(std::cos(_opening_angles[t])) << " radians\n";
+    stream << prefix << "reference direction: [" << v[0] * scale << ", "
+           << v[1] * scale << ", " << v[2] * scale << "]\n";
+  }
+  /* Tracker::output_tracker; MultiTracker::output_tracker,
+   * src/MultiTracker.cpp:127-143: one file per tracker of the MultiTracker
+   * and the named file as their table of contents */
+  void output_node(const Node &node, const std::string &filename) const {
+    if (node.leaf >= 0) {
+      output_leaf(node.leaf, filename);
+      return;
+    }
+    std::ofstream ofile(filename);
+    for (size_t i = 0; i < node.children.size(); ++i) {
+      std::string this_filename = node.names[i];
+      if (this_filename.empty())
+        this_filename = filename + "." + std::to_string(i) + ".txt";
+      output_node(node.children[i], this_filename);
+      ofile << "tracker[" << i << "]:\n";
+      ofile << "  output name: " << this_filename << "\n";
+      describe(node.children[i], "  ", ofile);
     }
   }
 
@@ -423,50 +567,24 @@ public:
     if (n < 0)
       throw ParameterError("\"number of trackers\" not found in \"" +
                            filename + "\"");
-    if (n > 16)
-      throw ParameterError("at most 16 trackers");
     for (long long i = 0; i < n; ++i) {
       const std::string name = "tracker[" + std::to_string(i) + "]:";
+      if (!blocks.has_value(name + "position"))
+        throw ParameterError("\"" + name + "position\" not found in \"" +
+                             filename + "\"");
       const std::array<double, 3> x =
           blocks.get_physical_vector(QUANTITY_LENGTH, name + "position", "");
-      /* TrackerFactory::generate, src/TrackerFactory.hpp:60-72 */
-      const std::string type = blocks.get_string(name + "type", "Spectrum");
-      if (type != "Spectrum" && type != "Absorption")
-        throw ParameterError("Unknown Tracker type: \"" + type + "\"");
-      const bool absorption = type == "Absorption";
-      _kinds.push_back(absorption ? CMI_GPU_TRACKER_ABSORPTION
-                                  : CMI_GPU_TRACKER_SPECTRUM);
-      double angle = 3.141592653589793;
-      double v[3] = {0., 0., 0.};
-      int32_t bins = 1; /* (an absorption tracker has no spectrum) */
-      if (!absorption) {
-        bins = (int32_t)blocks.get_integer(name + "number of bins", 100);
-        if (bins < 1)
-          throw ParameterError("a tracker needs at least one bin");
-        angle = blocks.get_physical_value(QUANTITY_ANGLE,
-                                          name + "opening angle",
-                                          "180. degrees");
-        /* (a vector of plain numbers) */
-        const std::string d =
-            blocks.get_string(name + "reference direction", "[0., 0., 0.]");
-        if (std::sscanf(d.c_str(), " [ %lf , %lf , %lf ]", &v[0], &v[1],
-                        &v[2]) != 3)
-          throw ParameterError("bad reference direction \"" + d + "\"");
-      }
-      _opening_angles.push_back(angle);
-      _number_of_bins.push_back(bins);
-      for (int a = 0; a < 3; ++a) {
-        _positions.push_back(x[a]);
-        _reference_directions.push_back(v[a]);
-      }
+      _trackers.push_back(generate(blocks, name, x));
+      for (int a = 0; a < 3; ++a)
+        _tracker_positions.push_back(x[a]);
       /* src/TrackerManager.hpp:132-138 */
       _output_names.push_back(blocks.get_string(
           name + "output name",
           "Tracker" + std::to_string(i) + (_hdf5_output ? "" : ".txt")));
     }
     if (_hdf5_output)
-      for (int32_t kind : _kinds)
-        if (kind != CMI_GPU_TRACKER_ABSORPTION)
+      for (const Node &node : _trackers)
+        if (node.leaf < 0 || _kinds[node.leaf] != CMI_GPU_TRACKER_ABSORPTION)
           throw ParameterError(
               "TrackerManager:HDF5 output: only Absorption trackers have an "
               "HDF5 form (as in the reference, src/Tracker.hpp:112-130)");
@@ -475,7 +593,10 @@ public:
   }
 
   uint_fast64_t get_number_of_photons() const { return _number_of_photons; }
-  size_t size() const { return _output_names.size(); }
+  /* the engine's trackers: the leaves */
+  size_t size() const { return _kinds.size(); }
+  /* the file's trackers */
+  size_t number_of_trackers() const { return _trackers.size(); }
 
   /* TrackerManager::add_trackers */
   int lower(cmi_gpu_engine *engine) const {
@@ -557,39 +678,8 @@ public:
       file.write(_hdf5_name);
       return;
     }
-    const double minimum_frequency = 3.289e15;
-    size_t first_bin = 0; /* bins of the trackers before t */
-    for (size_t t = 0; t < size(); ++t) {
-      const int32_t nbins = _number_of_bins[t];
-      const double frequency_width = 3. * 3.289e15 / nbins;
-      const uint64_t *c = _counts.data() + 3 * first_bin;
-      first_bin += (size_t)nbins;
-      std::ofstream ofile(_output_names[t]);
-      if (_kinds[t] == CMI_GPU_TRACKER_ABSORPTION) {
-        /* AbsorptionTracker::output_tracker, :145-160 */
-        ofile << "# Ion ";
-        for (int type = 0; type < 4; ++type)
-          ofile << "\t" << photontype_name(type);
-        ofile << "\n";
-        for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion) {
-          ofile << ion_name(ion);
-          for (int type = 0; type < 4; ++type)
-            ofile << "\t"
-                  << _absorption[(t * 4 + (size_t)type) * NUMBER_OF_IONNAMES +
-                                 ion];
-          ofile << "\n";
-        }
-        continue;
-      }
-      /* SpectrumTracker::output_tracker, :226-238 */
-      ofile << "# frequency (Hz)\tprimary count\tdiffuse H count\tdiffuse He "
-               "count\n";
-      for (int32_t i = 0; i < nbins; ++i) {
-        const double nu = minimum_frequency + (i + 0.5) * frequency_width;
-        ofile << nu << "\t" << c[i] << "\t" << c[nbins + i] << "\t"
-              << c[2 * nbins + i] << "\n";
-      }
-    }
+    for (size_t i = 0; i < _trackers.size(); ++i)
+      output_node(_trackers[i], _output_names[i]);
   }
 };
 

@@ -311,14 +311,23 @@ def test_c_caller_typed_from_the_reference_header(library, tmp_path):
     p = tmp_path / "caller.param"
     p.write_text(text)
     out = tmp_path / "caller.txt"
-    for mapping in ("Petkova", "centroid"):
+    for mapping in ("Petkova", "Petkova_oriented", "centroid"):
         run = subprocess.run([str(exe), str(p), mapping, str(out)],
                              cwd=tmp_path, capture_output=True, text=True,
                              timeout=600)
+        # 0 = every guard word intact and every nH element written
         assert run.returncode == 0, (mapping, run.returncode, run.stderr)
         data = np.loadtxt(out)
         pos, nH = data[:, :3], data[:, 3:]
         assert np.all(np.isfinite(nH))
+        # float positions against double positions, same periodic box
+        assert np.abs(nH[:, 2] - nH[:, 0]).max() < \
+            0.02 * max(1., np.abs(nH[:, 0]).max()), mapping
+        if mapping == "Petkova":
+            # the reference's sum of vertex integrals is not a volume integral
+            # on a Cartesian grid (PetkovaMapping::mass_fraction): its numbers
+            # are reproduced (test_petkova_mapping_known_answers), not physics
+            continue
         radius = np.linalg.norm(pos, axis=1)
         # a Stromgren sphere of ~3 pc (stromgren.param in a 10 pc box)
         assert nH[radius < 1.5].max() < 0.5, mapping

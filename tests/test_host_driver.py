@@ -796,3 +796,118 @@ def test_tracker_block_file_is_parsed(exe, tmp_path):
     (tmp_path / "trackers.yml").write_text("tracker[0]:\n  type: Spectrum\n")
     r = dry_run()
     assert r.returncode != 0 and "number of trackers" in r.stderr
+
+
+def multi_tracker_param(tmp_path, block_file):
+    text = open(os.path.join(BENCH, "stromgren_diffuse.param")).read()
+    text = text.replace("number of photons: 1e6", "number of photons: 100000")
+    text = text.replace("number of iterations: 20", "number of iterations: 2")
+    text = text.replace("[64, 64, 64]", "[16, 16, 16]")
+    text = text.replace("type: Gadget", "type: AsciiFile")
+    assert "IonizationSimulation:" in text
+    text = text.replace("IonizationSimulation:",
+                        "IonizationSimulation:\n  enable trackers: true")
+    text += "\nTrackerManager:\n  filename: %s\n" % block_file
+    (tmp_path / "run.param").write_text(text)
+
+
+def test_multi_tracker_fixture_is_parsed(exe, tmp_path):
+    """test/testMultiTracker.cpp:36-44 with the reference's block file
+    (tests/golden/test_multi_tracker.yml = test/test_multi_tracker.yml): its
+    tracker[0] is a Multi tracker of two Spectrum trackers. (The file
+    announces three trackers and holds one - the reference's test builds only
+    `tracker[0]:` -, so the manager is given its first line as 1.) Dry run:
+    no GPU."""
+    fixture = open(os.path.join(ROOT, "tests", "golden",
+                                "test_multi_tracker.yml")).read()
+    assert fixture.startswith("number of trackers: 3")
+    (tmp_path / "multi.yml").write_text(
+        fixture.replace("number of trackers: 3", "number of trackers: 1", 1))
+    multi_tracker_param(tmp_path, "multi.yml")
+    r = subprocess.run([exe, "--params", "run.param", "--dry-run"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    used = open(tmp_path / "multi.yml.used-values").read()
+    assert used.count("type: Spectrum") == 2 and "type: Multi" in used
+    assert used.count("number of bins: 100") == 2
+    # as it stands the file is short of two trackers: reported, like the
+    # reference's YAMLDictionary does for a missing key
+    (tmp_path / "multi.yml").write_text(fixture)
+    r = subprocess.run([exe, "--params", "run.param", "--dry-run"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode != 0 and "tracker[1]:position" in r.stderr
+    # a Multi tracker without its count
+    (tmp_path / "multi.yml").write_text(
+        "number of trackers: 1\ntracker[0]:\n  type: Multi\n"
+        "  position: [0. pc, 0. pc, 0. pc]\n")
+    r = subprocess.run([exe, "--params", "run.param", "--dry-run"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode != 0 and "number of trackers" in r.stderr
+
+
+@pytest.mark.gpu
+def test_multi_tracker_counts_equal_separate_trackers(exe, tmp_path):
+    """MultiTracker (src/MultiTracker.hpp, src/MultiTracker.cpp): every
+    tracker of a Multi tracker counts every photon of the cell
+    (count_photon, :104-124), and its output is one file per tracker plus a
+    table of contents (output_tracker, :127-143). The same three trackers
+    once as one Multi tracker and once as three trackers of their own at the
+    same position: identical files, on an undivided grid and in blocks."""
+    leaves = [
+        "type: Spectrum\n%s  number of bins: 50\n",
+        "type: Spectrum\n%s  opening angle: 60. degrees\n"
+        "%s  reference direction: [0., 0., 2.]\n",
+        "type: Absorption\n",
+    ]
+    position = "position: [1.1 pc, -0.4 pc, 0.7 pc]\n"
+    multi = ("number of trackers: 2\n"
+             "tracker[0]:\n  type: Multi\n  " + position +
+             "  output name: cell.txt\n  number of trackers: 3\n")
+    single = "number of trackers: 3\n"
+    for i, leaf in enumerate(leaves):
+        multi += "  tracker[%d]:\n    " % i + \
+            leaf.replace("%s", "  ").replace("\n  ", "\n    ")
+        if i == 1:
+            multi += "    output name: cone.txt\n"
+        single += "tracker[%d]:\n  " % i + position + "  " + \
+            leaf.replace("%s", "")
+    # a second, plain tracker after the Multi one keeps its own index
+    multi += "tracker[1]:\n  position: [-2. pc, 2. pc, 0.3 pc]\n"
+    (tmp_path / "multi.yml").write_text(multi)
+    (tmp_path / "single.yml").write_text(single)
+    for blocks in (None, "2,1,2"):
+        for name in ("multi", "single"):
+            d = tmp_path / ("%s_%s" % (name, "blocks" if blocks else "whole"))
+            d.mkdir()
+            multi_tracker_param(d, "../%s.yml" % name)
+            cmd = [exe, "--params", "run.param"]
+            if blocks:
+                cmd += ["--blocks", blocks]
+            r = subprocess.run(cmd, capture_output=True, text=True,
+                               cwd=str(d))
+            assert r.returncode == 0, r.stderr
+        dm = tmp_path / ("multi_" + ("blocks" if blocks else "whole"))
+        ds = tmp_path / ("single_" + ("blocks" if blocks else "whole"))
+        pairs = (("cell.txt.0.txt", "Tracker0.txt"),
+                 ("cone.txt", "Tracker1.txt"),
+                 ("cell.txt.2.txt", "Tracker2.txt"))
+        for a, b in pairs:
+            ta, tb = np.loadtxt(dm / a, usecols=(1, 2, 3)), \
+                np.loadtxt(ds / b, usecols=(1, 2, 3))
+            assert np.array_equal(ta, tb), (blocks, a)
+            assert ta.sum() > 0
+        assert np.loadtxt(dm / "cell.txt.0.txt").shape == (50, 4)
+        assert np.loadtxt(dm / "Tracker1.txt").shape == (100, 4)
+        # the cone sees fewer photons than the whole sphere
+        assert np.loadtxt(dm / "cone.txt")[:, 1:].sum() < \
+            np.loadtxt(dm / "cell.txt.0.txt")[:, 1:].sum()
+        toc = open(dm / "cell.txt").read()
+        assert toc == (
+            "tracker[0]:\n  output name: cell.txt.0.txt\n  type: Spectrum\n"
+            "  number of bins: 50\n  opening angle: 3.14159 radians\n"
+            "  reference direction: [0, 0, 0]\n"
+            "tracker[1]:\n  output name: cone.txt\n  type: Spectrum\n"
+            "  number of bins: 100\n  opening angle: 1.0472 radians\n"
+            "  reference direction: [0, 0, 1]\n"
+            "tracker[2]:\n  output name: cell.txt.2.txt\n"
+            "  type: AbsorptionTracker\n"), toc

@@ -38,9 +38,19 @@ namespace cmi {
 class Hdf5Reader {
 public:
   struct Type {
-    int cls = -1; /* 0 fixed point, 1 floating point, 3 string */
+    int cls = -1; /* 0 fixed point, 1 floating point, 3 string, 6 compound */
     uint32_t size = 0;
     bool is_signed = false;
+    /* a compound type's members (of the three simple classes) */
+    struct Member {
+      std::string name;
+      uint32_t offset = 0;
+      int cls = -1;
+      uint32_t size = 0;
+      bool is_signed = false;
+    };
+    std::vector<Member> members;
+    size_t message_bytes = 0; /* length of the datatype message */
   };
   struct Attribute {
     Type type;
@@ -95,21 +105,61 @@ private:
     Type t;
     const uint8_t head = get<uint8_t>(m, at);
     t.cls = head & 0x0f;
+    const int version = head >> 4;
     const uint8_t bits0 = get<uint8_t>(m, at + 1);
     t.size = get<uint32_t>(m, at + 4);
     if (t.cls == 0)
       t.is_signed = (bits0 & 0x08) != 0;
     if ((t.cls == 0 || t.cls == 1) && (bits0 & 0x01))
       throw std::runtime_error("HDF5: big-endian data are not read");
+    if (t.cls == 6) {
+      /* compound: class bits 0-15 = number of members; per member (versions
+       * 1 and 2) its name padded to a multiple of 8 bytes, the byte offset,
+       * (version 1: 28 bytes of array information,) its datatype message;
+       * version 3: name not padded, offset in as many bytes as the size of
+       * the compound needs */
+      const unsigned count = bits0 | ((unsigned)get<uint8_t>(m, at + 2) << 8);
+      size_t p = at + 8;
+      for (unsigned k = 0; k < count; ++k) {
+        Type::Member member;
+        size_t end = p;
+        while (get<uint8_t>(m, end) != 0)
+          ++end;
+        member.name.assign(reinterpret_cast<const char *>(m.data()) + p,
+                           end - p);
+        if (version < 3) {
+          p += ((end - p) / 8 + 1) * 8;
+          member.offset = get<uint32_t>(m, p);
+          p += version == 1 ? 32 : 4;
+        } else {
+          p = end + 1;
+          int nbytes = 1;
+          while (nbytes < 4 && (t.size >> (8 * nbytes)) != 0)
+            ++nbytes;
+          for (int b = 0; b < nbytes; ++b)
+            member.offset |= (uint32_t)get<uint8_t>(m, p + b) << (8 * b);
+          p += nbytes;
+        }
+        const Type inner = datatype(m, p);
+        if (inner.cls == 6)
+          throw std::runtime_error("HDF5: nested compound types are not read");
+        member.cls = inner.cls;
+        member.size = inner.size;
+        member.is_signed = inner.is_signed;
+        p += inner.message_bytes;
+        t.members.push_back(member);
+      }
+      t.message_bytes = p - at;
+      return t;
+    }
     if (t.cls != 0 && t.cls != 1 && t.cls != 3)
       throw std::runtime_error("HDF5: datatype class " +
                                std::to_string(t.cls) + " is not read");
+    t.message_bytes = t.cls == 0 ? 12 : (t.cls == 1 ? 20 : 8);
     return t;
   }
   /* size of a datatype message (to find what follows it in an attribute) */
-  static size_t datatype_bytes(const Type &t) {
-    return t.cls == 0 ? 12 : (t.cls == 1 ? 20 : 8);
-  }
+  static size_t datatype_bytes(const Type &t) { return t.message_bytes; }
   static std::vector<uint64_t> dataspace(const std::vector<uint8_t> &m,
                                          size_t at, size_t *used = nullptr) {
     const uint8_t version = get<uint8_t>(m, at);
@@ -527,6 +577,43 @@ public:
       }
     }
     return out;
+  }
+
+  /* HDF5Tools::read_dictionary (src/HDF5Tools.hpp:1228-1330): a dataset of
+   * {name: fixed-length string, value: number} records as a map; trailing
+   * spaces of the names stripped */
+  std::map<std::string, double> read_dictionary(const std::string &path) const {
+    const Object o = open(path);
+    if (o.type.cls != 6)
+      error("\"" + path + "\" is not a dataset of {name, value} records");
+    const Type::Member *name = nullptr, *value = nullptr;
+    for (const Type::Member &member : o.type.members) {
+      if (member.name == "name" && member.cls == 3)
+        name = &member;
+      if (member.name == "value" && (member.cls == 0 || member.cls == 1))
+        value = &member;
+    }
+    if (!name || !value)
+      error("\"" + path + "\" has no {name, value} records");
+    if ((uint64_t)name->offset + name->size > o.type.size ||
+        (uint64_t)value->offset + value->size > o.type.size)
+      error("\"" + path + "\": a member lies outside its record");
+    const std::vector<uint8_t> b = raw(o);
+    Type number;
+    number.cls = value->cls;
+    number.size = value->size;
+    number.is_signed = value->is_signed;
+    std::map<std::string, double> dictionary;
+    for (size_t at = 0; at + o.type.size <= b.size(); at += o.type.size) {
+      const char *text = reinterpret_cast<const char *>(b.data()) + at +
+                         name->offset;
+      size_t length = strnlen(text, name->size);
+      while (length > 0 && text[length - 1] == ' ')
+        --length;
+      dictionary[std::string(text, length)] =
+          as_doubles(number, b.data() + at + value->offset, 1)[0];
+    }
+    return dictionary;
   }
 
   /* HDF5Tools::read_dataset< double >: any number type, as doubles */

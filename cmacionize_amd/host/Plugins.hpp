@@ -34,6 +34,7 @@
 #include <cmath>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace cmi {
@@ -645,6 +646,357 @@ public:
   }
 };
 
+/* src/FLASHSnapshotDensityFunction.cpp:46-177,204-226: the density (and
+ * temperature) field of a FLASH snapshot - an adaptive mesh of blocks of n^3
+ * cells, "refine level" levels deep, of which the blocks of "node type" 1 are
+ * the leaves that hold data. A cell of the new grid takes the values of the
+ * FLASH cell its midpoint lies in. The reference rebuilds the mesh as an
+ * AMRGrid (an octree per top-level block) and walks down it for every
+ * query; here the leaf blocks sit in a hash map keyed by (level, block
+ * indices at that level) and a query tries the levels from the deepest
+ * upwards: the same cell - FLASH's blocks ARE the octree's nodes. Read with
+ * the dependency-free Hdf5Reader (the runtime-parameter dictionaries are
+ * datasets of {name, value} records, HDF5Tools::read_dictionary).
+ * "read cosmic ray heating" (:100-175,228-280: a per-cell heating factor from
+ * the magnetic field and the cosmic-ray energy gradient) needs a per-cell
+ * term the engine's temperature solve does not have: refused. */
+class FLASHSnapshotDensityFunction : public DensityFunction {
+  std::array<double, 3> _anchor, _sides;
+  std::array<int64_t, 3> _nblock;
+  std::array<uint64_t, 3> _block_cells; /* cells of a block along x, y, z */
+  int _deepest_level = 0;
+  /* (level, ix, iy, iz) of a leaf block -> its index in the file */
+  std::unordered_map<uint64_t, uint32_t> _leaves;
+  std::vector<double> _density, _temperature; /* [block][z][y][x], SI */
+  std::vector<double> _block_anchor, _block_sides; /* [block][3], m */
+  const double _fixed_temperature;
+
+  static uint64_t key(int level, int64_t ix, int64_t iy, int64_t iz) {
+    return ((uint64_t)level << 57) | ((uint64_t)ix << 38) |
+           ((uint64_t)iy << 19) | (uint64_t)iz;
+  }
+  /* index along axis a of the level's block that holds x */
+  int64_t block_index(int level, int a, double x) const {
+    const double side = _sides[a] / (double)(_nblock[a] << (level - 1));
+    return (int64_t)std::floor((x - _anchor[a]) / side);
+  }
+
+public:
+  FLASHSnapshotDensityFunction(const std::string &filename, double temperature,
+                               bool read_cosmic_ray_heating)
+      : _fixed_temperature(temperature) {
+    if (read_cosmic_ray_heating)
+      throw ParameterError(
+          "DensityFunction:read cosmic ray heating is not on this path (the "
+          "engine's temperature solve has no per-cell cosmic ray factor)");
+    Hdf5Reader file(filename);
+    /* centimetres, g cm^-3, K */
+    const double unit_length_in_SI = 0.01, unit_density_in_SI = 1000.;
+    std::map<std::string, double> real_runtime_pars =
+        file.read_dictionary("/real runtime parameters");
+    std::map<std::string, double> integer_runtime_pars =
+        file.read_dictionary("/integer runtime parameters");
+    auto need = [&](std::map<std::string, double> &pars, const char *name) {
+      const auto it = pars.find(name);
+      if (it == pars.end())
+        throw ParameterError("FLASH snapshot \"" + filename +
+                             "\" without the runtime parameter \"" + name +
+                             "\"");
+      return it->second;
+    };
+    const char *lo[3] = {"xmin", "ymin", "zmin"};
+    const char *hi[3] = {"xmax", "ymax", "zmax"};
+    const char *nb[3] = {"nblockx", "nblocky", "nblockz"};
+    for (int a = 0; a < 3; ++a) {
+      _anchor[a] = need(real_runtime_pars, lo[a]) * unit_length_in_SI;
+      _sides[a] =
+          need(real_runtime_pars, hi[a]) * unit_length_in_SI - _anchor[a];
+      _nblock[a] = (int64_t)need(integer_runtime_pars, nb[a]);
+      if (_nblock[a] < 1 || !(_sides[a] > 0.))
+        throw ParameterError("FLASH snapshot \"" + filename +
+                             "\": bad box or number of blocks");
+    }
+    const Hdf5Reader::Object extents = file.open("/bounding box");
+    const Hdf5Reader::Object dens = file.open("/dens");
+    if (extents.dims.size() != 3 || extents.dims[1] != 3 ||
+        extents.dims[2] != 2 || dens.dims.size() != 4 ||
+        dens.dims[0] != extents.dims[0])
+      throw ParameterError("FLASH snapshot \"" + filename +
+                           "\": unexpected dataset shapes");
+    const size_t nblocks = extents.dims[0];
+    /* the file's order is [block][z][y][x] */
+    _block_cells = {dens.dims[3], dens.dims[2], dens.dims[1]};
+    const std::vector<double> box = file.read_doubles("/bounding box");
+    _density = file.read_doubles("/dens");
+    for (double &rho : _density)
+      rho *= unit_density_in_SI;
+    if (temperature <= 0.) {
+      _temperature = file.read_doubles("/temp");
+      if (_temperature.size() != _density.size())
+        throw ParameterError("FLASH snapshot \"" + filename +
+                             "\": \"temp\" does not match \"dens\"");
+    }
+    const std::vector<double> levels = file.read_doubles("/refine level");
+    const std::vector<double> nodetypes = file.read_doubles("/node type");
+    if (levels.size() != nblocks || nodetypes.size() != nblocks)
+      throw ParameterError("FLASH snapshot \"" + filename +
+                           "\": one level and node type per block expected");
+    _block_anchor.resize(3 * nblocks);
+    _block_sides.resize(3 * nblocks);
+    for (size_t i = 0; i < nblocks; ++i) {
+      for (int a = 0; a < 3; ++a) {
+        _block_anchor[3 * i + a] = box[(i * 3 + a) * 2] * unit_length_in_SI;
+        _block_sides[3 * i + a] =
+            box[(i * 3 + a) * 2 + 1] * unit_length_in_SI -
+            _block_anchor[3 * i + a];
+      }
+      if ((int)nodetypes[i] != 1)
+        continue;
+      const int level = (int)levels[i]; /* FLASH counts from 1 */
+      if (level < 1 || level > 19)
+        throw ParameterError("FLASH snapshot \"" + filename +
+                             "\": refinement level out of range");
+      _deepest_level = std::max(_deepest_level, level);
+      /* the block's place among the blocks of its level, from its middle */
+      int64_t index[3];
+      for (int a = 0; a < 3; ++a)
+        index[a] = block_index(level, a, _block_anchor[3 * i + a] +
+                                             0.5 * _block_sides[3 * i + a]);
+      _leaves[key(level, index[0], index[1], index[2])] = (uint32_t)i;
+    }
+    if (_leaves.empty())
+      throw ParameterError("FLASH snapshot \"" + filename +
+                           "\" holds no leaf blocks");
+  }
+  explicit FLASHSnapshotDensityFunction(ParameterFile &params)
+      : FLASHSnapshotDensityFunction(
+            params.get_filename("DensityFunction:filename"),
+            params.get_physical_value(QUANTITY_TEMPERATURE,
+                                      "DensityFunction:temperature", "-1. K"),
+            params.get_bool("DensityFunction:read cosmic ray heating",
+                            false)) {}
+
+  /* :204-226 */
+  DensityValues operator()(const Cell &cell) override {
+    const CoordinateVector position = cell.get_cell_midpoint();
+    for (int level = _deepest_level; level >= 1; --level) {
+      int64_t index[3];
+      bool inside = true;
+      for (int a = 0; a < 3; ++a) {
+        index[a] = block_index(level, a, position[a]);
+        inside &= index[a] >= 0 && index[a] < (_nblock[a] << (level - 1));
+      }
+      if (!inside)
+        break;
+      const auto it = _leaves.find(key(level, index[0], index[1], index[2]));
+      if (it == _leaves.end())
+        continue;
+      const size_t block = it->second;
+      uint64_t c[3];
+      for (int a = 0; a < 3; ++a) {
+        const double u = (position[a] - _block_anchor[3 * block + a]) /
+                         _block_sides[3 * block + a] * (double)_block_cells[a];
+        c[a] = u <= 0. ? 0
+                       : std::min<uint64_t>((uint64_t)u, _block_cells[a] - 1);
+      }
+      const size_t at =
+          ((block * _block_cells[2] + c[2]) * _block_cells[1] + c[1]) *
+              _block_cells[0] +
+          c[0];
+      DensityValues values;
+      values.set_number_density(_density[at] / 1.6737236e-27);
+      values.set_temperature(_fixed_temperature <= 0. ? _temperature[at]
+                                                      : _fixed_temperature);
+      values.set_ionic_fraction(ION_H_n, 1.e-6);
+      values.set_ionic_fraction(ION_He_n, 1.e-6);
+      return values;
+    }
+    throw ParameterError("a cell midpoint lies outside the FLASH snapshot's "
+                         "box");
+  }
+};
+
+/* src/AmunSnapshotDensityFunction.cpp:55-276: the density and temperature
+ * field of an AMUN snapshot: a uniform grid in `number of files` HDF5 files,
+ * file f holding the brick (f / pdims[1] % pdims[0], f % pdims[1], f /
+ * (pdims[0] pdims[1])) of dims[0] x dims[1] x dims[2] cells ("/attributes":
+ * dims, pdims; "/variables": dens, pres, velx, vely, velz as [z][y][x]
+ * floats), in code units: rescaled to the given average number density and
+ * temperature (temperature = pressure / density, isothermal sound speed
+ * `AMUN soundspeed` in code units); the box is periodic and may be shifted.
+ * The velocities are read by the reference for its hydro integrator and have
+ * no use on this path: not kept. */
+class AmunSnapshotDensityFunction : public DensityFunction {
+  const std::string _folder, _prefix;
+  const uint_fast32_t _padding, _number_of_files;
+  const std::array<double, 3> _box_anchor, _box_sides;
+  const double _average_number_density, _sound_speed, _average_temperature,
+      _initial_neutral_fraction;
+  const std::array<double, 3> _shift;
+  std::array<uint64_t, 3> _number_of_cells = {0, 0, 0};
+  std::vector<double> _number_densities, _temperatures;
+
+  /* Utilities::compose_filename, src/Utilities.hpp */
+  std::string filename(uint_fast32_t index) const {
+    std::string number = std::to_string(index);
+    while (number.size() < _padding)
+      number = "0" + number;
+    std::string folder = _folder;
+    if (!folder.empty() && folder.back() != '/')
+      folder += "/";
+    return folder + _prefix + number + ".h5";
+  }
+
+public:
+  AmunSnapshotDensityFunction(const std::string &folder,
+                              const std::string &prefix, uint_fast32_t padding,
+                              uint_fast32_t number_of_files,
+                              const std::array<double, 3> &box_anchor,
+                              const std::array<double, 3> &box_sides,
+                              double number_density, double sound_speed,
+                              double temperature,
+                              double initial_neutral_fraction,
+                              const std::array<double, 3> &shift)
+      : _folder(folder), _prefix(prefix), _padding(padding),
+        _number_of_files(number_of_files), _box_anchor(box_anchor),
+        _box_sides(box_sides), _average_number_density(number_density),
+        _sound_speed(sound_speed), _average_temperature(temperature),
+        _initial_neutral_fraction(initial_neutral_fraction), _shift(shift) {}
+  explicit AmunSnapshotDensityFunction(ParameterFile &params)
+      : AmunSnapshotDensityFunction(
+            params.get_string("DensityFunction:folder", "."),
+            params.get_string("DensityFunction:prefix", ""),
+            (uint_fast32_t)params.get_integer("DensityFunction:padding", 5),
+            (uint_fast32_t)params.get_integer(
+                "DensityFunction:number of files", 4),
+            params.get_physical_vector(QUANTITY_LENGTH,
+                                       "DensityFunction:box anchor",
+                                       "[0. m, 0. m, 0. m]"),
+            params.get_physical_vector(QUANTITY_LENGTH,
+                                       "DensityFunction:box sides",
+                                       "[1. m, 1. m, 1. m]"),
+            params.get_physical_value(QUANTITY_NUMBER_DENSITY,
+                                      "DensityFunction:average number density",
+                                      "100. cm^-3"),
+            params.get_double("DensityFunction:AMUN soundspeed", 0.1),
+            params.get_physical_value(QUANTITY_TEMPERATURE,
+                                      "DensityFunction:average temperature",
+                                      "100. K"),
+            params.get_double("DensityFunction:initial neutral fraction",
+                              1.e-6),
+            plain_vector(params.get_string("DensityFunction:shift",
+                                           "[0., 0., 0.]"))) {
+    if (_prefix.empty())
+      throw ParameterError("\"DensityFunction:prefix\" not found");
+  }
+  static std::array<double, 3> plain_vector(const std::string &text) {
+    std::array<double, 3> v;
+    if (std::sscanf(text.c_str(), " [ %lf , %lf , %lf ]", &v[0], &v[1],
+                    &v[2]) != 3)
+      throw ParameterError("bad vector \"" + text + "\"");
+    return v;
+  }
+
+  /* :103-218 */
+  void initialize() override {
+    std::vector<double> dims, pdims;
+    {
+      Hdf5Reader file(filename(0));
+      const Hdf5Reader::Object attributes = file.open("/attributes");
+      auto vector3 = [&](const char *name) {
+        const auto it = attributes.attributes.find(name);
+        if (it == attributes.attributes.end())
+          throw ParameterError("AMUN snapshot \"" + filename(0) +
+                               "\" without \"" + name + "\"");
+        const std::vector<double> v = Hdf5Reader::as_doubles(it->second);
+        if (v.size() != 3 || !(v[0] >= 1. && v[1] >= 1. && v[2] >= 1.))
+          throw ParameterError("AMUN snapshot: bad \"" + std::string(name) +
+                               "\"");
+        return v;
+      };
+      dims = vector3("dims");
+      pdims = vector3("pdims");
+    }
+    const uint64_t d[3] = {(uint64_t)dims[0], (uint64_t)dims[1],
+                           (uint64_t)dims[2]};
+    const uint64_t pd[3] = {(uint64_t)pdims[0], (uint64_t)pdims[1],
+                            (uint64_t)pdims[2]};
+    for (int a = 0; a < 3; ++a)
+      _number_of_cells[a] = d[a] * pd[a];
+    const uint64_t totnumcell =
+        _number_of_cells[0] * _number_of_cells[1] * _number_of_cells[2];
+    _number_densities.assign(totnumcell, 0.);
+    _temperatures.assign(totnumcell, 0.);
+    double average_density = 0.;
+    for (uint_fast32_t ifile = 0; ifile < _number_of_files; ++ifile) {
+      /* the brick of this file */
+      const uint64_t brick_z = ifile / (pd[0] * pd[1]);
+      const uint64_t brick_x = (ifile - brick_z * pd[0] * pd[1]) / pd[1];
+      const uint64_t brick_y = ifile - brick_z * pd[0] * pd[1] - brick_x * pd[1];
+      if (brick_z >= pd[2])
+        throw ParameterError("AMUN snapshot: more files than bricks");
+      const uint64_t offset[3] = {brick_x * d[0], brick_y * d[1],
+                                  brick_z * d[2]};
+      Hdf5Reader file(filename(ifile));
+      const std::vector<double> dens = file.read_doubles("/variables/dens");
+      const std::vector<double> pres = file.read_doubles("/variables/pres");
+      if (dens.size() != d[0] * d[1] * d[2] || pres.size() != dens.size())
+        throw ParameterError("AMUN snapshot \"" + filename(ifile) +
+                             "\": variables do not match \"dims\"");
+      for (uint64_t iz = 0; iz < d[2]; ++iz)
+        for (uint64_t iy = 0; iy < d[1]; ++iy)
+          for (uint64_t ix = 0; ix < d[0]; ++ix) {
+            const uint64_t in_file = (iz * d[1] + iy) * d[0] + ix;
+            const uint64_t in_grid =
+                ((iz + offset[2]) * _number_of_cells[1] + iy + offset[1]) *
+                    _number_of_cells[0] +
+                ix + offset[0];
+            _number_densities[in_grid] = dens[in_file];
+            _temperatures[in_grid] = pres[in_file] / dens[in_file];
+            average_density += dens[in_file];
+          }
+    }
+    average_density /= (double)totnumcell;
+    const double number_density_unit =
+        _average_number_density / average_density;
+    const double temperature_conversion_factor =
+        _average_temperature / (_sound_speed * _sound_speed);
+    for (uint64_t i = 0; i < totnumcell; ++i) {
+      _number_densities[i] *= number_density_unit;
+      _temperatures[i] *= temperature_conversion_factor;
+    }
+  }
+  void free() override {
+    _number_densities.clear();
+    _temperatures.clear();
+  }
+
+  /* :234-270 */
+  DensityValues operator()(const Cell &cell) override {
+    const CoordinateVector midpoint = cell.get_cell_midpoint();
+    uint64_t index[3];
+    for (int a = 0; a < 3; ++a) {
+      double dx = midpoint[a] - _box_anchor[a];
+      dx -= _shift[a] * _box_sides[a];
+      while (dx >= _box_sides[a])
+        dx -= _box_sides[a];
+      while (dx < 0.)
+        dx += _box_sides[a];
+      index[a] = (uint64_t)(dx / _box_sides[a] * (double)_number_of_cells[a]);
+      if (index[a] >= _number_of_cells[a]) /* dx one ulp below the side */
+        index[a] = _number_of_cells[a] - 1;
+    }
+    const uint64_t at =
+        (index[2] * _number_of_cells[1] + index[1]) * _number_of_cells[0] +
+        index[0];
+    DensityValues values;
+    values.set_number_density(_number_densities[at]);
+    values.set_temperature(_temperatures[at]);
+    values.set_ionic_fraction(ION_H_n, _initial_neutral_fraction);
+    return values;
+  }
+};
+
 inline DensityFunction *generate_density_function(ParameterFile &params) {
   const std::string type =
       params.get_string("DensityFunction:type", "Homogeneous");
@@ -656,10 +1008,15 @@ inline DensityFunction *generate_density_function(ParameterFile &params) {
     return new CMacIonizeSnapshotDensityFunction(params);
   if (type == "GadgetSnapshot")
     return new GadgetSnapshotDensityFunction(params);
+  if (type == "FLASHSnapshot")
+    return new FLASHSnapshotDensityFunction(params);
+  if (type == "AmunSnapshot")
+    return new AmunSnapshotDensityFunction(params);
   throw ParameterError("Unknown DensityFunction type: \"" + type +
                        "\" (this engine provides Homogeneous, BlockSyntax, "
-                       "CMacIonizeSnapshot and GadgetSnapshot; pass your own "
-                       "DensityFunction to initialize())");
+                       "CMacIonizeSnapshot, GadgetSnapshot, FLASHSnapshot "
+                       "and AmunSnapshot; pass your own DensityFunction to "
+                       "initialize())");
 }
 
 /* ---------------------------------------------- PhotonSourceDistribution */

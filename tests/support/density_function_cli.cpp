@@ -1,0 +1,46 @@
+// Test helper: evaluates the DensityFunction a parameter file describes
+// (cmacionize_amd/host/Plugins.hpp: generate_density_function) at given
+// points, the way the reference's unit tests probe their density functions
+// with a DummyCell.  usage: density_function_cli PARAMETER_FILE < points
+// points: one "x y z" (in m) per line; output: one "number_density
+// temperature neutral_fraction_H" line per point (SI), 17 digits.
+#include "Plugins.hpp"
+
+#include <cstdio>
+#include <iostream>
+
+namespace {
+class PointCell : public cmi::Cell {
+  cmi::CoordinateVector _midpoint;
+
+public:
+  explicit PointCell(const cmi::CoordinateVector &p) : _midpoint(p) {}
+  cmi::CoordinateVector get_cell_midpoint() const override { return _midpoint; }
+  double get_volume() const override { return 1.; }
+};
+} // namespace
+
+int main(int argc, char **argv) {
+  if (argc != 2) {
+    std::fprintf(stderr, "usage: %s PARAMETER_FILE < points\n", argv[0]);
+    return 2;
+  }
+  try {
+    cmi::ParameterFile params{std::string(argv[1])};
+    std::unique_ptr<cmi::DensityFunction> f(
+        cmi::generate_density_function(params));
+    f->initialize();
+    double x, y, z;
+    while (std::cin >> x >> y >> z) {
+      const PointCell cell(cmi::CoordinateVector(x, y, z));
+      const cmi::DensityValues v = (*f)(cell);
+      std::printf("%.17g %.17g %.17g\n", v.get_number_density(),
+                  v.get_temperature(), v.get_ionic_fraction(cmi::ION_H_n));
+    }
+    f->free();
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -38,6 +38,18 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < o.dims.size(); ++i)
       std::printf("%s%llu", i ? ", " : "", (unsigned long long)o.dims[i]);
     std::printf("], \"layout\": %d, \"data\": [", o.layout);
+    if (o.layout >= 0 && o.type.cls == 6) {
+      /* a dataset of {name, value} records: "data": [], "dictionary": {} */
+      std::printf("], \"dictionary\": {");
+      bool first_entry = true;
+      for (const auto &kv : file.read_dictionary(argv[2])) {
+        std::printf("%s\"%s\": %.17g", first_entry ? "" : ", ",
+                    kv.first.c_str(), kv.second);
+        first_entry = false;
+      }
+      std::printf("}}\n");
+      return 0;
+    }
     if (o.layout >= 0) {
       const std::vector<double> v = file.read_doubles(argv[2]);
       for (size_t i = 0; i < v.size(); ++i)

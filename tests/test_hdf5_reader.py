@@ -516,3 +516,148 @@ def test_gadget_snapshot_fixture_of_the_reference(exe, cli, tmp_path):
     assert abs(in_grid - in_snapshot) <= 1e-4 * abs(in_grid + in_snapshot)
     assert in_snapshot > 0.
     assert fields[1].mean() == 0.
+
+
+# ---- FLASH and AMUN snapshots (round 4) ------------------------------------
+
+@pytest.fixture(scope="module")
+def density_cli(tmp_path_factory):
+    out = tmp_path_factory.mktemp("dfcli") / "density_function_cli"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror",
+                    "-I", os.path.join(ROOT, "cmacionize_amd", "host"),
+                    "-I", os.path.join(ROOT, "include"),
+                    "-o", str(out),
+                    os.path.join(ROOT, "tests", "support",
+                                 "density_function_cli.cpp"), "-lz"],
+                   check=True)
+    return str(out)
+
+
+def evaluate(density_cli, folder, block, points, expect_error=None):
+    """the DensityFunction of a parameter block at points [n][3] (m):
+    columns number density, temperature, neutral fraction of hydrogen"""
+    p = folder / "density.param"
+    p.write_text("DensityFunction:\n" + block)
+    text = "\n".join("%.17g %.17g %.17g" % tuple(x) for x in points)
+    r = subprocess.run([density_cli, str(p)], input=text,
+                       capture_output=True, text=True)
+    if expect_error is not None:
+        assert r.returncode != 0 and expect_error in r.stderr, r.stderr
+        return None
+    assert r.returncode == 0, r.stderr
+    return np.array([[float(v) for v in line.split()]
+                     for line in r.stdout.splitlines()])
+
+
+FLASH = os.path.join(ROOT, "tests", "golden", "FLASHtest.hdf5")
+
+
+def test_flash_snapshot_fixture_of_the_reference(cli, density_cli, tmp_path):
+    """test/testFLASHSnapshotDensityFunction.cpp:46-72 on the reference's own
+    fixture (tests/golden/FLASHtest.hdf5 = test/FLASHtest.hdf5, 82 blocks of
+    8^3 cells on three refinement levels, written by libhdf5): 128 points
+    along the diagonal of the 2 x 1 x 1 cm box against the linear density the
+    file was made from - the reference asserts the sum of the squared
+    relative differences, 0.0106294 (`assert_values_equal`: 1e-4), and a
+    temperature of exactly 4000 K everywhere."""
+    # the runtime parameters are datasets of {name, value} records
+    real = read(cli, FLASH, "/real runtime parameters")["dictionary"]
+    integer = read(cli, FLASH, "/integer runtime parameters")["dictionary"]
+    assert real == dict(xmin=0., xmax=2., ymin=0., ymax=1., zmin=0., zmax=1.)
+    assert integer == dict(nblockx=2, nblocky=1, nblockz=1)
+    i = np.arange(128)
+    points = np.stack([(i + 0.5) * 0.02 / 128, (i + 0.5) * 0.01 / 128,
+                       (i + 0.5) * 0.01 / 128], axis=1)
+    got = evaluate(density_cli, tmp_path,
+                   "  type: FLASHSnapshot\n  filename: %s\n" % FLASH, points)
+    rho = got[:, 0]
+    expected = (1. + 100. * points.sum(axis=1)) * 1.e3 / 1.6737236e-27
+    diff = (rho - expected) / (rho + expected)
+    xi2 = (diff * diff).sum()
+    assert abs(xi2 - 0.0106294) <= 1.e-4 * abs(xi2 + 0.0106294), xi2
+    assert np.all(got[:, 1] == 4000.)
+    assert np.all(got[:, 2] == 1.e-6)
+
+
+def test_flash_snapshot_cells_by_brute_force(cli, density_cli, tmp_path):
+    """Every query point gets the value of the leaf-block cell that contains
+    it: against a search through the file's leaf blocks (read with the test
+    helper), at random points - all refinement levels are hit."""
+    box = np.array(read(cli, FLASH, "/bounding box")["data"]).reshape(-1, 3, 2)
+    dens = np.array(read(cli, FLASH, "/dens")["data"]).reshape(-1, 8, 8, 8)
+    temp = np.array(read(cli, FLASH, "/temp")["data"]).reshape(-1, 8, 8, 8)
+    node = np.array(read(cli, FLASH, "/node type")["data"])
+    level = np.array(read(cli, FLASH, "/refine level")["data"])
+    rng = np.random.default_rng(11)
+    points = rng.uniform(0., 1., (400, 3)) * [0.02, 0.01, 0.01]
+    got = evaluate(density_cli, tmp_path,
+                   "  type: FLASHSnapshot\n  filename: %s\n" % FLASH, points)
+    fixed = evaluate(density_cli, tmp_path,
+                     "  type: FLASHSnapshot\n  filename: %s\n"
+                     "  temperature: 250. K\n" % FLASH, points)
+    levels_hit = set()
+    for p, row in zip(points, got):
+        cm = p * 100.
+        inside = [b for b in range(len(box)) if node[b] == 1 and
+                  np.all(cm >= box[b, :, 0]) and np.all(cm < box[b, :, 1])]
+        assert len(inside) == 1
+        b = inside[0]
+        levels_hit.add(level[b])
+        c = ((cm - box[b, :, 0]) / (box[b, :, 1] - box[b, :, 0]) *
+             8).astype(int)
+        assert row[0] == dens[b, c[2], c[1], c[0]] * 1.e3 / 1.6737236e-27
+        assert row[1] == temp[b, c[2], c[1], c[0]]
+    assert len(levels_hit) >= 2
+    assert np.all(fixed[:, 1] == 250.) and np.array_equal(fixed[:, 0],
+                                                          got[:, 0])
+    # outside the snapshot's box, and the per-cell cosmic ray factor
+    evaluate(density_cli, tmp_path,
+             "  type: FLASHSnapshot\n  filename: %s\n" % FLASH,
+             [[0.03, 0.005, 0.005]], expect_error="outside")
+    evaluate(density_cli, tmp_path,
+             "  type: FLASHSnapshot\n  filename: %s\n"
+             "  read cosmic ray heating: true\n" % FLASH,
+             [[0.01, 0.005, 0.005]], expect_error="cosmic ray")
+
+
+def test_amun_snapshot_fixture_of_the_reference(density_cli, tmp_path):
+    """test/testAmunSnapshotDensityFunction.cpp:38-64 reads the four bricks
+    tests/golden/Amun_test_0[0-3].h5 (= test/Amun_test_0*.h5: 2 x 2 x 1 bricks
+    of 16 x 16 x 32 cells) onto a 32 x 32 slice and only writes it out; the
+    files hold dens = 1 + x + y + z and pres = 2 + x + y + z at the cell
+    centres of the unit box, so every brick's place and orientation shows:
+    n = <n> (1 + x + y + z) / 2.5 and T = <T> / cs^2 x pres / dens, cell by
+    cell, with the reference's parameters (average density 1 m^-3, code sound
+    speed 0.1, 100 K)."""
+    block = ("  type: AmunSnapshot\n  folder: %s\n  prefix: Amun_test_\n"
+             "  padding: 2\n  number of files: 4\n"
+             "  average number density: 1. m^-3\n"
+             "  initial neutral fraction: 1.e-3\n" %
+             os.path.join(ROOT, "tests", "golden"))
+    ax = (np.arange(32) + 0.5) / 32
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    points = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    got = evaluate(density_cli, tmp_path, block, points)
+    s = points.sum(axis=1)
+    assert np.allclose(got[:, 0], (1. + s) / 2.5, rtol=1e-6, atol=0.)
+    assert np.allclose(got[:, 1], 100. / 0.01 * (2. + s) / (1. + s),
+                       rtol=1e-6, atol=0.)
+    assert np.all(got[:, 2] == 1.e-3)
+    assert abs(got[:, 0].mean() - 1.) < 1e-12
+    # the box is periodic and can be shifted (:236-246): a quarter of a box
+    # along x, a point outside the box along y
+    shifted = evaluate(density_cli, tmp_path,
+                       block + "  shift: [0.25, 0., 0.]\n",
+                       points[:2048] + [0., 1., 0.])
+    moved = points[:2048] - [0.25, 0., 0.]
+    moved[:, 0] %= 1.
+    assert np.allclose(shifted[:, 0], (1. + moved.sum(axis=1)) / 2.5,
+                       rtol=1e-6, atol=0.)
+    # another box: the same cells stretched over it
+    stretched = evaluate(density_cli, tmp_path, block +
+                         "  box anchor: [-1. m, -1. m, -1. m]\n"
+                         "  box sides: [2. m, 2. m, 2. m]\n",
+                         2. * points[::37] - 1.)
+    assert np.array_equal(stretched, got[::37])
+    evaluate(density_cli, tmp_path, block.replace("Amun_test_", "Amun_none_"),
+             points[:1], expect_error="Amun_none_00.h5")

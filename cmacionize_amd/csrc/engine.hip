@@ -1689,9 +1689,17 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                           : shoot_kernel<false, false, false, false, true>;
   }
   /* ... and, hydrogen only on a whole grid, marching through padded records */
+  /* (the kernel addresses padded records by 32-bit byte offsets:
+   * (nx + 2)(ny + 2)(nz + 2) < 2^29, which a flat grid of fewer than 2^28
+   * cells - 1 x 13400 x 13400 - can exceed) */
+  const int64_t padded_cells =
+      ((int64_t)e->grid.ncell[0] + 2 * CMI_PAD_LAYERS) *
+      ((int64_t)e->grid.ncell[1] + 2 * CMI_PAD_LAYERS) *
+      ((int64_t)e->grid.ncell[2] + 2 * CMI_PAD_LAYERS);
   const bool pad = kernel_first != kernel && !e->full_ions &&
                    e->tune.pad_march && !e->grid.decomposed &&
-                   e->grid.copy_count <= 1;
+                   e->grid.copy_count <= 1 &&
+                   padded_cells < ((int64_t)1 << 29);
   if (pad)
     kernel_first =
         heat ? shoot_kernel<false, true, false, false, true, false, true>

@@ -1259,39 +1259,89 @@ public:
            * outwards (the reference's restriction of the copy levels,
            * src/TaskBasedIonizationSimulation.cpp:533-556: a packet that
            * leaves a block with many copies must not find all of them queueing
-           * for one neighbour) - capped by the device pool like `want` */
-          std::vector<size_t> engines_of(originals, 1);
-          int top_level = 0;
-          for (size_t o = 0; o < originals; ++o)
-            if (has_source[o]) {
-              engines_of[o] = want;
-              while (((size_t)2 << top_level) <= want)
-                ++top_level;
-            }
-          for (int level = top_level; level > 1; --level) {
-            const size_t here = (size_t)1 << level;
-            for (size_t o = 0; o < originals; ++o) {
-              if (engines_of[o] < here || engines_of[o] >= 2 * here)
-                continue;
-              const int bx = (int)(o / ((size_t)_nblock[1] * _nblock[2]));
-              const int by = (int)((o / _nblock[2]) % _nblock[1]);
-              const int bz = (int)(o % _nblock[2]);
-              const int at[3] = {bx, by, bz};
-              for (int axis = 0; axis < 3; ++axis)
-                for (int side = -1; side <= 1; side += 2) {
-                  int nb[3] = {at[0], at[1], at[2]};
-                  nb[axis] += side;
-                  if (nb[axis] < 0 || nb[axis] >= _nblock[axis]) {
-                    if (!config.periodic[axis] || _nblock[axis] < 2)
-                      continue;
-                    nb[axis] = (nb[axis] + _nblock[axis]) % _nblock[axis];
+           * for one neighbour) - capped by the device pool like `want`.
+           * `rings_dropped`: the cascade stops that many rings early. */
+          auto plan = [&](size_t want_now, int rings_dropped) {
+            std::vector<size_t> engines_of(originals, 1);
+            int top_level = 0;
+            for (size_t o = 0; o < originals; ++o)
+              if (has_source[o]) {
+                engines_of[o] = want_now;
+                while (((size_t)2 << top_level) <= want_now)
+                  ++top_level;
+              }
+            for (int level = top_level; level > 1 + rings_dropped; --level) {
+              const size_t here = (size_t)1 << level;
+              for (size_t o = 0; o < originals; ++o) {
+                if (engines_of[o] < here || engines_of[o] >= 2 * here)
+                  continue;
+                const int bx = (int)(o / ((size_t)_nblock[1] * _nblock[2]));
+                const int by = (int)((o / _nblock[2]) % _nblock[1]);
+                const int bz = (int)(o % _nblock[2]);
+                const int at[3] = {bx, by, bz};
+                for (int axis = 0; axis < 3; ++axis)
+                  for (int side = -1; side <= 1; side += 2) {
+                    int nb[3] = {at[0], at[1], at[2]};
+                    nb[axis] += side;
+                    if (nb[axis] < 0 || nb[axis] >= _nblock[axis]) {
+                      if (!config.periodic[axis] || _nblock[axis] < 2)
+                        continue;
+                      nb[axis] = (nb[axis] + _nblock[axis]) % _nblock[axis];
+                    }
+                    const size_t n =
+                        ((size_t)nb[0] * _nblock[1] + nb[1]) * _nblock[2] +
+                        nb[2];
+                    engines_of[n] = std::max(engines_of[n], here / 2);
                   }
-                  const size_t n =
-                      ((size_t)nb[0] * _nblock[1] + nb[1]) * _nblock[2] + nb[2];
-                  engines_of[n] = std::max(engines_of[n], here / 2);
-                }
+              }
+            }
+            return engines_of;
+          };
+          /* A group holds at most 64 engines (and every copy is a whole block
+           * engine in device memory). The reference has no such limit, so a
+           * cascade that does not fit is cut back instead of refused: first
+           * the outermost rings of neighbour copies, one at a time, then the
+           * copies of the source blocks themselves are halved - the status
+           * line says what was granted. */
+          const size_t group_limit = 64;
+          if (originals > group_limit)
+            throw std::runtime_error(
+                "too many blocks (at most 64 engines in a group)");
+          size_t granted = want;
+          int rings_dropped = 0;
+          std::vector<size_t> engines_of;
+          for (;;) {
+            engines_of = plan(granted, rings_dropped);
+            size_t total = 0;
+            int rings = 0;
+            for (size_t n : engines_of)
+              total += n;
+            while (((size_t)4 << rings) <= granted)
+              ++rings; /* rings of neighbour copies a cascade from `granted`
+                          has: levels top ... 2 */
+            if (total <= group_limit)
+              break;
+            if (rings_dropped < rings) {
+              ++rings_dropped;
+            } else if (granted > 1) {
+              size_t half = 1;
+              while (2 * half < granted)
+                half *= 2;
+              granted = half; /* the next power of two below */
+              rings_dropped = 0;
+            } else {
+              break; /* (originals <= limit: cannot happen) */
             }
           }
+          if (granted != want || rings_dropped)
+            status("Copies: " + std::to_string(want) +
+                   " engines per source block asked for, " +
+                   std::to_string(granted) + " granted" +
+                   (rings_dropped
+                        ? ", the outermost " + std::to_string(rings_dropped) +
+                              " ring(s) of neighbour copies dropped"
+                        : std::string()) +
+                   " (at most 64 engines in a group).");
           for (size_t o = 0; o < originals; ++o) {
             const size_t want_here = engines_of[o];
             if (want_here < 2)
@@ -1322,9 +1372,6 @@ public:
                 ++_number_of_neighbour_copies;
             }
           }
-          if (_number_of_copies + originals > 64)
-            throw std::runtime_error(
-                "too many blocks and copies (at most 64 engines in a group)");
         }
         {
           std::vector<cmi_gpu_engine *> engines;

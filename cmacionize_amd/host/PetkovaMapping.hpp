@@ -267,7 +267,8 @@ public:
    * `oriented_towards` = NULL this function returns the reference's number
    * whatever it means - the known answers pin exactly that - and with a
    * point inside the cell (its midpoint) every face's normal is taken to
-   * point towards it, which makes the sum the integral (the mapping type
+   * point towards it (and the side of an edge is judged from the face's
+   * midpoint, below), which makes the sum the integral (the mapping type
    * "Petkova_oriented", not in the reference). */
   double mass_fraction(const std::vector<Face> &faces,
                        const double particle[3], double h,
@@ -332,8 +333,29 @@ public:
         const double phi_a = R_0 < rpa ? std::acos(cosphi_a) : 0.;
         const double phi_b = R_0 < rpb ? std::acos(cosphi_b) : 0.;
 
-        const double sign =
-            det3(projected, a, b) * face_orientation * side <= 0. ? -1. : 1.;
+        /* does the projected particle lie on the face's side of the edge?
+         * The reference compares two determinants of POSITION vectors
+         * (projected, a, b) and (v1, v2, v3): fine unless the face lies in a
+         * plane through the origin of the coordinates, where both vanish and
+         * every vertex integral of the face counts negative - a box centred
+         * on the origin with an even number of cells has such faces. The
+         * oriented variant asks the face's midpoint instead. */
+        double same_side = det3(projected, a, b) * face_orientation;
+        if (oriented_towards) {
+          const double *c = face.midpoint.v;
+          const double e[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+          const double p[3] = {projected[0] - a[0], projected[1] - a[1],
+                               projected[2] - a[2]};
+          const double q[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+          const double ep[3] = {e[1] * p[2] - e[2] * p[1],
+                                e[2] * p[0] - e[0] * p[2],
+                                e[0] * p[1] - e[1] * p[0]};
+          const double eq[3] = {e[1] * q[2] - e[2] * q[1],
+                                e[2] * q[0] - e[0] * q[2],
+                                e[0] * q[1] - e[1] * q[0]};
+          same_side = ep[0] * eq[0] + ep[1] * eq[1] + ep[2] * eq[2];
+        }
+        const double sign = same_side * side <= 0. ? -1. : 1.;
         const double Ia =
             interpolated_vertex_integral(phi_a, cosphi_a, ar0, R_0, h);
         const double Ib =

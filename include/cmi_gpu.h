@@ -383,7 +383,10 @@ int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *engine, int32_t n,
  * are the classic path's (no element abundance in them: the reference's
  * task-based packets carry A_element sigma, src/SourceDiscretePhotonTask
  * Context.hpp:172-180 - multiply the ion's column by its element's abundance
- * for that convention). On a block of a decomposed grid a tracker outside
+ * for that convention). An engine whose cross sections are FixedValue with
+ * sigma = 0 for every ion but H0 runs the hydrogen-only kernels, which add
+ * only the H0 column: the other thirteen are path length x 0 in the reference
+ * as well. On a block of a decomposed grid a tracker outside
  * the block counts nothing; the caller adds the blocks' (and copies') counts
  * (TrackerManager::normalize merges copies, src/TrackerManager.hpp:307-318). */
 #define CMI_GPU_TRACKER_SPECTRUM 0

@@ -853,24 +853,25 @@ def test_multi_tracker_counts_equal_separate_trackers(exe, tmp_path):
     table of contents (output_tracker, :127-143). The same three trackers
     once as one Multi tracker and once as three trackers of their own at the
     same position: identical files, on an undivided grid and in blocks."""
+    # (key: value lines of each tracker, without indentation)
     leaves = [
-        "type: Spectrum\n%s  number of bins: 50\n",
-        "type: Spectrum\n%s  opening angle: 60. degrees\n"
-        "%s  reference direction: [0., 0., 2.]\n",
-        "type: Absorption\n",
+        ["type: Spectrum", "number of bins: 50"],
+        ["type: Spectrum", "opening angle: 60. degrees",
+         "reference direction: [0., 0., 2.]"],
+        ["type: Absorption"],
     ]
-    position = "position: [1.1 pc, -0.4 pc, 0.7 pc]\n"
+    position = "position: [1.1 pc, -0.4 pc, 0.7 pc]"
     multi = ("number of trackers: 2\n"
              "tracker[0]:\n  type: Multi\n  " + position +
-             "  output name: cell.txt\n  number of trackers: 3\n")
+             "\n  output name: cell.txt\n  number of trackers: 3\n")
     single = "number of trackers: 3\n"
     for i, leaf in enumerate(leaves):
-        multi += "  tracker[%d]:\n    " % i + \
-            leaf.replace("%s", "  ").replace("\n  ", "\n    ")
+        multi += "  tracker[%d]:\n" % i
+        multi += "".join("    %s\n" % line for line in leaf)
         if i == 1:
             multi += "    output name: cone.txt\n"
-        single += "tracker[%d]:\n  " % i + position + "  " + \
-            leaf.replace("%s", "")
+        single += "tracker[%d]:\n  %s\n" % (i, position)
+        single += "".join("  %s\n" % line for line in leaf)
     # a second, plain tracker after the Multi one keeps its own index
     multi += "tracker[1]:\n  position: [-2. pc, 2. pc, 0.3 pc]\n"
     (tmp_path / "multi.yml").write_text(multi)
@@ -911,3 +912,55 @@ def test_multi_tracker_counts_equal_separate_trackers(exe, tmp_path):
             "  reference direction: [0, 0, 1]\n"
             "tracker[2]:\n  output name: cell.txt.2.txt\n"
             "  type: AbsorptionTracker\n"), toc
+
+
+@pytest.mark.gpu
+def test_copies_cascade_is_cut_back_to_the_group_limit(exe, tmp_path):
+    """Two stars in different blocks of a 4 x 4 x 2 decomposition with
+    --copies 8: the full cascade (8 engines per source block, 4 and 2 for the
+    rings of neighbours) needs far more than the 64 engines of a group. The
+    reference has no such limit, so the cascade is cut back - outermost rings
+    first, then fewer copies per source block - instead of refusing the run;
+    the result is the undivided grid's (copies only share work)."""
+    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = text.replace("[64, 64, 64]", "[24, 24, 12]")
+    text = text.replace("number of photons: 1e6", "number of photons: 40000")
+    text = text.replace("number of iterations: 20", "number of iterations: 3")
+    text = text.replace("type: Gadget", "type: AsciiFile")
+    old = text[text.index("PhotonSourceDistribution:"):]
+    old = old[:old.index("\n\n")]
+    text = text.replace(old, "PhotonSourceDistribution:\n  type: AsciiFile\n"
+                        "  filename: stars.yml")
+    stars = ("number of sources: 2\n"
+             "source[0]:\n  position: [-3.1 pc, -3.3 pc, -1.2 pc]\n"
+             "  luminosity: 3.e49 s^-1\n"
+             "source[1]:\n  position: [1.4 pc, 3.2 pc, 2.1 pc]\n"
+             "  luminosity: 1.26e49 s^-1\n")
+    runs = {}
+    for label, extra in (("whole", []),
+                         ("blocks", ["--blocks", "4,4,2", "--copies", "8"])):
+        d = tmp_path / label
+        d.mkdir()
+        (d / "run.param").write_text(text)
+        (d / "stars.yml").write_text(stars)
+        r = subprocess.run([exe, "--params", "run.param",
+                            "--output-statistics"] + extra,
+                           capture_output=True, text=True, cwd=str(d))
+        assert r.returncode == 0, r.stderr
+        snapshots = sorted(f for f in os.listdir(d) if f.endswith("003.txt"))
+        assert len(snapshots) == 1, os.listdir(d)
+        runs[label] = (np.loadtxt(d / snapshots[0]), r.stdout)
+    out = runs["blocks"][1]
+    assert "8 engines per source block asked for" in out, out
+    assert "granted" in out and "at most 64 engines" in out
+    line = [l for l in out.splitlines() if "Domain decomposition" in l][0]
+    # "Domain decomposition: 32 blocks and N copies of source blocks ..."
+    words = line.split()
+    nblocks, ncopies = int(words[2]), int(words[5])
+    assert nblocks == 32 and 0 < ncopies <= 32
+    whole, blocks = runs["whole"][0], runs["blocks"][0]
+    x = whole[:, 5]
+    assert 0.02 < (x < 0.5).mean() < 0.98
+    rel = np.abs(blocks[:, 5] - x) / x
+    assert np.median(rel) < 1e-5
+    assert (rel < 1e-2).mean() > 0.97, (rel > 1e-2).sum()

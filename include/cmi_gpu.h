@@ -570,6 +570,14 @@ int cmi_gpu_group_update_cells(cmi_gpu_group *group, uint32_t loop,
 int cmi_gpu_group_exchange_flights(cmi_gpu_group *group, uint32_t seed,
                                    uint32_t iteration, uint64_t first_packet,
                                    uint64_t *total_flights);
+/* What the exchange rounds cost on the HOST (the reference's counterpart is
+ * the queue handling of src/TaskBasedIonizationSimulation.cpp:643-1073): over
+ * the *rounds rounds that moved flights since the last reset, microseconds[0]
+ * = until the n x n counts were known on the host, [1] = starting and joining
+ * the owners' host threads beyond the longest cmi_gpu_shoot_flights call, [2]
+ * = the whole of cmi_gpu_group_exchange_flights (with the flights). */
+int cmi_gpu_group_exchange_stats(cmi_gpu_group *group, uint64_t *rounds,
+                                 double *microseconds, int32_t reset);
 
 /* --------------------------------------------------- test / measurement -- */
 

@@ -85,3 +85,46 @@ def test_more_ranks_than_gpus_is_refused():
     assert r.returncode != 0
     assert "GPU(s) are visible" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_eight_ranks_on_one_device():
+    """The driver's 8-GPU command line with all eight ranks on device 0
+    (collectives over gloo): replica mode on the Stromgren config and domain
+    mode (2 x 2 x 2 blocks, flights exchanged between ranks, per-rank cell
+    update) on lexingtonHII40 - config 5's shape. Eight ranks in every
+    collective, rank 0 prints the line, and the state is the one-rank run's
+    (domain mode flies the same packets)."""
+    small = ["--steps", "2", "--warmup", "1", "--ncell", "48", "--packets",
+             "2e5", "--converge-iterations", "6", "--no-cpu-baseline"]
+
+    def run(ranks, extra):
+        env = dict(os.environ, CMI_BENCH_BACKEND="gloo")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), "bench.py", "--gpus",
+               str(ranks)] if ranks > 1 else \
+            [sys.executable, "bench.py", "--gpus", "1"]
+        r = subprocess.run(cmd + small + extra, cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+
+    replica = run(8, [])
+    assert replica["n_gpus"] == 8 and replica["ranks_in_collective"] == 8
+    assert replica["scaling"] == "weak"
+    assert replica["packets_per_rank_per_step"] == 2e5
+    assert "strong_scaling" in replica
+    one = run(1, ["--config", "lexington"])
+    domain = run(8, ["--config", "lexington", "--decomposition", "domain"])
+    assert domain["n_gpus"] == 8 and domain["ranks_in_collective"] == 8
+    assert domain["scaling"] == "strong"
+    assert domain["packets_per_rank_per_step"] == 2e5 / 8
+    assert "domain x8" in domain["config"]["parallelism"]
+    assert domain["exchange_rounds_last_step"] >= 2
+    assert domain["flights_exchanged_last_step"] > 0
+    ref = one["ionized_volume_fraction"]
+    assert abs(domain["ionized_volume_fraction"] - ref) < 2e-3 * ref
+    assert abs(domain["dda_steps_per_packet"] -
+               one["dda_steps_per_packet"]) < 1e-3 * one["dda_steps_per_packet"]

@@ -34,7 +34,7 @@ for s in starts:
         if not m:
             continue
         back = [j for j in range(i + 1, len(body))
-                if re.search(r"s_cbranch\w*\s+" + re.escape(m.group(1)) + r"\b",
+                if re.search(r"s_c?branch\w*\s+" + re.escape(m.group(1)) + r"\b",
                              body[j])]
         if back:
             loops.append((i, back[-1]))

@@ -408,7 +408,19 @@ def main():
                          "accumulators are all-reduced (replica), or every "
                          "rank holds one block and flights are exchanged "
                          "(domain)")
+    ap.add_argument("--copies", type=int, default=1,
+                    help="engines per block that holds a source (the "
+                         "reference's copies of busy subgrids): only 1 here")
     args = ap.parse_args()
+    if args.copies != 1:
+        # (DomainIterationDriver hands a flight to THE rank that owns the cell
+        # it enters; it does not deal flights to several engines of a block)
+        raise SystemExit(
+            "bench.py: --copies %d: the torch.distributed drivers run one "
+            "engine per block (domain) or one per rank (replica) and know no "
+            "copies of busy blocks; copies are the C++ host's - "
+            "`cmi-gpu --blocks BX,BY,BZ --devices ... --copies K` over the "
+            "group API (cmi_gpu_group_*)" % args.copies)
     cfg = CONFIGS[args.config]
     if args.packets is None:
         args.packets = 1e8

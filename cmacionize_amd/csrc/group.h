@@ -222,6 +222,97 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   }
 }
 
+/* One host thread per engine, started once and parked between jobs: the
+ * calls that continue flights (with re-emission cmi_gpu_shoot_flights reads a
+ * few bytes back per generation and blocks its caller) and the sharded cell
+ * update run on them, so that the devices of a group work at the same time.
+ * Round 3 started and joined fresh threads in every exchange round (100-240
+ * us of host time per round, profiles/r04/group_rounds.txt). */
+class GroupWorkers {
+  std::vector<std::thread> _threads;
+  std::mutex _mutex;
+  std::condition_variable _work, _done;
+  const std::function<void(int)> *_job = nullptr;
+  std::vector<char> _wanted;
+  uint64_t _generation = 0;
+  int _pending = 0;
+  bool _stop = false;
+
+  void loop(int k) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int)> *job = nullptr;
+      {
+        std::unique_lock<std::mutex> lock(_mutex);
+        _work.wait(lock, [&] { return _stop || _generation != seen; });
+        if (_stop)
+          return;
+        seen = _generation;
+        if (_wanted[k])
+          job = _job;
+      }
+      if (!job)
+        continue;
+      (*job)(k);
+      {
+        std::lock_guard<std::mutex> lock(_mutex);
+        if (--_pending == 0)
+          _done.notify_all();
+      }
+    }
+  }
+
+public:
+  ~GroupWorkers() {
+    {
+      std::lock_guard<std::mutex> lock(_mutex);
+      _stop = true;
+    }
+    _work.notify_all();
+    for (std::thread &t : _threads)
+      t.join();
+  }
+  /* job(k) for every k with wanted[k], each on worker k; returns when all
+   * are done. (Called from one thread at a time.) */
+  void run(const std::vector<char> &wanted,
+           const std::function<void(int)> &job) {
+    const int n = (int)wanted.size();
+    int count = 0, only = -1;
+    for (int k = 0; k < n; ++k)
+      if (wanted[k]) {
+        ++count;
+        only = k;
+      }
+    if (count == 0)
+      return;
+    if (count == 1) {
+      job(only); /* nothing to overlap with */
+      return;
+    }
+    if ((int)_threads.size() < n) {
+      {
+        std::lock_guard<std::mutex> lock(_mutex);
+        _wanted.resize(n, 0);
+      }
+      while ((int)_threads.size() < n) {
+        const int k = (int)_threads.size();
+        _threads.emplace_back([this, k] { loop(k); });
+      }
+    }
+    {
+      std::lock_guard<std::mutex> lock(_mutex);
+      _wanted.assign(wanted.begin(), wanted.end());
+      _wanted.resize(_threads.size(), 0);
+      _job = &job;
+      _pending = count;
+      ++_generation;
+    }
+    _work.notify_all();
+    std::unique_lock<std::mutex> lock(_mutex);
+    _done.wait(lock, [&] { return _pending == 0; });
+  }
+};
+
 struct cmi_gpu_group {
   int n = 0;
   cmi_gpu_engine *engine[CMI_GROUP_MAX];
@@ -240,6 +331,10 @@ struct cmi_gpu_group {
    * call, summed over the rounds that moved flights */
   double stats_counts_us = 0., stats_threads_us = 0., stats_total_us = 0.;
   uint64_t stats_rounds = 0;
+  GroupWorkers workers;
+  /* pinned host memory for the rounds' counts: per source the rows it
+   * exported and how many of them go to each engine ([n][n + 1]) */
+  unsigned int *host_counts = nullptr;
 };
 
 /* fn(k), k < n, on one host thread each: the engines' cell updates block
@@ -385,6 +480,8 @@ int cmi_gpu_group_destroy(cmi_gpu_group *g) {
   for (GroupClass &c : g->classes)
     for (RcclApi::comm_t comm : c.comm)
       (void)g_rccl.CommDestroy(comm);
+  if (g->host_counts)
+    (void)hipHostFree(g->host_counts);
   delete g;
   return CMI_GPU_OK;
 }
@@ -660,26 +757,38 @@ int cmi_gpu_group_exchange_flights(cmi_gpu_group *g, uint32_t seed,
     group_route_count_kernel<<<e->num_cu * 4, CMI_BLOCK, 0, e->stream>>>(a);
     HIP_TRY(hipGetLastError());
   }
-  /* the n x n counts (and the overflow check of every export buffer) */
+  /* the n x n counts (and the overflow check of every export buffer): into
+   * pinned host memory, all copies enqueued before the first wait */
+  if (!g->host_counts)
+    HIP_TRY(hipHostMalloc(&g->host_counts,
+                          sizeof(unsigned int) * CMI_GROUP_MAX *
+                              (CMI_GROUP_MAX + 1)));
+  for (int s = 0; s < n; ++s) {
+    cmi_gpu_engine *e = g->engine[s];
+    HIP_TRY(hipSetDevice(e->device));
+    unsigned int *row = g->host_counts + (size_t)s * (n + 1);
+    HIP_TRY(hipMemcpyAsync(row, g->hist[s], sizeof(unsigned int) * n,
+                           hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(row + n, e->export_count, sizeof(unsigned int),
+                           hipMemcpyDeviceToHost, e->stream));
+  }
   std::vector<unsigned int> counts((size_t)n * n);
   std::vector<uint64_t> incoming(n, 0);
   for (int s = 0; s < n; ++s) {
     cmi_gpu_engine *e = g->engine[s];
     HIP_TRY(hipSetDevice(e->device));
-    unsigned int exported = 0;
-    HIP_TRY(hipMemcpyAsync(&exported, e->export_count, sizeof exported,
-                           hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(&counts[(size_t)s * n], g->hist[s],
-                           sizeof(unsigned int) * n, hipMemcpyDeviceToHost,
-                           e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    const unsigned int *row = g->host_counts + (size_t)s * (n + 1);
+    const unsigned int exported = row[n];
     if (exported > e->export_capacity)
       return fail(CMI_GPU_ENOMEM,
                   "export buffer overflow: %u flights left a block, room for "
                   "%llu - flights were lost, the iteration is invalid",
                   exported, (unsigned long long)e->export_capacity);
-    for (int d = 0; d < n; ++d)
-      incoming[d] += counts[(size_t)s * n + d];
+    for (int d = 0; d < n; ++d) {
+      counts[(size_t)s * n + d] = row[d];
+      incoming[d] += row[d];
+    }
   }
   uint64_t total = 0;
   for (int d = 0; d < n; ++d)
@@ -750,22 +859,11 @@ int cmi_gpu_group_exchange_flights(cmi_gpu_group *g, uint32_t seed,
     fly_us[d] = microseconds(t0, clock::now());
   };
   const clock::time_point t_fly = clock::now();
-  int owners = 0, last_owner = -1;
+  std::vector<char> wanted(n, 0);
   for (int d = 0; d < n; ++d)
-    if (incoming[d] != 0) {
-      ++owners;
-      last_owner = d;
-    }
-  if (owners == 1) {
-    fly(last_owner);
-  } else {
-    std::vector<std::thread> threads;
-    for (int d = 0; d < n; ++d)
-      if (incoming[d] != 0)
-        threads.emplace_back(fly, d);
-    for (std::thread &t : threads)
-      t.join();
-  }
+    wanted[d] = incoming[d] != 0;
+  const std::function<void(int)> job = fly;
+  g->workers.run(wanted, job);
   const clock::time_point t_end = clock::now();
   for (int d = 0; d < n; ++d)
     if (rcs[d])

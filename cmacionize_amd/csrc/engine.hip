@@ -736,11 +736,16 @@ void update_full_flag(cmi_gpu_engine *e) {
     for (int i = 1; i < CMI_NION; ++i)
       if (e->model.xsec_fixed[i] != 0.)
         full = true;
-  e->full_ions = full;
   /* accumulator layout follows the transport kernel: [16][ncell] when only
    * hydrogen is accumulated (neighbouring cells share 64-B lines), [ncell][16]
-   * when every step updates all 16 values of a cell. The block is zeroed by
-   * every reset_grid, so switching between iterations is safe. */
+   * when every step updates all 16 values of a cell. A switch zeroes the
+   * whole block (reset_grid of a hydrogen-only run clears only the fields
+   * such a run adds to), so switching between iterations is safe. */
+  if (full != e->full_ions && e->acc_block && hipSetDevice(e->device) == hipSuccess)
+    (void)hipMemsetAsync(e->acc_block, 0,
+                         (size_t)CMI_NACC * e->ncell * sizeof(double),
+                         e->stream);
+  e->full_ions = full;
   if (full) {
     e->cells.acc_field_stride = 1;
     e->cells.acc_cell_stride = CMI_NACC;
@@ -1309,9 +1314,19 @@ int cmi_gpu_reset_grid(cmi_gpu_engine *e) {
   if (!e)
     return fail(CMI_GPU_EINVAL, "null engine");
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipMemsetAsync(e->acc_block, 0,
-                         (size_t)CMI_NACC * e->ncell * sizeof(double),
-                         e->stream));
+  const size_t field_bytes = (size_t)e->ncell * sizeof(double);
+  if (e->full_ions) {
+    HIP_TRY(hipMemsetAsync(e->acc_block, 0, CMI_NACC * field_bytes,
+                           e->stream));
+  } else {
+    /* hydrogen-only runs add to J_H (and the two heating fields) only - the
+     * other thirteen fields of the [16][ncell] block stay as zero as the
+     * layout switch left them (update_full_flag) */
+    HIP_TRY(hipMemsetAsync(e->acc_block, 0, field_bytes, e->stream));
+    if (e->config.track_heating)
+      HIP_TRY(hipMemsetAsync(e->acc_block + (size_t)CMI_NION * e->ncell, 0,
+                             2 * field_bytes, e->stream));
+  }
   HIP_TRY(hipMemsetAsync(e->counters, 0,
                          sizeof(CountersDev) * CMI_COUNTER_SHARDS, e->stream));
   return CMI_GPU_OK;
@@ -2611,8 +2626,10 @@ int cmi_gpu_update_cells_range(cmi_gpu_engine *e, uint32_t loop,
     temperature_kernel<<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
   else if (e->full_ions)
     ionization_kernel<true><<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
-  else
+  else if (e->config.track_heating)
     ionization_kernel<false><<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
+  else
+    ionization_kernel<false, false><<<blocks, CMI_BLOCK, 0, e->stream>>>(a);
   HIP_TRY(hipGetLastError());
   {
     int trc = timer_end(e, e->update_events, ev, 0);

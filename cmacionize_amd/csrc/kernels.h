@@ -2319,7 +2319,10 @@ struct UpdateArgs {
 /* IonizationStateCalculator::calculate_ionization_state over the grid
  * (src/IonizationStateCalculator.cpp:511-530 -> :70-272), one cell per lane,
  * grid-stride; also rebuilds the transport record of each cell. */
-template <bool FULL>
+/* HEATING = false: a hydrogen-only run that does not track the heating terms
+ * (no transport kernel adds to them, no temperature solve reads them): their
+ * two fields are neither read nor normalised. */
+template <bool FULL, bool HEATING = true>
 __global__ void __launch_bounds__(CMI_BLOCK)
     ionization_kernel(const UpdateArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -2338,14 +2341,16 @@ __global__ void __launch_bounds__(CMI_BLOCK)
       for (int i = 1; i < CMI_NION; ++i)
         J[i] = 0.;
     }
-    heating[0] = (*acc_at(a.cells, CMI_NION, c));
-    heating[1] = (*acc_at(a.cells, CMI_NION + 1, c));
+    heating[0] = HEATING ? (*acc_at(a.cells, CMI_NION, c)) : 0.;
+    heating[1] = HEATING ? (*acc_at(a.cells, CMI_NION + 1, c)) : 0.;
     cmi_ionization_state_cell(a.model, a.jfac, a.hfac, ntot, T, J, heating, x);
 #pragma unroll
     for (int i = 0; i < CMI_NION; ++i)
       a.cells.x[i][c] = x[i];
-    (*acc_at(a.cells, CMI_NION, c)) = heating[0];
-    (*acc_at(a.cells, CMI_NION + 1, c)) = heating[1];
+    if (HEATING) {
+      (*acc_at(a.cells, CMI_NION, c)) = heating[0];
+      (*acc_at(a.cells, CMI_NION + 1, c)) = heating[1];
+    }
     a.cells.opacity[c] = (ntot > 0.)
                              ? make_double2(ntot * x[ION_H_n], ntot * x[ION_He_n])
                              : make_double2(-1., 0.);

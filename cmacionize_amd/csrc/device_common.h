@@ -291,9 +291,36 @@ struct CellsDev {
   double2 *opacity;
 };
 
+/* Where accumulator f (0-13: J of the ion, 14 / 15: the hydrogen / helium
+ * heating term) sits in a cell's 128-B row of the AoS layout: by ionization
+ * threshold, so that everything a photon below 24.59 eV (He0) can add to -
+ * H0 13.60, O0 13.62, N0 14.53, Ne0 21.56, S+ 23.33, C+ 24.38 eV, the
+ * hydrogen heating term; N+ 29.60 fills the half - lies in the FIRST 64-B
+ * line and the rest - He0, the helium heating term, S++ 34.83, O+ 35.12, Ne+
+ * 40.96, S+++ 47.30, N++ 47.45, C++ 47.89 - in the second. Atomic adds of
+ * zero are not sent, and nine in ten photons of a 40 000 K star (and most
+ * re-emitted ones) are that soft: their steps cost ONE memory-side 64-B
+ * request instead of two - the request rate is what bounds the kernels that
+ * add per step. (SoA blocks keep the accumulators' own order.)
+ * column -> accumulator: 0 7 4 14 9 11 2 5 | 1 15 12 8 10 13 6 3 */
+__host__ __device__ __forceinline__ constexpr int cmi_acc_column(int f) {
+  /* nibble f = column of accumulator f */
+  return (int)((0x93DA5C4B1E72F680ull >> (4 * f)) & 15ull);
+}
+__host__ __device__ __forceinline__ constexpr int cmi_acc_of_column(int col) {
+  /* nibble col = accumulator in column col */
+  return (int)((0x36DA8CF152B9E470ull >> (4 * col)) & 15ull);
+}
+static_assert(cmi_acc_column(0) == 0 && cmi_acc_of_column(3) == 14 &&
+                  cmi_acc_column(15) == 9 && cmi_acc_of_column(15) == 3,
+              "accumulator 0 (J_H) is column 0: a row's base is its address");
+/* columns that hold a mean intensity (not a heating term): bit per column */
+#define CMI_ACC_COLUMNS_OF_IONS 0xFDF7u
+
 __host__ __device__ __forceinline__ double *acc_at(const CellsDev &cells,
                                                    int field, int64_t cell) {
-  return cells.acc_base + field * cells.acc_field_stride +
+  const int at = cells.acc_field_stride == 1 ? cmi_acc_column(field) : field;
+  return cells.acc_base + at * cells.acc_field_stride +
          cell * cells.acc_cell_stride;
 }
 

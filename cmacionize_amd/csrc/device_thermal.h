@@ -182,8 +182,11 @@ struct CellIntegrals {
   const double *J;
   int64_t stride;
   double jfac;
+  /* J points at a cell's row of the AoS accumulator block: its 16 values
+   * stand in threshold order (cmi_acc_column), not in the ions' */
+  bool row = false;
   __device__ __forceinline__ double operator()(int ion) const {
-    return jfac * J[ion * stride];
+    return jfac * J[row ? cmi_acc_column(ion) : ion * stride];
   }
 };
 

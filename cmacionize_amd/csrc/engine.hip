@@ -337,8 +337,10 @@ double *field_pointer(cmi_gpu_engine *e, int field) {
     return nullptr;
   if (field < CMI_GPU_FIELD_MEAN_INTENSITY)
     return e->state_block + (int64_t)field * e->ncell;
-  return e->acc_block + (int64_t)(field - CMI_GPU_FIELD_MEAN_INTENSITY) *
-                            e->cells.acc_field_stride;
+  const int f = field - CMI_GPU_FIELD_MEAN_INTENSITY;
+  if (e->cells.acc_field_stride == 1) /* [ncell][16], rows in threshold order */
+    return e->acc_block + cmi_acc_column(f);
+  return e->acc_block + (int64_t)f * e->cells.acc_field_stride;
 }
 
 /* element stride of a field: 1 for the state fields, the accumulator layout's

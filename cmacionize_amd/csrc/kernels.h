@@ -619,8 +619,11 @@ accumulate_full_grouped(const ShootArgs &a, const double (&wq)[CMI_NACC],
                         double dsw, unsigned int &natomics) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15;
-  const bool writer = lane < 16 && (HEAT || i < CMI_NION);
-  /* accumulator i of cell c: AoS rows of CMI_NACC doubles */
+  /* (lane i: COLUMN i of the row - threshold order, cmi_acc_column - the
+   * transposed weights are staged in that order) */
+  const bool writer =
+      lane < 16 && (HEAT || ((CMI_ACC_COLUMNS_OF_IONS >> i) & 1u) != 0u);
+  /* column i of cell c: AoS rows of CMI_NACC doubles */
   double *const acc_i = a.cells.acc_base + i;
   while (remaining != 0ull) {
     const int lead = __ffsll((long long)remaining) - 1;
@@ -665,8 +668,10 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
                 double *table_val) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15;
-  const bool mine = HEAT || i < CMI_NION;
-  /* accumulator i of cell c: AoS rows of CMI_NACC doubles */
+  /* lane i works on COLUMN i of the cells' rows (threshold order,
+   * cmi_acc_column): the transposed weights are staged in that order */
+  const bool mine = HEAT || ((CMI_ACC_COLUMNS_OF_IONS >> i) & 1u) != 0u;
+  /* column i of cell c: AoS rows of CMI_NACC doubles */
   double *const acc_i = a.cells.acc_base + i;
   double *const table_i = table_val + i;
   double term = accumulate ? dsw : 0.;
@@ -1005,8 +1010,10 @@ __global__ void
       for (int k = threadIdx.x >> 4; k < lds_slots; k += CMI_BLOCK / 16) {
         const int32_t t = lds_tag[k];
         if (t >= 0) {
-          if (HEAT || i < CMI_NION) {
-            atomic_add_f64(acc_at(a.cells, i, t), lds_val[k * CMI_NACC + i]);
+          /* (table rows are in column order, like the cells' rows) */
+          if (HEAT || ((CMI_ACC_COLUMNS_OF_IONS >> i) & 1u) != 0u) {
+            atomic_add_f64(a.cells.acc_base + (int64_t)t * CMI_NACC + i,
+                           lds_val[k * CMI_NACC + i]);
             lds_val[k * CMI_NACC + i] = 0.;
             ++natomics;
           }
@@ -1309,7 +1316,7 @@ __global__ void
         if (FULL) {
 #pragma unroll
           for (int i = 0; i < CMI_NACC; ++i)
-            stage.weight[lane][i] = weights[i];
+            stage.weight[lane][i] = weights[cmi_acc_of_column(i)];
         }
         active = mine;
         last_cell = -1;
@@ -1519,7 +1526,8 @@ __global__ void
               const double dsw = ds * p.weight;
               if (FULL) {
                 for (int ion = 0; ion < CMI_NION; ++ion)
-                  atomic_add_f64(bins + ion, dsw * stage.weight[lane][ion]);
+                  atomic_add_f64(bins + ion,
+                                 dsw * stage.weight[lane][cmi_acc_column(ion)]);
               } else {
                 atomic_add_f64(bins + ION_H_n, dsw * p.sigma_H);
               }
@@ -1703,7 +1711,7 @@ __global__ void
             if (FULL) {
 #pragma unroll
               for (int i = 0; i < CMI_NACC; ++i)
-                stage.weight[lane][i] = weights[i];
+                stage.weight[lane][i] = weights[cmi_acc_of_column(i)];
             }
           }
         }
@@ -2454,6 +2462,7 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   CellIntegrals J;
   J.J = a.cells.acc_base;
   J.stride = a.cells.acc_field_stride;
+  J.row = a.cells.acc_field_stride == 1;
   J.jfac = a.jfac;
   for (;;) {
     /* take the next cell(s): up to four that need no solve per trip */

@@ -227,9 +227,14 @@ int cmi_gpu_download_field(cmi_gpu_engine *engine, int32_t field,
  * HEATING+0..1) share ONE contiguous block of 16 * ncell doubles starting at
  * the pointer of MEAN_INTENSITY+0 - that block is what a multi-process caller
  * sum-reduces; inside it element (field f, cell c) is at
- * f * field_stride + c * cell_stride, with the strides reported by
- * cmi_gpu_accumulator_layout ([16][ncell] for hydrogen-only transport,
- * [ncell][16] when all ions are transported). */
+ * (this function's pointer for f) + c * cell_stride, with the strides reported
+ * by cmi_gpu_accumulator_layout: [16][ncell] for hydrogen-only transport
+ * (field f at f * field_stride); [ncell][16] when all ions are transported,
+ * a cell's 16 values then in the order of their ionization thresholds - J of
+ * H0 O0 N0, the hydrogen heating term, J of Ne0 S+ C+ N+ | J of He0, the
+ * helium heating term, J of S++ O+ Ne+ S+++ N++ C++ - so that a photon below
+ * 24.59 eV touches one 64-B line of the row, not two (field_stride 1 tells
+ * the layout, not the field's offset: ask this function per field). */
 void *cmi_gpu_field_device_pointer(cmi_gpu_engine *engine, int32_t field);
 int cmi_gpu_accumulator_layout(cmi_gpu_engine *engine, int64_t *field_stride,
                                int64_t *cell_stride);

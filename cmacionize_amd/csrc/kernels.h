@@ -1437,9 +1437,15 @@ __global__ void
             }
           }
         }
+        /* (a GLOBAL load: through the laundered pointer the compiler knows
+         * no address space and issues flat_load, which also counts as an LDS
+         * operation - the wait for the table's compare-and-swap below would
+         * then wait for this record as well, every iteration) */
         if (stepping && p.tau >= 0.)
-          pad_next = *reinterpret_cast<const double *>(
-              pad_base + ((uint32_t)p.cell << 3));
+          pad_next = *reinterpret_cast<
+              const __attribute__((address_space(1))) double *>(
+              (const __attribute__((address_space(1))) char *)pad_base +
+              ((uint32_t)p.cell << 3));
         if (CMI_EXP(a) == 12) {
           /* experiment: the march alone (results are wrong) */
           asm volatile("" ::"v"(ds), "s"(accumulating));

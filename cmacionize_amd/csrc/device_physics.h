@@ -113,15 +113,22 @@ __host__ __device__ inline double verner_term_sigma(const VernerTermDev &t,
   if (is <= nint || e >= einn) {
     const double y = e * t.A_E_0_inv;
     const double ym1 = y - 1.;
-    const double Fy = (ym1 * ym1 + t.A_y_w_sq) * pow(y, t.A_Plconst) *
-                      pow(1. + sqrt(y * t.A_y_a_inv), -t.A_P);
+    /* y^a (1 + sqrt(y / y_a))^-P as ONE exponential of two logarithms: a
+     * third of the instructions of two pow() (each of which is a logarithm
+     * and an exponential in extended precision), relative difference
+     * ~|a ln y| x 1e-16 < 1e-14 (round 4: the key kernel of multi-ion runs
+     * spends its 22 ms per launch here) */
+    const double Fy = (ym1 * ym1 + t.A_y_w_sq) *
+                      exp(t.A_Plconst * log(y) -
+                          t.A_P * log(1. + sqrt(y * t.A_y_a_inv)));
     return t.A_sigma_0 * Fy;
   } else {
     const double x = e * t.B_E_0_inv - t.B_y_0;
     const double y = sqrt(x * x + t.B_y_1_sq);
     const double xm1 = x - 1.;
-    const double Fy = (xm1 * xm1 + t.B_y_w_sq) * pow(y, 0.5 * t.B_P - 5.5) *
-                      pow(1. + sqrt(y * t.B_y_a_inv), -t.B_P);
+    const double Fy = (xm1 * xm1 + t.B_y_w_sq) *
+                      exp((0.5 * t.B_P - 5.5) * log(y) -
+                          t.B_P * log(1. + sqrt(y * t.B_y_a_inv)));
     return t.B_sigma_0 * Fy;
   }
 }

@@ -21,7 +21,7 @@ __device__ inline double sample_planck_table(const double *cdf,
       (log10(x) - logcdf[ix]) / (logcdf[ix + 1] - logcdf[ix]) *
           (logfreq[ix + 1] - logfreq[ix]) +
       logfreq[ix];
-  const double frequency = pow(10., log_random_frequency);
+  const double frequency = exp10(log_random_frequency);
   return frequency * 3.288465385e15;
 }
 __device__ inline double sample_planck(const SpectraDev *s, PacketRng &rng) {

@@ -386,9 +386,94 @@ struct TrackersDev {
    * of path length x cross section x weight per photon type and ion */
   int32_t kind[CMI_MAX_TRACKERS]; /* CMI_TRACKER_* */
   double *absorption;             /* [n][4][CMI_NION] */
+  /* WeightedSpectrumTrackers (src/WeightedSpectrumTracker.hpp:44-420): every
+   * crossing adds 1 / (the unit cube's area as the photon sees it) to
+   * flux[4 first_bin[k] + type nbins[k] + bin], the bin from the tracker's
+   * FrequencyBins: type 0 = LinearFrequencyBins (src/LinearFrequencyBins.hpp:
+   * 115-125: nbins[k] bins between bins_min and bins_max, frequencies outside
+   * in the first / last bin), 1 = LevelFrequencyBins
+   * (src/LevelFrequencyBins.hpp:45-70: the 14 ionization energies in
+   * ascending order, up to 4 x hydrogen's) */
+  int32_t bins_type[CMI_MAX_TRACKERS];
+  /* (a weighted tracker's inverse_frequency_width[k] is that of its bins) */
+  double bins_min[CMI_MAX_TRACKERS], bins_max[CMI_MAX_TRACKERS];
+  double level_edges[CMI_NION + 1];
+  double *flux; /* [n][4][nbins[k]] */
 };
 #define CMI_TRACKER_SPECTRUM 0
 #define CMI_TRACKER_ABSORPTION 1
+#define CMI_TRACKER_WEIGHTED 2
+
+#define CMI_BINS_LINEAR 0
+#define CMI_BINS_LEVEL 1
+
+/* FrequencyBins::get_bin_number of tracker k: LinearFrequencyBins.hpp:115-125,
+ * LevelFrequencyBins.hpp:84-86 (Utilities::locate, src/Utilities.hpp:726-742:
+ * bisection for the last edge below the frequency, the last bin for anything
+ * above the upper edge) */
+__host__ __device__ inline int32_t cmi_frequency_bin(const TrackersDev &t,
+                                                     const int k,
+                                                     const double frequency) {
+  if (t.bins_type[k] == CMI_BINS_LEVEL) {
+    uint32_t jl = 0, ju = CMI_NION + 1;
+    while (ju - jl > 1) {
+      const uint32_t jm = (ju + jl) >> 1;
+      if (frequency > t.level_edges[jm])
+        jl = jm;
+      else
+        ju = jm;
+    }
+    return jl == CMI_NION ? CMI_NION - 1 : (int32_t)jl;
+  }
+  if (frequency < t.bins_min[k])
+    return 0;
+  if (frequency >= t.bins_max[k])
+    return t.nbins[k] - 1;
+  return (int32_t)((frequency - t.bins_min[k]) * t.inverse_frequency_width[k]);
+}
+
+/* WeightedSpectrumTracker::get_projected_area,
+ * src/WeightedSpectrumTracker.hpp:200-276: the area of the unit cube's
+ * shadow on a plane perpendicular to the direction. The reference projects
+ * seven corners onto that plane and adds up the areas of six triangles (half
+ * the norms of cross products, taken as sqrt(|u|^2 |w|^2 - (u . w)^2)); its
+ * own test asks for exactly 1 along the axes and exactly sqrt(2) along a face
+ * diagonal, so the same corners, pairs and order of operations are kept. */
+__host__ __device__ inline double cmi_projected_area(const double d[3]) {
+  /* corners 100 010 001 110 101 011 111, projected: v - ((v - m) . d) d */
+  const double corner[7][3] = {{1., 0., 0.}, {0., 1., 0.}, {0., 0., 1.},
+                               {1., 1., 0.}, {1., 0., 1.}, {0., 1., 1.},
+                               {1., 1., 1.}};
+  enum { P100 = 0, P010, P001, P110, P101, P011, P111 };
+  double p[7][3];
+  for (int v = 0; v < 7; ++v) {
+    const double along = (corner[v][0] - 0.5) * d[0] +
+                         (corner[v][1] - 0.5) * d[1] +
+                         (corner[v][2] - 0.5) * d[2];
+    for (int a = 0; a < 3; ++a)
+      p[v][a] = corner[v][a] - d[a] * along;
+  }
+  /* {from, to of the first edge, to of the second edge} of the six triangles */
+  const int triangle[6][3] = {{P100, P101, P111}, {P100, P110, P111},
+                              {P110, P111, P011}, {P110, P011, P010},
+                              {P101, P001, P011}, {P101, P011, P111}};
+  double twice_area = 0.;
+  for (int t = 0; t < 6; ++t) {
+    double u[3], w[3];
+    for (int a = 0; a < 3; ++a) {
+      u[a] = p[triangle[t][1]][a] - p[triangle[t][0]][a];
+      w[a] = p[triangle[t][2]][a] - p[triangle[t][0]][a];
+    }
+    const double uw = u[0] * w[0] + u[1] * w[1] + u[2] * w[2];
+    const double cross2 = (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) *
+                              (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) -
+                          uw * uw;
+    /* ("make sure we don't get NaN" - the reference guards four of the six;
+     * a difference of rounding errors below zero is no area either way) */
+    twice_area += cross2 > 0. ? sqrt(cross2) : 0.;
+  }
+  return 0.5 * twice_area;
+}
 
 struct CountersDev {
   double totweight;

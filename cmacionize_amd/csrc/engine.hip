@@ -10,6 +10,7 @@
 #include "kernels.h"
 #include "sort.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -934,6 +935,7 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->counters);
   (void)hipFree(e->trackers.counts);
   (void)hipFree(e->trackers.absorption);
+  (void)hipFree(e->trackers.flux);
   (void)hipFree(e->temp_pipe_block);
   (void)hipFree(e->pad_H);
   (void)hipFree(e->temp_pipe_counts);
@@ -2719,13 +2721,15 @@ int cmi_gpu_set_trackers(cmi_gpu_engine *e, int32_t n, const double *positions,
       return fail(CMI_GPU_EINVAL, "set_trackers: tracker %d with %d bins",
                   (int)k, (int)nbins[k]);
   for (int32_t k = 0; kinds && k < n; ++k)
-    if (kinds[k] != CMI_TRACKER_SPECTRUM && kinds[k] != CMI_TRACKER_ABSORPTION)
+    if (kinds[k] != CMI_TRACKER_SPECTRUM &&
+        kinds[k] != CMI_TRACKER_ABSORPTION && kinds[k] != CMI_TRACKER_WEIGHTED)
       return fail(CMI_GPU_EINVAL, "set_trackers: unknown kind %d of tracker "
                   "%d", (int)kinds[k], (int)k);
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   (void)hipFree(e->trackers.counts);
   (void)hipFree(e->trackers.absorption);
+  (void)hipFree(e->trackers.flux);
   e->trackers = TrackersDev();
   if (n == 0)
     return CMI_GPU_OK;
@@ -2738,6 +2742,32 @@ int cmi_gpu_set_trackers(cmi_gpu_engine *e, int32_t n, const double *positions,
     t.nbins[k] = nbins[k];
     t.first_bin[k + 1] = t.first_bin[k] + nbins[k];
     t.inverse_frequency_width[k] = 1. / (3. * 3.289e15 / nbins[k]);
+    if (kinds && kinds[k] == CMI_TRACKER_WEIGHTED) {
+      /* LinearFrequencyBins' defaults, src/LinearFrequencyBins.hpp:80-88:
+       * from 13.6 eV to 54.4 eV (in Hz: the electronvolt over Planck's
+       * constant, src/UnitConverter.hpp:156-159,271 with the values of
+       * src/PhysicalConstants.hpp); cmi_gpu_set_tracker_frequency_bins for
+       * others */
+      const double ev = 1.6021766208e-19 / 6.626070040e-34;
+      t.bins_type[k] = CMI_BINS_LINEAR;
+      t.bins_min[k] = 13.6 * ev;
+      t.bins_max[k] = 54.4 * ev;
+      t.inverse_frequency_width[k] = nbins[k] / (t.bins_max[k] - t.bins_min[k]);
+    }
+  }
+  /* LevelFrequencyBins::LevelFrequencyBins, src/LevelFrequencyBins.hpp:52-66:
+   * the ionization energies of src/ElementData.hpp:39-105 (Hz) in ascending
+   * order, closed by four times hydrogen's */
+  {
+    const double energies[CMI_NION] = {
+        3.28810279e+15, 5.94523574e+15, 5.89588678e+15, 1.15792700e+16,
+        3.51435505e+15, 7.15759434e+15, 1.14732262e+16, 3.29284691e+15,
+        8.49136314e+15, 5.21432028e+15, 9.90492110e+15, 5.64310422e+15,
+        8.41222200e+15, 1.14182796e+16};
+    for (int i = 0; i < CMI_NION; ++i)
+      t.level_edges[i] = energies[i];
+    std::sort(t.level_edges, t.level_edges + CMI_NION);
+    t.level_edges[CMI_NION] = 4. * energies[ION_H_n];
   }
   const GridDev &g = e->grid;
   for (int32_t k = 0; k < n; ++k) {
@@ -2777,7 +2807,64 @@ int cmi_gpu_set_trackers(cmi_gpu_engine *e, int32_t n, const double *positions,
   const size_t abytes = sizeof(double) * 4 * CMI_NION * (size_t)n;
   HIP_TRY(hipMalloc(&t.absorption, abytes));
   HIP_TRY(hipMemsetAsync(t.absorption, 0, abytes, e->stream));
+  const size_t fbytes = sizeof(double) * 4 * (size_t)t.first_bin[n];
+  HIP_TRY(hipMalloc(&t.flux, fbytes));
+  HIP_TRY(hipMemsetAsync(t.flux, 0, fbytes, e->stream));
   e->trackers = t;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_tracker_frequency_bins(cmi_gpu_engine *e, int32_t tracker,
+                                       int32_t type, double minimum_frequency,
+                                       double maximum_frequency) {
+  if (!e)
+    return fail(CMI_GPU_EINVAL, "null engine");
+  if (tracker < 0 || tracker >= e->trackers.n ||
+      e->trackers.kind[tracker] != CMI_TRACKER_WEIGHTED)
+    return fail(CMI_GPU_EINVAL, "set_tracker_frequency_bins: tracker %d is "
+                "not a weighted spectrum tracker", (int)tracker);
+  TrackersDev &t = e->trackers;
+  if (type == CMI_BINS_LEVEL) {
+    if (t.nbins[tracker] != CMI_NION)
+      return fail(CMI_GPU_EINVAL, "set_tracker_frequency_bins: level bins are "
+                  "%d bins, tracker %d has %d", CMI_NION, (int)tracker,
+                  (int)t.nbins[tracker]);
+    t.bins_type[tracker] = CMI_BINS_LEVEL;
+    return CMI_GPU_OK;
+  }
+  if (type != CMI_BINS_LINEAR)
+    return fail(CMI_GPU_EINVAL, "Unknown FrequencyBins type: %d", (int)type);
+  if (!(maximum_frequency > minimum_frequency))
+    return fail(CMI_GPU_EINVAL, "set_tracker_frequency_bins: empty frequency "
+                "range");
+  t.bins_type[tracker] = CMI_BINS_LINEAR;
+  t.bins_min[tracker] = minimum_frequency;
+  t.bins_max[tracker] = maximum_frequency;
+  t.inverse_frequency_width[tracker] =
+      t.nbins[tracker] / (maximum_frequency - minimum_frequency);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_projected_areas(const double *directions, int64_t n,
+                            double *areas) {
+  if (n < 0 || (n > 0 && (!directions || !areas)))
+    return fail(CMI_GPU_EINVAL, "projected_areas: bad argument");
+  for (int64_t i = 0; i < n; ++i)
+    areas[i] = cmi_projected_area(directions + 3 * i);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_get_tracker_flux(cmi_gpu_engine *e, double *flux) {
+  if (!e || !flux)
+    return fail(CMI_GPU_EINVAL, "get_tracker_flux: bad argument");
+  if (e->trackers.n == 0)
+    return fail(CMI_GPU_ESTATE, "get_tracker_flux: no trackers set");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(flux, e->trackers.flux,
+                    sizeof(double) * 4 *
+                        (size_t)e->trackers.first_bin[e->trackers.n],
+                    hipMemcpyDeviceToHost));
   return CMI_GPU_OK;
 }
 

@@ -1539,6 +1539,17 @@ __global__ void
               }
               continue;
             }
+            if (a.trackers.kind[k] == CMI_TRACKER_WEIGHTED) {
+              /* src/WeightedSpectrumTracker.hpp:300-319: one over the area
+               * the cell shows the packet, by photon type and frequency bin */
+              const double direction[3] = {p.dir[0], p.dir[1], p.dir[2]};
+              atomic_add_f64(
+                  a.trackers.flux + 4 * (size_t)a.trackers.first_bin[k] +
+                      (size_t)p.type * (size_t)a.trackers.nbins[k] +
+                      (size_t)cmi_frequency_bin(a.trackers, k, p.nu),
+                  1. / cmi_projected_area(direction));
+              continue;
+            }
             const double *d = a.trackers.direction[k];
             if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] > 0. &&
                 p.dir[0] * d[0] + p.dir[1] * d[1] + p.dir[2] * d[2] <

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CMI_GPU_LIBRARY",
                           os.path.join(_HERE, "libcmi_gpu.so"))
 
 NION = 14
-TRACKER_SPECTRUM, TRACKER_ABSORPTION = 0, 1
+TRACKER_SPECTRUM, TRACKER_ABSORPTION, TRACKER_WEIGHTED_SPECTRUM = 0, 1, 2
 NACC = 16
 NTYPE = 4
 
@@ -88,7 +88,8 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_compute_emissivities",
     "cmi_gpu_set_spectrum_trackers", "cmi_gpu_enable_trackers",
     "cmi_gpu_get_tracker_counts", "cmi_gpu_set_trackers",
-    "cmi_gpu_get_tracker_absorption",
+    "cmi_gpu_get_tracker_absorption", "cmi_gpu_set_tracker_frequency_bins",
+    "cmi_gpu_get_tracker_flux", "cmi_gpu_projected_areas",
 ]
 
 # the emission lines of EmissivityValues (src/EmissivityValues.hpp:36-81), in
@@ -203,6 +204,10 @@ def load_library():
                                        C.POINTER(C.c_int32), _dp, _dp]
     L.cmi_gpu_get_tracker_absorption.argtypes = [vp, _dp]
     L.cmi_gpu_enable_trackers.argtypes = [vp, C.c_int32]
+    L.cmi_gpu_set_tracker_frequency_bins.argtypes = [
+        vp, C.c_int32, C.c_int32, C.c_double, C.c_double]
+    L.cmi_gpu_get_tracker_flux.argtypes = [vp, _dp]
+    L.cmi_gpu_projected_areas.argtypes = [_dp, C.c_int64, _dp]
     L.cmi_gpu_get_tracker_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.cmi_gpu_update_cells_range.argtypes = [vp, C.c_uint32, C.c_double,
                                              C.c_int64, C.c_int64]
@@ -221,6 +226,17 @@ def load_library():
         vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_int32]
     _lib = L
     return L
+
+
+def projected_areas(directions):
+    """WeightedSpectrumTracker::get_projected_area of unit vectors ([n][3]),
+    by the function the kernels call, run on the host"""
+    d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros(len(d))
+    rc = load_library().cmi_gpu_projected_areas(_p(d), len(d), _p(out))
+    if rc != 0:
+        raise RuntimeError("cmi_gpu_projected_areas failed (%d)" % rc)
+    return out
 
 
 def _p(a):
@@ -586,6 +602,28 @@ class GpuEngine:
         n, _ = self._trackers
         out = np.zeros((n, 4, NION))
         self._check(self._lib.cmi_gpu_get_tracker_absorption(self._h, _p(out)))
+        return out
+
+    def set_tracker_frequency_bins(self, tracker, kind="Linear",
+                                   minimum_frequency=0., maximum_frequency=0.):
+        """FrequencyBins of a weighted spectrum tracker: "Linear" between
+        the two frequencies (Hz) or "Level" (one bin per ion)."""
+        self._check(self._lib.cmi_gpu_set_tracker_frequency_bins(
+            self._h, tracker, {"Linear": 0, "Level": 1}[kind],
+            minimum_frequency, maximum_frequency))
+
+    def get_tracker_flux(self):
+        """flux[tracker][photon type (4)][bin]: the sums of the weighted
+        spectrum trackers (zeros for the other kinds); a list of [4][bins]
+        arrays"""
+        n, nbins = self._trackers
+        bins = [nbins] * n if np.isscalar(nbins) else list(nbins)
+        flat = np.zeros(4 * max(sum(bins), 1))
+        self._check(self._lib.cmi_gpu_get_tracker_flux(self._h, _p(flat)))
+        out, at = [], 0
+        for b in bins:
+            out.append(flat[at:at + 4 * b].reshape(4, b))
+            at += 4 * b
         return out
 
     def enable_trackers(self, on=True):

@@ -407,6 +407,55 @@ class TrackerManager {
   const std::string _hdf5_name;
   std::vector<uint64_t> _counts;
   std::vector<double> _absorption; /* [leaf][4 types][14 ions] */
+  /* WeightedSpectrum leaves (src/WeightedSpectrumTracker.hpp): their
+   * FrequencyBins (src/FrequencyBinsFactory.hpp:57-72) per leaf, the side of
+   * the cell they sit in, and their sums [leaf][4 types][bins of the leaf] */
+  std::vector<int32_t> _bins_type;
+  std::vector<double> _bins_minimum, _bins_maximum;
+  double _side_length = 0.;
+  std::vector<double> _flux;
+  /* HDF5 output (src/TrackerManager.hpp:141-161): trackers that are the
+   * same_group() share a group of the file */
+  std::vector<size_t> _tracker_groups, _group_size, _group_index;
+
+  /* LevelFrequencyBins: the ionization energies in ascending order with their
+   * ions (src/LevelFrequencyBins.hpp:52-66, src/ElementData.hpp:39-105) */
+  static const std::pair<double, int> *level_bins() {
+    static const std::pair<double, int> bins[NUMBER_OF_IONNAMES] = {
+        {3.28810279e+15, ION_H_n},   {3.29284691e+15, ION_O_n},
+        {3.51435505e+15, ION_N_n},   {5.21432028e+15, ION_Ne_n},
+        {5.64310422e+15, ION_S_p1},  {5.89588678e+15, ION_C_p1},
+        {5.94523574e+15, ION_He_n},  {7.15759434e+15, ION_N_p1},
+        {8.41222200e+15, ION_S_p2},  {8.49136314e+15, ION_O_p1},
+        {9.90492110e+15, ION_Ne_p1}, {1.14182796e+16, ION_S_p3},
+        {1.14732262e+16, ION_N_p2},  {1.15792700e+16, ION_C_p2}};
+    return bins;
+  }
+  /* FrequencyBins::get_frequency of a weighted leaf's bin
+   * (src/LinearFrequencyBins.hpp:133-135: the middle of the bin;
+   * src/LevelFrequencyBins.hpp:94-96: its lower edge) */
+  double bin_frequency(int t, int32_t bin) const {
+    if (_bins_type[t] == CMI_GPU_FREQUENCY_BINS_LEVEL)
+      return level_bins()[bin].first;
+    const double width =
+        (_bins_maximum[t] - _bins_minimum[t]) / _number_of_bins[t];
+    return _bins_minimum[t] + (0.5 + bin) * width;
+  }
+  /* Tracker::same_group (src/AbsorptionTracker.hpp:170-172,
+   * src/WeightedSpectrumTracker.hpp:348-357 with FrequencyBins::is_same) */
+  bool same_group(const Node &a, const Node &b) const {
+    if (a.leaf < 0 || b.leaf < 0 || _kinds[a.leaf] != _kinds[b.leaf])
+      return false;
+    if (_kinds[a.leaf] == CMI_GPU_TRACKER_ABSORPTION)
+      return true;
+    const int s = a.leaf, t = b.leaf;
+    if (_bins_type[s] != _bins_type[t])
+      return false;
+    return _bins_type[s] == CMI_GPU_FREQUENCY_BINS_LEVEL ||
+           (_number_of_bins[s] == _number_of_bins[t] &&
+            _bins_minimum[s] == _bins_minimum[t] &&
+            _bins_maximum[s] == _bins_maximum[t]);
+  }
 
   static const char *photontype_name(int type) {
     /* get_photontype_name, src/PhotonType.hpp:64-85 */
@@ -439,18 +488,47 @@ class TrackerManager {
       }
       return node;
     }
-    if (type != "Spectrum" && type != "Absorption")
+    if (type != "Spectrum" && type != "Absorption" &&
+        type != "WeightedSpectrum")
       throw ParameterError("Unknown Tracker type: \"" + type + "\"");
     if (_kinds.size() == 16)
       throw ParameterError("at most 16 trackers");
     const bool absorption = type == "Absorption";
+    const bool weighted = type == "WeightedSpectrum";
     node.leaf = (int)_kinds.size();
     _kinds.push_back(absorption ? CMI_GPU_TRACKER_ABSORPTION
+                     : weighted ? CMI_GPU_TRACKER_WEIGHTED_SPECTRUM
                                 : CMI_GPU_TRACKER_SPECTRUM);
     double angle = 3.141592653589793;
     double v[3] = {0., 0., 0.};
     int32_t bins = 1; /* (an absorption tracker has no spectrum) */
-    if (!absorption) {
+    int32_t bins_type = CMI_GPU_FREQUENCY_BINS_LINEAR;
+    double bins_minimum = 0., bins_maximum = 0.;
+    if (weighted) {
+      /* WeightedSpectrumTracker(name, blocks) ->
+       * FrequencyBinsFactory::generate, src/FrequencyBinsFactory.hpp:57-72;
+       * LinearFrequencyBins(name, blocks), src/LinearFrequencyBins.hpp:80-88 */
+      const std::string bins_name = name + "FrequencyBins:";
+      const std::string bt = blocks.get_string(bins_name + "type", "Linear");
+      if (bt == "Level") {
+        bins_type = CMI_GPU_FREQUENCY_BINS_LEVEL;
+        bins = NUMBER_OF_IONNAMES;
+      } else if (bt == "Linear") {
+        bins = (int32_t)blocks.get_integer(bins_name + "number of bins", 100);
+        if (bins < 1)
+          throw ParameterError("a tracker needs at least one bin");
+        bins_minimum = blocks.get_physical_value(
+            QUANTITY_FREQUENCY, bins_name + "minimum frequency", "13.6 eV");
+        bins_maximum = blocks.get_physical_value(
+            QUANTITY_FREQUENCY, bins_name + "maximum frequency", "54.4 eV");
+      } else {
+        throw ParameterError("Unknown FrequencyBins type: \"" + bt + "\".");
+      }
+    }
+    _bins_type.push_back(bins_type);
+    _bins_minimum.push_back(bins_minimum);
+    _bins_maximum.push_back(bins_maximum);
+    if (!absorption && !weighted) {
       bins = (int32_t)blocks.get_integer(name + "number of bins", 100);
       if (bins < 1)
         throw ParameterError("a tracker needs at least one bin");
@@ -487,6 +565,21 @@ class TrackerManager {
     const double frequency_width = 3. * 3.289e15 / nbins;
     const uint64_t *c = _counts.data() + 3 * first_bin_of(t);
     std::ofstream ofile(filename);
+    if (_kinds[t] == CMI_GPU_TRACKER_WEIGHTED_SPECTRUM) {
+      /* WeightedSpectrumTracker::output_tracker, :325-341 */
+      const double *f = _flux.data() + 4 * first_bin_of(t);
+      ofile << "# frequency (Hz)";
+      for (int type = 0; type < 4; ++type)
+        ofile << "\t" << photontype_name(type) << " flux (s^-1 m^-2)";
+      ofile << "\n";
+      for (int32_t i = 0; i < nbins; ++i) {
+        ofile << bin_frequency(t, i);
+        for (int type = 0; type < 4; ++type)
+          ofile << "\t" << f[(size_t)type * (size_t)nbins + i];
+        ofile << "\n";
+      }
+      return;
+    }
     if (_kinds[t] == CMI_GPU_TRACKER_ABSORPTION) {
       ofile << "# Ion ";
       for (int type = 0; type < 4; ++type)
@@ -521,6 +614,12 @@ class TrackerManager {
     const int t = node.leaf;
     if (_kinds[t] == CMI_GPU_TRACKER_ABSORPTION) {
       stream << prefix << "type: AbsorptionTracker\n";
+      return;
+    }
+    if (_kinds[t] == CMI_GPU_TRACKER_WEIGHTED_SPECTRUM) {
+      /* src/WeightedSpectrumTracker.hpp:441-445 */
+      stream << prefix << "type: WeightedSpectrum\n";
+      stream << prefix << "number of bins: " << _number_of_bins[t] << "\n";
       return;
     }
     /* (the reference keeps the cosine and the normalised direction) */
@@ -582,12 +681,28 @@ public:
           name + "output name",
           "Tracker" + std::to_string(i) + (_hdf5_output ? "" : ".txt")));
     }
-    if (_hdf5_output)
+    if (_hdf5_output) {
       for (const Node &node : _trackers)
-        if (node.leaf < 0 || _kinds[node.leaf] != CMI_GPU_TRACKER_ABSORPTION)
+        if (node.leaf < 0 || _kinds[node.leaf] == CMI_GPU_TRACKER_SPECTRUM)
           throw ParameterError(
-              "TrackerManager:HDF5 output: only Absorption trackers have an "
-              "HDF5 form (as in the reference, src/Tracker.hpp:112-130)");
+              "TrackerManager:HDF5 output: only Absorption and "
+              "WeightedSpectrum trackers have an HDF5 form (as in the "
+              "reference, src/Tracker.hpp:112-130)");
+      /* src/TrackerManager.hpp:141-161 */
+      _group_index.assign(_trackers.size(), 0);
+      for (size_t i = 0; i < _trackers.size(); ++i) {
+        size_t group_id = 0;
+        while (group_id < _tracker_groups.size() &&
+               !same_group(_trackers[_tracker_groups[group_id]], _trackers[i]))
+          ++group_id;
+        if (group_id == _tracker_groups.size()) {
+          _tracker_groups.push_back(i);
+          _group_size.push_back(0);
+        }
+        _group_index[i] = group_id;
+        ++_group_size[group_id];
+      }
+    }
     std::ofstream ofile(filename + ".used-values");
     blocks.print_contents(ofile);
   }
@@ -606,9 +721,21 @@ public:
                                   _kinds.data(), _number_of_bins.data(),
                                   _opening_angles.data(),
                                   _reference_directions.data());
+    for (size_t t = 0; t < size() && rc == CMI_GPU_OK; ++t)
+      if (_kinds[t] == CMI_GPU_TRACKER_WEIGHTED_SPECTRUM)
+        rc = cmi_gpu_set_tracker_frequency_bins(engine, (int32_t)t,
+                                                _bins_type[t], _bins_minimum[t],
+                                                _bins_maximum[t]);
     if (rc == CMI_GPU_OK)
       rc = cmi_gpu_enable_trackers(engine, 1);
     return rc;
+  }
+  /* Tracker::normalize_for_cell of the cells the trackers sit in
+   * (src/TrackerManager.hpp:216,250; WeightedSpectrumTracker::
+   * normalize_for_cell, :96-98): the cells of the Cartesian grid all have
+   * this volume */
+  void normalize_for_cell(const double cell_volume) {
+    _side_length = std::cbrt(cell_volume);
   }
   /* the counts of one engine, added to the total (the copies of a tracker
    * are merged, src/TrackerManager.hpp:307-318) */
@@ -632,6 +759,13 @@ public:
     _absorption.resize(sums.size(), 0.);
     for (size_t k = 0; k < sums.size(); ++k)
       _absorption[k] += sums[k];
+    std::vector<double> flux(4 * total_bins);
+    rc = cmi_gpu_get_tracker_flux(engine, flux.data());
+    if (rc != CMI_GPU_OK)
+      return rc;
+    _flux.resize(flux.size(), 0.);
+    for (size_t k = 0; k < flux.size(); ++k)
+      _flux[k] += flux[k];
     return CMI_GPU_OK;
   }
   /* TrackerManager::normalize -> AbsorptionTracker::normalize
@@ -639,42 +773,97 @@ public:
   void normalize(const double luminosity_per_weight) {
     for (double &v : _absorption)
       v *= luminosity_per_weight;
+    /* WeightedSpectrumTracker::normalize, :106-116 */
+    bool weighted = false;
+    for (int32_t kind : _kinds)
+      weighted = weighted || kind == CMI_GPU_TRACKER_WEIGHTED_SPECTRUM;
+    if (!weighted)
+      return;
+    if (!(_side_length > 0.))
+      throw std::runtime_error("Tracker was not normalized!");
+    const double norm = luminosity_per_weight / (_side_length * _side_length);
+    for (double &v : _flux)
+      v *= norm;
   }
   /* TrackerManager::output_trackers, :323-375 */
   void output_trackers() const {
     if (_hdf5_output) {
-      /* one group: all trackers are AbsorptionTrackers
-       * (AbsorptionTracker::same_group / create_group / append_to_group,
-       * src/AbsorptionTracker.hpp:170-223) */
+      /* one group of the file per set of trackers that are the same_group():
+       * AbsorptionTracker::create_group / append_to_group
+       * (src/AbsorptionTracker.hpp:179-223), WeightedSpectrumTracker's
+       * (src/WeightedSpectrumTracker.hpp:366-428) */
       Hdf5Writer file;
-      const std::string group = "Group0";
-      file.attribute(group, "type", std::string("Absorption"));
-      std::vector<std::string> ion_names;
-      for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
-        ion_names.push_back(ion_name(ion));
-      file.dataset(group, "ion name", ion_names);
-      const size_t n = size();
-      for (int type = 0; type < 4; ++type) {
-        std::vector<double> table(n * NUMBER_OF_IONNAMES);
-        for (size_t t = 0; t < n; ++t)
+      auto table_of = [](const std::vector<double> &table) {
+        return [table](std::ostream &os) {
+          os.write(reinterpret_cast<const char *>(table.data()),
+                   8 * table.size());
+        };
+      };
+      for (size_t igroup = 0; igroup < _tracker_groups.size(); ++igroup) {
+        const std::string group = "Group" + std::to_string(igroup);
+        std::vector<int> leaves; /* of the group's trackers, in file order */
+        std::vector<double> positions;
+        std::vector<std::string> labels;
+        for (size_t i = 0; i < _trackers.size(); ++i)
+          if (_group_index[i] == igroup) {
+            leaves.push_back(_trackers[i].leaf);
+            for (int a = 0; a < 3; ++a)
+              positions.push_back(_tracker_positions[3 * i + a]);
+            labels.push_back(_output_names[i]);
+          }
+        const uint64_t n = leaves.size();
+        const int first = leaves[0];
+        if (_kinds[first] == CMI_GPU_TRACKER_ABSORPTION) {
+          file.attribute(group, "type", std::string("Absorption"));
+          std::vector<std::string> ion_names;
           for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
-            table[t * NUMBER_OF_IONNAMES + ion] =
-                _absorption[(t * 4 + (size_t)type) * NUMBER_OF_IONNAMES + ion];
-        file.dataset(group, std::string(photontype_name(type)) + " absorption",
-                     {(uint64_t)n, (uint64_t)NUMBER_OF_IONNAMES},
-                     [table](std::ostream &os) {
-                       os.write(reinterpret_cast<const char *>(table.data()),
-                                8 * table.size());
-                     });
+            ion_names.push_back(ion_name(ion));
+          file.dataset(group, "ion name", ion_names);
+          for (int type = 0; type < 4; ++type) {
+            std::vector<double> table(n * NUMBER_OF_IONNAMES);
+            for (size_t k = 0; k < n; ++k)
+              for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+                table[k * NUMBER_OF_IONNAMES + ion] =
+                    _absorption[((size_t)leaves[k] * 4 + (size_t)type) *
+                                    NUMBER_OF_IONNAMES +
+                                ion];
+            file.dataset(group,
+                         std::string(photontype_name(type)) + " absorption",
+                         {n, (uint64_t)NUMBER_OF_IONNAMES}, table_of(table));
+          }
+        } else {
+          const uint64_t nbins = (uint64_t)_number_of_bins[first];
+          file.attribute(group, "type", std::string("WeightedSpectrum"));
+          file.attribute(group, "frequency unit", std::string("s^-1"));
+          file.attribute(group, "flux unit", std::string("m^-2 s^-1"));
+          std::vector<double> frequencies(nbins);
+          for (uint64_t i = 0; i < nbins; ++i)
+            frequencies[i] = bin_frequency(first, (int32_t)i);
+          file.dataset(group, "frequencies", {nbins}, table_of(frequencies));
+          if (_bins_type[first] == CMI_GPU_FREQUENCY_BINS_LEVEL) {
+            /* LevelFrequencyBins::get_label, src/LevelFrequencyBins.hpp:
+             * 106-108 */
+            std::vector<std::string> bin_labels;
+            for (uint64_t i = 0; i < nbins; ++i)
+              bin_labels.push_back(ion_name(level_bins()[i].second));
+            file.dataset(group, "bin labels", bin_labels);
+          }
+          for (int type = 0; type < 4; ++type) {
+            std::vector<double> table(n * nbins);
+            for (size_t k = 0; k < n; ++k) {
+              const double *f = _flux.data() + 4 * first_bin_of(leaves[k]) +
+                                (size_t)type * nbins;
+              for (uint64_t i = 0; i < nbins; ++i)
+                table[k * nbins + i] = f[i];
+            }
+            file.dataset(group, std::string(photontype_name(type)) + " flux",
+                         {n, nbins}, table_of(table));
+          }
+        }
+        file.dataset(group, "positions", {n, 3}, table_of(positions));
+        file.dataset(group, "tracker labels", labels);
+        file.attribute(group, "position unit", std::string("m"));
       }
-      const std::vector<double> positions = _positions;
-      file.dataset(group, "positions", {(uint64_t)n, 3},
-                   [positions](std::ostream &os) {
-                     os.write(reinterpret_cast<const char *>(positions.data()),
-                              8 * positions.size());
-                   });
-      file.dataset(group, "tracker labels", _output_names);
-      file.attribute(group, "position unit", std::string("m"));
       file.write(_hdf5_name);
       return;
     }
@@ -1495,6 +1684,7 @@ public:
         lnumphoton = _number_of_photons_init;
       /* src/IonizationSimulation.cpp:367-370 */
       if (_trackers && loop == _number_of_iterations - 1) {
+        _trackers->normalize_for_cell(_density_grid->get_cell_volume());
         for_each_engine([&](cmi_gpu_engine *e) {
           check(_trackers->lower(e), "set_spectrum_trackers");
         });

@@ -393,14 +393,52 @@ int cmi_gpu_set_spectrum_trackers(cmi_gpu_engine *engine, int32_t n,
  * only the H0 column: the other thirteen are path length x 0 in the reference
  * as well. On a block of a decomposed grid a tracker outside
  * the block counts nothing; the caller adds the blocks' (and copies') counts
- * (TrackerManager::normalize merges copies, src/TrackerManager.hpp:307-318). */
+ * (TrackerManager::normalize merges copies, src/TrackerManager.hpp:307-318).
+ *
+ * CMI_GPU_TRACKER_WEIGHTED_SPECTRUM is a WeightedSpectrumTracker
+ * (src/WeightedSpectrumTracker.hpp:44-446): every packet crossing the cell
+ * adds 1 / (the area the unit cube shows along the packet's direction,
+ * get_projected_area, :212-290) to the bin of its frequency, by photon type
+ * (cmi_gpu_get_tracker_flux). Its nbins[k] bins are LinearFrequencyBins from
+ * 13.6 eV to 54.4 eV (src/LinearFrequencyBins.hpp:80-88) until
+ * cmi_gpu_set_tracker_frequency_bins says otherwise; opening angle and
+ * reference direction are not used. */
 #define CMI_GPU_TRACKER_SPECTRUM 0
 #define CMI_GPU_TRACKER_ABSORPTION 1
+#define CMI_GPU_TRACKER_WEIGHTED_SPECTRUM 2
 int cmi_gpu_set_trackers(cmi_gpu_engine *engine, int32_t n,
                          const double *positions, const int32_t *kinds,
                          const int32_t *nbins, const double *opening_angles,
                          const double *reference_directions);
 int cmi_gpu_enable_trackers(cmi_gpu_engine *engine, int32_t enable);
+/* replaces: FrequencyBinsFactory::generate for a WeightedSpectrumTracker
+ * (src/FrequencyBinsFactory.hpp:57-72, `FrequencyBins:type`).
+ * CMI_GPU_FREQUENCY_BINS_LINEAR: the tracker's nbins bins between
+ * minimum_frequency and maximum_frequency (Hz), lower frequencies counted in
+ * the first bin and higher ones in the last (LinearFrequencyBins::
+ * get_bin_number, src/LinearFrequencyBins.hpp:115-125).
+ * CMI_GPU_FREQUENCY_BINS_LEVEL: one bin per ion, from its ionization energy
+ * (src/ElementData.hpp:39-105) to the next higher one, the last up to four
+ * times hydrogen's (src/LevelFrequencyBins.hpp:52-86; the tracker must have
+ * been set with 14 bins; the two frequencies are not used). After
+ * cmi_gpu_set_trackers, before packets fly. */
+#define CMI_GPU_FREQUENCY_BINS_LINEAR 0
+#define CMI_GPU_FREQUENCY_BINS_LEVEL 1
+int cmi_gpu_set_tracker_frequency_bins(cmi_gpu_engine *engine, int32_t tracker,
+                                       int32_t type, double minimum_frequency,
+                                       double maximum_frequency);
+/* The weighted trackers' sums since the trackers were set, tracker after
+ * tracker: tracker k's at flux[4 first_k + type nbins_k + bin], first_k = the
+ * bins of the trackers before it, type in the order of
+ * src/PhotonType.hpp:36-50 (zero rows for the other kinds of tracker). Not
+ * normalised (WeightedSpectrumTracker::normalize multiplies by luminosity /
+ * total weight / the cell's side squared, :106-116). Synchronous. */
+int cmi_gpu_get_tracker_flux(cmi_gpu_engine *engine, double *flux);
+/* probe: WeightedSpectrumTracker::get_projected_area for n directions
+ * ([n][3], unit vectors), evaluated on the host by the function the kernels
+ * call (test/testWeightedSpectrumTracker.cpp's known answers) */
+int cmi_gpu_projected_areas(const double *directions, int64_t n,
+                            double *areas);
 /* absorption[(k * 4 + type) * 14 + ion] since the trackers were set, type in
  * the order of src/PhotonType.hpp:36-50 (the row of PHOTONTYPE_ABSORBED stays
  * zero: no packet flies with that type). Not normalised

@@ -260,6 +260,19 @@ void cmio_set_tracker_kinds(const int32_t *kind, double *absorption);
 /* ... each with its own number of bins (bins[n]; counts then tracker after
  * tracker, [3][bins[k]] each). Call after cmio_set_trackers. */
 void cmio_set_tracker_bins(const int32_t *bins);
+/* ... and some (kind[k] == 2) WeightedSpectrumTrackers
+ * (src/WeightedSpectrumTracker.hpp:44-446): 1 / projected area per crossing in
+ * flux[4 x (bins of the trackers before k) + type bins[k] + bin], the bin from
+ * LinearFrequencyBins between bins_min[k] and bins_max[k] (bins_type[k] == 0)
+ * or LevelFrequencyBins (1, 14 bins). Call after cmio_set_tracker_kinds. */
+void cmio_set_tracker_weighted(double *flux, const int32_t *bins_type,
+                               const double *bins_min, const double *bins_max);
+/* WeightedSpectrumTracker::get_projected_area, :212-290 */
+double cmio_projected_area(const double *direction);
+/* FrequencyBins::get_bin_number (src/LinearFrequencyBins.hpp:115-125 for type
+ * 0, src/LevelFrequencyBins.hpp:84-86 for type 1) */
+int32_t cmio_frequency_bin(int32_t type, int32_t nbins, double minimum,
+                           double maximum, double frequency);
 
 /* A photon packet: src/Photon.hpp:36-69 */
 typedef struct {

@@ -238,7 +238,15 @@ static struct {
   /* a number of bins per tracker (NULL: nbins for all): tracker k's counts
    * then start at 3 x (the bins of the trackers before it) */
   const int32_t *bins;
-} trackers = {0, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL};
+  /* WeightedSpectrumTrackers (src/WeightedSpectrumTracker.hpp:44-446): kind[k]
+   * == 2, sums in flux[4 x (bins of the trackers before k) + type bins[k] +
+   * bin]; bins_type[k] 0 = LinearFrequencyBins between bins_min[k] and
+   * bins_max[k], 1 = LevelFrequencyBins */
+  double *flux;
+  const int32_t *bins_type;
+  const double *bins_min, *bins_max;
+} trackers = {0,    0,    NULL, NULL, NULL, NULL, NULL,
+              NULL, NULL, NULL, NULL, NULL, NULL};
 
 void cmio_set_trackers(int32_t n, int32_t nbins, const int64_t *cell,
                        const double *cos_opening_angle,
@@ -252,6 +260,7 @@ void cmio_set_trackers(int32_t n, int32_t nbins, const int64_t *cell,
   trackers.kind = NULL;
   trackers.absorption = NULL;
   trackers.bins = NULL;
+  trackers.flux = NULL;
 }
 
 void cmio_set_tracker_bins(const int32_t *bins) { trackers.bins = bins; }
@@ -259,6 +268,91 @@ void cmio_set_tracker_bins(const int32_t *bins) { trackers.bins = bins; }
 void cmio_set_tracker_kinds(const int32_t *kind, double *absorption) {
   trackers.kind = kind;
   trackers.absorption = absorption;
+}
+
+void cmio_set_tracker_weighted(double *flux, const int32_t *bins_type,
+                               const double *bins_min, const double *bins_max) {
+  trackers.flux = flux;
+  trackers.bins_type = bins_type;
+  trackers.bins_min = bins_min;
+  trackers.bins_max = bins_max;
+}
+
+/* sqrt(|u|^2 |w|^2 - (u . w)^2) for u = b - a, w = c - a: twice the area of
+ * the triangle a b c, the way src/WeightedSpectrumTracker.hpp:240-278 writes
+ * it (norm2 and dot_product of src/CoordinateVector.hpp: x, y, z in order) */
+static double twice_triangle(const double *a, const double *b, const double *c,
+                             int guarded) {
+  const double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+  const double w[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+  const double uw = u[0] * w[0] + u[1] * w[1] + u[2] * w[2];
+  const double u2 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+  const double w2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double a2 = u2 * w2 - uw * uw;
+  /* "make sure we don't get NaN": only the y and z pairs are guarded */
+  if (guarded)
+    return a2 > 0. ? sqrt(a2) : 0.;
+  return sqrt(a2);
+}
+
+/* WeightedSpectrumTracker::get_projected_area,
+ * src/WeightedSpectrumTracker.hpp:212-290: the corners of the unit cube
+ * around m = (1/2, 1/2, 1/2) projected along the direction, p = v - ((v - m)
+ * . d) d, and the hexagon they span as three pairs of triangles */
+double cmio_projected_area(const double *direction) {
+  double p[2][2][2][3];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int k = 0; k < 2; ++k) {
+        const double v[3] = {(double)i, (double)j, (double)k};
+        const double along = (v[0] - 0.5) * direction[0] +
+                             (v[1] - 0.5) * direction[1] +
+                             (v[2] - 0.5) * direction[2];
+        for (int a = 0; a < 3; ++a)
+          p[i][j][k][a] = v[a] - along * direction[a];
+      }
+  const double ax1 = twice_triangle(p[1][0][0], p[1][0][1], p[1][1][1], 0);
+  const double ax2 = twice_triangle(p[1][0][0], p[1][1][0], p[1][1][1], 0);
+  const double ay1 = twice_triangle(p[1][1][0], p[1][1][1], p[0][1][1], 1);
+  const double ay2 = twice_triangle(p[1][1][0], p[0][1][1], p[0][1][0], 1);
+  const double az1 = twice_triangle(p[1][0][1], p[0][0][1], p[0][1][1], 1);
+  const double az2 = twice_triangle(p[1][0][1], p[0][1][1], p[1][1][1], 1);
+  return 0.5 * (ax1 + ax2 + ay1 + ay2 + az1 + az2);
+}
+
+/* LevelFrequencyBins (src/LevelFrequencyBins.hpp:52-86): get_bin_number is
+ * Utilities::locate (src/Utilities.hpp:726-742) over the ionization energies
+ * of src/ElementData.hpp:39-105 in ascending order and 4 x hydrogen's */
+static int32_t level_bin(double frequency) {
+  static const double edges[CMIO_NION + 1] = {
+      3.28810279e+15, 3.29284691e+15, 3.51435505e+15, 5.21432028e+15,
+      5.64310422e+15, 5.89588678e+15, 5.94523574e+15, 7.15759434e+15,
+      8.41222200e+15, 8.49136314e+15, 9.90492110e+15, 1.14182796e+16,
+      1.14732262e+16, 1.15792700e+16, 4 * 3.28810279e+15};
+  uint32_t jl = 0, ju = CMIO_NION + 1;
+  while (ju - jl > 1) {
+    const uint32_t jm = (ju + jl) >> 1;
+    if (frequency > edges[jm])
+      jl = jm;
+    else
+      ju = jm;
+  }
+  if (jl == CMIO_NION)
+    --jl;
+  return (int32_t)jl;
+}
+
+int32_t cmio_frequency_bin(int32_t type, int32_t nbins, double minimum,
+                           double maximum, double frequency) {
+  if (type == 1)
+    return level_bin(frequency);
+  /* LinearFrequencyBins::get_bin_number, src/LinearFrequencyBins.hpp:115-125,
+   * with the constructor's inverse width, :66-67 */
+  if (frequency < minimum)
+    return 0;
+  if (frequency >= maximum)
+    return nbins - 1;
+  return (int32_t)((frequency - minimum) * (nbins / (maximum - minimum)));
 }
 
 /* SpectrumTracker::count_photon, src/SpectrumTracker.hpp:176-212, and
@@ -275,6 +369,21 @@ static void count_photon(int64_t cell, const cmio_photon *photon, double ds) {
     const double inverse_frequency_width = 1. / (3. * 3.289e15 / nbins);
     if (trackers.cell[k] != cell)
       continue;
+    if (trackers.kind && trackers.kind[k] == 2) {
+      /* WeightedSpectrumTracker::count_photon, :300-319 */
+      if (photon->type >= 0 && photon->type < 4) {
+        const int32_t index = cmio_frequency_bin(
+            trackers.bins_type[k], nbins, trackers.bins_min[k],
+            trackers.bins_max[k], photon->energy);
+        const double inverse_weight =
+            1. / cmio_projected_area(photon->direction);
+        double *bin = trackers.flux + 4 * (base / 3) +
+                      (size_t)photon->type * (size_t)nbins + index;
+#pragma omp atomic
+        *bin += inverse_weight;
+      }
+      continue;
+    }
     if (trackers.kind && trackers.kind[k] != 0) {
       if (photon->type >= 0 && photon->type < 4) {
         double *bins = trackers.absorption +

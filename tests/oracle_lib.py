@@ -556,14 +556,45 @@ def lexington_simulation(ncell=32, star_temperature=40000.):
     return sim
 
 
+def projected_area(direction):
+    """WeightedSpectrumTracker::get_projected_area (cmio_projected_area)"""
+    L = lib()
+    L.cmio_projected_area.argtypes = [dp]
+    L.cmio_projected_area.restype = C.c_double
+    d = np.ascontiguousarray(direction, dtype=np.float64)
+    return L.cmio_projected_area(_ptr(d))
+
+
+def frequency_bin(kind, nbins, minimum, maximum, frequency):
+    """FrequencyBins::get_bin_number (cmio_frequency_bin) of the kind "Linear"
+    or "Level" of bins"""
+    L = lib()
+    L.cmio_frequency_bin.argtypes = [C.c_int32, C.c_int32, C.c_double,
+                                     C.c_double, C.c_double]
+    L.cmio_frequency_bin.restype = C.c_int32
+    return L.cmio_frequency_bin(int(kind == "Level"), nbins, minimum, maximum,
+                                frequency)
+
+
 class Trackers:
     """SpectrumTrackers on cells of the oracle's grid (cmio_set_trackers):
     installed while the object is used as a context manager."""
 
     def __init__(self, cells, nbins=100, opening_angles=None,
-                 reference_directions=None, kinds=None):
+                 reference_directions=None, kinds=None, frequency_bins=None):
         self.cells = np.ascontiguousarray(cells, dtype=np.int64)
         n = len(self.cells)
+        # kinds[k] == 2: a WeightedSpectrumTracker, sums in flux[k][type][bin]
+        # (a list of views); frequency_bins[k] = ("Linear", minimum, maximum)
+        # or ("Level",) - default: Linear from 13.6 eV to 54.4 eV
+        ev = 1.6021766208e-19 / 6.626070040e-34
+        fb = [None] * n if frequency_bins is None else list(frequency_bins)
+        fb = [("Linear", 13.6 * ev, 54.4 * ev) if f is None else tuple(f)
+              for f in fb]
+        self.bins_type = np.array([f[0] == "Level" for f in fb],
+                                  dtype=np.int32)
+        self.bins_min = np.array([f[1] if len(f) > 1 else 0. for f in fb])
+        self.bins_max = np.array([f[2] if len(f) > 2 else 0. for f in fb])
         # nbins: one number for all trackers, or one per tracker (counts is
         # then a list of [3][bins] views)
         self.bins = None
@@ -592,6 +623,12 @@ class Trackers:
             for b in self.bins:
                 self.counts.append(self._flat[at:at + 3 * b].reshape(3, b))
                 at += 3 * int(b)
+        each = [nbins] * n if self.bins is None else [int(b) for b in self.bins]
+        self._flux = np.zeros(4 * max(sum(each), 1))
+        self.flux, at = [], 0
+        for b in each:
+            self.flux.append(self._flux[at:at + 4 * b].reshape(4, b))
+            at += 4 * b
 
     def __enter__(self):
         L = lib()
@@ -615,6 +652,13 @@ class Trackers:
             L.cmio_set_tracker_kinds(
                 self.kinds.ctypes.data_as(C.POINTER(C.c_int32)),
                 _ptr(self.absorption))
+            L.cmio_set_tracker_weighted.argtypes = [
+                dp, C.POINTER(C.c_int32), dp, dp]
+            L.cmio_set_tracker_weighted.restype = None
+            L.cmio_set_tracker_weighted(
+                _ptr(self._flux),
+                self.bins_type.ctypes.data_as(C.POINTER(C.c_int32)),
+                _ptr(self.bins_min), _ptr(self.bins_max))
         return self
 
     def __exit__(self, *exc):

@@ -220,3 +220,69 @@ def test_trackers_with_their_own_numbers_of_bins(oracle):
     assert got[0].sum() == got[2].sum() > 50
     assert got[1].sum() > 0 and got[3].sum() > 0
     eng.close()
+
+
+def test_weighted_spectrum_trackers_match_oracle(oracle):
+    """WeightedSpectrumTrackers (src/WeightedSpectrumTracker.hpp:44-446) with
+    LinearFrequencyBins and LevelFrequencyBins beside a SpectrumTracker in the
+    same cell: every crossing adds 1 / projected area to the bin of the
+    packet's frequency. Engine and oracle see the same crossings; the sums
+    differ by the order of the additions only."""
+    from cmacionize_amd import engine as E
+    ncell, npacket = 20, 40000
+    sim = oracle.lexington_simulation(ncell)
+    eng = lexington_engine(ncell, sim)
+    pc = oracle.PC
+    anchor, side = -5. * pc, 10. * pc
+    positions = np.array([[1.3 * pc, 0.4 * pc, -0.7 * pc],
+                          [1.3 * pc, 0.4 * pc, -0.7 * pc],
+                          [1.3 * pc, 0.4 * pc, -0.7 * pc],
+                          [-2.1 * pc, 1.9 * pc, 0.2 * pc],
+                          [0.01 * pc, 0.01 * pc, 0.01 * pc]])  # in the hole
+    W = E.TRACKER_WEIGHTED_SPECTRUM
+    kinds = [W, E.TRACKER_SPECTRUM, W, W, W]
+    bins = [100, 60, 14, 25, 10]
+    frequency_bins = [None, None, ("Level",), ("Linear", 3.5e15, 6.e15), None]
+    eng.set_trackers(positions, kinds, bins)
+    eng.set_tracker_frequency_bins(2, "Level")
+    eng.set_tracker_frequency_bins(3, "Linear", 3.5e15, 6.e15)
+    with pytest.raises(E.EngineError, match="not a weighted"):
+        eng.set_tracker_frequency_bins(1, "Level")
+    with pytest.raises(E.EngineError, match="level bins are 14"):
+        eng.set_tracker_frequency_bins(0, "Level")
+    cells = [cell_of(p, anchor, side, ncell) for p in positions]
+    sim.run(npacket, 1, seed=42)
+    eng.upload_cells(sim.number_density, sim.temperature,
+                     np.array([np.asarray(x) for x in sim.x]))
+    eng.enable_trackers(True)
+    eng.reset_grid()
+    eng.shoot(42, 1, 0, npacket)
+    got = eng.get_tracker_flux()
+    counts = eng.get_tracker_counts()
+    with oracle.Trackers(cells, bins, kinds=kinds,
+                         frequency_bins=frequency_bins) as t:
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(42, 1, 0, npacket)
+    assert [g.shape for g in got] == [(4, b) for b in bins]
+    for k, (g, want) in enumerate(zip(got, t.flux)):
+        assert np.allclose(g, want, rtol=1e-12, atol=0.), k
+        # an empty bin is empty in both
+        assert np.array_equal(g == 0., want == 0.), k
+    for c, want in zip(counts, t.counts):
+        assert np.array_equal(c, want)
+    # the weighted trackers of the cell saw the SpectrumTracker's packets (and
+    # those outside its frequency range, in their end bins): at least one per
+    # crossing / sqrt(3), at most one per crossing
+    crossings = counts[1].sum()
+    assert crossings > 50
+    for k in (0, 2):
+        total = got[k][:3].sum()
+        assert total >= crossings / np.sqrt(3.) * (1. - 1e-12)
+        assert abs(got[k].sum() - got[0].sum()) <= 1e-12 * got[0].sum()
+    assert got[0][0].sum() > 0. and got[0][1].sum() > 0.
+    assert not got[1].any() and not got[4].any() and not got[0][3].any()
+    # the narrow linear bins collect what lies outside them at their ends
+    assert got[3][:, 0].sum() > 0. and got[3][:, -1].sum() > 0.
+    eng.close()

@@ -564,7 +564,7 @@ def test_ascii_file_source_distribution(exe, tmp_path):
     assert r.returncode == 1 and "number of sources" in r.stderr
 
 
-def tracker_run(exe, tmp_path, label, blocks, hdf5=False):
+def tracker_run(exe, tmp_path, label, blocks, hdf5=False, block_file=None):
     """lexingtonHII40.param at 16^3 with trackers in the last iteration"""
     import shutil
     text = open(os.path.join(BENCH, "lexingtonHII40.param")).read()
@@ -581,7 +581,9 @@ def tracker_run(exe, tmp_path, label, blocks, hdf5=False):
     assert "enable trackers: true" in text
     d = tmp_path / label
     d.mkdir()
-    if hdf5:
+    if block_file is not None:
+        (d / "trackers.yml").write_text(block_file)
+    elif hdf5:
         (d / "trackers.yml").write_text(
             "number of trackers: 2\n"
             "tracker[0]:\n"
@@ -709,6 +711,144 @@ def test_absorption_trackers_as_one_hdf5_file(exe, tmp_path):
         # (text files hold 6 significant digits)
         assert np.allclose(table[0], absorbed[:, column], rtol=1e-5, atol=0.)
     assert not os.path.exists(d / "Tracker0.txt")
+
+
+WEIGHTED_BLOCK_FILE = (
+    "number of trackers: 4\n"
+    "tracker[0]:\n"
+    "  position: [1.3 pc, 0.4 pc, -0.7 pc]\n"
+    "  type: WeightedSpectrum\n"
+    "tracker[1]:\n"
+    "  position: [1.3 pc, 0.4 pc, -0.7 pc]\n"
+    "  type: WeightedSpectrum\n"
+    "  output name: levels\n"
+    "  FrequencyBins:\n"
+    "    type: Level\n"
+    "tracker[2]:\n"
+    "  position: [-2.1 pc, 1.9 pc, 0.2 pc]\n"
+    "  type: WeightedSpectrum\n"
+    "  FrequencyBins:\n"
+    "    type: Linear\n"
+    "    number of bins: 20\n"
+    "    minimum frequency: 13.6 eV\n"
+    "    maximum frequency: 24.6 eV\n"
+    "tracker[3]:\n"
+    "  position: [-2.1 pc, 1.9 pc, 0.2 pc]\n"
+    "  type: WeightedSpectrum\n"
+    "  output name: far levels\n"
+    "  FrequencyBins:\n"
+    "    type: Level\n")
+
+
+def test_weighted_spectrum_block_file_is_parsed(exe, tmp_path):
+    """TrackerFactory's "WeightedSpectrum" (src/TrackerFactory.hpp:60-77) with
+    its FrequencyBins block (src/FrequencyBinsFactory.hpp:57-72,
+    src/LinearFrequencyBins.hpp:80-88 for the defaults). Dry run: no GPU."""
+    (tmp_path / "weighted.yml").write_text(WEIGHTED_BLOCK_FILE)
+    multi_tracker_param(tmp_path, "weighted.yml")
+    run = [exe, "--params", "run.param", "--dry-run"]
+    r = subprocess.run(run, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    used = open(tmp_path / "weighted.yml.used-values").read()
+    assert used.count("type: WeightedSpectrum") == 4
+    assert used.count("type: Level") == 2
+    # the first tracker's bins are all defaults, the third's are given
+    assert "number of bins: 100" in used and "number of bins: 20" in used
+    # (used values are written in SI units: 13.6, 54.4 and 24.6 eV in Hz)
+    assert "minimum frequency: 3.28847e+15 Hz # (default value)" in used
+    assert "maximum frequency: 1.31539e+16 Hz # (default value)" in used
+    assert "maximum frequency: 5.94825e+15 Hz # (24.6 eV)" in used
+    (tmp_path / "weighted.yml").write_text(
+        WEIGHTED_BLOCK_FILE.replace("type: Level", "type: Logarithmic", 1))
+    r = subprocess.run(run, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode != 0
+    assert 'Unknown FrequencyBins type: "Logarithmic".' in r.stderr
+    # HDF5 output: weighted trackers have a form, Spectrum trackers do not
+    text = open(tmp_path / "run.param").read()
+    (tmp_path / "run.param").write_text(text + "  HDF5 output: true\n")
+    (tmp_path / "weighted.yml").write_text(WEIGHTED_BLOCK_FILE)
+    r = subprocess.run(run, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    (tmp_path / "weighted.yml").write_text(
+        WEIGHTED_BLOCK_FILE.replace("type: WeightedSpectrum",
+                                    "type: Spectrum", 1))
+    r = subprocess.run(run, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode != 0 and "HDF5 form" in r.stderr
+
+
+@pytest.mark.gpu
+def test_weighted_spectrum_trackers_through_the_driver(exe, tmp_path):
+    """WeightedSpectrum trackers (src/WeightedSpectrumTracker.hpp) with the
+    two kinds of FrequencyBins (src/FrequencyBinsFactory.hpp:57-72) as text
+    files (output_tracker, :325-341) and as groups of one HDF5 file
+    (create_group / append_to_group, :366-428; trackers with the same bins
+    share a group, src/TrackerManager.hpp:141-161): fluxes per area, the same
+    numbers in both forms."""
+    import hdf5_mini
+    d = tracker_run(exe, tmp_path, "text", None, block_file=WEIGHTED_BLOCK_FILE)
+    head = open(d / "Tracker0.txt").read().splitlines()[0]
+    assert head == ("# frequency (Hz)\tsource photon flux (s^-1 m^-2)\t"
+                    "diffuse H photon flux (s^-1 m^-2)\t"
+                    "diffuse He photon flux (s^-1 m^-2)\t"
+                    "absorbed photon flux (s^-1 m^-2)")
+    a = np.loadtxt(d / "Tracker0.txt")
+    lv = np.loadtxt(d / "levels")
+    c = np.loadtxt(d / "Tracker2.txt")
+    assert a.shape == (100, 5) and lv.shape == (14, 5) and c.shape == (20, 5)
+    ev = 1.6021766208e-19 / 6.626070040e-34
+    width = (54.4 - 13.6) * ev / 100
+    assert np.allclose(a[:, 0], 13.6 * ev + (np.arange(100) + 0.5) * width,
+                       rtol=1e-5)
+    # LevelFrequencyBins::get_frequency: the ionization energies, ascending
+    assert np.allclose(lv[:3, 0], [3.28810e15, 3.29285e15, 3.51436e15],
+                       rtol=1e-5)
+    assert np.all(np.diff(lv[:, 0]) > 0.)
+    # the same crossings in both trackers of the first cell
+    assert np.allclose(a[:, 1:].sum(axis=0), lv[:, 1:].sum(axis=0), rtol=1e-4)
+    assert a[:, 1].sum() > 0. and a[:, 2].sum() > 0. and not a[:, 4].any()
+    # a flux: crossings / projected area x luminosity / total weight / cell
+    # side^2 - of the order of Q / (4 pi r^2) at r = 1.5 pc from a star of
+    # 1e49 photons per second
+    pc = 3.086e16
+    r2 = (1.3 ** 2 + 0.4 ** 2 + 0.7 ** 2) * pc * pc
+    geometric = 1.e49 / (4. * np.pi * r2)
+    assert 0.1 * geometric < a[:, 1].sum() < 1.5 * geometric
+    # the narrow range collects the harder photons in its last bin
+    assert c[-1, 1] > c[-2, 1]
+    h = tracker_run(exe, tmp_path, "hdf5", None, hdf5=True,
+                    block_file=WEIGHTED_BLOCK_FILE)
+    f = hdf5_mini.read(str(h / "absorbed.hdf5"))
+    # groups in the order of their first trackers: [0], [1, 3], [2]
+    g0, g1, g2 = f["/Group0"], f["/Group1"], f["/Group2"]
+    for g in (g0, g1, g2):
+        assert g.attrs["type"] == "WeightedSpectrum"
+        assert g.attrs["frequency unit"] == "s^-1"
+        assert g.attrs["flux unit"] == "m^-2 s^-1"
+        assert g.attrs["position unit"] == "m"
+    assert f["/Group0/tracker labels"].data == ["Tracker0"]
+    assert f["/Group1/tracker labels"].data == ["levels", "far levels"]
+    assert f["/Group2/tracker labels"].data == ["Tracker2"]
+    # (get_ion_name of the ions in the order of their ionization energies)
+    assert f["/Group1/bin labels"].data[:4] == ["H", "O", "N", "Ne"]
+    assert len(f["/Group1/bin labels"].data) == 14
+    assert np.allclose(f["/Group1/positions"].data,
+                       [[1.3 * pc, 0.4 * pc, -0.7 * pc],
+                        [-2.1 * pc, 1.9 * pc, 0.2 * pc]], rtol=1e-12)
+    assert np.allclose(f["/Group0/frequencies"].data, a[:, 0], rtol=1e-5)
+    assert np.allclose(f["/Group1/frequencies"].data, lv[:, 0], rtol=1e-5)
+    for column, name in enumerate(("source photon", "diffuse H photon",
+                                   "diffuse He photon", "absorbed photon")):
+        t0 = np.asarray(f["/Group0/" + name + " flux"].data)
+        t1 = np.asarray(f["/Group1/" + name + " flux"].data)
+        t2 = np.asarray(f["/Group2/" + name + " flux"].data)
+        assert t0.shape == (1, 100) and t1.shape == (2, 14)
+        assert t2.shape == (1, 20)
+        # (text files hold 6 significant digits)
+        assert np.allclose(t0[0], a[:, 1 + column], rtol=1e-5, atol=0.)
+        assert np.allclose(t1[0], lv[:, 1 + column], rtol=1e-5, atol=0.)
+        assert np.allclose(t2[0], c[:, 1 + column], rtol=1e-5, atol=0.)
+    assert np.allclose(np.asarray(f["/Group1/source photon flux"].data)[1],
+                       np.loadtxt(d / "far levels")[:, 1], rtol=1e-5)
 
 
 @pytest.mark.gpu

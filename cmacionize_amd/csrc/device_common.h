@@ -208,6 +208,14 @@ struct TablesDev {
  * HeliumTwoPhotonContinuumSpectrum. 1.65 MB, lives in HBM (L2 resident). */
 #define CMI_NFREQ 1000
 #define CMI_NTEMP 100
+/* Guide tables of the cumulative distributions: guide[k] = the last entry of
+ * the distribution below k / CMI_NGUIDE (0 if there is none). A uniform x
+ * then lies between entries guide[floor(x CMI_NGUIDE)] and guide[.. + 1] + 1:
+ * Utilities::locate's bisection (src/Utilities.hpp:726-742) started from that
+ * bracket ends at the same index as from [0, length) - in 0-2 steps instead
+ * of 10, each a dependent load that a lane of the interaction kernels waits
+ * for. */
+#define CMI_NGUIDE 1024
 struct SpectraDev {
   double planck_logfreq[CMI_NFREQ];
   double planck_cdf[CMI_NFREQ];
@@ -221,6 +229,10 @@ struct SpectraDev {
   double planck2_logfreq[CMI_NFREQ];
   double planck2_cdf[CMI_NFREQ];
   double planck2_logcdf[CMI_NFREQ];
+  uint16_t planck_guide[CMI_NGUIDE + 2];
+  uint16_t planck2_guide[CMI_NGUIDE + 2];
+  uint16_t he2pc_guide[CMI_NGUIDE + 2];
+  uint16_t lyc_guide[2][CMI_NTEMP][CMI_NGUIDE + 2];
 };
 
 /* Physics set-up passed by value to the kernels */

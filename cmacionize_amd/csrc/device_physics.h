@@ -94,6 +94,43 @@ __device__ __forceinline__ uint32_t cmi_locate(double x, const double *arr,
   return (lo == length - 1) ? lo - 1 : lo;
 }
 
+/* the same index for a uniform x in (0, 1) and a cumulative distribution
+ * with its guide table (SpectraDev): the bisection from the bracket the guide
+ * gives. Invariants of the bisection - arr[lo] < x or lo == 0, arr[hi] >= x or
+ * hi == length - hold for the bracket: arr[guide[k]] < k / G <= x and
+ * arr[guide[k + 1] + 1] >= (k + 1) / G > x. */
+__host__ __device__ __forceinline__ uint32_t
+cmi_locate_guided(double x, const double *arr, const uint16_t *guide,
+                  uint32_t length) {
+  const uint32_t k = (uint32_t)(x * CMI_NGUIDE);
+  uint32_t lo = guide[k], hi = (uint32_t)guide[k + 1] + 1u;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (x > arr[mid])
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return (lo == length - 1) ? lo - 1 : lo;
+}
+
+/* ... and for a table that is close to linear in its index (the temperatures
+ * of the Lyman continuum spectra): the index a linear table would give, moved
+ * to where the bisection ends - the last entry below x (0 if none) */
+__host__ __device__ __forceinline__ uint32_t
+cmi_locate_linear(double x, const double *arr, uint32_t length) {
+  const double guess =
+      (x - arr[0]) * ((double)(length - 1) / (arr[length - 1] - arr[0]));
+  uint32_t g = guess > 0. ? (guess < (double)(length - 1) ? (uint32_t)guess
+                                                          : length - 1)
+                          : 0u;
+  while (g > 0 && !(x > arr[g]))
+    --g;
+  while (g < length - 1 && x > arr[g + 1])
+    ++g;
+  return (g == length - 1) ? g - 1 : g;
+}
+
 /* ------------------------------------------------ Verner cross section -- */
 
 /* VernerCrossSections::get_cross_section_verner,

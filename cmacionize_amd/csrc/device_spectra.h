@@ -14,9 +14,10 @@
 __device__ inline double sample_planck_table(const double *cdf,
                                              const double *logcdf,
                                              const double *logfreq,
+                                             const uint16_t *guide,
                                              PacketRng &rng) {
   const double x = rng.next();
-  const uint32_t ix = cmi_locate(x, cdf, CMI_NFREQ);
+  const uint32_t ix = cmi_locate_guided(x, cdf, guide, CMI_NFREQ);
   const double log_random_frequency =
       (log10(x) - logcdf[ix]) / (logcdf[ix + 1] - logcdf[ix]) *
           (logfreq[ix + 1] - logfreq[ix]) +
@@ -26,7 +27,7 @@ __device__ inline double sample_planck_table(const double *cdf,
 }
 __device__ inline double sample_planck(const SpectraDev *s, PacketRng &rng) {
   return sample_planck_table(s->planck_cdf, s->planck_logcdf,
-                             s->planck_logfreq, rng);
+                             s->planck_logfreq, s->planck_guide, rng);
 }
 
 /* Hydrogen/HeliumLymanContinuumSpectrum::get_random_frequency,
@@ -37,10 +38,13 @@ __device__ inline double sample_planck(const SpectraDev *s, PacketRng &rng) {
 __device__ inline double sample_lyman_continuum(const SpectraDev *s, int which,
                                                 double temperature,
                                                 PacketRng &rng) {
-  const uint32_t iT = cmi_locate(temperature, s->lyc_T, CMI_NTEMP);
+  const uint32_t iT = cmi_locate_linear(temperature, s->lyc_T, CMI_NTEMP);
   const double x = rng.next();
-  const uint32_t inu1 = cmi_locate(x, s->lyc_cdf[which][iT], CMI_NFREQ);
-  const uint32_t inu2 = cmi_locate(x, s->lyc_cdf[which][iT + 1], CMI_NFREQ);
+  const uint32_t inu1 = cmi_locate_guided(x, s->lyc_cdf[which][iT],
+                                          s->lyc_guide[which][iT], CMI_NFREQ);
+  const uint32_t inu2 =
+      cmi_locate_guided(x, s->lyc_cdf[which][iT + 1],
+                        s->lyc_guide[which][iT + 1], CMI_NFREQ);
   const double *nu = s->lyc_freq[which];
   return nu[inu1] + (temperature - s->lyc_T[iT]) * (nu[inu2] - nu[inu1]) /
                         (s->lyc_T[iT + 1] - s->lyc_T[iT]);
@@ -51,7 +55,8 @@ __device__ inline double sample_lyman_continuum(const SpectraDev *s, int which,
 __device__ inline double sample_he_two_photon(const SpectraDev *s,
                                               PacketRng &rng) {
   const double x = rng.next();
-  const uint32_t inu = cmi_locate(x, s->he2pc_cdf, CMI_NFREQ);
+  const uint32_t inu =
+      cmi_locate_guided(x, s->he2pc_cdf, s->he2pc_guide, CMI_NFREQ);
   return s->he2pc_freq[inu] + (s->he2pc_freq[inu + 1] - s->he2pc_freq[inu]) *
                                   (x - s->he2pc_cdf[inu]) /
                                   (s->he2pc_cdf[inu + 1] - s->he2pc_cdf[inu]);
@@ -66,7 +71,8 @@ __device__ inline double sample_source_spectrum(const ModelDev &m,
     if (m.continuous_spectrum_type == 0)
       return m.continuous_mono_frequency;
     return sample_planck_table(m.spectra->planck2_cdf, m.spectra->planck2_logcdf,
-                               m.spectra->planck2_logfreq, rng);
+                               m.spectra->planck2_logfreq,
+                               m.spectra->planck2_guide, rng);
   }
   if (m.spectrum_type == 0) {
     /* MonochromaticPhotonSourceSpectrum: no random number is drawn

@@ -555,6 +555,17 @@ void build_tables(TablesDev &t) {
                   std::pow(2. * M_PI * CMI_ELECTRON_MASS, 1.5));
 }
 
+/* the guide table of a cumulative distribution (SpectraDev) */
+void build_guide(const double *cdf, uint16_t *guide) {
+  uint32_t last = 0; /* last entry below the current k / G */
+  for (uint32_t k = 0; k <= CMI_NGUIDE + 1; ++k) {
+    const double edge = (double)k / CMI_NGUIDE;
+    while (last + 1 < CMI_NFREQ && cdf[last + 1] < edge)
+      ++last;
+    guide[k] = (uint16_t)((cdf[last] < edge) ? last : 0u);
+  }
+}
+
 /* Tabulate the sampled spectra on the host: the constructors of
  * PlanckPhotonSourceSpectrum (src/PlanckPhotonSourceSpectrum.cpp:53-113),
  * Hydrogen/HeliumLymanContinuumSpectrum
@@ -681,6 +692,12 @@ void build_spectra(const ModelDev &host_model, SpectraDev &s) {
     for (int i = 0; i < CMI_NFREQ; ++i)
       s.he2pc_cdf[i] /= total;
   }
+  build_guide(s.planck_cdf, s.planck_guide);
+  build_guide(s.planck2_cdf, s.planck2_guide);
+  build_guide(s.he2pc_cdf, s.he2pc_guide);
+  for (int which = 0; which < 2; ++which)
+    for (int iT = 0; iT < CMI_NTEMP; ++iT)
+      build_guide(s.lyc_cdf[which][iT], s.lyc_guide[which][iT]);
 }
 
 /* (re)build and upload the spectra tables if a sampled spectrum is in use */

@@ -1838,9 +1838,17 @@ interaction_decide(const InteractArgs &a, double nu, int32_t cell,
     sigma_H = a.model.xsec_fixed[ION_H_n];
     sigma_He = a.model.xsec_fixed[ION_He_n];
   }
+  /* helium takes nothing where A_He sigma_He == 0 (the H-only models: no
+   * helium, or FixedValue cross sections with sigma_He = 0): the reference's
+   * pHabs = x_H sigma_H / (x_H sigma_H + 0) is exactly 1 whatever x_H > 0 the
+   * cell of the absorption has (its opacity was positive), and x_H, x_He are
+   * used nowhere else on that side of the decision - their two gathers (of
+   * three, the bound of this kernel) are left out */
+  const bool helium = FULL || (a.model.abundance[0] * sigma_He != 0.);
+  const double xH = helium ? a.cells.x[ION_H_n][cell] : 1.;
+  const double xHe = helium ? a.cells.x[ION_He_n][cell] : 0.;
   return physical_reemit(a.model, sigma_H, sigma_He, a.cells.temperature[cell],
-                         a.cells.x[ION_H_n][cell], a.cells.x[ION_He_n][cell],
-                         rng, type);
+                         xH, xHe, rng, type);
 }
 
 /* PhotonSource::reemit + IonizationPhotonShootJob::execute
@@ -1903,63 +1911,119 @@ block_reserve(bool mine, unsigned int *counter, unsigned int *s_count,
 #ifndef CMI_INTERACT_WAVES_H
 #define CMI_INTERACT_WAVES_H 4
 #endif
+/* Ended flights a workgroup decides on before it asks for room in the output
+ * (x CMI_BLOCK). Two things are bought with the batch: (1) the returning
+ * atomic on the output counter - ~90 per microsecond chip-wide on one word, so
+ * 1e8 ended flights at one atomic per 256 were 4.3 ms on their own - is paid
+ * once per batch; (2) the survivors of the batch (a third of the packets of
+ * stromgren_diffuse) are staged in LDS and the long second half - direction,
+ * optical depth, wall parameters, the row - runs on full waves instead of on
+ * the surviving lanes of every wave. */
+#ifndef CMI_INTERACT_BATCH
+#define CMI_INTERACT_BATCH 4
+#endif
 template <bool FULL, bool ROWS, bool DEFER = false>
 __global__ void __launch_bounds__(CMI_BLOCK,
                                   (FULL && !DEFER) ? 1 : CMI_INTERACT_WAVES_H)
     interaction_kernel(const InteractArgs a) {
-  __shared__ unsigned int s_count[CMI_BLOCK / 64], s_base;
+  constexpr unsigned int BATCH = CMI_INTERACT_BATCH * CMI_BLOCK;
+  /* a survivor: where it is in the batch, the state of its random stream and
+   * its photon type (packed like a flight's meta word), its new frequency */
+  __shared__ uint32_t s_item[BATCH], s_state[BATCH];
+  __shared__ double s_frequency[BATCH], s_cached[BATCH];
+  __shared__ unsigned int s_n, s_base;
   const int lane = threadIdx.x & 63;
   const uint64_t count = *a.qin.count;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t stride = (uint64_t)gridDim.x * BATCH;
   double tw = 0., tc3 = 0.;
   double tc1 = 0., tc2 = 0.; /* ROWS: re-emitted outside the box (rounding) */
   /* (the trip count is the same for every thread of a workgroup) */
-  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < count;
+  for (uint64_t base = (uint64_t)blockIdx.x * BATCH; base < count;
        base += stride) {
-    const uint64_t i = base + threadIdx.x;
-    const bool valid = i < count;
-    double new_frequency = 0.;
-    int32_t type = TYPE_ABSORBED;
-    PacketRng rng;
-    uint32_t id = 0, origin = 0;
-    double w = 0.; /* the packet's weight */
-    if (valid) {
-      id = a.qin.id[i];
-      const uint32_t meta = a.qin.meta[i];
-      origin = cmi_meta_origin(meta);
-      w = a.model.photon_weight[origin];
-      rng.resume(a.seed, a.iteration, a.first_packet + id, meta & 0xffffffu,
-                 (meta >> 24) & 1u);
-      new_frequency =
-          interaction_decide<FULL>(a, a.qin.nu[i], a.qin.cell[i], rng, type);
-    }
-    const bool again = valid && new_frequency != 0.;
-    if (ROWS) {
-      bool fly = false;
-      Packet<FULL> p;
-      double weights[CMI_NACC];
-      uint32_t plc = 0, key = 0;
+    if (threadIdx.x == 0)
+      s_n = 0;
+    __syncthreads();
+    /* the handler's decision for every ended flight of the batch */
+    for (unsigned int local = threadIdx.x; local < BATCH; local += CMI_BLOCK) {
+      const uint64_t i = base + local;
+      const bool valid = i < count;
+      double new_frequency = 0.;
+      int32_t type = TYPE_ABSORBED;
+      PacketRng rng;
+      uint32_t origin = 0;
+      double w = 0.; /* the packet's weight */
+      if (valid) {
+        const uint32_t meta = a.qin.meta[i];
+        origin = cmi_meta_origin(meta);
+        w = a.model.photon_weight[origin];
+        rng.resume(a.seed, a.iteration, a.first_packet + a.qin.id[i],
+                   meta & 0xffffffu, (meta >> 24) & 1u);
+        new_frequency =
+            interaction_decide<FULL>(a, a.qin.nu[i], a.qin.cell[i], rng, type);
+      }
+      const bool again = valid && new_frequency != 0.;
+      const unsigned long long want = __ballot(again);
+      unsigned int at = 0;
+      if (lane == 0 && want)
+        at = atomicAdd(&s_n, (unsigned int)__popcll(want));
+      at = __builtin_amdgcn_readfirstlane(at) +
+           (unsigned int)__popcll(want & ((1ull << lane) - 1ull));
       if (again) {
+        s_item[at] = local;
+        s_state[at] = cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin);
+        s_frequency[at] = new_frequency;
+        s_cached[at] = rng.cached;
+      } else if (valid) {
+        tw += w;
+        tc3 += w;
+      }
+    }
+    __syncthreads();
+    const unsigned int n = s_n;
+    if (threadIdx.x == 0)
+      s_base = n ? atomicAdd(ROWS ? a.rows.count : a.qout.count, n) : 0u;
+    __syncthreads();
+    const unsigned int q0 = s_base;
+    /* the survivors, one per lane: PhotonSource::reemit's new direction and
+     * the new optical depth */
+    for (unsigned int j = threadIdx.x; j < n; j += CMI_BLOCK) {
+      const uint64_t i = base + s_item[j];
+      const uint32_t state = s_state[j];
+      const uint32_t id = a.qin.id[i];
+      const uint32_t origin = cmi_meta_origin(state);
+      const int32_t type = (int32_t)(state >> 28);
+      const double new_frequency = s_frequency[j];
+      PacketRng rng;
+      rng.init(a.seed, a.iteration, a.first_packet + id);
+      rng.block = state & 0xffffffu;
+      rng.have = (state >> 24) & 1u;
+      rng.cached = s_cached[j];
+      const unsigned int q = q0 + j;
+      if (ROWS) {
+        Packet<FULL> p;
+        double weights[CMI_NACC];
+        uint32_t plc = 0, key = 0;
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax)
           p.pos[ax] = a.qin.pos[ax][i];
-        fly = interaction_new_flight<FULL, DEFER>(a, new_frequency, type, rng,
-                                                  p, weights, plc, key);
+        const bool fly = interaction_new_flight<FULL, DEFER>(
+            a, new_frequency, type, rng, p, weights, plc, key);
         if (!fly) {
+          const double w = a.model.photon_weight[origin];
           tw += w;
           tc1 += (type == TYPE_DIFFUSE_HI) ? w : 0.;
           tc2 += (type == TYPE_DIFFUSE_HeI) ? w : 0.;
         }
-      }
-      const unsigned int q = block_reserve(fly, a.rows.count, s_count, &s_base);
-      if (fly && q < a.rows.capacity)
-        write_flight_row<FULL, DEFER>(
-            a.rows, q, p, plc, key, id,
-            cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin),
-            weights);
-    } else {
-      const unsigned int q = block_reserve(again, a.qout.count, s_count, &s_base);
-      if (again) {
+        if (q < a.rows.capacity) {
+          if (fly)
+            write_flight_row<FULL, DEFER>(
+                a.rows, q, p, plc, key, id,
+                cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin),
+                weights);
+          else /* its row stays a free slot */
+            a.rows.keys[q] = CMI_TILE_KEY_DEAD(a.tiles);
+        }
+      } else {
         Packet<false> p;
         random_direction(p, rng);
         const double tau = -log(rng.next());
@@ -1975,10 +2039,8 @@ __global__ void __launch_bounds__(CMI_BLOCK,
             cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin);
       }
     }
-    if (valid && !again) {
-      tw += w;
-      tc3 += w;
-    }
+    /* (the staging arrays are rewritten after the barrier at the head of the
+     * next batch) */
   }
   tw = wave_sum(tw);
   tc3 = wave_sum(tc3);

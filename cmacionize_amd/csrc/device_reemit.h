@@ -31,20 +31,26 @@ __device__ inline void reemission_probabilities(double temperature,
   pHe[3] = pHe[2] + alpha_e_2sP / alphaHe;
 }
 
+/* What becomes of an absorbed packet: the spectrum its new frequency is drawn
+ * from (the last draw of every branch of the handlers' reemit) */
+#define CMI_REEMIT_ABSORBED 0   /* absorbed for good */
+#define CMI_REEMIT_LYC_H 1      /* hydrogen Lyman continuum at the cell's T */
+#define CMI_REEMIT_LYC_HE 2     /* helium Lyman continuum at the cell's T */
+#define CMI_REEMIT_HE_19_8 3    /* He 2^3S -> 1^1S, 19.8 eV: no draw */
+#define CMI_REEMIT_HE_2PHOTON 4 /* helium two-photon continuum */
+#define CMI_REEMIT_FIXED 5      /* FixedValue handler's frequency: no draw */
+
 /* PhysicalDiffuseReemissionHandler::reemit,
  * src/PhysicalDiffuseReemissionHandler.cpp:219-370 (Wood, Mathis & Ercolano
- * 2004, section 3.3). Returns the new frequency, 0 = absorbed for good. */
-__device__ inline double physical_reemit(const ModelDev &m, double sigma_H,
-                                         double sigma_He, double T, double xH,
-                                         double xHe, PacketRng &rng,
-                                         int32_t &type) {
-  const SpectraDev *s = m.spectra;
+ * 2004, section 3.3), up to the choice of the spectrum: CMI_REEMIT_* */
+__device__ inline int32_t physical_reemit_kind(const ModelDev &m,
+                                               double sigma_H, double sigma_He,
+                                               double T, double xH, double xHe,
+                                               PacketRng &rng) {
   const double AHe = m.abundance[0];
   const double nH0anuH0 = xH * sigma_H;
   const double nHe0anuHe0 = xHe * AHe * sigma_He;
   const double pHabs = nH0anuH0 / (nH0anuH0 + nHe0anuHe0);
-  double new_frequency = 0.;
-  type = TYPE_ABSORBED;
 
   double x = rng.next();
   if (x <= pHabs) {
@@ -53,49 +59,69 @@ __device__ inline double physical_reemit(const ModelDev &m, double sigma_H,
     const double pH = (1.58e-13 * exp(-0.53 * lnT4)) /
                       (4.18e-13 * exp(-0.7 * lnT4));
     x = rng.next();
-    if (x <= pH) {
-      new_frequency = sample_lyman_continuum(s, 0, T, rng);
-      type = TYPE_DIFFUSE_HI;
-    }
-  } else {
-    /* absorbed by helium: pick the recombination channel */
-    double pH, pHe[4];
-    reemission_probabilities(T, pH, pHe);
-    x = rng.next();
-    if (x <= pHe[0]) {
-      new_frequency = sample_lyman_continuum(s, 1, T, rng);
-      type = TYPE_DIFFUSE_HeI;
-    } else if (x <= pHe[1]) {
-      new_frequency = 4.788e15; /* 2^3S -> 1^1S, 19.8 eV */
-      type = TYPE_DIFFUSE_HeI;
-    } else if (x <= pHe[2]) {
-      /* two-photon continuum: 56 % chance of an H-ionizing photon */
-      x = rng.next();
-      if (x < 0.56) {
-        new_frequency = sample_he_two_photon(s, rng);
-        type = TYPE_DIFFUSE_HeI;
-      }
-    } else if (x <= pHe[3]) {
-      /* He Lyman alpha: absorbed on the spot by H, or two-photon decay */
-      const double sqrtTnH0 = sqrt(T) * xH;
-      const double pHots = sqrtTnH0 / (sqrtTnH0 + 77. * xHe);
-      x = rng.next();
-      if (x < pHots) {
-        x = rng.next();
-        if (x <= pH) {
-          new_frequency = sample_lyman_continuum(s, 0, T, rng);
-          type = TYPE_DIFFUSE_HI;
-        }
-      } else {
-        x = rng.next();
-        if (x < 0.56) {
-          new_frequency = sample_he_two_photon(s, rng);
-          type = TYPE_DIFFUSE_HeI;
-        }
-      }
-    }
+    return (x <= pH) ? CMI_REEMIT_LYC_H : CMI_REEMIT_ABSORBED;
   }
-  return new_frequency;
+  /* absorbed by helium: pick the recombination channel */
+  double pH, pHe[4];
+  reemission_probabilities(T, pH, pHe);
+  x = rng.next();
+  if (x <= pHe[0])
+    return CMI_REEMIT_LYC_HE;
+  if (x <= pHe[1])
+    return CMI_REEMIT_HE_19_8;
+  if (x <= pHe[2]) {
+    /* two-photon continuum: 56 % chance of an H-ionizing photon */
+    x = rng.next();
+    return (x < 0.56) ? CMI_REEMIT_HE_2PHOTON : CMI_REEMIT_ABSORBED;
+  }
+  if (x <= pHe[3]) {
+    /* He Lyman alpha: absorbed on the spot by H, or two-photon decay */
+    const double sqrtTnH0 = sqrt(T) * xH;
+    const double pHots = sqrtTnH0 / (sqrtTnH0 + 77. * xHe);
+    x = rng.next();
+    if (x < pHots) {
+      x = rng.next();
+      return (x <= pH) ? CMI_REEMIT_LYC_H : CMI_REEMIT_ABSORBED;
+    }
+    x = rng.next();
+    return (x < 0.56) ? CMI_REEMIT_HE_2PHOTON : CMI_REEMIT_ABSORBED;
+  }
+  return CMI_REEMIT_ABSORBED;
+}
+
+/* ... and the frequency from that spectrum, with the photon type of the
+ * re-emitted packet; 0 = absorbed for good */
+__device__ inline double sample_reemission(const ModelDev &m, int32_t kind,
+                                           double T, PacketRng &rng,
+                                           int32_t &type) {
+  type = TYPE_DIFFUSE_HeI;
+  switch (kind) {
+  case CMI_REEMIT_LYC_H:
+    type = TYPE_DIFFUSE_HI;
+    return sample_lyman_continuum(m.spectra, 0, T, rng);
+  case CMI_REEMIT_LYC_HE:
+    return sample_lyman_continuum(m.spectra, 1, T, rng);
+  case CMI_REEMIT_HE_19_8:
+    return 4.788e15;
+  case CMI_REEMIT_HE_2PHOTON:
+    return sample_he_two_photon(m.spectra, rng);
+  case CMI_REEMIT_FIXED:
+    type = TYPE_DIFFUSE_HI;
+    return m.reemit_fixed_frequency;
+  default:
+    type = TYPE_ABSORBED;
+    return 0.;
+  }
+}
+
+/* both halves: returns the new frequency, 0 = absorbed for good */
+__device__ inline double physical_reemit(const ModelDev &m, double sigma_H,
+                                         double sigma_He, double T, double xH,
+                                         double xHe, PacketRng &rng,
+                                         int32_t &type) {
+  const int32_t kind =
+      physical_reemit_kind(m, sigma_H, sigma_He, T, xH, xHe, rng);
+  return sample_reemission(m, kind, T, rng, type);
 }
 
 /* First half of PhotonSource::reemit (src/PhotonSource.cpp:272-308): the

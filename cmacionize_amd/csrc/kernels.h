@@ -1815,21 +1815,50 @@ struct InteractArgs {
   unsigned int *new_count;
 };
 
-/* the handler's decision for a packet of frequency nu absorbed in `cell`:
- * new frequency (0 = absorbed for good) and photon type */
+/* The handler's decision for an absorbed packet, in two halves so that the
+ * interaction kernels can take the first for a batch of ended flights and the
+ * second - the sampled spectrum - only for the survivors, on full waves.
+ *
+ * What the first half reads from the cell of the absorption: */
+struct InteractCell {
+  double T, xH, xHe;
+};
+/* helium takes nothing where A_He sigma_He == 0 (the H-only models: no
+ * helium, or FixedValue cross sections with sigma_He = 0): the reference's
+ * pHabs = x_H sigma_H / (x_H sigma_H + 0) is exactly 1 whatever x_H > 0 the
+ * cell of the absorption has (its opacity was positive), and x_H, x_He are
+ * used nowhere else on that side of the decision - their two gathers (of
+ * three) are left out */
 template <bool FULL>
-__device__ __forceinline__ double
-interaction_decide(const InteractArgs &a, double nu, int32_t cell,
-                   PacketRng &rng, int32_t &type) {
-  type = TYPE_ABSORBED;
+__device__ __forceinline__ bool interaction_needs_helium(const InteractArgs &a) {
+  return FULL ||
+         (a.model.abundance[0] * a.model.xsec_fixed[ION_He_n] != 0.);
+}
+template <bool FULL>
+__device__ __forceinline__ InteractCell
+interaction_gather(const InteractArgs &a, int32_t cell, bool valid) {
+  InteractCell c = {1.e4, 1., 0.};
+  if (valid && a.model.reemit_type != 2) {
+    c.T = a.cells.temperature[cell];
+    if (interaction_needs_helium<FULL>(a)) {
+      c.xH = a.cells.x[ION_H_n][cell];
+      c.xHe = a.cells.x[ION_He_n][cell];
+    }
+  }
+  return c;
+}
+/* CMI_REEMIT_*: what becomes of a packet of frequency nu absorbed in that
+ * cell */
+template <bool FULL>
+__device__ __forceinline__ int32_t
+interaction_decide(const InteractArgs &a, double nu, const InteractCell &c,
+                   PacketRng &rng) {
   if (a.model.reemit_type == 2) {
     /* FixedValueDiffuseReemissionHandler::reemit,
      * src/FixedValueDiffuseReemissionHandler.hpp:73-86 */
-    if (rng.next() < a.model.reemit_fixed_probability) {
-      type = TYPE_DIFFUSE_HI;
-      return a.model.reemit_fixed_frequency;
-    }
-    return 0.;
+    return (rng.next() < a.model.reemit_fixed_probability)
+               ? CMI_REEMIT_FIXED
+               : CMI_REEMIT_ABSORBED;
   }
   double sigma_H, sigma_He;
   if (FULL) {
@@ -1838,17 +1867,31 @@ interaction_decide(const InteractArgs &a, double nu, int32_t cell,
     sigma_H = a.model.xsec_fixed[ION_H_n];
     sigma_He = a.model.xsec_fixed[ION_He_n];
   }
-  /* helium takes nothing where A_He sigma_He == 0 (the H-only models: no
-   * helium, or FixedValue cross sections with sigma_He = 0): the reference's
-   * pHabs = x_H sigma_H / (x_H sigma_H + 0) is exactly 1 whatever x_H > 0 the
-   * cell of the absorption has (its opacity was positive), and x_H, x_He are
-   * used nowhere else on that side of the decision - their two gathers (of
-   * three, the bound of this kernel) are left out */
-  const bool helium = FULL || (a.model.abundance[0] * sigma_He != 0.);
-  const double xH = helium ? a.cells.x[ION_H_n][cell] : 1.;
-  const double xHe = helium ? a.cells.x[ION_He_n][cell] : 0.;
-  return physical_reemit(a.model, sigma_H, sigma_He, a.cells.temperature[cell],
-                         xH, xHe, rng, type);
+  return physical_reemit_kind(a.model, sigma_H, sigma_He, c.T, c.xH, c.xHe,
+                              rng);
+}
+
+/* a workgroup's survivors of one batch, staged in LDS: where the ended flight
+ * is, the state of its random stream with the kind of its re-emission (packed
+ * like a flight's meta word, the kind in the place of the photon type), and
+ * the temperature its spectrum is sampled at */
+template <unsigned int BATCH> struct InteractStage {
+  uint32_t item[BATCH], state[BATCH];
+  double T[BATCH], cached[BATCH];
+  unsigned int n, base;
+};
+/* called by all lanes of a wave: a place in the stage for the lanes that
+ * want one */
+template <unsigned int BATCH>
+__device__ __forceinline__ unsigned int
+stage_reserve(InteractStage<BATCH> &stage, bool mine) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long want = __ballot(mine);
+  unsigned int at = 0;
+  if (lane == 0 && want)
+    at = atomicAdd(&stage.n, (unsigned int)__popcll(want));
+  return __builtin_amdgcn_readfirstlane(at) +
+         (unsigned int)__popcll(want & ((1ull << lane) - 1ull));
 }
 
 /* PhotonSource::reemit + IonizationPhotonShootJob::execute
@@ -1911,6 +1954,12 @@ block_reserve(bool mine, unsigned int *counter, unsigned int *s_count,
 #ifndef CMI_INTERACT_WAVES_H
 #define CMI_INTERACT_WAVES_H 4
 #endif
+/* multi-ion transport with deferred weights: the two Verner cross sections of
+ * the decision and the new flight want ~150 registers; at 4 waves per SIMD
+ * (128) they spill 70-110 bytes per lane */
+#ifndef CMI_INTERACT_WAVES_FULL
+#define CMI_INTERACT_WAVES_FULL 3
+#endif
 /* Ended flights a workgroup decides on before it asks for room in the output
  * (x CMI_BLOCK). Two things are bought with the batch: (1) the returning
  * atomic on the output counter - ~90 per microsecond chip-wide on one word, so
@@ -1924,14 +1973,16 @@ block_reserve(bool mine, unsigned int *counter, unsigned int *s_count,
 #endif
 template <bool FULL, bool ROWS, bool DEFER = false>
 __global__ void __launch_bounds__(CMI_BLOCK,
-                                  (FULL && !DEFER) ? 1 : CMI_INTERACT_WAVES_H)
+                                  (FULL && !DEFER) ? 1
+                                  : FULL           ? CMI_INTERACT_WAVES_FULL
+                                                   : CMI_INTERACT_WAVES_H)
     interaction_kernel(const InteractArgs a) {
-  constexpr unsigned int BATCH = CMI_INTERACT_BATCH * CMI_BLOCK;
-  /* a survivor: where it is in the batch, the state of its random stream and
-   * its photon type (packed like a flight's meta word), its new frequency */
-  __shared__ uint32_t s_item[BATCH], s_state[BATCH];
-  __shared__ double s_frequency[BATCH], s_cached[BATCH];
-  __shared__ unsigned int s_n, s_base;
+  constexpr int TRIPS = CMI_INTERACT_BATCH;
+  /* (multi-ion transport: the decision holds two Verner cross sections; the
+   * records of four trips beside them spill) */
+  constexpr int GROUP = FULL ? 1 : TRIPS;
+  constexpr unsigned int BATCH = TRIPS * CMI_BLOCK;
+  __shared__ InteractStage<BATCH> stage;
   const int lane = threadIdx.x & 63;
   const uint64_t count = *a.qin.count;
   const uint64_t stride = (uint64_t)gridDim.x * BATCH;
@@ -1941,63 +1992,85 @@ __global__ void __launch_bounds__(CMI_BLOCK,
   for (uint64_t base = (uint64_t)blockIdx.x * BATCH; base < count;
        base += stride) {
     if (threadIdx.x == 0)
-      s_n = 0;
+      stage.n = 0;
     __syncthreads();
-    /* the handler's decision for every ended flight of the batch */
-    for (unsigned int local = threadIdx.x; local < BATCH; local += CMI_BLOCK) {
-      const uint64_t i = base + local;
-      const bool valid = i < count;
-      double new_frequency = 0.;
-      int32_t type = TYPE_ABSORBED;
-      PacketRng rng;
-      uint32_t origin = 0;
-      double w = 0.; /* the packet's weight */
-      if (valid) {
-        const uint32_t meta = a.qin.meta[i];
-        origin = cmi_meta_origin(meta);
-        w = a.model.photon_weight[origin];
-        rng.resume(a.seed, a.iteration, a.first_packet + a.qin.id[i],
-                   meta & 0xffffffu, (meta >> 24) & 1u);
-        new_frequency =
-            interaction_decide<FULL>(a, a.qin.nu[i], a.qin.cell[i], rng, type);
+    /* the handler's decision for every ended flight of the batch: the loads
+     * of GROUP trips first (records, then the cells they point to), so that
+     * their latencies overlap */
+    for (int k0 = 0; k0 < TRIPS; k0 += GROUP) {
+      uint32_t meta[GROUP], id[GROUP];
+      int32_t cell[GROUP];
+      double nu[GROUP];
+      InteractCell at_cell[GROUP];
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g) {
+        const uint64_t i =
+            base + (unsigned int)(k0 + g) * CMI_BLOCK + threadIdx.x;
+        meta[g] = id[g] = 0;
+        cell[g] = 0;
+        nu[g] = 0.;
+        if (i < count) {
+          meta[g] = a.qin.meta[i];
+          id[g] = a.qin.id[i];
+          cell[g] = a.qin.cell[i];
+          if (FULL)
+            nu[g] = a.qin.nu[i];
+        }
       }
-      const bool again = valid && new_frequency != 0.;
-      const unsigned long long want = __ballot(again);
-      unsigned int at = 0;
-      if (lane == 0 && want)
-        at = atomicAdd(&s_n, (unsigned int)__popcll(want));
-      at = __builtin_amdgcn_readfirstlane(at) +
-           (unsigned int)__popcll(want & ((1ull << lane) - 1ull));
-      if (again) {
-        s_item[at] = local;
-        s_state[at] = cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin);
-        s_frequency[at] = new_frequency;
-        s_cached[at] = rng.cached;
-      } else if (valid) {
-        tw += w;
-        tc3 += w;
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g)
+        at_cell[g] = interaction_gather<FULL>(
+            a, cell[g],
+            base + (unsigned int)(k0 + g) * CMI_BLOCK + threadIdx.x < count);
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g) {
+        const unsigned int local =
+            (unsigned int)(k0 + g) * CMI_BLOCK + threadIdx.x;
+        const bool valid = base + local < count;
+        const uint32_t origin = cmi_meta_origin(meta[g]);
+        int32_t kind = CMI_REEMIT_ABSORBED;
+        PacketRng rng;
+        if (valid) {
+          rng.resume(a.seed, a.iteration, a.first_packet + id[g],
+                     meta[g] & 0xffffffu, (meta[g] >> 24) & 1u);
+          kind = interaction_decide<FULL>(a, nu[g], at_cell[g], rng);
+        }
+        const bool again = kind != CMI_REEMIT_ABSORBED;
+        const unsigned int at = stage_reserve(stage, again);
+        if (again) {
+          stage.item[at] = local;
+          stage.state[at] =
+              cmi_pack_meta(rng.block, rng.have, (uint32_t)kind, origin);
+          stage.T[at] = at_cell[g].T;
+          stage.cached[at] = rng.cached;
+        } else if (valid) {
+          const double w = a.model.photon_weight[origin];
+          tw += w;
+          tc3 += w;
+        }
       }
     }
     __syncthreads();
-    const unsigned int n = s_n;
+    const unsigned int n = stage.n;
     if (threadIdx.x == 0)
-      s_base = n ? atomicAdd(ROWS ? a.rows.count : a.qout.count, n) : 0u;
+      stage.base = n ? atomicAdd(ROWS ? a.rows.count : a.qout.count, n) : 0u;
     __syncthreads();
-    const unsigned int q0 = s_base;
-    /* the survivors, one per lane: PhotonSource::reemit's new direction and
-     * the new optical depth */
+    const unsigned int q0 = stage.base;
+    /* the survivors, one per lane: the new frequency from its spectrum,
+     * PhotonSource::reemit's new direction and the new optical depth */
     for (unsigned int j = threadIdx.x; j < n; j += CMI_BLOCK) {
-      const uint64_t i = base + s_item[j];
-      const uint32_t state = s_state[j];
-      const uint32_t id = a.qin.id[i];
+      const uint64_t i = base + stage.item[j];
+      const uint32_t state = stage.state[j];
+      const uint32_t packet = a.qin.id[i];
       const uint32_t origin = cmi_meta_origin(state);
-      const int32_t type = (int32_t)(state >> 28);
-      const double new_frequency = s_frequency[j];
       PacketRng rng;
-      rng.init(a.seed, a.iteration, a.first_packet + id);
+      rng.init(a.seed, a.iteration, a.first_packet + packet);
       rng.block = state & 0xffffffu;
       rng.have = (state >> 24) & 1u;
-      rng.cached = s_cached[j];
+      rng.cached = stage.cached[j];
+      int32_t type;
+      const double new_frequency = sample_reemission(
+          a.model, (int32_t)(state >> 28), stage.T[j], rng, type);
       const unsigned int q = q0 + j;
       if (ROWS) {
         Packet<FULL> p;
@@ -2017,7 +2090,7 @@ __global__ void __launch_bounds__(CMI_BLOCK,
         if (q < a.rows.capacity) {
           if (fly)
             write_flight_row<FULL, DEFER>(
-                a.rows, q, p, plc, key, id,
+                a.rows, q, p, plc, key, packet,
                 cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin),
                 weights);
           else /* its row stays a free slot */
@@ -2034,13 +2107,13 @@ __global__ void __launch_bounds__(CMI_BLOCK,
         }
         a.qout.tau[q] = tau;
         a.qout.nu[q] = new_frequency;
-        a.qout.id[q] = id;
+        a.qout.id[q] = packet;
         a.qout.meta[q] =
             cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin);
       }
     }
-    /* (the staging arrays are rewritten after the barrier at the head of the
-     * next batch) */
+    /* (the stage is rewritten after the barrier at the head of the next
+     * batch) */
   }
   tw = wave_sum(tw);
   tc3 = wave_sum(tc3);
@@ -2093,87 +2166,175 @@ __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
     absorbed_before[n] = partial[threadIdx.x];
 }
 
-/* ... then one lane per record, whatever unit it belongs to (the decision is
- * long and divergent - for multi-ion transport it ends with 14 Verner cross
- * sections - so every lane should have one) */
+/* ... then one lane per record, whatever unit it belongs to, in the batches
+ * of interaction_kernel: the decisions of a batch with their loads overlapped,
+ * then the survivors' new flights on full waves (for multi-ion transport that
+ * half ends with 14 Verner cross sections unless they are deferred). The
+ * running totals of the units around the batch are searched in LDS. */
+#define CMI_SLOTS_WINDOW 128
 template <bool FULL, bool DEFER = false>
 __global__ void __launch_bounds__(CMI_BLOCK,
-                                  (FULL && !DEFER) ? 1 : CMI_INTERACT_WAVES_H)
+                                  (FULL && !DEFER) ? 1
+                                  : FULL           ? CMI_INTERACT_WAVES_FULL
+                                                   : CMI_INTERACT_WAVES_H)
     interaction_slots_kernel(const InteractArgs a) {
-  __shared__ unsigned int s_count[CMI_BLOCK / 64], s_base;
+  constexpr int TRIPS = CMI_INTERACT_BATCH;
+  constexpr int GROUP = FULL ? 1 : TRIPS;
+  constexpr unsigned int BATCH = TRIPS * CMI_BLOCK;
+  __shared__ InteractStage<BATCH> stage;
+  __shared__ uint32_t s_slot[BATCH];
+  __shared__ uint32_t s_before[CMI_SLOTS_WINDOW + 1];
   const int lane = threadIdx.x & 63;
   const uint32_t key_dead = CMI_TILE_KEY_DEAD(a.tiles);
   const uint32_t nitems = *a.nitems;
   const uint64_t total = a.absorbed_before[nitems];
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t stride = (uint64_t)gridDim.x * BATCH;
   double tw = 0., tc1 = 0., tc2 = 0., tc3 = 0.;
-  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < total;
+  for (uint64_t base = (uint64_t)blockIdx.x * BATCH; base < total;
        base += stride) {
-    /* the unit of work the workgroup's first record belongs to: last k with
-     * before[k] <= base (a uniform search: scalar loads) ... */
-    uint32_t lo = 0, hi = nitems;
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
+    /* the unit of work the batch's first record belongs to: last k with
+     * before[k] <= base (a uniform search: scalar loads), and the totals of
+     * the units that follow it */
+    uint32_t first = 0, hi = nitems;
+    while (hi - first > 1) {
+      const uint32_t mid = (first + hi) >> 1;
       if (a.absorbed_before[mid] <= (uint32_t)base)
-        lo = mid;
+        first = mid;
       else
         hi = mid;
     }
-    const uint64_t j = base + threadIdx.x;
-    const bool valid = j < total;
-    bool made = false; /* a new flight in this lane's slot */
-    uint32_t slot = 0;
-    if (valid) {
-      /* ... and this lane's, a few units further at most */
-      while (a.absorbed_before[lo + 1] <= (uint32_t)j)
-        ++lo;
-      const unsigned int i =
-          a.items[lo].begin + ((uint32_t)j - a.absorbed_before[lo]);
-      slot = a.ended_slot[i];
-      const uint32_t id = a.qin.id[i];
-      const uint32_t meta = a.qin.meta[i];
-      const uint32_t origin = cmi_meta_origin(meta);
-      const double w = a.model.photon_weight[origin]; /* the packet's weight */
-      PacketRng rng;
-      rng.resume(a.seed, a.iteration, a.first_packet + id, meta & 0xffffffu,
-                 (meta >> 24) & 1u);
-      int32_t type;
-      const double new_frequency =
-          interaction_decide<FULL>(a, a.qin.nu[i], a.qin.cell[i], rng, type);
-      uint32_t key = key_dead;
-      if (new_frequency != 0.) {
-        Packet<FULL> p;
-        double weights[CMI_NACC];
-        uint32_t plc = 0;
+    if (threadIdx.x == 0)
+      stage.n = 0;
+    if (threadIdx.x <= CMI_SLOTS_WINDOW)
+      s_before[threadIdx.x] = first + threadIdx.x <= nitems
+                                  ? a.absorbed_before[first + threadIdx.x]
+                                  : 0xffffffffu;
+    __syncthreads();
+    for (int k0 = 0; k0 < TRIPS; k0 += GROUP) {
+      uint32_t record[GROUP], slot[GROUP], meta[GROUP], id[GROUP];
+      int32_t cell[GROUP];
+      double nu[GROUP];
+      InteractCell at_cell[GROUP];
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax)
-          p.pos[ax] = a.qin.pos[ax][i];
-        if (interaction_new_flight<FULL, DEFER>(a, new_frequency, type, rng, p,
-                                                weights, plc, key)) {
-          write_flight_row<FULL, DEFER>(
-              a.rows, slot, p, plc, key, id,
-              cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin),
-              weights);
-          made = true;
-        } else {
-          key = key_dead;
-          tw += w;
-          tc1 += (type == TYPE_DIFFUSE_HI) ? w : 0.;
-          tc2 += (type == TYPE_DIFFUSE_HeI) ? w : 0.;
+      for (int g = 0; g < GROUP; ++g) {
+        const uint64_t j =
+            base + (unsigned int)(k0 + g) * CMI_BLOCK + threadIdx.x;
+        record[g] = 0;
+        if (j < total) {
+          /* this lane's unit: the last l with before[first + l] <= j */
+          uint32_t l = 0, h = CMI_SLOTS_WINDOW + 1;
+          while (h - l > 1) {
+            const uint32_t mid = (l + h) >> 1;
+            if (s_before[mid] <= (uint32_t)j)
+              l = mid;
+            else
+              h = mid;
+          }
+          uint32_t unit = first + l;
+          uint32_t before = s_before[l];
+          if (l == CMI_SLOTS_WINDOW) /* further on than the window */
+            while (a.absorbed_before[unit + 1] <= (uint32_t)j)
+              before = a.absorbed_before[++unit];
+          record[g] = a.items[unit].begin + ((uint32_t)j - before);
         }
-      } else {
-        tw += w;
-        tc3 += w;
       }
-      if (key == key_dead)
-        a.rows.keys[slot] = key;
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g) {
+        const uint64_t j =
+            base + (unsigned int)(k0 + g) * CMI_BLOCK + threadIdx.x;
+        slot[g] = meta[g] = id[g] = 0;
+        cell[g] = 0;
+        nu[g] = 0.;
+        if (j < total) {
+          const uint32_t i = record[g];
+          slot[g] = a.ended_slot[i];
+          meta[g] = a.qin.meta[i];
+          id[g] = a.qin.id[i];
+          cell[g] = a.qin.cell[i];
+          if (FULL)
+            nu[g] = a.qin.nu[i];
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g)
+        at_cell[g] = interaction_gather<FULL>(
+            a, cell[g],
+            base + (unsigned int)(k0 + g) * CMI_BLOCK + threadIdx.x < total);
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g) {
+        const bool valid =
+            base + (unsigned int)(k0 + g) * CMI_BLOCK + threadIdx.x < total;
+        const uint32_t origin = cmi_meta_origin(meta[g]);
+        int32_t kind = CMI_REEMIT_ABSORBED;
+        PacketRng rng;
+        if (valid) {
+          rng.resume(a.seed, a.iteration, a.first_packet + id[g],
+                     meta[g] & 0xffffffu, (meta[g] >> 24) & 1u);
+          kind = interaction_decide<FULL>(a, nu[g], at_cell[g], rng);
+        }
+        const bool again = kind != CMI_REEMIT_ABSORBED;
+        const unsigned int at = stage_reserve(stage, again);
+        if (again) {
+          stage.item[at] = record[g];
+          s_slot[at] = slot[g];
+          stage.state[at] =
+              cmi_pack_meta(rng.block, rng.have, (uint32_t)kind, origin);
+          stage.T[at] = at_cell[g].T;
+          stage.cached[at] = rng.cached;
+        } else if (valid) {
+          const double w = a.model.photon_weight[origin];
+          tw += w;
+          tc3 += w;
+          a.rows.keys[slot[g]] = key_dead;
+        }
+      }
     }
+    __syncthreads();
+    const unsigned int n = stage.n;
     if (DEFER) {
-      /* (the trip count is the same for every thread of a workgroup) */
-      const unsigned int q = block_reserve(made, a.new_count, s_count, &s_base);
-      if (made)
-        a.new_slots[q] = slot;
+      /* the slots that are filled, for flight_weights_kernel (a flight that
+       * starts outside the box is listed too: weights for a free slot) */
+      if (threadIdx.x == 0)
+        stage.base = n ? atomicAdd(a.new_count, n) : 0u;
+      __syncthreads();
     }
+    for (unsigned int j = threadIdx.x; j < n; j += CMI_BLOCK) {
+      const uint32_t i = stage.item[j];
+      const uint32_t state = stage.state[j];
+      const uint32_t to = s_slot[j];
+      const uint32_t packet = a.qin.id[i];
+      const uint32_t origin = cmi_meta_origin(state);
+      PacketRng rng;
+      rng.init(a.seed, a.iteration, a.first_packet + packet);
+      rng.block = state & 0xffffffu;
+      rng.have = (state >> 24) & 1u;
+      rng.cached = stage.cached[j];
+      int32_t type;
+      const double new_frequency = sample_reemission(
+          a.model, (int32_t)(state >> 28), stage.T[j], rng, type);
+      Packet<FULL> p;
+      double weights[CMI_NACC];
+      uint32_t plc = 0, key = key_dead;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax)
+        p.pos[ax] = a.qin.pos[ax][i];
+      if (interaction_new_flight<FULL, DEFER>(a, new_frequency, type, rng, p,
+                                              weights, plc, key)) {
+        write_flight_row<FULL, DEFER>(
+            a.rows, to, p, plc, key, packet,
+            cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin),
+            weights);
+      } else {
+        const double w = a.model.photon_weight[origin];
+        a.rows.keys[to] = key_dead;
+        tw += w;
+        tc1 += (type == TYPE_DIFFUSE_HI) ? w : 0.;
+        tc2 += (type == TYPE_DIFFUSE_HeI) ? w : 0.;
+      }
+      if (DEFER)
+        a.new_slots[stage.base + j] = to;
+    }
+    __syncthreads(); /* stage.n is reset at the head of the next batch */
   }
   tw = wave_sum(tw);
   tc1 = wave_sum(tc1);

@@ -43,8 +43,11 @@ def test_spectrum_samplers_match_oracle(oracle):
     m.xsec_type = oracle.XSEC_VERNER
     m.tables = oracle.lib().cmio_tables_create(C.byref(m))
     n = 200000
+    # (temperatures inside the table of the Lyman continuum spectra, in its
+    # first and last intervals and outside it on either side)
     for kind, T in ((0, 0.), (1, 8888.), (1, 1600.), (1, 14990.), (2, 8888.),
-                    (3, 0.)):
+                    (3, 0.), (1, 1000.), (2, 1567.5), (1, 14932.5),
+                    (2, 20000.)):
         got = eng.sample_spectrum(kind, T, 77, n)
         want = np.empty(n)
         oracle.lib().cmio_sample_spectrum(C.byref(m), kind, T, 77, n, p(want))

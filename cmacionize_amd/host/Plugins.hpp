@@ -390,6 +390,243 @@ public:
   }
 };
 
+/* src/BufferedCMacIonizeSnapshotDensityFunction.hpp:46-716: the density field
+ * of a snapshot of the reference's TASK-BASED simulation - cells stored
+ * subgrid after subgrid (`DensitySubGridCreator:number of subgrids` in the
+ * snapshot's parameters), the cells of a subgrid x-major, no coordinates -
+ * for a new box inside the old one at the old resolution or at 1 / k of it
+ * (k^3 old cells averaged per new cell, never across subgrid boundaries).
+ * The reference keeps `buffer size` subgrids in memory at a time and reads the
+ * others on demand; here all are read by initialize() - the values a cell is
+ * given are the same, and `DensityFunction:buffer size` is accepted. Values
+ * are SI (as in the reference, which applies no units here). */
+class BufferedCMacIonizeSnapshotDensityFunction : public DensityFunction {
+  const std::string _filename;
+  std::array<double, 3> _old_anchor, _subgrid_width;
+  std::array<long long, 3> _number_of_subgrids, _original_subgrid_ncell,
+      _mapped_subgrid_ncell;
+  long long _number_of_old_cells_per_new_cell_1D = 1;
+  size_t _original_subgrid_size = 0, _mapped_subgrid_size = 0;
+  /* [subgrid][cell of the mapped subgrid] */
+  std::vector<double> _number_density, _temperature;
+  std::array<std::vector<double>, NUMBER_OF_IONNAMES> _ionic_fraction;
+
+public:
+  /* :123-371 */
+  BufferedCMacIonizeSnapshotDensityFunction(
+      const std::string &filename, const std::array<double, 3> &new_anchor,
+      const std::array<double, 3> &new_sides,
+      const std::array<long long, 3> &new_ncell)
+      : _filename(filename) {
+    {
+      std::ifstream file(filename);
+      if (!file.is_open())
+        throw ParameterError("Could not open file \"" + filename + "\"!");
+    }
+    Hdf5Reader file(filename);
+    ParameterFile parameters;
+    for (const auto &kv : file.open("/Parameters").attributes)
+      parameters.add_value(kv.first, Hdf5Reader::as_string(kv.second));
+    if (!parameters.has_value("DensitySubGridCreator:number of subgrids"))
+      throw ParameterError(
+          "A BufferedCMacIonizeSnapshotDensityFunction can only be used to "
+          "read task-based CMacIonize snapshots!");
+    _number_of_subgrids = parameters.get_integer_vector(
+        "DensitySubGridCreator:number of subgrids", {-1, -1, -1});
+    _old_anchor = parameters.get_physical_vector(QUANTITY_LENGTH,
+                                                 "SimulationBox:anchor", "");
+    const std::array<double, 3> old_sides = parameters.get_physical_vector(
+        QUANTITY_LENGTH, "SimulationBox:sides", "");
+    const std::array<long long, 3> old_ncell = parameters.get_integer_vector(
+        "DensityGrid:number of cells", {-1, -1, -1});
+    /* :176-196: the new box inside the old one */
+    std::array<double, 3> anchor_in_old_box, available_sides;
+    for (int a = 0; a < 3; ++a) {
+      anchor_in_old_box[a] = new_anchor[a] - _old_anchor[a];
+      available_sides[a] = (new_anchor[a] + new_sides[a]) - _old_anchor[a];
+      if (anchor_in_old_box[a] < 0. || available_sides[a] < new_sides[a])
+        throw ParameterError(
+            "New simulation box is not inside old simulation box!");
+    }
+    /* :198-240: ... on cell boundaries of the old grid */
+    std::array<double, 3> old_cell_size, new_cell_size;
+    std::array<long long, 3> cell_sides;
+    for (int a = 0; a < 3; ++a) {
+      old_cell_size[a] = old_sides[a] / old_ncell[a];
+      new_cell_size[a] = new_sides[a] / new_ncell[a];
+      const double cell_offset_float = anchor_in_old_box[a] / old_cell_size[a];
+      const double cell_sides_float = available_sides[a] / old_cell_size[a];
+      const long long cell_offset = (long long)std::round(cell_offset_float);
+      cell_sides[a] = (long long)std::round(cell_sides_float);
+      if (std::abs(cell_offset_float) - cell_offset > 1.e-10 ||
+          std::abs(cell_sides_float) - cell_sides[a] > 1.e-10)
+        throw ParameterError("New box not compatible with old resolution!");
+    }
+    /* :242-262 */
+    for (int a = 1; a < 3; ++a)
+      if (std::abs(old_sides[0] - old_sides[a]) > 1.e-10 ||
+          std::abs(new_sides[0] - new_sides[a]) > 1.e-10 ||
+          std::abs(old_cell_size[0] - old_cell_size[a]) > 1.e-10 ||
+          std::abs(new_cell_size[0] - new_cell_size[a]) > 1.e-10)
+        throw ParameterError("Buffered snapshot reading currently only works "
+                             "for square boxes and cells!");
+    /* :263-272 */
+    if (cell_sides[0] <= new_ncell[0]) {
+      _number_of_old_cells_per_new_cell_1D = 1;
+    } else {
+      if (cell_sides[0] % new_ncell[0] != 0)
+        throw ParameterError(
+            "New resolution not compatible with old resolution!");
+      _number_of_old_cells_per_new_cell_1D = cell_sides[0] / new_ncell[0];
+    }
+    /* :273-316 */
+    for (int a = 0; a < 3; ++a) {
+      _original_subgrid_ncell[a] = old_ncell[a] / _number_of_subgrids[a];
+      _subgrid_width[a] = old_sides[a] / _number_of_subgrids[a];
+      const double subgrid_offset_float =
+          anchor_in_old_box[a] / _subgrid_width[a];
+      const long long subgrid_offset =
+          (long long)std::round(subgrid_offset_float);
+      if (_number_of_old_cells_per_new_cell_1D > 1 &&
+          (std::abs(subgrid_offset_float - subgrid_offset) > 1.e-10 ||
+           _original_subgrid_ncell[0] % _number_of_old_cells_per_new_cell_1D !=
+               0))
+        throw ParameterError("Degrading resolution across subgrid boundaries "
+                             "not yet supported!");
+      _mapped_subgrid_ncell[a] =
+          _original_subgrid_ncell[a] / _number_of_old_cells_per_new_cell_1D;
+    }
+    _original_subgrid_size = (size_t)(_original_subgrid_ncell[0] *
+                                      _original_subgrid_ncell[1] *
+                                      _original_subgrid_ncell[2]);
+    _mapped_subgrid_size =
+        (size_t)(_mapped_subgrid_ncell[0] * _mapped_subgrid_ncell[1] *
+                 _mapped_subgrid_ncell[2]);
+    if (!file.exists("/PartType0/NumberDensity") &&
+        !file.exists("/PartType0/Density"))
+      throw ParameterError("No density variable present in snapshot file!");
+    if (!file.exists("/PartType0/Temperature") &&
+        !file.exists("/PartType0/Pressure"))
+      throw ParameterError("No temperature variable present in snapshot file!");
+  }
+  explicit BufferedCMacIonizeSnapshotDensityFunction(ParameterFile &params)
+      : BufferedCMacIonizeSnapshotDensityFunction(
+            (params.get_integer("DensityFunction:buffer size", 100),
+             params.get_filename("DensityFunction:filename")),
+            params.get_physical_vector(QUANTITY_LENGTH, "SimulationBox:anchor",
+                                       ""),
+            params.get_physical_vector(QUANTITY_LENGTH, "SimulationBox:sides",
+                                       ""),
+            params.get_integer_vector("DensityGrid:number of cells",
+                                      {-1, -1, -1})) {}
+
+  /* buffer_subgrid for every subgrid, :452-585 */
+  void initialize() override {
+    Hdf5Reader file(_filename);
+    const bool read_number_density = file.exists("/PartType0/NumberDensity");
+    const bool read_temperature = file.exists("/PartType0/Temperature");
+    std::vector<double> number_density = file.read_doubles(
+        read_number_density ? "/PartType0/NumberDensity" : "/PartType0/Density");
+    std::vector<double> temperature = file.read_doubles(
+        read_temperature ? "/PartType0/Temperature" : "/PartType0/Pressure");
+    const size_t nsub = (size_t)(_number_of_subgrids[0] *
+                                 _number_of_subgrids[1] * _number_of_subgrids[2]);
+    const size_t n = nsub * _original_subgrid_size;
+    if (number_density.size() != n || temperature.size() != n)
+      throw ParameterError("snapshot with " +
+                           std::to_string(number_density.size()) +
+                           " cells, its parameters say " + std::to_string(n));
+    std::array<std::vector<double>, NUMBER_OF_IONNAMES> fractions;
+    for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion) {
+      const std::string name =
+          std::string("/PartType0/NeutralFraction") + ion_name(ion);
+      if (file.exists(name))
+        fractions[ion] = file.read_doubles(name);
+      else
+        fractions[ion].assign(n, 1.e-6);
+      if (fractions[ion].size() != n)
+        throw ParameterError("snapshot dataset " + name + " has the wrong size");
+    }
+    for (size_t i = 0; i < n; ++i) {
+      if (!read_number_density)
+        number_density[i] /= constants::proton_mass;
+      if (!read_temperature) {
+        const double mu = 0.5 * (1. + fractions[ION_H_n][i]);
+        temperature[i] *= mu / (number_density[i] * constants::boltzmann);
+      }
+    }
+    const long long k = _number_of_old_cells_per_new_cell_1D;
+    const double norm = 1. / (double)(k * k * k);
+    _number_density.assign(nsub * _mapped_subgrid_size, 0.);
+    _temperature.assign(nsub * _mapped_subgrid_size, 0.);
+    for (auto &f : _ionic_fraction)
+      f.assign(nsub * _mapped_subgrid_size, 0.);
+    for (size_t subgrid = 0; subgrid < nsub; ++subgrid) {
+      const size_t from = subgrid * _original_subgrid_size;
+      const size_t to = subgrid * _mapped_subgrid_size;
+      for (long long ix = 0; ix < _mapped_subgrid_ncell[0]; ++ix)
+        for (long long iy = 0; iy < _mapped_subgrid_ncell[1]; ++iy)
+          for (long long iz = 0; iz < _mapped_subgrid_ncell[2]; ++iz) {
+            const size_t mapped =
+                to + (size_t)((ix * _mapped_subgrid_ncell[1] + iy) *
+                                  _mapped_subgrid_ncell[2] +
+                              iz);
+            for (long long oix = 0; oix < k; ++oix)
+              for (long long oiy = 0; oiy < k; ++oiy)
+                for (long long oiz = 0; oiz < k; ++oiz) {
+                  const size_t original =
+                      from + (size_t)(((k * ix + oix) *
+                                           _original_subgrid_ncell[1] +
+                                       (k * iy + oiy)) *
+                                          _original_subgrid_ncell[2] +
+                                      (k * iz + oiz));
+                  _number_density[mapped] += number_density[original];
+                  _temperature[mapped] += temperature[original];
+                  for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+                    _ionic_fraction[ion][mapped] += fractions[ion][original];
+                }
+            _number_density[mapped] *= norm;
+            _temperature[mapped] *= norm;
+            for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+              _ionic_fraction[ion][mapped] *= norm;
+          }
+    }
+  }
+
+  void free() override {
+    std::vector<double>().swap(_number_density);
+    std::vector<double>().swap(_temperature);
+    for (auto &f : _ionic_fraction)
+      std::vector<double>().swap(f);
+  }
+
+  /* :640-712 */
+  DensityValues operator()(const Cell &cell) override {
+    const CoordinateVector p = cell.get_cell_midpoint();
+    size_t subgrid = 0, index = 0;
+    for (int a = 0; a < 3; ++a) {
+      const long long si =
+          (long long)((p[a] - _old_anchor[a]) / _subgrid_width[a]);
+      if (si < 0 || si >= _number_of_subgrids[a])
+        throw ParameterError("cell midpoint outside the snapshot's box");
+      const double subgrid_anchor = _old_anchor[a] + si * _subgrid_width[a];
+      long long ci = (long long)((p[a] - subgrid_anchor) / _subgrid_width[a] *
+                                 _mapped_subgrid_ncell[a]);
+      if (ci >= _mapped_subgrid_ncell[a]) /* (rounding at a subgrid's top) */
+        ci = _mapped_subgrid_ncell[a] - 1;
+      subgrid = subgrid * (size_t)_number_of_subgrids[a] + (size_t)si;
+      index = index * (size_t)_mapped_subgrid_ncell[a] + (size_t)ci;
+    }
+    const size_t at = subgrid * _mapped_subgrid_size + index;
+    DensityValues values;
+    values.set_number_density(_number_density[at]);
+    values.set_temperature(_temperature[at]);
+    for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+      values.set_ionic_fraction(ion, _ionic_fraction[ion][at]);
+    return values;
+  }
+};
+
 /* src/GadgetSnapshotDensityFunction.cpp:60-372: the gas particles of a Gadget
  * / SWIFT HDF5 snapshot (PartType0: Coordinates, Masses, SmoothingLength,
  * Density, optionally Temperature and NeutralFractionH) mapped onto the
@@ -1006,6 +1243,8 @@ inline DensityFunction *generate_density_function(ParameterFile &params) {
     return new BlockSyntaxDensityFunction(params);
   if (type == "CMacIonizeSnapshot")
     return new CMacIonizeSnapshotDensityFunction(params);
+  if (type == "BufferedCMacIonizeSnapshot")
+    return new BufferedCMacIonizeSnapshotDensityFunction(params);
   if (type == "GadgetSnapshot")
     return new GadgetSnapshotDensityFunction(params);
   if (type == "FLASHSnapshot")
@@ -1014,8 +1253,8 @@ inline DensityFunction *generate_density_function(ParameterFile &params) {
     return new AmunSnapshotDensityFunction(params);
   throw ParameterError("Unknown DensityFunction type: \"" + type +
                        "\" (this engine provides Homogeneous, BlockSyntax, "
-                       "CMacIonizeSnapshot, GadgetSnapshot, FLASHSnapshot "
-                       "and AmunSnapshot; pass your own DensityFunction to "
+                       "CMacIonizeSnapshot, BufferedCMacIonizeSnapshot, "
+                       "GadgetSnapshot, FLASHSnapshot and AmunSnapshot; pass your own DensityFunction to "
                        "initialize())");
 }
 

@@ -186,7 +186,17 @@ __host__ __device__ inline void cmi_cross_sections(const ModelDev &m, double nu,
   for (int i = 0; i < CMI_NION; ++i)
     sigma[i] = 0.;
   const VernerTermDev *terms = m.tables->verner;
-  for (int k = 0; k < CMI_VERNER_NTERM_DEV; ++k) {
+#ifndef CMI_EXP_VERNER_TERMS /* (timing experiments: fewer terms, wrong sums) */
+#define CMI_EXP_VERNER_TERMS CMI_VERNER_NTERM_DEV
+#endif
+  for (int k = 0; k < CMI_EXP_VERNER_TERMS; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* a term none of the wave's photons reaches is a jump, not a masked-off
+     * fit (the callers that evaluate all 14 cross sections order their
+     * photons by verner_class so that this is the rule) */
+    if (__builtin_amdgcn_ballot_w64(nu >= terms[k].E_th) == 0ull)
+      continue;
+#endif
     const double s = verner_term_sigma(terms[k], nu);
     const int ion = terms[k].ion;
     /* static indexing keeps sigma[] in registers */
@@ -196,6 +206,19 @@ __host__ __device__ inline void cmi_cross_sections(const ModelDev &m, double nu,
         sigma[i] += s;
   }
 }
+
+/* how many of the fits' thresholds a photon lies above: photons of a class
+ * skip the same terms */
+__device__ inline uint32_t verner_class(const ModelDev &m, double nu) {
+  if (!m.xsec_verner)
+    return 0;
+  const VernerTermDev *terms = m.tables->verner;
+  uint32_t c = 0;
+  for (int k = 0; k < CMI_VERNER_NTERM_DEV; ++k)
+    c += (nu >= terms[k].E_th) ? 1u : 0u;
+  return c;
+}
+#define CMI_VERNER_NCLASS (CMI_VERNER_NTERM_DEV + 1)
 
 /* the cross sections of H0 and He0 alone (the re-emission decision needs no
  * others): same terms, same order of summation as cmi_cross_sections */

@@ -2364,26 +2364,63 @@ struct FlightWeightsArgs {
 };
 
 /* (159 VGPRs, 3 waves/SIMD; bounded to 128 registers it spills and is 15 %
- * slower) */
+ * slower.) A workgroup takes the flights of a batch in the order of their
+ * verner_class (order_by_verner_class, below): re-emitted photons are mostly
+ * hydrogen's Lyman continuum just above 13.6 eV, and a wave of those jumps
+ * over 19 of the 22 fits. */
+template <int TRIPS>
+__device__ __forceinline__ void
+order_by_verner_class(const uint32_t (&cls)[TRIPS], unsigned int n,
+                      uint32_t *s_count, uint16_t *order);
+#ifndef CMI_WEIGHTS_BATCH
+#define CMI_WEIGHTS_BATCH 4
+#endif
 __global__ void __launch_bounds__(CMI_BLOCK)
     flight_weights_kernel(const FlightWeightsArgs a) {
-  uint64_t n = a.count ? (uint64_t)*a.count : a.n;
-  if (n > a.rows.capacity)
-    n = a.rows.capacity;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += stride) {
-    const uint32_t q = a.slots ? a.slots[i] : (uint32_t)i;
-    Packet<true> p;
-    p.nu = a.rows.rows[(size_t)CMI_FLIGHT_DOUBLES * q + 6];
-    double weights[CMI_NACC];
-    set_cross_sections<true>(a.model, p, weights);
-    double4 *w = reinterpret_cast<double4 *>(a.rows.weights +
-                                             (size_t)CMI_NACC * q);
+  constexpr int TRIPS = CMI_WEIGHTS_BATCH;
+  constexpr unsigned int BATCH = TRIPS * CMI_BLOCK;
+  __shared__ double s_nu[BATCH];
+  __shared__ uint32_t s_slot[BATCH];
+  __shared__ uint16_t s_order[BATCH];
+  __shared__ uint32_t s_count[CMI_VERNER_NCLASS];
+  uint64_t total = a.count ? (uint64_t)*a.count : a.n;
+  if (total > a.rows.capacity)
+    total = a.rows.capacity;
+  const uint64_t stride = (uint64_t)gridDim.x * BATCH;
+  for (uint64_t base = (uint64_t)blockIdx.x * BATCH; base < total;
+       base += stride) {
+    const unsigned int n =
+        total - base < BATCH ? (unsigned int)(total - base) : BATCH;
+    uint32_t cls[TRIPS];
 #pragma unroll
-    for (int k = 0; k < CMI_NACC; k += 4)
-      w[k >> 2] = make_double4(weights[k], weights[k + 1], weights[k + 2],
-                               weights[k + 3]);
+    for (int k = 0; k < TRIPS; ++k) {
+      const unsigned int local = (unsigned int)k * CMI_BLOCK + threadIdx.x;
+      cls[k] = 0;
+      if (local < n) {
+        const uint64_t i = base + local;
+        const uint32_t q = a.slots ? a.slots[i] : (uint32_t)i;
+        const double nu = a.rows.rows[(size_t)CMI_FLIGHT_DOUBLES * q + 6];
+        s_slot[local] = q;
+        s_nu[local] = nu;
+        cls[k] = verner_class(a.model, nu);
+      }
+    }
+    order_by_verner_class<TRIPS>(cls, n, s_count, s_order);
+    for (unsigned int j = threadIdx.x; j < n; j += CMI_BLOCK) {
+      const unsigned int local = s_order[j];
+      const uint32_t q = s_slot[local];
+      Packet<true> p;
+      p.nu = s_nu[local];
+      double weights[CMI_NACC];
+      set_cross_sections<true>(a.model, p, weights);
+      double4 *w = reinterpret_cast<double4 *>(a.rows.weights +
+                                               (size_t)CMI_NACC * q);
+#pragma unroll
+      for (int k = 0; k < CMI_NACC; k += 4)
+        w[k >> 2] = make_double4(weights[k], weights[k + 1], weights[k + 2],
+                                 weights[k + 3]);
+    }
+    __syncthreads(); /* the batch's arrays are rewritten by the next one */
   }
 }
 
@@ -2472,8 +2509,147 @@ __device__ inline float approximate_opacity_cross_section(const ModelDev &m,
 #ifndef CMI_KEY_WAVES
 #define CMI_KEY_WAVES 3
 #endif
+/* A workgroup's photons in the order of their verner_class: in `order` the
+ * indices [0, n) of the batch, class after class (any order inside a class).
+ * cls = the class of the photon local = trip * CMI_BLOCK + threadIdx.x of each
+ * of the thread's TRIPS photons (ignored beyond n). Called by all threads;
+ * ends with a barrier. */
+template <int TRIPS>
+__device__ __forceinline__ void
+order_by_verner_class(const uint32_t (&cls)[TRIPS], unsigned int n,
+                      uint32_t *s_count /* [CMI_VERNER_NCLASS] */,
+                      uint16_t *order) {
+  if (threadIdx.x < CMI_VERNER_NCLASS)
+    s_count[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < TRIPS; ++k)
+    if ((unsigned int)k * CMI_BLOCK + threadIdx.x < n)
+      atomicAdd(&s_count[cls[k]], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t at = 0;
+    for (int c = 0; c < CMI_VERNER_NCLASS; ++c) {
+      const uint32_t here = s_count[c];
+      s_count[c] = at;
+      at += here;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < TRIPS; ++k) {
+    const unsigned int local = (unsigned int)k * CMI_BLOCK + threadIdx.x;
+    if (local < n)
+      order[atomicAdd(&s_count[cls[k]], 1u)] = (uint16_t)local;
+  }
+  __syncthreads();
+}
+
+/* direction_key_kernel with the emission physics (pre_rows): the 22 Verner
+ * fits of a packet's 14 cross sections are two logarithms, an exponential and
+ * a square root each - 8 of this kernel's 16 ms per 1e8 packets of a 40 000 K
+ * star when every wave evaluates every term because one of its 64 photons
+ * lies above the term's threshold. Four in five of that star's photons lie
+ * below 21.6 eV and above three thresholds only. So: a workgroup draws the
+ * packets of a batch (direction, frequency, optical depth) into LDS, orders
+ * them by the number of thresholds they lie above, and evaluates the fits in
+ * that order - most waves then jump over most terms (cmi_cross_sections). */
+#ifndef CMI_KEY_BATCH
+#define CMI_KEY_BATCH 4
+#endif
+__device__ __forceinline__ void
+direction_key_batches(const KeyArgs &a) {
+  constexpr int TRIPS = CMI_KEY_BATCH;
+  constexpr unsigned int BATCH = TRIPS * CMI_BLOCK;
+  __shared__ double s_nu[BATCH], s_tau[BATCH];
+  __shared__ uint32_t s_src[BATCH], s_morton[BATCH];
+  __shared__ uint16_t s_order[BATCH];
+  __shared__ uint32_t s_count[CMI_VERNER_NCLASS];
+  const uint32_t lo_bits = a.dir_bits - a.dir_hi_bits;
+  const uint64_t stride = (uint64_t)gridDim.x * BATCH;
+  for (uint64_t base = (uint64_t)blockIdx.x * BATCH; base < a.n_packets;
+       base += stride) {
+    const unsigned int n = a.n_packets - base < BATCH
+                               ? (unsigned int)(a.n_packets - base)
+                               : BATCH;
+    uint32_t cls[TRIPS];
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {
+      const unsigned int local = (unsigned int)k * CMI_BLOCK + threadIdx.x;
+      cls[k] = 0;
+      if (local >= n)
+        continue;
+      /* the draws of emit_packet, in its order */
+      PacketRng rng;
+      rng.init(a.seed, a.iteration, a.first_packet + base + local);
+      const uint32_t origin =
+          rng.next() >= a.model.continuous_probability ? 0u : 1u;
+      uint32_t src = 0;
+      if (origin == 0) {
+        const double xs = rng.next(); /* source pick */
+        while (xs > a.model.source_cumulative[src])
+          ++src;
+      } else {
+        src = (uint32_t)a.model.nsource;
+        (void)rng.next();
+        (void)rng.next();
+        if (a.model.continuous_type == 1)
+          (void)rng.next();
+      }
+      const double u_cost = rng.next(); /* cos(theta) = 2 u - 1 */
+      const double u_phi = rng.next();  /* phi = 2 pi u */
+      const uint32_t ic = (uint32_t)(u_cost * 2048.);
+      const uint32_t ip = (uint32_t)(u_phi * 2048.);
+      const double nu = sample_source_spectrum(a.model, rng, origin);
+      s_nu[local] = nu;
+      s_tau[local] = -log(rng.next());
+      s_src[local] = src;
+      s_morton[local] = (spread_bits_11(ic) | (spread_bits_11(ip) << 1)) >>
+                        (22u - a.dir_bits);
+      cls[k] = verner_class(a.model, nu);
+    }
+    order_by_verner_class<TRIPS>(cls, n, s_count, s_order);
+    for (unsigned int j = threadIdx.x; j < n; j += CMI_BLOCK) {
+      const unsigned int local = s_order[j];
+      const uint64_t i = base + local;
+      Packet<true> q;
+      double weights[CMI_NACC];
+      q.nu = s_nu[local];
+      set_cross_sections<true>(a.model, q, weights);
+      const double tau = s_tau[local];
+      weights[CMI_NION] = q.nu;
+      weights[CMI_NION + 1] = tau;
+      double4 *row =
+          reinterpret_cast<double4 *>(a.pre_rows + (size_t)CMI_NACC * i);
+#pragma unroll
+      for (int k = 0; k < CMI_NACC; k += 4)
+        row[k >> 2] = make_double4(weights[k], weights[k + 1], weights[k + 2],
+                                   weights[k + 3]);
+      uint32_t tau_class = 0;
+      if (a.tau_bits != 0) {
+        const double range = tau * a.sigma_ref / (q.sigma_H + q.sigma_He_corr);
+        const int octave = (int)floor(log2(range)) + (1 << (a.tau_bits - 1));
+        const int top = (1 << a.tau_bits) - 1;
+        tau_class = (uint32_t)(octave < 0 ? 0 : (octave > top ? top : octave));
+      }
+      const uint32_t morton = s_morton[local];
+      const uint32_t hi = morton >> lo_bits;
+      const uint32_t lo = morton & ((1u << lo_bits) - 1u);
+      a.keys[i] = ((s_src[local] & a.source_mask)
+                   << (a.dir_bits + a.tau_bits)) |
+                  (hi << (a.tau_bits + lo_bits)) | (tau_class << lo_bits) | lo;
+      a.ids[i] = (uint32_t)i;
+    }
+    __syncthreads(); /* the batch's arrays are rewritten by the next one */
+  }
+}
+
 __global__ void __launch_bounds__(CMI_BLOCK, CMI_KEY_WAVES)
     direction_key_kernel(const KeyArgs a) {
+  if (a.pre_rows != nullptr) {
+    direction_key_batches(a);
+    return;
+  }
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint32_t lo_bits = a.dir_bits - a.dir_hi_bits;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2503,30 +2679,7 @@ __global__ void __launch_bounds__(CMI_BLOCK, CMI_KEY_WAVES)
     const uint32_t morton =
         (spread_bits_11(ic) | (spread_bits_11(ip) << 1)) >> (22u - a.dir_bits);
     uint32_t tau_class = 0;
-    if (a.pre_rows != nullptr) {
-      /* the whole of emit_physics, here where every lane has a packet and the
-       * registers are free (the transport kernel runs it at 3 waves/SIMD
-       * between its refills) */
-      Packet<true> q;
-      double weights[CMI_NACC];
-      q.nu = sample_source_spectrum(a.model, rng, origin);
-      set_cross_sections<true>(a.model, q, weights);
-      const double tau = -log(rng.next());
-      weights[CMI_NION] = q.nu;
-      weights[CMI_NION + 1] = tau;
-      double4 *row = reinterpret_cast<double4 *>(a.pre_rows +
-                                                 (size_t)CMI_NACC * i);
-#pragma unroll
-      for (int k = 0; k < CMI_NACC; k += 4)
-        row[k >> 2] = make_double4(weights[k], weights[k + 1], weights[k + 2],
-                                   weights[k + 3]);
-      if (a.tau_bits != 0) {
-        const double range = tau * a.sigma_ref / (q.sigma_H + q.sigma_He_corr);
-        const int octave = (int)floor(log2(range)) + (1 << (a.tau_bits - 1));
-        const int top = (1 << a.tau_bits) - 1;
-        tau_class = (uint32_t)(octave < 0 ? 0 : (octave > top ? top : octave));
-      }
-    } else if (a.tau_bits != 0) {
+    if (a.tau_bits != 0) {
       if (!a.full_ions) {
         (void)sample_source_spectrum(a.model, rng, origin); /* its draws */
         const double u_tau = rng.next();            /* tau = -ln u */

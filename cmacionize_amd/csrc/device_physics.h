@@ -189,6 +189,10 @@ __host__ __device__ inline void cmi_cross_sections(const ModelDev &m, double nu,
 #ifndef CMI_EXP_VERNER_TERMS /* (timing experiments: fewer terms, wrong sums) */
 #define CMI_EXP_VERNER_TERMS CMI_VERNER_NTERM_DEV
 #endif
+  /* (one copy of the fit in the code, not 22: the unrolled loop was 100 KB of
+   * instructions per call site - more than the instruction cache holds - and
+   * most of the library's compile time) */
+#pragma unroll 1
   for (int k = 0; k < CMI_EXP_VERNER_TERMS; ++k) {
 #if defined(__HIP_DEVICE_COMPILE__)
     /* a term none of the wave's photons reaches is a jump, not a masked-off
@@ -233,6 +237,7 @@ __host__ __device__ inline void cmi_cross_sections_H_He(const ModelDev &m, doubl
   sigma_H = 0.;
   sigma_He = 0.;
   const VernerTermDev *terms = m.tables->verner;
+#pragma unroll 1
   for (int k = 0; k < CMI_VERNER_NTERM_DEV; ++k) {
     const int ion = terms[k].ion; /* wave-uniform: the table is */
     if (ion == ION_H_n)

@@ -62,10 +62,13 @@ struct PacketRng {
     uint32_t k0 = seed, k1 = iteration;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-      const uint32_t hi0 = __umulhi(0xD2511F53u, c0);
-      const uint32_t lo0 = 0xD2511F53u * c0;
-      const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2);
-      const uint32_t lo1 = 0xCD9E8D57u * c2;
+      /* (64-bit products: one v_mad_u64_u32 each instead of v_mul_hi_u32 +
+       * v_mul_lo_u32 - a block costs a SIMD 97-106 ns instead of 143,
+       * tools/microbench/philox_mul.hip) */
+      const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+      const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+      const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+      const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
       c0 = hi1 ^ c1 ^ k0;
       c1 = lo1;
       c2 = hi0 ^ c3 ^ k1;

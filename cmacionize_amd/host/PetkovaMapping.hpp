@@ -167,7 +167,9 @@ public:
    * this mapping type) */
   PetkovaMapping() : _table((size_t)NROW * NCOL * NCOL, 0.) {
     const int last = NR_FINE + NR_COARSE;
+#ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1)
+#endif
     for (int i = 1; i <= last; ++i) {
       const double r0 = radius_node(i);
       double *row = &_table[(size_t)i * NCOL * NCOL];
@@ -270,9 +272,13 @@ public:
    * point towards it (and the side of an edge is judged from the face's
    * midpoint, below), which makes the sum the integral (the mapping type
    * "Petkova_oriented", not in the reference). */
+  /* tabulated = false: the closed form itself at every vertex, as
+   * PhantomSnapshotDensityFunction::mass_contribution does
+   * (src/PhantomSnapshotDensityFunction.cpp:279-378) */
   double mass_fraction(const std::vector<Face> &faces,
                        const double particle[3], double h,
-                       const double *oriented_towards = nullptr) const {
+                       const double *oriented_towards = nullptr,
+                       bool tabulated = true) const {
     auto det3 = [](const double *p, const double *q, const double *r) {
       return p[0] * (q[1] * r[2] - q[2] * r[1]) +
              p[1] * (q[2] * r[0] - q[0] * r[2]) +
@@ -357,9 +363,13 @@ public:
         }
         const double sign = same_side * side <= 0. ? -1. : 1.;
         const double Ia =
-            interpolated_vertex_integral(phi_a, cosphi_a, ar0, R_0, h);
+            tabulated
+                ? interpolated_vertex_integral(phi_a, cosphi_a, ar0, R_0, h)
+                : vertex_integral(phi_a, cosphi_a, ar0, R_0, h);
         const double Ib =
-            interpolated_vertex_integral(phi_b, cosphi_b, ar0, R_0, h);
+            tabulated
+                ? interpolated_vertex_integral(phi_b, cosphi_b, ar0, R_0, h)
+                : vertex_integral(phi_b, cosphi_b, ar0, R_0, h);
         const double sinphi_a = std::sqrt((1. - cosphi_a) * (1. + cosphi_a));
         const double sinphi_b = std::sqrt((1. - cosphi_b) * (1. + cosphi_b));
         /* the foot of the perpendicular outside the edge: the difference of
@@ -370,8 +380,9 @@ public:
           total += sign * (Ia + Ib);
       }
     }
-    /* "Ensure there is no negative mass" */
-    return std::max(total, 1.e-6);
+    /* "Ensure there is no negative mass" (SPHArrayInterface's version; the
+     * Phantom density function's returns the sum as it is) */
+    return tabulated ? std::max(total, 1.e-6) : total;
   }
 };
 

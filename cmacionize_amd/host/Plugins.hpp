@@ -1234,6 +1234,8 @@ public:
   }
 };
 
+DensityFunction *generate_sph_snapshot_density_function(const std::string &type,
+                                                        ParameterFile &params);
 inline DensityFunction *generate_density_function(ParameterFile &params) {
   const std::string type =
       params.get_string("DensityFunction:type", "Homogeneous");
@@ -1251,10 +1253,14 @@ inline DensityFunction *generate_density_function(ParameterFile &params) {
     return new FLASHSnapshotDensityFunction(params);
   if (type == "AmunSnapshot")
     return new AmunSnapshotDensityFunction(params);
+  /* the binary dumps of SPH codes: SphSnapshots.hpp */
+  if (DensityFunction *f = generate_sph_snapshot_density_function(type, params))
+    return f;
   throw ParameterError("Unknown DensityFunction type: \"" + type +
                        "\" (this engine provides Homogeneous, BlockSyntax, "
                        "CMacIonizeSnapshot, BufferedCMacIonizeSnapshot, "
-                       "GadgetSnapshot, FLASHSnapshot and AmunSnapshot; pass your own DensityFunction to "
+                       "GadgetSnapshot, FLASHSnapshot, AmunSnapshot, "
+                       "PhantomSnapshot and SPHNGSnapshot; pass your own DensityFunction to "
                        "initialize())");
 }
 
@@ -1771,5 +1777,9 @@ struct SimulationBox {
 };
 
 } // namespace cmi
+
+/* (after everything above: it uses the plugin surfaces and the Petkova
+ * mapping, which uses them too) */
+#include "SphSnapshots.hpp"
 
 #endif

@@ -21,8 +21,9 @@ public:
 } // namespace
 
 int main(int argc, char **argv) {
-  if (argc != 2) {
-    std::fprintf(stderr, "usage: %s PARAMETER_FILE < points\n", argv[0]);
+  if (argc != 2 && !(argc == 3 && std::string(argv[2]) == "--particles")) {
+    std::fprintf(stderr, "usage: %s PARAMETER_FILE [--particles] < points\n",
+                 argv[0]);
     return 2;
   }
   try {
@@ -30,6 +31,20 @@ int main(int argc, char **argv) {
     std::unique_ptr<cmi::DensityFunction> f(
         cmi::generate_density_function(params));
     f->initialize();
+    if (argc == 3) {
+      /* the particles of an SPH snapshot: "x y z mass h" per particle (SI) */
+      if (auto *p = dynamic_cast<cmi::SphKernelDensityFunction *>(
+              f.get())) {
+        for (size_t i = 0; i < p->get_number_of_particles(); ++i) {
+          const cmi::CoordinateVector x = p->get_position(i);
+          std::printf("%.17g %.17g %.17g %.17g %.17g\n", x[0], x[1], x[2],
+                      p->get_mass(i), p->get_smoothing_length(i));
+        }
+        return 0;
+      }
+      std::fprintf(stderr, "error: not a particle snapshot\n");
+      return 1;
+    }
     double x, y, z;
     while (std::cin >> x >> y >> z) {
       const PointCell cell(cmi::CoordinateVector(x, y, z));

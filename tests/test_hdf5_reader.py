@@ -772,3 +772,140 @@ def test_buffered_snapshot_refusals(density_cli, tmp_path):
              expect_error="")
     buffered(density_cli, tmp_path, 8, point, filename="/nonexistent.hdf5",
              expect_error="Could not open file")
+
+
+# ---- Phantom dumps (round 4) -------------------------------------------------
+
+PHANTOM = os.path.join(ROOT, "tests", "golden", "Phantomtest.dat")
+
+
+def phantom_block(extra=""):
+    return ("  type: PhantomSnapshot\n  filename: %s\n%s" % (PHANTOM, extra))
+
+
+def test_phantom_snapshot_fixture_of_the_reference(density_cli, tmp_path):
+    """test/testPhantomSnapshotDensityFunction.cpp:40-75 on the reference's
+    fixture (tests/golden/Phantomtest.dat = test/Phantomtest.dat, a tagged
+    Phantom dump of 100 particles written by test/write_Phantomtest.py; its
+    positions and smoothing lengths in cm in Phantom_data.txt): every
+    particle's position, mass (1e-5 kg: massoftype 0.01 x umass 1 g) and
+    smoothing length to 1e-14, as the reference asserts."""
+    p = tmp_path / "density.param"
+    p.write_text("DensityFunction:\n" + phantom_block())
+    r = subprocess.run([density_cli, str(p), "--particles"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.array([[float(v) for v in line.split()]
+                    for line in r.stdout.splitlines()])
+    want = np.loadtxt(os.path.join(ROOT, "tests", "golden",
+                                   "Phantom_data.txt"))
+    assert got.shape == (100, 5) and want.shape == (100, 4)
+    # UnitConverter: cm -> m
+    assert np.allclose(got[:, :3], want[:, :3] * 0.01, rtol=1e-14, atol=0.)
+    assert np.allclose(got[:, 3], 1.e-5, rtol=1e-14, atol=0.)
+    assert np.allclose(got[:, 4], want[:, 3] * 0.01, rtol=1e-14, atol=0.)
+
+
+def test_phantom_snapshot_mappings(density_cli, tmp_path):
+    """The two mappings of the Phantom particles onto cells
+    (src/PhantomSnapshotDensityFunction.cpp:720-832): the kernel of Price
+    (2007) at the point - against the sum written out here - and, through the
+    host driver's grid, the Petkova integral over the cells, which conserves
+    the particles' mass where the kernel at the midpoints only approximates
+    it."""
+    want = np.loadtxt(os.path.join(ROOT, "tests", "golden",
+                                   "Phantom_data.txt")) * 0.01
+    rng = np.random.default_rng(5)
+    points = rng.uniform(0.001, 0.009, (200, 3))
+    got = evaluate(density_cli, tmp_path, phantom_block(), points)
+    r = np.sqrt(((points[:, None, :] - want[None, :, :3]) ** 2).sum(axis=2))
+    h = want[None, :, 3]
+    q = r / h
+    w = np.where(q < 1., 1. - 1.5 * q ** 2 + 0.75 * q ** 3,
+                 np.where(q < 2., 0.25 * (2. - q) ** 3, 0.)) / (np.pi * h ** 3)
+    rho = (1.e-5 * w).sum(axis=1)
+    assert np.allclose(got[:, 0], rho / 1.6737236e-27, rtol=1e-12)
+    assert np.all(got[:, 1] == 8000.) and np.all(got[:, 2] == 1.e-6)
+    assert (got[:, 0] > 0.).sum() > 50
+    hot = evaluate(density_cli, tmp_path,
+                   phantom_block("  initial temperature: 250. K\n"), points)
+    assert np.all(hot[:, 1] == 250.)
+    evaluate(density_cli, tmp_path,
+             "  type: PhantomSnapshot\n  filename: /nonexistent.dat\n",
+             points[:1], expect_error="Unable to open file")
+    evaluate(density_cli, tmp_path, phantom_block("  use periodic box: true\n"),
+             points[:1], expect_error="periodic box")
+
+
+def test_phantom_snapshot_on_a_grid_conserves_mass(exe, cli, tmp_path):
+    """PhantomSnapshot through the driver (dry run, initial snapshot only):
+    the Petkova integral over the cells (`use new algorithm`, with the cells'
+    faces oriented - the reference's face conventions do not sum to the
+    integral on a Cartesian grid) puts the mass of every
+    particle whose kernel lies inside the box into the grid - the sum over the
+    cells is the particles' 100 x 1e-5 kg - where the kernel at the cell
+    midpoints only approximates it."""
+    totals = {}
+    for label, new in (("midpoints", "false"),
+                       ("integral", "true\n  oriented cell faces: true")):
+        d = tmp_path / label
+        d.mkdir()
+        text = lexington_params(20)
+        a = text.index("DensityFunction:")
+        b = text.index("\n\n", a) if "\n\n" in text[a:] else len(text)
+        text = text[:a] + ("DensityFunction:\n" + phantom_block(
+            "  use new algorithm: %s\n" % new)) + text[b:]
+        # (a box that holds the kernels of all particles, no cell face in a
+        # plane through the origin - see INTEGRATION.md 2b on the reference's
+        # Petkova mapping there)
+        text = text.replace("anchor: [-5. pc, -5. pc, -5. pc]",
+                            "anchor: [-2.1 cm, -2.1 cm, -2.1 cm]")
+        text = text.replace("sides: [10. pc, 10. pc, 10. pc]",
+                            "sides: [5.2 cm, 5.2 cm, 5.2 cm]")
+        assert "-2.1 cm" in text and "5.2 cm" in text
+        snapshot = dry_run_snapshot(exe, d, text)
+        n = np.array(read(cli, snapshot, "/PartType0/NumberDensity")["data"])
+        assert n.shape == (8000,)
+        volume = (0.052 / 20) ** 3
+        totals[label] = (n * 1.6737236e-27 * volume).sum()
+    assert abs(totals["integral"] - 1.e-3) < 2.e-6 * 1.e-3 * 1000
+    assert abs(totals["integral"] - 1.e-3) < abs(totals["midpoints"] - 1.e-3)
+    assert abs(totals["midpoints"] - 1.e-3) < 0.1e-3
+
+
+# ---- SPHNG dumps (round 4) ---------------------------------------------------
+
+@pytest.mark.parametrize("name", ["SPHNGtest.dat", "SPHNGtest_notags.dat"])
+def test_sphng_snapshot_fixtures_of_the_reference(density_cli, tmp_path, name):
+    """test/testSPHNGSnapshotDensityFunction.cpp:45-150 on the reference's
+    fixtures (tests/golden/SPHNGtest.dat and SPHNGtest_notags.dat = the files
+    of test/, written by test/write_SPHNGtest.py in the tagged and the
+    untagged format; positions, masses and smoothing lengths in cm and g in
+    SPHNG_data.txt): every gas particle's position, mass and smoothing length
+    to 1e-14, as the reference asserts."""
+    p = tmp_path / "density.param"
+    p.write_text("DensityFunction:\n  type: SPHNGSnapshot\n  filename: %s\n" %
+                 os.path.join(ROOT, "tests", "golden", name))
+    r = subprocess.run([density_cli, str(p), "--particles"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.array([[float(v) for v in line.split()]
+                    for line in r.stdout.splitlines()])
+    want = np.loadtxt(os.path.join(ROOT, "tests", "golden", "SPHNG_data.txt"))
+    assert want.shape[1] == 5 and got.shape == want.shape
+    assert np.allclose(got[:, :3], want[:, :3] * 0.01, rtol=1e-14, atol=0.)
+    assert np.allclose(got[:, 3], want[:, 3] * 0.001, rtol=1e-14, atol=0.)
+    assert np.allclose(got[:, 4], want[:, 4] * 0.01, rtol=1e-14, atol=0.)
+    # the density at a point: Price's kernel over the particles in reach
+    points = np.random.default_rng(3).uniform(0.002, 0.008, (50, 3))
+    dens = evaluate(density_cli, tmp_path,
+                    "  type: SPHNGSnapshot\n  filename: %s\n" %
+                    os.path.join(ROOT, "tests", "golden", name), points)
+    r = np.sqrt(((points[:, None, :] - got[None, :, :3]) ** 2).sum(axis=2))
+    h = got[None, :, 4]
+    q = r / h
+    w = np.where(q < 1., 1. - 1.5 * q ** 2 + 0.75 * q ** 3,
+                 np.where(q < 2., 0.25 * (2. - q) ** 3, 0.)) / (np.pi * h ** 3)
+    rho = (got[None, :, 3] * w).sum(axis=1)
+    assert np.allclose(dens[:, 0], rho / 1.6737236e-27, rtol=1e-12)
+    assert np.all(dens[:, 1] == 8000.)

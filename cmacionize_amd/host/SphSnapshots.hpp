@@ -28,12 +28,16 @@ namespace cmi {
  * src/PhantomSnapshotDensityFunction.hpp:89-181). */
 class FortranRecords {
   std::ifstream _file;
+  long long _size = 0;
 
 public:
   explicit FortranRecords(const std::string &filename)
       : _file(filename, std::ios::binary | std::ios::in) {
     if (!_file)
       throw ParameterError("Unable to open file \"" + filename + "\"!");
+    _file.seekg(0, std::ios_base::end);
+    _size = (long long)_file.tellg();
+    _file.seekg(0, std::ios_base::beg);
   }
   /* the next record; if `expected` is given its size must be that */
   std::vector<uint8_t> read(long long expected = -1) {
@@ -41,6 +45,9 @@ public:
     _file.read(reinterpret_cast<char *>(&length1), 4);
     if (!_file)
       throw ParameterError("unexpected end of a Fortran unformatted file");
+    /* (a damaged length must not become an allocation) */
+    if ((long long)_file.tellg() + (long long)length1 + 4 > _size)
+      throw ParameterError("Wrong block size!");
     if (expected >= 0 && (long long)length1 != expected)
       throw ParameterError(
           "Wrong number of variables passed on to read_block()! Block size "
@@ -56,6 +63,8 @@ public:
   void skip() {
     uint32_t length1 = 0, length2 = 0;
     _file.read(reinterpret_cast<char *>(&length1), 4);
+    if (!_file || (long long)_file.tellg() + (long long)length1 + 4 > _size)
+      throw ParameterError("Wrong block size!");
     _file.seekg(length1, std::ios_base::cur);
     _file.read(reinterpret_cast<char *>(&length2), 4);
     if (!_file || length1 != length2)

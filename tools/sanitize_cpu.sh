@@ -93,4 +93,60 @@ for trial in range(300):
 print("hdf5 reader: 300 damaged files, %s" % ("clean" if not bad else "FAILED"))
 sys.exit(1 if bad else 0)
 PY
+# the readers of the other snapshot formats (Fortran unformatted dumps of
+# Phantom and SPHNG, task-based CMacIonize snapshots) on damaged copies of the
+# reference's fixtures, through the DensityFunction factory
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer \
+    -Icmacionize_amd/host -Iinclude -o "$TMP/dfcli" \
+    tests/support/density_function_cli.cpp -lz
+python3 - "$TMP" "$REPO" <<'PY'
+import random, subprocess, sys, os
+tmp, repo = sys.argv[1], sys.argv[2]
+golden = os.path.join(repo, "tests", "golden")
+cases = [("PhantomSnapshot", "Phantomtest.dat", ""),
+         ("SPHNGSnapshot", "SPHNGtest.dat", ""),
+         ("SPHNGSnapshot", "SPHNGtest_notags.dat", ""),
+         ("BufferedCMacIonizeSnapshot", "taskbased.hdf5",
+          "SimulationBox:\n  anchor: [-5. pc, -5. pc, -5. pc]\n"
+          "  sides: [10. pc, 10. pc, 10. pc]\n"
+          "DensityGrid:\n  number of cells: [8, 8, 8]\n")]
+rng = random.Random(7)
+bad = 0
+for kind, fixture, extra in cases:
+    data = open(os.path.join(golden, fixture), "rb").read()
+    for trial in range(120):
+        b = bytearray(data)
+        if trial == 0:
+            pass  # the intact file
+        elif trial % 3 == 0:
+            b = b[:rng.randrange(1, len(b))]
+        else:
+            for _ in range(rng.randrange(1, 6)):
+                at = rng.randrange(0, min(len(b), 3000))
+                b[at] = rng.randrange(256)
+        name = os.path.join(tmp, "fuzz.dat")
+        open(name, "wb").write(b)
+        param = os.path.join(tmp, "fuzz.param")
+        open(param, "w").write(extra + "DensityFunction:\n  type: %s\n"
+                               "  filename: %s\n" % (kind, name))
+        r = subprocess.run([os.path.join(tmp, "dfcli"), param],
+                           input="0.001 0.002 0.003\n", capture_output=True,
+                           text=True, errors="replace",
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:"
+                                    "allocator_may_return_null=1"))
+        if trial == 0 and r.returncode != 0:
+            bad += 1
+            print(kind, fixture, "intact file rejected:", r.stderr[-500:])
+        if "Sanitizer" in r.stderr or "runtime error" in r.stderr or \
+                r.returncode not in (0, 1):
+            bad += 1
+            print(kind, fixture, "trial", trial, "rc", r.returncode)
+            print(r.stderr[-1500:])
+            break
+    if bad:
+        break
+print("snapshot readers: 4 x 120 damaged files, %s" %
+      ("clean" if not bad else "FAILED"))
+sys.exit(1 if bad else 0)
+PY
 echo "sanitizer pass clean"

@@ -14,7 +14,12 @@
  * data files) - see tests/test_oracle_*.py. The reference itself cannot be
  * built in this image without running its cmake build (it needs the generated
  * Configuration.hpp and *DataLocation.hpp headers), so there is no
- * oracle/_ref binary; parity is pinned through the fixtures.
+ * oracle/_ref binary; parity is pinned through the fixtures - and, end to
+ * end, through a result of the reference itself: tests/golden/taskbased.hdf5
+ * (the reference's test/taskbased.hdf5) is the final snapshot of its own
+ * task-based run of the Stromgren benchmark at 16^3; the same run with this
+ * oracle, in both transport semantics, gives its neutral fractions to Monte
+ * Carlo noise (tests/test_reference_taskbased_snapshot.py).
  *
  * One deliberate difference from the reference: the random number generator.
  * The reference uses a sequential ranlxd2 stream per thread

@@ -85,6 +85,11 @@ def setup_engine(backend, ncell, cfg, block=None):
     """block = (offset, size): the engine holds only that part of the grid."""
     from cmacionize_amd import STROMGREN as S
     eng = backend.engine
+    # CMI_BENCH_TUNE="key=value,key=value": performance knobs of the engine
+    # (cmi_gpu_set_tuning) for kernel experiments; nothing is set by default
+    for item in filter(None, os.environ.get("CMI_BENCH_TUNE", "").split(",")):
+        key, value = item.split("=")
+        eng.set_tuning(**{key: int(value)})
     offset, size = block if block else ((0, 0, 0), (ncell,) * 3)
     n = int(np.prod(size))
     x = np.zeros((14, n))

@@ -46,7 +46,12 @@
 /* tile side (log2) and workgroup size per transport flavour */
 #define CMI_TILE_LOG2_H 4    /* hydrogen-only: 16^3 cells */
 #define CMI_TILE_LOG2_FULL 3 /* 14 ions + heating: 8^3 cells */
+#ifndef CMI_TILE_THREADS
 #define CMI_TILE_THREADS 512
+#endif
+#ifndef CMI_TILE_WAVES
+#define CMI_TILE_WAVES 4
+#endif
 /* flights per unit of work: a tile with more is shared by several workgroups
  * (each with its own LDS copy, all written back with atomics); measured on
  * 256^3: half as many cost 1 ms (H-only) / 3 ms (multi-ion) per iteration,
@@ -362,7 +367,8 @@ write_flight_row(const FlightRowsDev &out, unsigned int q,
  * memory.
  */
 template <bool FULL, bool HEAT>
-__global__ void __launch_bounds__(CMI_TILE_THREADS, (!FULL && HEAT) ? 2 : 4)
+__global__ void __launch_bounds__(CMI_TILE_THREADS,
+                                  (!FULL && HEAT) ? 2 : CMI_TILE_WAVES)
     tile_kernel(const TileArgs a) {
   constexpr int L = FULL ? CMI_TILE_LOG2_FULL : CMI_TILE_LOG2_H;
   constexpr int T = 1 << L;

@@ -1045,48 +1045,10 @@ __global__ void
     __syncthreads();
     return any_work != 0;
   };
-  /* add (v0[, v1]) to `cell` through the block table; called by all 64 lanes */
-  auto table_add = [&](bool add, int32_t cell, double v0, double v1) {
-    /* (PAD: a full-rate 24-bit multiply - the cells of a bundle differ in
-     * their low bits) */
-    uint32_t slot;
-    if (PAD) {
-      /* (asm: the compiler widens __umul24 to the quarter-rate v_mul_lo_u32) */
-      uint32_t product;
-      asm("v_mul_u32_u24 %0, %1, %2"
-          : "=v"(product)
-          : "v"(cell), "v"(0x9E3779u));
-      slot = (product >> (24 - CMI_TABLE_BITS)) & (CMI_TABLE_SLOTS - 1);
-    } else {
-      slot = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_TABLE_BITS);
-    }
-    bool pending = add;
-    for (int probe = 0; probe < CMI_TABLE_PROBES; ++probe) {
-      if (pending) {
-        const int32_t prev = atomicCAS(&lds_tag[slot], -1, cell);
-        if (prev == -1 || prev == cell) {
-          atomicAdd(&lds_val[slot], v0); /* ds_add_f64 */
-          if (HEAT)
-            atomicAdd(&lds_val[CMI_TABLE_SLOTS + slot], v1);
-          pending = false;
-        } else {
-          slot = (slot + 1) & (CMI_TABLE_SLOTS - 1);
-        }
-      }
-      if (wave_ballot(pending) == 0ull)
-        break;
-    }
-    if (pending) {
-      const int32_t c = PAD ? cmi_unpad_cell(a, a.grid, cell) : cell;
-      atomic_add_f64(acc_at(a.cells, ION_H_n, c), v0);
-      if (HEAT)
-        atomic_add_f64(acc_at(a.cells, CMI_NION, c), v1);
-      natomics += HEAT ? 2 : 1;
-    }
-  };
-  /* the same with the lanes that add given as a mask, and the search for a
-   * slot kept as one: `looking` loses the lanes that found theirs; the probe
-   * loop's exit is a scalar test */
+  /* add (v0[, v1]) to `cell` through the block table, for the lanes given as
+   * a mask (called by all 64 lanes): the search for a slot is kept as that
+   * mask - `looking` loses the lanes that found theirs - and the probe loop's
+   * exit is a scalar test */
   auto table_add_masked = [&](unsigned long long looking, int32_t cell,
                               double v0, double v1) {
     uint32_t slot;

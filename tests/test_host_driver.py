@@ -816,6 +816,18 @@ def test_weighted_spectrum_trackers_through_the_driver(exe, tmp_path):
     assert 0.3 * geometric < a[:, 1].sum() < 1.0 * geometric
     # the narrow range collects the harder photons in its last bin
     assert c[-1, 1] > c[-2, 1]
+    # the same on 2 x 2 x 1 blocks: every block counts the trackers in its
+    # cells (TRACK builds of the incremental marcher), the driver merges them
+    # (the two runs' states differ by rounding after three iterations, and the
+    # undivided grid counts in the exact marcher: the same cells except on
+    # corner ties)
+    b = tracker_run(exe, tmp_path, "blocks", "2,2,1",
+                    block_file=WEIGHTED_BLOCK_FILE)
+    a2 = np.loadtxt(b / "Tracker0.txt")
+    lv2 = np.loadtxt(b / "levels")
+    assert np.allclose(a2[:, 1:].sum(axis=0), a[:, 1:].sum(axis=0), rtol=2e-2)
+    assert np.allclose(lv2[:, 1], lv[:, 1], rtol=5e-2,
+                       atol=2e-3 * lv[:, 1].max())
     h = tracker_run(exe, tmp_path, "hdf5", None, hdf5=True,
                     block_file=WEIGHTED_BLOCK_FILE)
     f = hdf5_mini.read(str(h / "absorbed.hdf5"))

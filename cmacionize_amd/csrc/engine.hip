@@ -1947,8 +1947,12 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       k.ids = e->sort_ids[0];
       k.pre_rows = kernel_first_pre ? e->tile_rows[1].weights : nullptr;
       a.pre_rows = k.pre_rows;
-      direction_key_kernel<<<grid_blocks(e, (int64_t)n, 8), CMI_BLOCK, 0,
-                             e->stream>>>(k);
+      if (k.pre_rows)
+        emission_key_kernel<<<grid_blocks(e, (int64_t)n, 8), CMI_BLOCK, 0,
+                              e->stream>>>(k);
+      else
+        direction_key_kernel<<<grid_blocks(e, (int64_t)n, 8), CMI_BLOCK, 0,
+                               e->stream>>>(k);
       HIP_TRY(hipGetLastError());
       HIP_TRY(cmi_sort_pairs(e->sort_temp, e->sort_temp_bytes, e->sort_keys[0],
                              e->sort_keys[1], e->sort_ids[0], e->sort_ids[1],

@@ -2607,11 +2607,14 @@ direction_key_batches(const KeyArgs &a) {
 }
 
 __global__ void __launch_bounds__(CMI_BLOCK, CMI_KEY_WAVES)
+    emission_key_kernel(const KeyArgs a) {
+  direction_key_batches(a);
+}
+
+/* ... and without (pre_rows == nullptr): a kernel of its own, so that its few
+ * registers are not the other's 168 */
+__global__ void __launch_bounds__(CMI_BLOCK)
     direction_key_kernel(const KeyArgs a) {
-  if (a.pre_rows != nullptr) {
-    direction_key_batches(a);
-    return;
-  }
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint32_t lo_bits = a.dir_bits - a.dir_hi_bits;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -26,7 +26,8 @@ def short(n):
 
 
 starts = [i for i, r in enumerate(rows)
-          if r["Kernel_Name"].startswith("direction_key_kernel")]
+          if r["Kernel_Name"].startswith(("direction_key_kernel",
+                                          "emission_key_kernel"))]
 first = starts[-1] if starts else 0
 # the iteration ends before the next reset (fillBuffer after the update)
 end = len(rows)

@@ -1922,6 +1922,10 @@ block_reserve(bool mine, unsigned int *counter, unsigned int *s_count,
 #ifndef CMI_INTERACT_WAVES_FULL
 #define CMI_INTERACT_WAVES_FULL 3
 #endif
+/* trips of a batch whose loads are issued together (multi-ion transport) */
+#ifndef CMI_INTERACT_GROUP_FULL
+#define CMI_INTERACT_GROUP_FULL 2
+#endif
 /* Ended flights a workgroup decides on before it asks for room in the output
  * (x CMI_BLOCK). Two things are bought with the batch: (1) the returning
  * atomic on the output counter - ~90 per microsecond chip-wide on one word, so
@@ -1942,7 +1946,7 @@ __global__ void __launch_bounds__(CMI_BLOCK,
   constexpr int TRIPS = CMI_INTERACT_BATCH;
   /* (multi-ion transport: the decision holds two Verner cross sections; the
    * records of four trips beside them spill) */
-  constexpr int GROUP = FULL ? 1 : TRIPS;
+  constexpr int GROUP = FULL ? CMI_INTERACT_GROUP_FULL : TRIPS;
   constexpr unsigned int BATCH = TRIPS * CMI_BLOCK;
   __shared__ InteractStage<BATCH> stage;
   const int lane = threadIdx.x & 63;
@@ -2141,7 +2145,7 @@ __global__ void __launch_bounds__(CMI_BLOCK,
                                                    : CMI_INTERACT_WAVES_H)
     interaction_slots_kernel(const InteractArgs a) {
   constexpr int TRIPS = CMI_INTERACT_BATCH;
-  constexpr int GROUP = FULL ? 1 : TRIPS;
+  constexpr int GROUP = FULL ? CMI_INTERACT_GROUP_FULL : TRIPS;
   constexpr unsigned int BATCH = TRIPS * CMI_BLOCK;
   __shared__ InteractStage<BATCH> stage;
   __shared__ uint32_t s_slot[BATCH];

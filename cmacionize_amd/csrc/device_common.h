@@ -99,6 +99,8 @@ struct ExchangeDev {
  *   [12] optical depth left
  *   [13] (2 x uint32) long index of the cell being entered, in this engine's
  *        grid | its coordinates inside the tile, x | y<<8 | z<<16
+ *   [14-15] the spacing of the x and y walls along the flight (tdelta of
+ *        start_flight(); constant, carried so that a visit divides once)
  * An absorbed packet leaves its absorption record in the same slot: position
  * in [0-2], cell in [13]. */
 #define CMI_SLOT_NU 6

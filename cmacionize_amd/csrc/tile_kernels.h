@@ -345,7 +345,7 @@ write_flight_row(const FlightRowsDev &out, unsigned int q,
       p.tau,
       __longlong_as_double((long long)(((unsigned long long)packed_lc << 32) |
                                        (uint32_t)p.cell)),
-      0., 0.);
+      p.tdelta[0], p.tdelta[1]);
   out.keys[q] = key;
   if (FULL && !DEFER) {
     double4 *w = reinterpret_cast<double4 *>(out.weights + (size_t)CMI_NACC * q);
@@ -513,14 +513,20 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS,
             weights[ION_H_n] = sigma_H * pw;
             weights[CMI_NION] = sigma_H * (nu - a.model.nu_H) * pw;
           }
+          /* the wall spacings start_flight() computed: two travel in the
+           * slot, the third is its expression again (the increments must be
+           * the same numbers in every tile the flight crosses) - two
+           * divisions less per visit */
+          tdelta[0] = r3.z;
+          tdelta[1] = r3.w;
+          {
+            const double inv_dir = 1. / dir[2];
+            tdelta[2] =
+                (dir[2] != 0.) ? a.grid.cellside[2] * fabs(inv_dir) : 0.;
+          }
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax) {
             lc[ax] = (int32_t)((plc >> (8 * ax)) & 0xffu);
-            /* exactly start_flight()'s expression: the increments must be
-             * the same numbers in every tile the flight crosses */
-            const double inv_dir = 1. / dir[ax];
-            tdelta[ax] =
-                (dir[ax] != 0.) ? a.grid.cellside[ax] * fabs(inv_dir) : 0.;
             lsgn[ax] = (dir[ax] > 0.) ? 1 : -1;
           }
           active = true;
@@ -718,7 +724,7 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS,
               tau,
               __longlong_as_double(
                   (long long)(((unsigned long long)plc << 32) | cell)),
-              0., 0.);
+              tdelta[0], tdelta[1]);
         } else if (absorbed) {
           /* the absorption record, for the interaction kernel of this round:
            * where (end_flight()), in which cell, which packet - densely, in

@@ -209,9 +209,14 @@ __global__ void __launch_bounds__(CMI_TILE_SORT_THREADS)
    * (a thread summing its 32 consecutive totals from global memory waited for
    * every one of them: 48 us per round with 32768 tiles), and the begins back
    * the same way */
-  __shared__ uint32_t staged[CMI_TILE_SORT_MAX_TILES];
+  /* (one word of padding per 32: a thread's consecutive entries and its
+   * neighbours' then lie in different banks - without it all 64 lanes of a
+   * wave hit one bank in the loops below) */
+  __shared__ uint32_t staged[CMI_TILE_SORT_MAX_TILES +
+                             CMI_TILE_SORT_MAX_TILES / 32];
+  auto at_lds = [](uint32_t t) { return t + (t >> 5); };
   for (uint32_t t = threadIdx.x; t < a.ntiles; t += CMI_TILE_SORT_THREADS)
-    staged[t] = a.total[t];
+    staged[at_lds(t)] = a.total[t];
   __syncthreads();
   const uint32_t per =
       (a.ntiles + CMI_TILE_SORT_THREADS - 1) / CMI_TILE_SORT_THREADS;
@@ -219,7 +224,7 @@ __global__ void __launch_bounds__(CMI_TILE_SORT_THREADS)
   const uint32_t t1 = t0 + per < a.ntiles ? t0 + per : a.ntiles;
   uint32_t mine = 0;
   for (uint32_t t = t0; t < t1; ++t)
-    mine += staged[t];
+    mine += staged[at_lds(t)];
   partial[threadIdx.x] = mine;
   __syncthreads();
   for (int off = 1; off < CMI_TILE_SORT_THREADS; off <<= 1) {
@@ -231,13 +236,13 @@ __global__ void __launch_bounds__(CMI_TILE_SORT_THREADS)
   }
   uint32_t at = partial[threadIdx.x] - mine;
   for (uint32_t t = t0; t < t1; ++t) {
-    const uint32_t here = staged[t];
-    staged[t] = at;
+    const uint32_t here = staged[at_lds(t)];
+    staged[at_lds(t)] = at;
     at += here;
   }
   __syncthreads();
   for (uint32_t t = threadIdx.x; t < a.ntiles; t += CMI_TILE_SORT_THREADS)
-    a.tile_begin[t] = staged[t];
+    a.tile_begin[t] = staged[at_lds(t)];
   if (threadIdx.x == CMI_TILE_SORT_THREADS - 1) {
     /* the dead slots follow the flights (tile_begin_kernel's convention) */
     a.tile_begin[a.ntiles] = partial[threadIdx.x];
@@ -269,14 +274,17 @@ __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
   const uint32_t ntiles = (uint32_t)a.tiles.ntiles;
   const uint32_t M = a.item_flights;
   /* (the begins through LDS where they fit: see tile_offsets_kernel) */
-  __shared__ uint32_t staged[CMI_TILE_SORT_MAX_TILES + 1];
+  __shared__ uint32_t staged[CMI_TILE_SORT_MAX_TILES +
+                             CMI_TILE_SORT_MAX_TILES / 32 + 2];
   const bool in_lds = ntiles <= CMI_TILE_SORT_MAX_TILES;
   if (in_lds) {
     for (uint32_t t = threadIdx.x; t <= ntiles; t += CMI_TILE_PLAN_THREADS)
-      staged[t] = a.tile_begin[t];
+      staged[t + (t >> 5)] = a.tile_begin[t];
     __syncthreads();
   }
-  const uint32_t *tile_begin = in_lds ? staged : a.tile_begin;
+  auto tile_begin = [&](uint32_t t) {
+    return in_lds ? staged[t + (t >> 5)] : a.tile_begin[t];
+  };
   /* thread k owns a contiguous range of tiles */
   const uint32_t per = (ntiles + CMI_TILE_PLAN_THREADS - 1) /
                        CMI_TILE_PLAN_THREADS;
@@ -284,7 +292,7 @@ __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
   const uint32_t t1 = t0 + per < ntiles ? t0 + per : ntiles;
   uint32_t mine = 0;
   for (uint32_t t = t0; t < t1; ++t)
-    mine += (tile_begin[t + 1] - tile_begin[t] + M - 1) / M;
+    mine += (tile_begin(t + 1) - tile_begin(t) + M - 1) / M;
   partial[threadIdx.x] = mine;
   __syncthreads();
   /* inclusive scan of the 1024 partial counts (Hillis-Steele in LDS) */
@@ -297,7 +305,7 @@ __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
   }
   uint32_t at = partial[threadIdx.x] - mine;
   for (uint32_t t = t0; t < t1; ++t) {
-    const uint32_t begin = tile_begin[t], end = tile_begin[t + 1];
+    const uint32_t begin = tile_begin(t), end = tile_begin(t + 1);
     for (uint32_t b = begin; b < end; b += M) {
       TileItemDev it;
       it.tile = t;
@@ -310,7 +318,7 @@ __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
   if (threadIdx.x == CMI_TILE_PLAN_THREADS - 1) {
     *a.nitems = partial[threadIdx.x];
     *a.next_item = 0;
-    *a.nlive = tile_begin[ntiles];
+    *a.nlive = tile_begin(ntiles);
   }
 }
 

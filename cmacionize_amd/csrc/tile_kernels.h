@@ -139,7 +139,9 @@ __global__ void __launch_bounds__(CMI_BLOCK)
  *                       the chunk] = slot
  * The order of a tile's flights within a chunk is whatever the LDS atomics
  * make it: it only decides which unit of work a flight lands in. */
+#ifndef CMI_TILE_SORT_BLOCKS
 #define CMI_TILE_SORT_BLOCKS 256
+#endif
 #define CMI_TILE_SORT_THREADS 1024
 #define CMI_TILE_SORT_MAX_TILES 32768
 

@@ -2080,16 +2080,25 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
           sa.keys = e->tile_rows[cur].keys;
           sa.nslots = nslots;
           sa.ntiles = (uint32_t)tg.ntiles;
+          /* (about a counter per slot and workgroup at least) */
+          {
+            uint64_t nb = ((uint64_t)nslots / sa.ntiles + 7) / 8 * 8;
+            if (nb < 8)
+              nb = 8;
+            if (nb > CMI_TILE_SORT_BLOCKS)
+              nb = CMI_TILE_SORT_BLOCKS;
+            sa.nblocks = (uint32_t)nb;
+          }
           sa.blockhist = e->tile_blockhist;
           sa.total = e->tile_total;
           sa.tile_begin = e->tile_begin;
           sa.order = e->sort_ids[1];
-          tile_count_kernel<<<CMI_TILE_SORT_BLOCKS, CMI_TILE_SORT_THREADS, 0,
+          tile_count_kernel<<<sa.nblocks, CMI_TILE_SORT_THREADS, 0,
                               e->stream>>>(sa);
           tile_column_kernel<<<(sa.ntiles + CMI_BLOCK - 1) / CMI_BLOCK,
                                CMI_BLOCK, 0, e->stream>>>(sa);
           tile_offsets_kernel<<<1, CMI_TILE_SORT_THREADS, 0, e->stream>>>(sa);
-          tile_scatter_kernel<<<CMI_TILE_SORT_BLOCKS, CMI_TILE_SORT_THREADS, 0,
+          tile_scatter_kernel<<<sa.nblocks, CMI_TILE_SORT_THREADS, 0,
                                 e->stream>>>(sa);
           HIP_TRY(hipGetLastError());
         } else {

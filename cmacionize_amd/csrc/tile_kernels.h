@@ -149,6 +149,10 @@ struct TileSortArgs {
   const uint32_t *keys;
   unsigned int nslots;
   uint32_t ntiles;
+  /* workgroups that share the slots: a multiple of 8, at most
+   * CMI_TILE_SORT_BLOCKS - fewer when there are few slots (every workgroup
+   * costs a pass over one counter per tile in each of the three kernels) */
+  uint32_t nblocks;
   uint32_t *blockhist; /* [CMI_TILE_SORT_BLOCKS][ntiles] */
   uint32_t *total;     /* [ntiles] */
   uint32_t *tile_begin; /* [ntiles + 2] */
@@ -158,8 +162,7 @@ struct TileSortArgs {
 __device__ __forceinline__ void tile_sort_chunk(const TileSortArgs &a,
                                                 uint64_t &first,
                                                 uint64_t &last) {
-  const uint64_t chunk =
-      ((uint64_t)a.nslots + CMI_TILE_SORT_BLOCKS - 1) / CMI_TILE_SORT_BLOCKS;
+  const uint64_t chunk = ((uint64_t)a.nslots + a.nblocks - 1) / a.nblocks;
   first = (uint64_t)blockIdx.x * chunk;
   last = first + chunk < a.nslots ? first + chunk : a.nslots;
 }
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     return;
   uint32_t run = 0;
   uint32_t *column = a.blockhist + t;
-  for (int b = 0; b < CMI_TILE_SORT_BLOCKS; b += 8) {
+  for (uint32_t b = 0; b < a.nblocks; b += 8) {
     uint32_t v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k)

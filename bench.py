@@ -69,16 +69,23 @@ CONFIGS = {
 
 # The CPU baseline (oracle/cmio_transport_fast.c) against the REFERENCE on the
 # same cores: 8-thread Xeon 2.1 GHz of the build container, 64^3, the whole
-# 20-iteration run of each .param file (tests/
-# calibrate_cpu_baseline.py reproduces the port's side).
-CALIBRATION = {
-    "stromgren": dict(port=1.50e6, reference_classic=1.24e6,
-                      reference_task_based=2.79e6),
-    "stromgren_diffuse": dict(port=1.17e6, reference_classic=0.98e6,
-                              reference_task_based=1.84e6),
-    "lexington": dict(port=1.10e6, reference_classic=1.04e6,
-                      reference_task_based=1.52e6),
-}
+# 20-iteration run of each .param file. The record is committed:
+# profiles/<round>/cpu_calibration.json, written by
+# tests/calibrate_cpu_baseline.py (the port's side, run in the build
+# container) from BASELINE.md section 2 (the reference's side).
+CALIBRATION_FILES = [os.path.join("profiles", r, "cpu_calibration.json")
+                     for r in ("r05",)]
+
+
+def load_calibration(config):
+    for rel in CALIBRATION_FILES:
+        path = os.path.join(ROOT, rel)
+        if os.path.exists(path):
+            record = json.load(open(path))
+            cal = dict(record["configs"][config])
+            cal["record"] = rel
+            return cal
+    return None
 
 
 def setup_engine(backend, ncell, cfg, block=None):
@@ -139,11 +146,13 @@ def cpu_quota():
     return None
 
 
-def cpu_baseline(ncell, config, cfg, engine, seconds=12.):
+def cpu_baseline(ncell, config, cfg, engine, seconds=12., hint=None):
     """The CPU form of the transport loop (oracle/cmio_transport_fast.c:
     the reference's classic organisation - cells as structures, one lock per
     cell - OpenMP over all host cores) on a bounded sample of the same
-    workload: the converged state of the GPU run."""
+    workload: the converged state of the GPU run. `hint` = (threads, radius)
+    found by an earlier leg of the same process: the probing of thread counts
+    is then not repeated."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from cmacionize_amd import engine as E
@@ -168,56 +177,69 @@ def cpu_baseline(ncell, config, cfg, engine, seconds=12.):
     # tools/host_cores_probe.c): probe thread counts around the quota.
     all_cores = oracle_lib.num_threads()
     quota = cpu_quota()
-    budget = min(all_cores, int(round(quota))) if quota else all_cores
-    candidates = sorted(set(max(1, min(all_cores, t)) for t in
-                            (budget, 2 * budget, max(budget // 2, 1))),
-                        reverse=True)
-    best = None
-    for threads in candidates:
-        for radius in (16, 32):
-            os.environ["CMIO_FAST_HOT_RADIUS"] = str(radius)
-            oracle_lib.set_num_threads(threads)
-            n = 20000 * threads
-            sim.reset()
-            t0 = time.perf_counter()
-            sim.shoot_fast(42, 1000, 0, n)
-            rate = n / (time.perf_counter() - t0)
-            if best is None or rate > best[0]:
-                best = (rate, threads, radius)
-    rate, cores, radius = best
+    if hint is None:
+        budget = min(all_cores, int(round(quota))) if quota else all_cores
+        candidates = sorted(set(max(1, min(all_cores, t)) for t in
+                                (budget, 2 * budget, max(budget // 2, 1))),
+                            reverse=True)
+        best = None
+        for threads in candidates:
+            for radius in (16, 32):
+                os.environ["CMIO_FAST_HOT_RADIUS"] = str(radius)
+                oracle_lib.set_num_threads(threads)
+                n = 10000 * threads
+                sim.reset()
+                t0 = time.perf_counter()
+                sim.shoot_fast(42, 1000, 0, n)
+                rate = n / (time.perf_counter() - t0)
+                if best is None or rate > best[0]:
+                    best = (rate, threads, radius)
+        rate, cores, radius = best
+    else:
+        cores, radius = hint
+        os.environ["CMIO_FAST_HOT_RADIUS"] = str(radius)
+        oracle_lib.set_num_threads(cores)
+        n = 5000 * cores
+        sim.reset()
+        t0 = time.perf_counter()
+        sim.shoot_fast(42, 1000, 0, n)
+        rate = n / (time.perf_counter() - t0)
     os.environ["CMIO_FAST_HOT_RADIUS"] = str(radius)
     oracle_lib.set_num_threads(cores)
-    n2 = int(max(20000 * cores, min(rate * seconds, 2e8)))
+    n2 = int(max(10000 * cores, min(rate * seconds, 2e8)))
     sim.reset()
     t0 = time.perf_counter()
     sim.shoot_fast(42, 1001, 0, n2)
     dt = time.perf_counter() - t0
     oracle_lib.set_num_threads(all_cores)
-    cal = CALIBRATION[config]
+    cal = load_calibration(config)
+    sample = ("%d packets on the converged %d^3 %s state, transport "
+              "only, %.1f s, at the best of {1/2, 1, 2} x the CPUs "
+              "the cgroup grants this process; the reference's "
+              "classic loop restated in C (cells as structures, one "
+              "lock per cell, per-thread copies of the accumulators "
+              "around the source as in the task-based path, OpenMP)." %
+              (n2, ncell, cfg["name"], dt))
+    if cal:
+        sample += (" Calibration against the reference itself (%s), %d "
+                   "threads, 64^3, whole 20-iteration run: this port %.3g, "
+                   "reference classic %.3g, reference task-based %.3g "
+                   "packets/s (port / classic = %.2f)" %
+                   (cal["record"], cal.get("threads", 8), cal["port"],
+                    cal["reference_classic"], cal["reference_task_based"],
+                    cal["port"] / cal["reference_classic"]))
     return {"value": n2 / dt, "unit": "packets/s", "cores": cores,
             "kind": "port",
             "host_threads_available": all_cores,
             "host_cpu_quota": quota,
             "private_accumulator_radius_cells": radius,
-            "sample": "%d packets on the converged %d^3 %s state, transport "
-                      "only, %.1f s, at the best of {1/2, 1, 2} x the CPUs "
-                      "the cgroup grants this process; the reference's "
-                      "classic loop restated in C (cells as structures, one "
-                      "lock per cell, per-thread copies of the accumulators "
-                      "around the source as in the task-based path, OpenMP). "
-                      "Calibration against the reference itself, 8 threads, "
-                      "64^3, whole 20-iteration run: this port %.3g, reference "
-                      "classic %.3g, reference task-based %.3g packets/s "
-                      "(port / classic = %.2f)" %
-                      (n2, ncell, cfg["name"], dt, cal["port"],
-                       cal["reference_classic"], cal["reference_task_based"],
-                       cal["port"] / cal["reference_classic"]),
+            "sample": sample,
             "calibration": cal}
 
 
 # PMC profiles of this very command, newest first (tools/round_measure.sh)
 PROFILES = [os.path.join("profiles", r, "counters.json")
-            for r in ("r04", "r03")]
+            for r in ("r05", "r04", "r03")]
 
 # what each unit of the chip can do per second (MI355X_MICROARCH.md; the
 # atomic-request rate is measured: profiles/r01/atomic_rates.txt)
@@ -389,7 +411,7 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -407,6 +429,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true",
                     help="N > 1: skip the strong-scaling leg")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the `also` legs (the other single-GPU configs "
+                         "of BASELINE.json, run after the headline one when "
+                         "--config is the default and N = 1)")
+    ap.add_argument("--also-steps", type=int, default=None,
+                    help="timed steps of each `also` leg (default: "
+                         "min(--steps, 20))")
     ap.add_argument("--decomposition", default="replica",
                     choices=["replica", "domain"],
                     help="N > 1: every rank holds the whole grid and the "
@@ -426,53 +455,75 @@ def main():
             "copies of busy blocks; copies are the C++ host's - "
             "`cmi-gpu --blocks BX,BY,BZ --devices ... --copies K` over the "
             "group API (cmi_gpu_group_*)" % args.copies)
-    cfg = CONFIGS[args.config]
     if args.packets is None:
         args.packets = 1e8
-    if args.converge_iterations is None:
-        args.converge_iterations = cfg["converge_iterations"]
     if args.converge_packets is None:
         args.converge_packets = args.packets
+    return args
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: start the N ranks ourselves, as
-        # child processes, before anything in this process touches a GPU
-        # (one process per GPU; the reference: one MPI rank per node,
-        # src/MPICommunicator.hpp:207-222)
-        sys.exit(launch_ranks(args.gpus))
 
+class Ranks:
+    """This process's place among the ranks of the run."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        # (CMI_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on
+        # a box with fewer GPUs than ranks - ranks then share devices)
+        collective = os.environ.get("CMI_BENCH_BACKEND", "nccl")
+        if collective != "nccl":
+            self.local_rank %= max(torch.cuda.device_count(), 1)
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(self.local_rank)
+            if collective == "nccl":
+                dist.init_process_group(
+                    "nccl", rank=self.rank, world_size=self.world,
+                    device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(collective, rank=self.rank,
+                                        world_size=self.world)
+        if args.gpus != self.world:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d: start "
+                             "one rank per GPU (plain `python bench.py --gpus "
+                             "N` does that by itself)" %
+                             (args.gpus, self.world))
+        if collective == "nccl" and torch.cuda.device_count() < self.world:
+            raise SystemExit("bench.py: %d ranks asked for, %d GPUs visible" %
+                             (self.world, torch.cuda.device_count()))
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+
+def run_leg(args, ranks, config, steps, warmup, cpu_seconds=None,
+            cpu_hint=None):
+    """One benchmark configuration from the ionised start to the JSON record:
+    the reference's run (untimed for `value`), `warmup` + `steps` iterations
+    on the converged state, the roofline of the first-generation kernel and
+    the CPU baseline on the same state. Returns the record on rank 0, None on
+    the other ranks; the engine is closed before returning."""
     import torch
     from cmacionize_amd.simulation import GpuBackend, ReplicaIterationDriver
     from cmacionize_amd import STROMGREN as S
     from cmacionize_amd import engine as E
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    # (CMI_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a
-    # box with fewer GPUs than ranks - ranks then share devices)
-    collective = os.environ.get("CMI_BENCH_BACKEND", "nccl")
-    if collective != "nccl":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if collective == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda",
-                                                           local_rank))
-        else:
-            dist.init_process_group(collective, rank=rank, world_size=world)
-    if args.gpus != world:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d: start "
-                         "one rank per GPU (plain `python bench.py --gpus N` "
-                         "does that by itself)" % (args.gpus, world))
-    if collective == "nccl" and torch.cuda.device_count() < world:
-        raise SystemExit("bench.py: %d ranks asked for, %d GPUs visible" %
-                         (world, torch.cuda.device_count()))
-
+    cfg = CONFIGS[config]
+    world, rank, local_rank, dist = (ranks.world, ranks.rank,
+                                     ranks.local_rank, ranks.dist)
+    barrier = ranks.barrier
+    converge_iterations = (args.converge_iterations
+                           if args.converge_iterations is not None
+                           else cfg["converge_iterations"])
     ncell = args.ncell
     npk = int(args.packets)
     domain = args.decomposition == "domain"
@@ -496,12 +547,6 @@ def main():
         setup_engine(backend, ncell, cfg)
         driver = ReplicaIterationDriver(backend, rank, world, dist)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     def ionized_fraction():
         """V(x_H < 0.5) / V_box; in domain mode every rank counts its block."""
         if not domain and rank != 0:
@@ -519,13 +564,14 @@ def main():
     # fraction for the iterations-to-converge figure (first
     # iteration after which V(x_H < 0.5) / V_box changes by less than 1 %
     # between consecutive iterations) and the shooting times for the
-    # whole-run rate.
+    # whole-run rate (the reference's "Total photon shooting time",
+    # src/IonizationSimulation.cpp:667-674).
     loop = 0
     volume = []
     whole_run_shoot_ms = 0.
     whole_run_wall = 0.
     backend.engine.get_timing(reset=True)
-    for _ in range(args.converge_iterations):
+    for _ in range(converge_iterations):
         barrier()
         t0 = time.perf_counter()
         driver.iteration(loop, int(args.converge_packets) *
@@ -549,20 +595,19 @@ def main():
 
     lanes_per_wave_step = None
 
-    def timed(global_packets, steps):
-        nonlocal loop
+    def timed(global_packets, nsteps_timed):
+        nonlocal loop, lanes_per_wave_step
         barrier()
         backend.engine.get_timing(reset=True)
         nsteps = 0
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(nsteps_timed):
             driver.iteration(loop, global_packets, 42)
             nsteps += driver.nsteps
             loop += 1
         barrier()
         elapsed = time.perf_counter() - t0
         # (the last iteration's counters: lanes that step per wave iteration)
-        nonlocal lanes_per_wave_step
         wave_steps = backend.engine.get_wave_steps()
         if wave_steps:
             lanes_per_wave_step = backend.engine.get_counters()[2] / wave_steps
@@ -582,29 +627,29 @@ def main():
     # replica mode: every rank shoots npk packets, global = npk * world (weak
     # scaling); domain mode: npk packets in total (strong scaling)
     global_packets = npk if domain else npk * world
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         driver.iteration(loop, global_packets, 42)
         loop += 1
-    elapsed, nsteps_total, timing, launches = timed(global_packets,
-                                                    args.steps)
+    elapsed, nsteps_total, timing, launches = timed(global_packets, steps)
     strong = None
     if world > 1 and not domain and not args.no_strong:
         # the same iteration with npk packets IN TOTAL (npk / world per rank)
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             driver.iteration(loop, npk, 42)
             loop += 1
-        s_elapsed, _, s_timing, _ = timed(npk, args.steps)
-        strong = {"value": float(npk) * args.steps / s_elapsed,
+        s_elapsed, _, s_timing, _ = timed(npk, steps)
+        strong = {"value": float(npk) * steps / s_elapsed,
                   "unit": "packets/s",
                   "packets_per_iteration_all_gpus": npk,
-                  "ms_per_step": 1e3 * s_elapsed / args.steps,
-                  "transport_ms_per_step": s_timing["shoot_ms"] / args.steps,
+                  "ms_per_step": 1e3 * s_elapsed / steps,
+                  "transport_ms_per_step": s_timing["shoot_ms"] / steps,
                   "cell_update_ms_per_step": s_timing["update_ms"] /
                   max(s_timing["update_launches"], 1)}
 
     final_volume = ionized_fraction()
+    out = None
     if rank == 0:
-        total_packets = float(global_packets) * args.steps
+        total_packets = float(global_packets) * steps
         value = total_packets / elapsed
         shoot_s = timing["shoot_ms"] * 1e-3
         # the first-generation transport launch of every iteration: the
@@ -625,11 +670,10 @@ def main():
         first_gen_steps = float(np.mean([f[1] for f in first_gen])) \
             if first_gen else None
         kernel_s = timing["kernel_ms"] * 1e-3
-        steps_per_iteration = nsteps_total / world / max(args.steps, 1)
         conv_packets = float(args.converge_packets) * \
-            (1 if domain else world) * args.converge_iterations
+            (1 if domain else world) * converge_iterations
         out = {
-            "metric": "photon packets/sec, %d^3 %s" % (ncell, args.config),
+            "metric": "photon packets/sec, %d^3 %s" % (ncell, config),
             "value": value,
             "unit": "packets/s",
             "n_gpus": world,
@@ -637,9 +681,9 @@ def main():
                                     else 1),
             "packets_per_rank_per_step": (float(npk) / world if domain
                                           else float(npk)),
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True,
             "scaling": "strong" if domain else "weak",
             "vs_baseline": None,
@@ -658,25 +702,26 @@ def main():
                                 "replica x%d (sum all-reduce of accumulators)")
                                % world,
             },
-            "transport_only_packets_per_s": (float(npk) * args.steps /
-                                             shoot_s),
-            "transport_kernels_ms_per_step": 1e3 * kernel_s / args.steps,
-            "transport_launches_per_step": len(launches) / args.steps,
+            "transport_only_packets_per_s": (float(npk) * steps / shoot_s),
+            "transport_kernels_ms_per_step": 1e3 * kernel_s / steps,
+            "transport_launches_per_step": len(launches) / steps,
             "dda_steps_per_packet": nsteps_total / total_packets,
             "cell_update_ms_per_step": timing["update_ms"] /
             max(timing["update_launches"], 1),
             "ionized_volume_fraction": final_volume,
             # SURVEY 8d's metric: the whole run from the ionised start,
             # N_iter x N_p / sum of the shooting times (and wall clock)
-            "whole_run_packets_per_s": conv_packets /
-            (whole_run_shoot_ms * 1e-3 * (1 if domain else 1)),
+            "whole_run_packets_per_s": (conv_packets /
+                                        (whole_run_shoot_ms * 1e-3)
+                                        if whole_run_shoot_ms else None),
             "whole_run": {
-                "iterations": args.converge_iterations,
+                "iterations": converge_iterations,
                 "packets_per_iteration": args.converge_packets *
                 (1 if domain else world),
                 "shoot_s": whole_run_shoot_ms * 1e-3,
                 "wall_s": whole_run_wall,
-                "end_to_end_packets_per_s": conv_packets / whole_run_wall,
+                "end_to_end_packets_per_s": (conv_packets / whole_run_wall
+                                             if whole_run_wall else None),
             },
             "iterations_to_converge": {
                 "value": converged_at,
@@ -687,30 +732,94 @@ def main():
                 (1 if domain else world),
                 "ionized_volume_fraction_by_iteration": volume,
             },
-            "roofline": roofline(args.config, ncell, cfg, first_gen_steps,
+            "roofline": roofline(config, ncell, cfg, first_gen_steps,
                                  lanes_per_wave_step, first_gen_ms),
         }
         if strong is not None:
             out["strong_scaling"] = strong
         if cfg["lexington"]:
             out["roofline_cell_update"] = roofline_cell_update(
-                args.config, ncell, cfg, out["cell_update_ms_per_step"])
+                config, ncell, cfg, out["cell_update_ms_per_step"])
         if lanes_per_wave_step:
             # 64-lane iterations of the march loops per packet (all
             # generations of the last timed step)
             out["wave_iterations_per_packet"] = (
                 nsteps_total / total_packets / lanes_per_wave_step)
-        if not args.no_cpu_baseline and world == 1:
+        if cpu_seconds and world == 1:
             # (rank 0 at N = 1 only: the other ranks would wait for it)
-            out["cpu_baseline"] = cpu_baseline(ncell, args.config, cfg,
-                                               backend.engine)
+            out["cpu_baseline"] = cpu_baseline(ncell, config, cfg,
+                                               backend.engine,
+                                               seconds=cpu_seconds,
+                                               hint=cpu_hint)
         if domain:
             out["exchange_rounds_last_step"] = driver.rounds
             out["flights_exchanged_last_step"] = driver.flights_exchanged
+    # the next leg needs the memory (flight slots and queues of 1e8 packets)
+    barrier()
+    backend.engine.close()
+    del driver, backend
+    torch.cuda.empty_cache()
+    return out
+
+
+# what an `also` leg carries into the headline line
+ALSO_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step",
+             "transport_only_packets_per_s", "transport_kernels_ms_per_step",
+             "cell_update_ms_per_step", "dda_steps_per_packet",
+             "ionized_volume_fraction", "whole_run_packets_per_s",
+             "wave_iterations_per_packet", "config")
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as
+        # child processes, before anything in this process touches a GPU
+        # (one process per GPU; the reference: one MPI rank per node,
+        # src/MPICommunicator.hpp:207-222)
+        sys.exit(launch_ranks(args.gpus))
+
+    t_start = time.perf_counter()
+    ranks = Ranks(args)
+    also = (ranks.world == 1 and args.config == "stromgren" and
+            not args.no_also and args.decomposition == "replica")
+    cpu = not args.no_cpu_baseline and ranks.world == 1
+    # the CPU sample: ~12 s when the headline config runs alone, ~6 s per leg
+    # when the line carries all three (the driver's default run: <= 90 s)
+    out = run_leg(args, ranks, args.config, args.steps, args.warmup,
+                  cpu_seconds=(6. if also else 12.) if cpu else None)
+    if also and ranks.rank == 0:
+        # BASELINE.json configs[2] and configs[3] - the other benchmarks
+        # north_star names - under the same clock, one after the other on the
+        # same GPU: each a full leg of its own (converge, warm up, time,
+        # roofline, CPU baseline); the headline keys above stay config 2's
+        hint = None
+        if "cpu_baseline" in out:
+            hint = (out["cpu_baseline"]["cores"],
+                    out["cpu_baseline"]["private_accumulator_radius_cells"])
+        steps = args.also_steps or min(args.steps, 20)
+        out["also"] = {}
+        for config in ("stromgren_diffuse", "lexington"):
+            leg = run_leg(args, ranks, config, steps, args.warmup,
+                          cpu_seconds=5. if cpu else None, cpu_hint=hint)
+            rec = {k: leg[k] for k in ALSO_KEYS if k in leg}
+            rec["iterations_to_converge"] = \
+                leg["iterations_to_converge"]["value"]
+            rec["roofline"] = {k: v for k, v in leg["roofline"].items()
+                               if k != "other_kernels"}
+            if "roofline_cell_update" in leg:
+                rec["roofline_cell_update"] = leg["roofline_cell_update"]
+            if "cpu_baseline" in leg:
+                rec["cpu_baseline"] = {k: v for k, v in
+                                       leg["cpu_baseline"].items()
+                                       if k != "calibration"}
+            out["also"][config] = rec
+        out["bench_wall_s"] = time.perf_counter() - t_start
+    if ranks.rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ranks.world > 1:
+        ranks.dist.barrier()
+        ranks.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--steps", "2", "--warmup", "1", "--ncell", "64", "--packets", "4e5",
-          "--converge-iterations", "8", "--no-cpu-baseline"]
+          "--converge-iterations", "8", "--no-cpu-baseline", "--no-also"]
 
 
 def free_port():
@@ -71,6 +71,41 @@ def test_two_ranks_replica_and_domain_reach_the_one_rank_state():
     assert replica["value"] > 0. and domain["value"] > 0.
 
 
+def test_default_line_carries_the_other_single_gpu_configs():
+    """The driver's command (`bench.py --gpus 1`, default config) prints the
+    headline config's line with the other two single-GPU configs of
+    BASELINE.json under `also`, each with its own value, roofline and CPU
+    baseline, timed one after the other on the same device."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps",
+                        "3", "--warmup", "1", "--ncell", "48", "--packets",
+                        "2e5", "--converge-iterations", "6"],
+                       cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["metric"] == "photon packets/sec, 48^3 stromgren"
+    assert line["cpu_baseline"]["calibration"]["record"].endswith(
+        "cpu_calibration.json")
+    assert sorted(line["also"]) == ["lexington", "stromgren_diffuse"]
+    for name, leg in line["also"].items():
+        assert name in leg["metric"]
+        assert leg["value"] > 0. and leg["steps"] == 3
+        assert abs(leg["ms_per_step"] * 1e-3 * leg["value"] - 2e5) < 1.
+        assert leg["transport_only_packets_per_s"] >= leg["value"]
+        assert "roofline" in leg and "kernel_avg_ms" in leg["roofline"]
+        assert leg["cpu_baseline"]["value"] > 0.
+        assert "iterations_to_converge" in leg
+    # re-emitted packets fly further than those of the headline config
+    assert line["also"]["stromgren_diffuse"]["dda_steps_per_packet"] > \
+        line["dda_steps_per_packet"]
+    assert "roofline_cell_update" in line["also"]["lexington"]
+    assert line["bench_wall_s"] > 0.
+
+
 def test_more_ranks_than_gpus_is_refused():
     """`--gpus N` with fewer than N devices fails loudly instead of running
     fewer ranks and printing an N-GPU line."""
@@ -95,7 +130,8 @@ def test_eight_ranks_on_one_device():
     collective, rank 0 prints the line, and the state is the one-rank run's
     (domain mode flies the same packets)."""
     small = ["--steps", "2", "--warmup", "1", "--ncell", "48", "--packets",
-             "2e5", "--converge-iterations", "6", "--no-cpu-baseline"]
+             "2e5", "--converge-iterations", "6", "--no-cpu-baseline",
+             "--no-also"]
 
     def run(ranks, extra):
         env = dict(os.environ, CMI_BENCH_BACKEND="gloo")

@@ -401,26 +401,44 @@ __device__ inline void cmi_ionization_states_hydrogen_helium(
  * (TablesDev::metal_ct; the others are zero rows): one loop body for the 12
  * ions instead of 12 + 19 inlined fit evaluations, then the reference's
  * products and normalisations per element. */
+/* ratio_k of ion ION_C_p1 + k (the loop body below; temp_finish_kernel
+ * evaluates the 12 ions of a cell side by side, one lane each) */
+template <class Integrals>
+__device__ __forceinline__ double
+cmi_metal_ratio(const ModelDev &m, const Integrals &j, int ion, double ne,
+                double T, double T4, double nh0, double nhe0, double nhp) {
+  const TablesDev *tb = m.tables;
+  const double alpha = cmi_recombination_rate(m, ion, T);
+  const double num = j(ion) + nhp * ct_eval(tb->metal_ct[ion][1], T4);
+  const double den = ne * alpha + nh0 * ct_eval(tb->metal_ct[ion][0], T4) +
+                     nhe0 * ct_eval(tb->metal_ct[ion][2], T4);
+  return num / den;
+}
+
+__device__ __forceinline__ void cmi_metal_fractions(const double (&ratio)[12],
+                                                    double x[CMI_NION]);
+
 template <class Integrals>
 __device__ inline void cmi_ionization_states_metals(
     const ModelDev &m, const Integrals &j, double ne, double T, double T4,
     double nh0, double nhe0, double nhp, double x[CMI_NION]) {
-  const TablesDev *tb = m.tables;
   double ratio[12];
 #pragma unroll 1
   for (int k = 0; k < 12; ++k) {
-    const int ion = ION_C_p1 + k;
-    const double alpha = cmi_recombination_rate(m, ion, T);
-    const double num = j(ion) + nhp * ct_eval(tb->metal_ct[ion][1], T4);
-    const double den = ne * alpha + nh0 * ct_eval(tb->metal_ct[ion][0], T4) +
-                       nhe0 * ct_eval(tb->metal_ct[ion][2], T4);
-    const double r = num / den;
+    const double r =
+        cmi_metal_ratio(m, j, ION_C_p1 + k, ne, T, T4, nh0, nhe0, nhp);
     /* static indexing keeps ratio[] in registers */
 #pragma unroll
     for (int i = 0; i < 12; ++i)
       if (i == k)
         ratio[i] = r;
   }
+  cmi_metal_fractions(ratio, x);
+}
+
+/* the reference's products and normalisations per element */
+__device__ __forceinline__ void cmi_metal_fractions(const double (&ratio)[12],
+                                                    double x[CMI_NION]) {
 #define R(ion) ratio[(ion)-ION_C_p1]
   { /* carbon */
     const double C21 = R(ION_C_p1);

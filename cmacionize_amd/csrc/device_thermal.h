@@ -93,6 +93,77 @@ __device__ __forceinline__ double lc_collision_strength(const double *a,
  * (a first version kept all 20 rates and spilled ~700 registers per lane:
  * the temperature kernel moved 340 GB of scratch per 256^3 update). The sums
  * run in a different order than the reference's sumC (same terms). */
+/* the cooling of five-level ion e per unit of abundance and kb:
+ * sum_i pop_i sum_j A_ji E_ji (the body of line_cooling's first loop) */
+__device__ __forceinline__ double
+lc_five_level_cooling(const LineCoolingDev &lc, int e, double prefactor,
+                      double temperature, double Tinv, double logT) {
+  const double *A = lc.A[e];
+  const double *w = lc.inv_weight[e];
+  double M[5][5];
+  double pop[5] = {1., 0., 0., 0., 0.};
+  double sumC[5] = {0., 0., 0., 0., 0.}; /* collisions out of each level */
+#pragma unroll
+  for (int lo = 0; lo < 4; ++lo) {
+#pragma unroll
+    for (int hi = lo + 1; hi < 5; ++hi) {
+      const int t = lc_tr(lo, hi);
+      const double down = lc_collision_strength(lc.cs[e][t], prefactor,
+                                                temperature, Tinv, logT);
+      const double up = down * exp(-lc.energy[e][t] * Tinv);
+      /* level hi is fed from lo, level lo from hi (row 0 is replaced by
+       * the normalisation below) */
+      M[hi][lo] = up * w[lo];
+      if (lo > 0)
+        M[lo][hi] = A[t] + w[hi] * down;
+      sumC[hi] += down;
+      sumC[lo] += up;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    M[0][k] = 1.; /* populations sum to 1 */
+#pragma unroll
+  for (int i = 1; i < 5; ++i) {
+    double sumA = A[lc_tr(0, i)];
+#pragma unroll
+    for (int j = 1; j < i; ++j)
+      sumA += A[lc_tr(j, i)];
+    M[i][i] = -(sumA + w[i] * sumC[i]);
+  }
+  /* a singular matrix aborts the reference (cmac_error); here the ion then
+   * contributes the populations of the unsolved right-hand side */
+  (void)solve_5x5(M, pop);
+  const double *E = lc.energy[e];
+  double cl[5];
+  cl[1] = pop[1] * A[lc_tr(0, 1)] * E[lc_tr(0, 1)];
+#pragma unroll
+  for (int i = 2; i < 5; ++i) {
+    double s = A[lc_tr(0, i)] * E[lc_tr(0, i)];
+#pragma unroll
+    for (int j = 1; j < i; ++j)
+      s += A[lc_tr(j, i)] * E[lc_tr(j, i)];
+    cl[i] = pop[i] * s;
+  }
+  return cl[1] + cl[2] + cl[3] + cl[4];
+}
+
+/* two-level ion i: the population of its upper level (the body of
+ * line_cooling's second loop) */
+__device__ __forceinline__ double
+lc_two_level_cooling(const LineCoolingDev &lc, int i, double prefactor,
+                     double temperature, double Tinv, double logT) {
+  const double ksi = lc.two_energy[i];
+  const double cs = lc_collision_strength(lc.two_cs[i], prefactor, temperature,
+                                          Tinv, logT);
+  const double Texp = exp(-ksi * Tinv);
+  const double pop =
+      cs * Texp * lc.two_inv_weight[i][0] /
+      (lc.two_A[i] +
+       cs * (lc.two_inv_weight[i][1] + Texp * lc.two_inv_weight[i][0]));
+  return pop;
+}
+
 __device__ inline double line_cooling(const LineCoolingDev &lc,
                                       double temperature,
                                       double electron_density,
@@ -110,69 +181,14 @@ __device__ inline double line_cooling(const LineCoolingDev &lc,
    * secant step inlined the solve was 286 KB and ran out of the instruction
    * cache) */
 #pragma unroll 1
-  for (int e = 0; e < CMI_LC_NFIVE_DEV; ++e) {
-    const double *A = lc.A[e];
-    const double *w = lc.inv_weight[e];
-    double M[5][5];
-    double pop[5] = {1., 0., 0., 0., 0.};
-    double sumC[5] = {0., 0., 0., 0., 0.}; /* collisions out of each level */
-#pragma unroll
-    for (int lo = 0; lo < 4; ++lo) {
-#pragma unroll
-      for (int hi = lo + 1; hi < 5; ++hi) {
-        const int t = lc_tr(lo, hi);
-        const double down = lc_collision_strength(lc.cs[e][t], prefactor,
-                                                  temperature, Tinv, logT);
-        const double up = down * exp(-lc.energy[e][t] * Tinv);
-        /* level hi is fed from lo, level lo from hi (row 0 is replaced by
-         * the normalisation below) */
-        M[hi][lo] = up * w[lo];
-        if (lo > 0)
-          M[lo][hi] = A[t] + w[hi] * down;
-        sumC[hi] += down;
-        sumC[lo] += up;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-      M[0][k] = 1.; /* populations sum to 1 */
-#pragma unroll
-    for (int i = 1; i < 5; ++i) {
-      double sumA = A[lc_tr(0, i)];
-#pragma unroll
-      for (int j = 1; j < i; ++j)
-        sumA += A[lc_tr(j, i)];
-      M[i][i] = -(sumA + w[i] * sumC[i]);
-    }
-    /* a singular matrix aborts the reference (cmac_error); here the ion then
-     * contributes the populations of the unsolved right-hand side */
-    (void)solve_5x5(M, pop);
-    const double *E = lc.energy[e];
-    double cl[5];
-    cl[1] = pop[1] * A[lc_tr(0, 1)] * E[lc_tr(0, 1)];
-#pragma unroll
-    for (int i = 2; i < 5; ++i) {
-      double s = A[lc_tr(0, i)] * E[lc_tr(0, i)];
-#pragma unroll
-      for (int j = 1; j < i; ++j)
-        s += A[lc_tr(j, i)] * E[lc_tr(j, i)];
-      cl[i] = pop[i] * s;
-    }
-    cooling += abund[e * abund_stride] * kb * (cl[1] + cl[2] + cl[3] + cl[4]);
-  }
+  for (int e = 0; e < CMI_LC_NFIVE_DEV; ++e)
+    cooling += abund[e * abund_stride] * kb *
+               lc_five_level_cooling(lc, e, prefactor, temperature, Tinv, logT);
 #pragma unroll 1
-  for (int i = 0; i < CMI_LC_NTWO_DEV; ++i) {
-    const double ksi = lc.two_energy[i];
-    const double cs = lc_collision_strength(lc.two_cs[i], prefactor,
-                                            temperature, Tinv, logT);
-    const double Texp = exp(-ksi * Tinv);
-    const double pop =
-        cs * Texp * lc.two_inv_weight[i][0] /
-        (lc.two_A[i] +
-         cs * (lc.two_inv_weight[i][1] + Texp * lc.two_inv_weight[i][0]));
-    cooling += abund[(CMI_LC_NFIVE_DEV + i) * abund_stride] * kb * ksi *
-               lc.two_A[i] * pop;
-  }
+  for (int i = 0; i < CMI_LC_NTWO_DEV; ++i)
+    cooling += abund[(CMI_LC_NFIVE_DEV + i) * abund_stride] * kb *
+               lc.two_energy[i] * lc.two_A[i] *
+               lc_two_level_cooling(lc, i, prefactor, temperature, Tinv, logT);
   return cooling;
 }
 

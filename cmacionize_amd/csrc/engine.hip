@@ -171,8 +171,11 @@ struct cmi_gpu_engine {
     bool xcd_remap = false;
     /* the temperature solve as a pipeline of kernels (0: one kernel) */
     bool temperature_pipeline = true;
-    /* ... whose last slots one launch finishes (temp_finish_kernel) */
-    uint32_t temperature_finish_slots = 32768;
+    /* ... whose last slots one launch finishes (temp_finish_kernel: a wave
+     * per slot; measured at 256^3, ms per update with 32768 / 8192 / 2048 /
+     * 512: 51.2 / 50.7 / 50.7 / 49.8 - the wide steps are the cheaper way
+     * while many slots are left) */
+    uint32_t temperature_finish_slots = 1024;
     /* the free slots are squeezed out once there are this many slots per
      * flight (measured: 2 beats 4, 8 and never by 1 % - rows in tile order
      * are read faster than rows scattered among free slots) */
@@ -2579,8 +2582,8 @@ static int temperature_pipeline(cmi_gpu_engine *e, const UpdateArgs &a) {
     while (nactive != 0) {
       p.nactive = nactive;
       if (nactive <= e->tune.temperature_finish_slots) {
-        /* the stragglers: one launch, four lanes per slot */
-        temp_finish_kernel<<<(unsigned)((4ull * nactive + CMI_BLOCK - 1) /
+        /* the stragglers: one launch, a wave per slot */
+        temp_finish_kernel<<<(unsigned)((64ull * nactive + CMI_BLOCK - 1) /
                                         CMI_BLOCK),
                              CMI_BLOCK, 0, e->stream>>>(p);
         HIP_TRY(hipGetLastError());

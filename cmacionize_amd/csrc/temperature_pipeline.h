@@ -16,7 +16,8 @@
  *     temp_secant_kernel    one lane per slot: the step's new temperature;
  *                           converged cells are finished and stored, the rest
  *                           is listed for the next step
- *   temp_finish_kernel    the last few slots, all their remaining steps
+ *   temp_finish_kernel    the last few slots, all their remaining steps, one
+ *                         wave per slot
  *
  * One kernel holding a whole solve keeps ~400 values alive (256 registers +
  * 137 spilled, 2 waves/SIMD) and its lanes take 1 to ~10 steps each; here
@@ -418,72 +419,161 @@ __global__ void __launch_bounds__(CMI_BLOCK)
 
 /* The last slots - a handful of cells whose secant iteration wanders until
  * t_max_iterations ends it; as pipeline steps they would cost a hundred rounds
- * of three nearly empty launches each - are finished by one launch: four
- * lanes per slot, three of which run the step's three balance evaluations
- * side by side (cooling_and_heating_balance, whole); all of them then take
- * the same secant step from the exchanged gains and losses. */
+ * of three nearly empty launches each - are finished by one launch. A slot's
+ * remaining steps are ONE dependent chain, so what counts is the length of a
+ * step, not the lanes it occupies: a slot gets a whole wave. Lanes 16 k ..
+ * 16 k + 15 hold evaluation k of the step (at 1.1 T0, 0.9 T0, T0; the fourth
+ * quarter repeats the third); inside a quarter
+ *   - the hydrogen / helium balance and the gains run on every lane alike
+ *     (the same numbers 16 times: nothing to exchange),
+ *   - lane r < 12 takes the ratio of metal ion r (cmi_metal_ratio: its
+ *     recombination and charge transfer fits), the twelve ratios are then
+ *     read by every lane,
+ *   - lane r < 10 solves the level populations of five-level ion r, lanes 10
+ *     .. 12 the two-level ions; the thirteen cooling terms are summed by
+ *     every lane in line_cooling()'s order.
+ * Every number is computed by the statements of cooling_and_heating_balance
+ * (device_thermal.h) in their order - the results equal temperature_kernel's
+ * bit for bit - but a step is as long as one ion's fits, not thirteen ions':
+ * round 4's form (four lanes per slot, an evaluation whole on one lane) spent
+ * 7.2 ms per 256^3 update on a few dozen cells while the GPU idled. */
 __global__ void __launch_bounds__(CMI_BLOCK)
     temp_finish_kernel(const TempPipeArgs a_in) {
   __shared__ TablesDev lds_tables;
-  __shared__ double abund_s[13 * CMI_BLOCK];
   TempPipeArgs a = a_in;
   temp_stage_tables(a_in.u.model.tables, &lds_tables);
   a.u.model.tables = &lds_tables;
-  double *const abund = abund_s + threadIdx.x;
+  const ModelDev &m = a.u.model;
   const int lane = threadIdx.x & 63;
-  const int sub = lane & 3;          /* evaluation of this lane (3: none) */
-  const int first = lane & ~3;       /* the slot's first lane */
-  const uint64_t group =
-      ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-  const bool valid = group < a.nactive;
-  uint32_t slot = 0;
+  const int role = lane & 15;
+  const int quarter = lane & ~15;        /* first lane of the evaluation */
+  const int k = (lane >> 4) < 3 ? (lane >> 4) : 2;
+  const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (w >= a.nactive)
+    return; /* (the whole wave; no barrier follows) */
+  const uint32_t slot = a.list[a.current][w];
   TemperatureSolve s;
-  double ntot = 0., zmid = 0.;
-  CellIntegrals J = temp_integrals(a.u, a.chunk_first);
-  bool again = false;
-  if (valid) {
-    slot = a.list[a.current][group];
-    temp_load_state(a, slot, s);
-    ntot = a.state[(size_t)TS_NTOT * a.capacity + slot];
-    zmid = a.state[(size_t)TS_ZMID * a.capacity + slot];
-    J = temp_integrals(a.u, a.chunk_first + a.slot_cell[slot]);
-    again = true; /* listed: its last step left it unconverged */
-  }
-  while (__ballot(again) != 0ull) {
-    double gaink = 0., lossk = 0., h0k = 0., he0k = 0.;
+  temp_load_state(a, slot, s);
+  const double n = a.state[(size_t)TS_NTOT * a.capacity + slot];
+  const double midpoint_z = a.state[(size_t)TS_ZMID * a.capacity + slot];
+  const int64_t cell = a.chunk_first + a.slot_cell[slot];
+  const CellIntegrals j = temp_integrals(a.u, cell);
+  enum { NI = 0, NII, OI, OII, OIII, NeIII, SII, SIII, CII, CIII, NIII, NeII,
+         SIV };
+  const double AHe = m.abundance[0];
+  const double AC = m.abundance[1], AN = m.abundance[2], AO = m.abundance[3],
+               ANe = m.abundance[4], AS = m.abundance[5];
+  /* (listed: its last step left it unconverged) */
+  do {
     const double T0 = s.T0;
-    if (again && sub < 3) {
-      const double T1 = 1.1 * T0;
-      const double Tk = (sub == 0) ? T1 : ((sub == 1) ? 0.9 * T0 : T0);
-      double x[CMI_NION];
-      cooling_and_heating_balance(a.u.model, h0k, he0k, gaink, lossk, Tk, ntot,
-                                  zmid, J, s.h, x, abund, CMI_BLOCK);
+    const double T = (k == 0) ? 1.1 * T0 : ((k == 1) ? 0.9 * T0 : T0);
+    /* ---- cooling_and_heating_balance(m, h0, he0, gain, loss, T, n, ...) */
+    double h0, he0, gain, loss;
+    const double alphaH = cmi_recombination_rate(m, ION_H_n, T);
+    const double alphaHe = cmi_recombination_rate(m, ION_He_n, T);
+    const double T4 = T * 1.e-4;
+    const double sqrtT = sqrt(T);
+    const double logT = log(T);
+    cmi_ionization_states_hydrogen_helium(alphaH, alphaHe, j(ION_H_n),
+                                          j(ION_He_n), n, AHe, T, h0, he0);
+    const double ne = n * (1. - h0 + AHe * (1. - he0));
+    const double nhp = n * (1. - h0);
+    const double nhep = (1. - he0) * n * AHe;
+    const double nenhp = ne * nhp;
+    const double nenhep = ne * nhep;
+    gain = n * (s.h[0] * h0 + s.h[1] * AHe * he0);
+    const double alpha_e_2sP =
+        4.17e-20 * exp(-0.861 * (logT - 9.210340371976184));
+    const double pHots = 1. / (1. + 77. * he0 / (sqrtT * h0));
+    gain += pHots * 1.21765423e-18 * alpha_e_2sP * nenhep;
+    gain += 1.5e-37 * n * ne * m.pahfac;
+    double heatcr = 0.;
+    if (m.crfac > 0.) {
+      heatcr = m.crfac * 1.2e-25 / sqrt(ne);
+      if (m.crscale > 0.)
+        heatcr *= exp(-fabs(midpoint_z) / m.crscale);
     }
-    /* (every lane of the wave takes part in the exchange) */
-    const double gain1 = __shfl(gaink, first, 64);
-    const double loss1 = __shfl(lossk, first, 64);
-    const double gain2 = __shfl(gaink, first + 1, 64);
-    const double loss2 = __shfl(lossk, first + 1, 64);
-    const double gain0 = __shfl(gaink, first + 2, 64);
-    const double loss0 = __shfl(lossk, first + 2, 64);
-    const double h0 = __shfl(h0k, first + 2, 64);
-    const double he0 = __shfl(he0k, first + 2, 64);
-    if (again) {
-      ++s.niter;
-      s.Tlast = T0;
-      s.h0 = h0;
-      s.he0 = he0;
-      s.gain0 = gain0;
-      s.loss0 = loss0;
-      temperature_step_finish(a.u.model, s, T0, gain1, loss1, gain2, loss2);
-      again = temperature_goes_on(a.u.model, s);
+    gain += heatcr;
+    const double nh0 = n * h0;
+    const double nhe0 = n * he0 * AHe;
+    /* cmi_ionization_states_metals: one ion per lane */
+    double my_ratio = 0.;
+    if (role < 12)
+      my_ratio = cmi_metal_ratio(m, j, ION_C_p1 + role, ne, T, T4, nh0, nhe0,
+                                 nhp);
+    double ratio[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+      ratio[i] = __shfl(my_ratio, quarter + i, 64);
+    double x[CMI_NION];
+    cmi_metal_fractions(ratio, x);
+    double ab[13];
+    ab[CII] = AC * (1. - x[ION_C_p1] - x[ION_C_p2]);
+    ab[CIII] = AC * x[ION_C_p1];
+    ab[NI] = AN * (1. - x[ION_N_n] - x[ION_N_p1] - x[ION_N_p2]);
+    ab[NII] = AN * x[ION_N_n];
+    ab[NIII] = AN * x[ION_N_p1];
+    ab[OI] = AO * (1. - x[ION_O_n] - x[ION_O_p1]);
+    ab[OII] = AO * x[ION_O_n];
+    ab[OIII] = AO * x[ION_O_p1];
+    ab[NeII] = ANe * x[ION_Ne_n];
+    ab[NeIII] = ANe * x[ION_Ne_p1];
+    ab[SII] = AS * (1. - x[ION_S_p1] - x[ION_S_p2] - x[ION_S_p3]);
+    ab[SIII] = AS * x[ION_S_p1];
+    ab[SIV] = AS * x[ION_S_p2];
+    double my_ab = 0.;
+#pragma unroll
+    for (int i = 0; i < 13; ++i)
+      if (role == i)
+        my_ab = ab[i];
+    /* line_cooling(lc, T, ne, abund): one ion per lane */
+    const LineCoolingDev &lc = m.tables->lc;
+    const double kb = CMI_BOLTZMANN;
+    double term = 0.;
+    if (ne != 0.) {
+      const double prefactor = lc.prefactor * ne / sqrt(T);
+      const double Tinv = 1. / T;
+      const double logT_lc = log(T);
+      if (role < CMI_LC_NFIVE_DEV)
+        term = my_ab * kb *
+               lc_five_level_cooling(lc, role, prefactor, T, Tinv, logT_lc);
+      else if (role < CMI_LC_NFIVE_DEV + CMI_LC_NTWO_DEV) {
+        const int i = role - CMI_LC_NFIVE_DEV;
+        term = my_ab * kb * lc.two_energy[i] * lc.two_A[i] *
+               lc_two_level_cooling(lc, i, prefactor, T, Tinv, logT_lc);
+      }
     }
-  }
-  if (valid && sub == 0) {
-    const int64_t c = a.chunk_first + a.slot_cell[slot];
+    double cooling = 0.;
+#pragma unroll
+    for (int e = 0; e < CMI_LC_NFIVE_DEV + CMI_LC_NTWO_DEV; ++e)
+      cooling += __shfl(term, quarter + e, 64);
+    loss = ((ne == 0.) ? 1.e-99 : cooling) * n;
+    const double c = 5.5 - logT;
+    const double gff = 1.1 + 0.34 * exp(-c * c / 3.);
+    loss += 1.42e-40 * gff * sqrtT * (nenhp + nenhep);
+    const double Lhp =
+        2.85e-40 * nenhp * sqrtT * (5.914 - 0.5 * logT + 0.01184 * cbrt(T));
+    const double Lhep = 1.55e-39 * nenhep * exp(0.3647 * logT);
+    loss += Lhp + Lhep;
+    loss = fmax(loss, 0.);
+    gain = fmax(gain, 0.);
+    /* ---- temperature_step's bookkeeping, on every lane alike */
+    const double gain1 = __shfl(gain, 0, 64);
+    const double loss1 = __shfl(loss, 0, 64);
+    const double gain2 = __shfl(gain, 16, 64);
+    const double loss2 = __shfl(loss, 16, 64);
+    ++s.niter;
+    s.Tlast = T0;
+    s.h0 = __shfl(h0, 32, 64);
+    s.he0 = __shfl(he0, 32, 64);
+    s.gain0 = __shfl(gain, 32, 64);
+    s.loss0 = __shfl(loss, 32, 64);
+    temperature_step_finish(m, s, T0, gain1, loss1, gain2, loss2);
+  } while (temperature_goes_on(m, s));
+  if (lane == 0) {
     double T, heating[2], x[CMI_NION];
-    temperature_end(a.u.model, ntot, J, s, T, heating, x);
-    temp_store_cell(a.u, c, ntot, T, x, heating);
+    temperature_end(m, n, j, s, T, heating, x);
+    temp_store_cell(a.u, cell, n, T, x, heating);
   }
 }
 

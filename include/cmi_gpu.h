@@ -510,8 +510,9 @@ int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);
  *                           of a secant step (ionization balance / line
  *                           cooling / update), each dense in like work -
  *                           0: one kernel holding the whole solve of a cell
- *   "temperature_finish_slots" (32768)  ... and once so few cells are still
+ *   "temperature_finish_slots" (1024)  ... and once so few cells are still
  *                           iterating, one launch takes them to their end
+ *                           (a wave per cell)
  *   "pad_march" (1)         hydrogen-only runs on a whole, non-periodic grid:
  *                           the first generation marches through a copy of
  *                           n x_H with one layer of ghost cells, whose record

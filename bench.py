@@ -442,6 +442,17 @@ def parse_args():
                          "accumulators are all-reduced (replica), or every "
                          "rank holds one block and flights are exchanged "
                          "(domain)")
+    ap.add_argument("--driver", default="torch", choices=["torch", "native"],
+                    help="torch: one process per GPU over torch.distributed "
+                         "(RCCL) - the form the round's driver launches; "
+                         "native: ONE process drives an engine per GPU "
+                         "through the C ABI's group API (cmi_gpu_group_*: "
+                         "RCCL reduce / device-side routing of flights over "
+                         "peer access) - what the C++ host `cmi-gpu` does")
+    ap.add_argument("--config5-ncell", type=int, default=None,
+                    help="N > 1, default config: cells per axis of the "
+                         "`config5` leg (lexingtonHII40 in blocks; default "
+                         "512 at 8 ranks, else 256)")
     ap.add_argument("--copies", type=int, default=1,
                     help="engines per block that holds a source (the "
                          "reference's copies of busy subgrids): only 1 here")
@@ -599,6 +610,8 @@ def run_leg(args, ranks, config, steps, warmup, cpu_seconds=None,
         nonlocal loop, lanes_per_wave_step
         barrier()
         backend.engine.get_timing(reset=True)
+        if domain:
+            driver.idle_s = 0.
         nsteps = 0
         t0 = time.perf_counter()
         for _ in range(nsteps_timed):
@@ -647,6 +660,15 @@ def run_leg(args, ranks, config, steps, warmup, cpu_seconds=None,
                   max(s_timing["update_launches"], 1)}
 
     final_volume = ionized_fraction()
+    idle_ms = None
+    if domain:
+        # per rank: time blocked in the rounds' collectives per timed step
+        idle_ms = [1e3 * driver.idle_s / max(steps, 1)]
+        if world > 1:
+            t = torch.tensor(idle_ms, dtype=torch.float64, device="cuda")
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            idle_ms = [float(x.item()) for x in parts]
     out = None
     if rank == 0:
         total_packets = float(global_packets) * steps
@@ -754,12 +776,207 @@ def run_leg(args, ranks, config, steps, warmup, cpu_seconds=None,
         if domain:
             out["exchange_rounds_last_step"] = driver.rounds
             out["flights_exchanged_last_step"] = driver.flights_exchanged
+            out["idle_ms_per_step_by_rank"] = idle_ms
     # the next leg needs the memory (flight slots and queues of 1e8 packets)
     barrier()
     backend.engine.close()
     del driver, backend
     torch.cuda.empty_cache()
     return out
+
+
+class _Holder:
+    """what setup_engine() configures: something with an `engine`"""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+
+def run_native(args, config, ncell, domain, steps, warmup, devices):
+    """The same iteration through the C ABI's group API - ONE process, one
+    engine per device (include/cmi_gpu.h, cmi_gpu_group_*; the reference:
+    src/TaskBasedIonizationSimulation.cpp:514-560,643-1073 for the blocks,
+    src/IonizationSimulation.cpp:459-618 for the replicas): replicas shoot
+    their share of the packets, cmi_gpu_group_reduce_accumulators (RCCL),
+    sharded update; blocks shoot, cmi_gpu_group_exchange_flights until no
+    flight moves (rows routed on the device, written into the owner's inbox
+    over peer access), every block updates its cells. Engines are driven from
+    one host thread each where a call blocks (re-emission reads a few bytes
+    back per round). Returns the record."""
+    from concurrent.futures import ThreadPoolExecutor
+    from cmacionize_amd import GpuEngine, STROMGREN as S
+    from cmacionize_amd import engine as E
+    from cmacionize_amd.engine import EngineGroup
+    from cmacionize_amd.simulation import (DomainDecomposition,
+                                           DomainGpuBackend, default_blocks,
+                                           distribute_packets)
+    cfg = CONFIGS[config]
+    n = len(devices)
+    npk = int(args.packets)
+    converge_iterations = (args.converge_iterations
+                           if args.converge_iterations is not None
+                           else cfg["converge_iterations"])
+    backends = []
+    if domain:
+        dec = DomainDecomposition((ncell,) * 3, default_blocks(n))
+        for r in range(n):
+            b = DomainGpuBackend(dec, r, S["anchor"], S["sides"],
+                                 device=devices[r],
+                                 track_heating=cfg["lexington"],
+                                 export_capacity=max(npk // 4, 1 << 20))
+            setup_engine(b, ncell, cfg, dec.block(r))
+            backends.append(b)
+    else:
+        for r in range(n):
+            b = _Holder(GpuEngine((ncell,) * 3, S["anchor"], S["sides"],
+                                  S["periodic"], device=devices[r],
+                                  track_heating=cfg["lexington"]))
+            setup_engine(b, ncell, cfg)
+            backends.append(b)
+    group = EngineGroup([b.engine for b in backends])
+    pool = ThreadPoolExecutor(max_workers=n)
+    state = dict(rounds=0, flights=0, nsteps=0)
+
+    def start(job):
+        r, loop, total = job
+        b = backends[r]
+        if domain:
+            b.reset_grid()
+            b.shoot(42, loop, 0, total)
+        else:
+            first, count = distribute_packets(total, r, n)
+            b.engine.reset_grid()
+            b.engine.shoot(42, loop, first, count)
+        return b.engine.get_counters()
+
+    def iteration(loop, total):
+        counters = list(pool.map(start, [(r, loop, total) for r in range(n)]))
+        rounds = flights = 0
+        if domain:
+            while True:
+                moved = group.exchange_flights(42, loop)
+                if moved == 0:
+                    break
+                flights += moved
+                rounds += 1
+            counters = [b.engine.get_counters() for b in backends]
+        else:
+            group.reduce_accumulators()
+        tw = sum(c[0] for c in counters)
+        state.update(rounds=rounds, flights=flights,
+                     nsteps=sum(c[2] for c in counters))
+        group.update_cells(loop, tw)
+
+    def synchronize():
+        for b in backends:
+            b.engine.synchronize()
+
+    # replicas: weak scaling, every engine shoots npk; blocks: npk in total
+    total = npk if domain else npk * n
+    loop = 0
+    for _ in range(converge_iterations):
+        iteration(loop, int(args.converge_packets) * (1 if domain else n))
+        loop += 1
+    for _ in range(warmup):
+        iteration(loop, total)
+        loop += 1
+    synchronize()
+    group.exchange_stats(reset=True)
+    nsteps = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        iteration(loop, total)
+        nsteps += state["nsteps"]
+        loop += 1
+    synchronize()
+    elapsed = time.perf_counter() - t0
+    st = group.exchange_stats(reset=True)
+    xH = np.concatenate([b.engine.download_field(E.FIELD_IONIC_FRACTION)
+                         for b in (backends if domain else backends[:1])])
+    out = {
+        "metric": "photon packets/sec, %d^3 %s" % (ncell, config),
+        "value": float(total) * steps / elapsed,
+        "unit": "packets/s",
+        "driver": "native (cmi_gpu_group_*: one process, %d engines on "
+                  "devices %s)" % (n, sorted(set(devices))),
+        "n_gpus": len(set(devices)),
+        "engines": n,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps,
+        "scaling": "strong" if domain else "weak",
+        "config": {
+            "workload": "%s %d^3 grid, %.0e packets per %s" %
+                        (cfg["name"], ncell, npk,
+                         "iteration (all GPUs together)" if domain
+                         else "GPU per iteration"),
+            "parallelism": ("domain x%d: blocks %s, flights routed on the "
+                            "device into the owner's inbox (peer access)" %
+                            (n, "x".join(map(str, default_blocks(n))))
+                            if domain else
+                            "replica x%d: RCCL all-reduce of the accumulator "
+                            "block, sharded cell update" % n),
+        },
+        "dda_steps_per_packet": nsteps / (float(total) * steps),
+        "ionized_volume_fraction": float((xH < 0.5).mean()),
+    }
+    if domain:
+        per = max(st["rounds"], 1)
+        out["exchange_rounds_last_step"] = state["rounds"]
+        out["flights_exchanged_last_step"] = state["flights"]
+        out["exchange_host_us_per_round"] = {
+            "until_counts_known": st["counts_us"] / per,
+            "owner_threads_beyond_longest_flight": st["threads_us"] / per,
+            "whole_round": st["total_us"] / per}
+    pool.shutdown()
+    group.close()
+    for b in backends:
+        b.engine.close()
+    return out
+
+
+def native_devices(n):
+    """device of each of the n engines: 0 .. n - 1, or - the rehearsal on a
+    box with fewer GPUs (CMI_BENCH_BACKEND=gloo) - shared round robin"""
+    import torch
+    have = torch.cuda.device_count()
+    if have >= n:
+        return list(range(n))
+    if os.environ.get("CMI_BENCH_BACKEND", "nccl") == "nccl":
+        raise SystemExit("bench.py: --driver native --gpus %d but only %d "
+                         "GPU(s) are visible" % (n, have))
+    return [r % max(have, 1) for r in range(n)]
+
+
+def native_child(args, config, ncell, domain, steps, warmup, timeout=900.):
+    """run_native in a process of its own (started by rank 0 once the ranks'
+    engines are closed): whatever happens to it - RCCL inside one process
+    next to torch's, peer access that the box refuses - the line of the torch
+    driver survives; what went wrong is recorded instead."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--driver", "native",
+           "--gpus", str(args.gpus), "--steps", str(steps), "--warmup",
+           str(warmup), "--config", config, "--ncell", str(ncell),
+           "--packets", repr(float(args.packets)), "--converge-packets",
+           repr(float(args.converge_packets)), "--decomposition",
+           "domain" if domain else "replica", "--no-cpu-baseline",
+           "--no-also"]
+    if args.converge_iterations is not None:
+        cmd += ["--converge-iterations", str(args.converge_iterations)]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT",
+                        "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                        "TORCHELASTIC_RUN_ID")}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True,
+                           timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "no result after %.0f s" % timeout}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "exit code %d: %s" % (r.returncode,
+                                               r.stderr.strip()[-600:])}
+    return json.loads(lines[-1])
 
 
 # what an `also` leg carries into the headline line
@@ -772,6 +989,15 @@ ALSO_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step",
 
 def main():
     args = parse_args()
+    if args.driver == "native":
+        # one process for all GPUs; under a launcher only rank 0 works
+        if int(os.environ.get("RANK", "0")) == 0:
+            out = run_native(args, args.config, args.ncell,
+                             args.decomposition == "domain", args.steps,
+                             args.warmup, native_devices(args.gpus))
+            print(json.dumps(out))
+        return
+
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, as
         # child processes, before anything in this process touches a GPU
@@ -815,6 +1041,43 @@ def main():
                                        if k != "calibration"}
             out["also"][config] = rec
         out["bench_wall_s"] = time.perf_counter() - t_start
+    extras = (ranks.world > 1 and args.config == "stromgren" and
+              not args.no_also and args.decomposition == "replica")
+    if extras:
+        # N > 1, the driver's command: the line also carries config 5's shape
+        # (lexingtonHII40 in one block per GPU, flights exchanged over RCCL)
+        # and the product's own multi-GPU path (the group API) on both shapes
+        import copy
+        steps = args.also_steps or min(args.steps, 20)
+        a5 = copy.copy(args)
+        a5.decomposition = "domain"
+        a5.ncell = args.config5_ncell or (512 if ranks.world == 8 else 256)
+        leg = run_leg(a5, ranks, "lexington", steps, args.warmup)
+        if ranks.rank == 0:
+            rec = {k: leg[k] for k in ALSO_KEYS + (
+                "n_gpus", "ranks_in_collective", "packets_per_rank_per_step",
+                "scaling", "exchange_rounds_last_step",
+                "flights_exchanged_last_step", "idle_ms_per_step_by_rank")
+                if k in leg}
+            rec["iterations_to_converge"] = \
+                leg["iterations_to_converge"]["value"]
+            out["config5"] = rec
+        # the native driver needs the GPUs to itself: the other ranks wait on
+        # the rendezvous store (a host-side wait: a collective would spin on
+        # their devices)
+        from datetime import timedelta
+        store = ranks.dist.distributed_c10d._get_default_store()
+        if ranks.rank == 0:
+            out["native"] = {
+                "replica": native_child(args, "stromgren", args.ncell, False,
+                                        steps, args.warmup),
+                "config5": native_child(args, "lexington", a5.ncell, True,
+                                        steps, args.warmup)}
+            store.set("cmi_bench_native_done", "1")
+        else:
+            store.wait(["cmi_bench_native_done"], timedelta(minutes=45))
+        if ranks.rank == 0:
+            out["bench_wall_s"] = time.perf_counter() - t_start
     if ranks.rank == 0:
         print(json.dumps(out))
     if ranks.world > 1:

@@ -82,7 +82,8 @@ struct ExchangeDev {
 };
 
 /* Tile rounds (incoherent flights: re-emitted packets, flights handed over):
- * the engine's grid is cut into tiles of T^3 cells (T = 2^log2_side), a
+ * the engine's grid is cut into tiles of 2^log2[0] x 2^log2[1] x 2^log2[2]
+ * cells (TileShape), a
  * flight is marched one tile at a time by a workgroup that keeps the tile's
  * accumulators in LDS; between rounds the flights wait as rows of
  * CMI_FLIGHT_DOUBLES doubles (the marcher's state, as in a hand-over between
@@ -111,9 +112,33 @@ struct ExchangeDev {
 #define CMI_SLOT_CELL 13
 
 struct TileGridDev {
-  int32_t log2_side; /* tile side = 1 << log2_side cells */
-  int32_t ntile[3];  /* tiles per axis (the last one may be clipped) */
+  int32_t log2[3];  /* tile sides = 1 << log2[axis] cells */
+  int32_t ntile[3]; /* tiles per axis (the last one may be clipped) */
   int32_t ntiles;
+};
+/* tile sides (log2) per transport flavour: hydrogen-only 16^3 cells (32 KB of
+ * J_H + 32 KB of records in LDS), 14 ions + heating 8^3 (64 KB + 8 KB); the
+ * experiment builds of tools/exp_tiles.sh override them */
+#ifndef CMI_TILE_LX_H
+#define CMI_TILE_LX_H 4
+#define CMI_TILE_LY_H 4
+#define CMI_TILE_LZ_H 4
+#endif
+#ifndef CMI_TILE_LX_FULL
+#define CMI_TILE_LX_FULL 3
+#define CMI_TILE_LY_FULL 3
+#define CMI_TILE_LZ_FULL 3
+#endif
+template <bool FULL> struct TileShape {
+  static constexpr int LX = FULL ? CMI_TILE_LX_FULL : CMI_TILE_LX_H;
+  static constexpr int LY = FULL ? CMI_TILE_LY_FULL : CMI_TILE_LY_H;
+  static constexpr int LZ = FULL ? CMI_TILE_LZ_FULL : CMI_TILE_LZ_H;
+  static constexpr int TX = 1 << LX, TY = 1 << LY, TZ = 1 << LZ;
+  static constexpr int CELLS = TX * TY * TZ;
+  /* index of tile-local coordinates in the tile's LDS arrays */
+  __host__ __device__ static constexpr int index(int x, int y, int z) {
+    return (x << (LY + LZ)) | (y << LZ) | z;
+  }
 };
 struct FlightRowsDev {
   double *rows;     /* [capacity][CMI_FLIGHT_DOUBLES] */
@@ -333,7 +358,10 @@ static_assert(cmi_acc_column(0) == 0 && cmi_acc_of_column(3) == 14 &&
 
 __host__ __device__ __forceinline__ double *acc_at(const CellsDev &cells,
                                                    int field, int64_t cell) {
-  const int at = cells.acc_field_stride == 1 ? cmi_acc_column(field) : field;
+  /* (the row layout is the one whose CELLS are 16 values apart: on a grid of
+   * one cell the field stride of the SoA layout is 1 as well) */
+  const int at =
+      cells.acc_cell_stride != 1 ? cmi_acc_column(field) : field;
   return cells.acc_base + at * cells.acc_field_stride +
          cell * cells.acc_cell_stride;
 }

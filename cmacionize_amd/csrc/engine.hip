@@ -127,6 +127,11 @@ struct cmi_gpu_engine {
   unsigned int *tile_counts = nullptr; /* [8]: rows, live, nitems, next item,
                                           absorbed */
   uint64_t tile_rounds_run = 0;
+  /* hydrogen-only runs: something other than a transport step may have
+   * written one of the accumulator fields such a run never adds to (a field
+   * upload, a caller-owned block, a failed clear at a layout switch):
+   * cmi_gpu_reset_grid then clears the whole block once */
+  bool acc_block_dirty = false;
 
   struct Tuning {
     bool sort_packets = true;
@@ -342,7 +347,7 @@ double *field_pointer(cmi_gpu_engine *e, int field) {
   if (field < CMI_GPU_FIELD_MEAN_INTENSITY)
     return e->state_block + (int64_t)field * e->ncell;
   const int f = field - CMI_GPU_FIELD_MEAN_INTENSITY;
-  if (e->cells.acc_field_stride == 1) /* [ncell][16], rows in threshold order */
+  if (e->cells.acc_cell_stride != 1) /* [ncell][16], rows in threshold order */
     return e->acc_block + cmi_acc_column(f);
   return e->acc_block + (int64_t)f * e->cells.acc_field_stride;
 }
@@ -764,10 +769,15 @@ void update_full_flag(cmi_gpu_engine *e) {
    * when every step updates all 16 values of a cell. A switch zeroes the
    * whole block (reset_grid of a hydrogen-only run clears only the fields
    * such a run adds to), so switching between iterations is safe. */
-  if (full != e->full_ions && e->acc_block && hipSetDevice(e->device) == hipSuccess)
-    (void)hipMemsetAsync(e->acc_block, 0,
-                         (size_t)CMI_NACC * e->ncell * sizeof(double),
-                         e->stream);
+  if (full != e->full_ions && e->acc_block) {
+    /* (a clear that could not be enqueued is made up for, with its error
+     * reported, by the next cmi_gpu_reset_grid) */
+    if (hipSetDevice(e->device) != hipSuccess ||
+        hipMemsetAsync(e->acc_block, 0,
+                       (size_t)CMI_NACC * e->ncell * sizeof(double),
+                       e->stream) != hipSuccess)
+      e->acc_block_dirty = true;
+  }
   e->full_ions = full;
   if (full) {
     e->cells.acc_field_stride = 1;
@@ -1277,6 +1287,8 @@ int cmi_gpu_upload_field(cmi_gpu_engine *e, int32_t field,
     (void)hipFree(tmp);
     HIP_TRY(err);
   }
+  if (field >= CMI_GPU_FIELD_MEAN_INTENSITY)
+    e->acc_block_dirty = true; /* an accumulator field */
   if (field == CMI_GPU_FIELD_NUMBER_DENSITY ||
       field == CMI_GPU_FIELD_IONIC_FRACTION + ION_H_n ||
       field == CMI_GPU_FIELD_IONIC_FRACTION + ION_He_n) {
@@ -1339,13 +1351,15 @@ int cmi_gpu_reset_grid(cmi_gpu_engine *e) {
     return fail(CMI_GPU_EINVAL, "null engine");
   HIP_TRY(hipSetDevice(e->device));
   const size_t field_bytes = (size_t)e->ncell * sizeof(double);
-  if (e->full_ions) {
+  if (e->full_ions || e->acc_block_dirty) {
     HIP_TRY(hipMemsetAsync(e->acc_block, 0, CMI_NACC * field_bytes,
                            e->stream));
+    e->acc_block_dirty = false;
   } else {
     /* hydrogen-only runs add to J_H (and the two heating fields) only - the
      * other thirteen fields of the [16][ncell] block stay as zero as the
-     * layout switch left them (update_full_flag) */
+     * layout switch left them (update_full_flag); whatever else writes one
+     * of them marks the block dirty */
     HIP_TRY(hipMemsetAsync(e->acc_block, 0, field_bytes, e->stream));
     if (e->config.track_heating)
       HIP_TRY(hipMemsetAsync(e->acc_block + (size_t)CMI_NION * e->ncell, 0,
@@ -1406,6 +1420,8 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
         (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
   else if (k == "tile_compact_ratio")
     e->tune.tile_compact_ratio = (int)(value < 1 ? 1 : value);
+  else if (k == "accumulators_dirty")
+    e->acc_block_dirty = e->acc_block_dirty || value != 0;
   else if (k == "temperature_finish_slots")
     e->tune.temperature_finish_slots = (uint32_t)(value < 0 ? 0 : value);
   else if (k == "temperature_pipeline")
@@ -1506,10 +1522,18 @@ __global__ void iota_kernel(uint32_t *out, uint64_t n) {
 /* tiles of the engine's grid for the current transport flavour */
 static TileGridDev tile_grid(const cmi_gpu_engine *e) {
   TileGridDev t;
-  t.log2_side = e->full_ions ? CMI_TILE_LOG2_FULL : CMI_TILE_LOG2_H;
-  const int side = 1 << t.log2_side;
+  if (e->full_ions) {
+    t.log2[0] = TileShape<true>::LX;
+    t.log2[1] = TileShape<true>::LY;
+    t.log2[2] = TileShape<true>::LZ;
+  } else {
+    t.log2[0] = TileShape<false>::LX;
+    t.log2[1] = TileShape<false>::LY;
+    t.log2[2] = TileShape<false>::LZ;
+  }
   int64_t total = 1;
   for (int a = 0; a < 3; ++a) {
+    const int side = 1 << t.log2[a];
     t.ntile[a] = (e->grid.ncell[a] + side - 1) / side;
     total *= t.ntile[a];
   }
@@ -1795,8 +1819,13 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     if (rc)
       return rc;
   }
-  /* later generations in tile rounds: needs the incremental marcher */
-  const bool tiles = passes && e->tune.tile_rounds && !exact && !tracking;
+  /* later generations in tile rounds: needs the incremental marcher (and,
+   * with the heating term of a hydrogen-only run, a tile whose J, heating
+   * and records fit the LDS of a CU together) */
+  constexpr bool HYDROGEN_TILE_HEAT =
+      3 * sizeof(double) * TileShape<false>::CELLS <= 160 * 1024 - 64;
+  const bool tiles = passes && e->tune.tile_rounds && !exact && !tracking &&
+                     (e->full_ions || !heat || HYDROGEN_TILE_HEAT);
   void (*tkernel)(const TileArgs) = nullptr;
   int tile_threads = 0, tile_blocks_per_cu = 0;
   if (tiles) {
@@ -1810,8 +1839,9 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     if (e->full_ions)
       tkernel = heat ? tile_kernel<true, true> : tile_kernel<true, false>;
     else
-      tkernel = heat ? tile_kernel<false, true> : tile_kernel<false, false>;
-    tile_threads = CMI_TILE_THREADS;
+      tkernel = heat ? tile_kernel<false, HYDROGEN_TILE_HEAT>
+                     : tile_kernel<false, false>;
+    tile_threads = e->full_ions ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &tile_blocks_per_cu, tkernel, tile_threads, 0));
     if (tile_blocks_per_cu < 1)

@@ -759,10 +759,13 @@ int cmi_gpu_group_exchange_flights(cmi_gpu_group *g, uint32_t seed,
   }
   /* the n x n counts (and the overflow check of every export buffer): into
    * pinned host memory, all copies enqueued before the first wait */
+  /* (portable: the engines of a group sit on different devices and every
+   * one of them copies into this buffer on its own stream) */
   if (!g->host_counts)
     HIP_TRY(hipHostMalloc(&g->host_counts,
                           sizeof(unsigned int) * CMI_GROUP_MAX *
-                              (CMI_GROUP_MAX + 1)));
+                              (CMI_GROUP_MAX + 1),
+                          hipHostMallocPortable));
   for (int s = 0; s < n; ++s) {
     cmi_gpu_engine *e = g->engine[s];
     HIP_TRY(hipSetDevice(e->device));

@@ -1867,7 +1867,7 @@ interaction_new_flight(const InteractArgs &a, double new_frequency,
                        int32_t type, PacketRng &rng, Packet<FULL> &p,
                        double (&weights)[CMI_NACC], uint32_t &plc,
                        uint32_t &key) {
-  constexpr int L = FULL ? CMI_TILE_LOG2_FULL : CMI_TILE_LOG2_H;
+  using Shape = TileShape<FULL>;
   p.nu = new_frequency;
   random_direction(p, rng);
   if (!DEFER)
@@ -1877,11 +1877,11 @@ interaction_new_flight(const InteractArgs &a, double new_frequency,
   start_flight<FULL, false>(a.grid, p);
   if (fast_outside(p))
     return false;
-  plc = 0;
-#pragma unroll
-  for (int ax = 0; ax < 3; ++ax)
-    plc |= (uint32_t)(p.index[ax] & ((1 << L) - 1)) << (8 * ax);
-  key = tile_index(a.tiles, p.index[0] >> L, p.index[1] >> L, p.index[2] >> L);
+  plc = (uint32_t)(p.index[0] & (Shape::TX - 1)) |
+        ((uint32_t)(p.index[1] & (Shape::TY - 1)) << 8) |
+        ((uint32_t)(p.index[2] & (Shape::TZ - 1)) << 16);
+  key = tile_index(a.tiles, p.index[0] >> Shape::LX, p.index[1] >> Shape::LY,
+                   p.index[2] >> Shape::LZ);
   return true;
 }
 
@@ -2824,7 +2824,7 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   CellIntegrals J;
   J.J = a.cells.acc_base;
   J.stride = a.cells.acc_field_stride;
-  J.row = a.cells.acc_field_stride == 1;
+  J.row = a.cells.acc_cell_stride != 1;
   J.jfac = a.jfac;
   for (;;) {
     /* take the next cell(s): up to four that need no solve per trip */

@@ -107,7 +107,7 @@ __device__ __forceinline__ CellIntegrals temp_integrals(const UpdateArgs &a,
   CellIntegrals J;
   J.J = acc_at(a.cells, 0, cell);
   J.stride = a.cells.acc_field_stride;
-  J.row = a.cells.acc_field_stride == 1;
+  J.row = a.cells.acc_cell_stride != 1;
   J.jfac = a.jfac;
   return J;
 }

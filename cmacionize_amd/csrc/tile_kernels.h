@@ -43,11 +43,13 @@
 #include "device_reemit.h"
 #include "device_transport.h"
 
-/* tile side (log2) and workgroup size per transport flavour */
-#define CMI_TILE_LOG2_H 4    /* hydrogen-only: 16^3 cells */
-#define CMI_TILE_LOG2_FULL 3 /* 14 ions + heating: 8^3 cells */
-#ifndef CMI_TILE_THREADS
-#define CMI_TILE_THREADS 512
+/* workgroup size per transport flavour (the tile sides: TileShape,
+ * device_common.h) and waves per SIMD the kernels are built for */
+#ifndef CMI_TILE_THREADS_H
+#define CMI_TILE_THREADS_H 512
+#endif
+#ifndef CMI_TILE_THREADS_FULL
+#define CMI_TILE_THREADS_FULL 512
 #endif
 #ifndef CMI_TILE_WAVES
 #define CMI_TILE_WAVES 4
@@ -401,21 +403,23 @@ write_flight_row(const FlightRowsDev &out, unsigned int q,
  * memory.
  */
 template <bool FULL, bool HEAT>
-__global__ void __launch_bounds__(CMI_TILE_THREADS,
-                                  (!FULL && HEAT) ? 2 : CMI_TILE_WAVES)
+__global__ void
+__launch_bounds__(FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H,
+                  (!FULL && HEAT) ? 2 : CMI_TILE_WAVES)
     tile_kernel(const TileArgs a) {
-  constexpr int L = FULL ? CMI_TILE_LOG2_FULL : CMI_TILE_LOG2_H;
-  constexpr int T = 1 << L;
-  constexpr int TC = T * T * T;
+  using Shape = TileShape<FULL>;
+  constexpr int LX = Shape::LX, LY = Shape::LY, LZ = Shape::LZ;
+  constexpr int TX = Shape::TX, TY = Shape::TY, TZ = Shape::TZ;
+  constexpr int TC = Shape::CELLS;
   constexpr int NV = FULL ? CMI_NACC : (HEAT ? 2 : 1);
-  constexpr int NT = CMI_TILE_THREADS;
+  constexpr int NT = FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H;
   /* value v of tile cell k lives at acc[v * TC + k]: neighbouring cells in
    * neighbouring banks whatever the value */
   __shared__ double acc[NV * TC];
   /* transport records of the tile's cells: n x_H (< 0: vacuum), and n x_He
    * for multi-ion transport */
   __shared__ double opac[(FULL ? 2 : 1) * TC];
-  __shared__ unsigned int s_item, s_next, s_nabs;
+  __shared__ unsigned int s_ring[2], s_next, s_nabs;
 
   const int lane = threadIdx.x & 63;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
@@ -434,51 +438,112 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS,
   for (int ax = 0; ax < 3; ++ax)
     pos[ax] = dir[ax] = tmax[ax] = tdelta[ax] = 0.;
 
-  for (;;) {
+  /* The units of work of this workgroup, claimed one after the other from
+   * the round's counter - two ahead: while the flights of unit k are in the
+   * march, the descriptor and the transport records of unit k + 1 are on
+   * their way into registers (multi-ion tiles: one record per thread) and
+   * the claim of unit k + 2 is in flight. Late rounds consist of thousands of
+   * units with a hundred flights each; claimed, described and loaded one
+   * after the other, each unit cost ~18 us of dependent latencies (returning
+   * atomic -> descriptor -> records -> order -> rows) whatever its flights -
+   * 1.2 ms per round of a 256^3 grid's 32768 multi-ion tiles, half the tile
+   * kernel's time in lexingtonHII40. */
+  constexpr bool PREFETCH = (TC <= NT); /* one record per thread */
+  const unsigned int nitems = *a.nitems;
+  if (threadIdx.x == 0) {
+    s_ring[0] = atomicAdd(a.next_item, 1u);
+    s_ring[1] = atomicAdd(a.next_item, 1u);
+  }
+  __syncthreads();
+  unsigned int item = s_ring[0], item_next = s_ring[1];
+  TileItemDev it;
+  it.tile = it.begin = it.end = it.pad = 0;
+  double2 rec_ahead = make_double2(-1., 0.);
+  /* tile coordinates of a unit's tile and its extent (the last tile of an
+   * axis may be clipped) */
+  auto tile_origin = [&](const TileItemDev &d, int32_t (&o)[3],
+                         int32_t (&td)[3]) {
+    const int32_t tz = (int32_t)(d.tile % (uint32_t)a.tiles.ntile[2]);
+    const int32_t ty = (int32_t)((d.tile / (uint32_t)a.tiles.ntile[2]) %
+                                 (uint32_t)a.tiles.ntile[1]);
+    const int32_t tx = (int32_t)(d.tile / ((uint32_t)a.tiles.ntile[2] *
+                                           (uint32_t)a.tiles.ntile[1]));
+    o[0] = tx << LX;
+    o[1] = ty << LY;
+    o[2] = tz << LZ;
+    td[0] = a.grid.ncell[0] - o[0] < TX ? a.grid.ncell[0] - o[0] : TX;
+    td[1] = a.grid.ncell[1] - o[1] < TY ? a.grid.ncell[1] - o[1] : TY;
+    td[2] = a.grid.ncell[2] - o[2] < TZ ? a.grid.ncell[2] - o[2] : TZ;
+  };
+  auto load_record = [&](const int32_t (&o)[3], const int32_t (&td)[3], int k) {
+    const int32_t lx = k >> (LY + LZ), ly = (k >> LZ) & (TY - 1),
+                  lz = k & (TZ - 1);
+    double2 rec = make_double2(-1., 0.);
+    if (lx < td[0] && ly < td[1] && lz < td[2])
+      rec = a.cells.opacity[((int64_t)(o[0] + lx) * a.grid.ncell[1] + o[1] +
+                             ly) * a.grid.ncell[2] + o[2] + lz];
+    return rec;
+  };
+  if (item < nitems) {
+    it = a.items[item];
+    if (PREFETCH) {
+      int32_t o[3], td[3];
+      tile_origin(it, o, td);
+      if ((int)threadIdx.x < TC)
+        rec_ahead = load_record(o, td, threadIdx.x);
+    }
+  }
+
+  for (int trip = 0; item < nitems; ++trip) {
     if (threadIdx.x == 0) {
-      s_item = atomicAdd(a.next_item, 1u);
+      s_ring[trip & 1] = atomicAdd(a.next_item, 1u); /* the unit after next */
       s_nabs = 0;
+      s_next = it.begin;
     }
     for (int k = threadIdx.x; k < NV * TC; k += NT)
       acc[k] = 0.;
-    __syncthreads();
-    const unsigned int item = s_item;
-    if (item >= *a.nitems)
-      break;
-    const TileItemDev it = a.items[item];
-    if (threadIdx.x == 0)
-      s_next = it.begin;
-    /* the tile: coordinates of its first cell, its extent (the last tile of
-     * an axis may be clipped) */
-    const int32_t tz = (int32_t)(it.tile % (uint32_t)a.tiles.ntile[2]);
-    const int32_t ty = (int32_t)((it.tile / (uint32_t)a.tiles.ntile[2]) %
-                                 (uint32_t)a.tiles.ntile[1]);
-    const int32_t tx = (int32_t)(it.tile / ((uint32_t)a.tiles.ntile[2] *
-                                            (uint32_t)a.tiles.ntile[1]));
-    const int32_t o[3] = {tx << L, ty << L, tz << L};
-    int32_t td[3];
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax)
-      td[ax] = a.grid.ncell[ax] - o[ax] < T ? a.grid.ncell[ax] - o[ax] : T;
-    const bool clipped = (td[0] | td[1] | td[2]) != T;
-    for (int k = threadIdx.x; k < TC; k += NT) {
-      const int32_t lx = k >> (2 * L), ly = (k >> L) & (T - 1),
-                    lz = k & (T - 1);
-      double2 rec = make_double2(-1., 0.);
-      if (lx < td[0] && ly < td[1] && lz < td[2])
-        rec = a.cells.opacity[((int64_t)(o[0] + lx) * a.grid.ncell[1] + o[1] +
-                               ly) * a.grid.ncell[2] + o[2] + lz];
-      opac[k] = rec.x;
-      if (FULL)
-        opac[TC + k] = rec.y;
+    int32_t o[3], td[3];
+    tile_origin(it, o, td);
+    const bool clipped = td[0] != TX || td[1] != TY || td[2] != TZ;
+    if (PREFETCH) {
+      if ((int)threadIdx.x < TC) {
+        opac[threadIdx.x] = rec_ahead.x;
+        if (FULL)
+          opac[TC + threadIdx.x] = rec_ahead.y;
+      }
+    } else {
+      for (int k = threadIdx.x; k < TC; k += NT) {
+        const double2 rec = load_record(o, td, k);
+        opac[k] = rec.x;
+        if (FULL)
+          opac[TC + k] = rec.y;
+      }
     }
     __syncthreads();
+    /* the next unit's descriptor and records: needed after this unit's march */
+    TileItemDev it_ahead = it;
+    if (item_next < nitems) {
+      it_ahead = a.items[item_next];
+      if (PREFETCH) {
+        int32_t on[3], tdn[3];
+        tile_origin(it_ahead, on, tdn);
+        if ((int)threadIdx.x < TC)
+          rec_ahead = load_record(on, tdn, threadIdx.x);
+      }
+    }
 
     bool active = false;
     int32_t last_lidx = 0;
     bool stepped = false; /* the flight has crossed a cell in this tile */
+    /* not zero once a coordinate has left [0, side) (negative ones included) */
+    auto beyond = [&]() -> int32_t {
+      if constexpr (LX == LY && LY == LZ)
+        return (int32_t)(((uint32_t)(lc[0] | lc[1] | lc[2])) >> LX);
+      else
+        return (lc[0] >> LX) | (lc[1] >> LY) | (lc[2] >> LZ);
+    };
     auto in_tile = [&]() {
-      bool in = (((uint32_t)(lc[0] | lc[1] | lc[2])) >> L) == 0u;
+      bool in = beyond() == 0;
       if (clipped)
         in = in && lc[0] < td[0] && lc[1] < td[1] && lc[2] < td[2];
       return in;
@@ -573,7 +638,7 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS,
       /* ---- hot loop: fast_step() of device_transport.h (the same
        * floating-point operations in the same order) on tile-local
        * coordinates, records and accumulators in LDS ---- */
-      int32_t lidx = (lc[0] << (2 * L)) | (lc[1] << L) | lc[2];
+      int32_t lidx = Shape::index(lc[0], lc[1], lc[2]);
       double kx = 0., ky = 0.;
       if (active && tau > 0. && in_tile()) {
         kx = opac[lidx];
@@ -589,7 +654,7 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS,
       for (;;) {
         unsigned long long flying =
             active_lanes & mask_gt(tau, 0.) &
-            mask_eq((int32_t)(((uint32_t)(lc[0] | lc[1] | lc[2])) >> L), 0);
+            mask_eq(beyond(), 0);
         if (clipped)
           flying &= wave_ballot(lc[0] < td[0] && lc[1] < td[1] &&
                                 lc[2] < td[2]);
@@ -629,7 +694,7 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS,
             t = t_old + ds;
           }
           ++nsteps;
-          lidx = (lc[0] << (2 * L)) | (lc[1] << L) | lc[2];
+          lidx = Shape::index(lc[0], lc[1], lc[2]);
           if (tau > 0. && in_tile()) {
             kx = opac[lidx];
             if (FULL)
@@ -739,11 +804,10 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS,
         uint32_t key = key_dead;
         if (moved) {
           /* the marcher's state at the wall, into the same slot */
-          uint32_t plc = 0;
-#pragma unroll
-          for (int ax = 0; ax < 3; ++ax)
-            plc |= (uint32_t)(g[ax] & (T - 1)) << (8 * ax);
-          key = tile_index(a.tiles, g[0] >> L, g[1] >> L, g[2] >> L);
+          const uint32_t plc = (uint32_t)(g[0] & (TX - 1)) |
+                               ((uint32_t)(g[1] & (TY - 1)) << 8) |
+                               ((uint32_t)(g[2] & (TZ - 1)) << 16);
+          key = tile_index(a.tiles, g[0] >> LX, g[1] >> LY, g[2] >> LZ);
           const uint32_t cell =
               (uint32_t)((g[0] * a.grid.ncell[1] + g[1]) * a.grid.ncell[2] +
                          g[2]);
@@ -764,9 +828,9 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS,
            * where (end_flight()), in which cell, which packet - densely, in
            * this unit's stretch of the record arrays; the slot keeps its key
            * until that kernel has decided */
-          const int32_t lx = last_lidx >> (2 * L),
-                        ly = (last_lidx >> L) & (T - 1),
-                        lz = last_lidx & (T - 1);
+          const int32_t lx = last_lidx >> (LY + LZ),
+                        ly = (last_lidx >> LZ) & (TY - 1),
+                        lz = last_lidx & (TZ - 1);
           const int32_t cell =
               ((o[0] + lx) * a.grid.ncell[1] + o[1] + ly) * a.grid.ncell[2] +
               o[2] + lz;
@@ -804,8 +868,8 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS,
         for (int k = threadIdx.x >> 4; k < TC; k += NT / 16) {
           const double v = acc[i * TC + k];
           if (v != 0.) {
-            const int32_t lx = k >> (2 * L), ly = (k >> L) & (T - 1),
-                          lz = k & (T - 1);
+            const int32_t lx = k >> (LY + LZ), ly = (k >> LZ) & (TY - 1),
+                          lz = k & (TZ - 1);
             const int64_t cell =
                 ((int64_t)(o[0] + lx) * a.grid.ncell[1] + o[1] + ly) *
                     a.grid.ncell[2] +
@@ -820,8 +884,8 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS,
         const double v = acc[k];
         const double h = HEAT ? acc[TC + k] : 0.;
         if (v != 0. || h != 0.) {
-          const int32_t lx = k >> (2 * L), ly = (k >> L) & (T - 1),
-                        lz = k & (T - 1);
+          const int32_t lx = k >> (LY + LZ), ly = (k >> LZ) & (TY - 1),
+                        lz = k & (TZ - 1);
           const int64_t cell =
               ((int64_t)(o[0] + lx) * a.grid.ncell[1] + o[1] + ly) *
                   a.grid.ncell[2] +
@@ -838,6 +902,9 @@ __global__ void __launch_bounds__(CMI_TILE_THREADS,
       }
     }
     __syncthreads();
+    item = item_next;
+    item_next = s_ring[trip & 1];
+    it = it_ahead;
   }
 
   const double s0 = wave_sum(tc0);

@@ -165,7 +165,13 @@ public:
 
   /* SPHArrayInterface::gridding (called by the reference's constructors for
    * this mapping type) */
-  PetkovaMapping() : _table((size_t)NROW * NCOL * NCOL, 0.) {
+  /* tabulate = false: for callers that only use the closed form
+   * (mass_fraction(..., tabulated = false): the Phantom / SPHNG density
+   * functions) - no 182 MB table, no seconds of tabulation */
+  explicit PetkovaMapping(bool tabulate = true)
+      : _table(tabulate ? (size_t)NROW * NCOL * NCOL : 0, 0.) {
+    if (!tabulate)
+      return;
     const int last = NR_FINE + NR_COARSE;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1)

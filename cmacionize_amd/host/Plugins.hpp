@@ -999,6 +999,13 @@ public:
       for (int a = 0; a < 3; ++a)
         index[a] = block_index(level, a, _block_anchor[3 * i + a] +
                                              0.5 * _block_sides[3 * i + a]);
+      /* (the key packs an index into 19 bits: refuse a file whose blocks do
+       * not fit instead of letting two leaves share a key) */
+      for (int a = 0; a < 3; ++a)
+        if (index[a] < 0 || index[a] >= ((int64_t)1 << 19))
+          throw ParameterError("FLASH snapshot \"" + filename +
+                               "\": more than 2^19 blocks along an axis at "
+                               "refinement level " + std::to_string(level));
       _leaves[key(level, index[0], index[1], index[2])] = (uint32_t)i;
     }
     if (_leaves.empty())

@@ -261,7 +261,7 @@ public:
       _reach[i] = 2. * _smoothing_lengths[i];
     _bins.reset(new SphParticleBins(_positions, _reach));
     if (_use_new_algorithm)
-      _petkova.reset(new PetkovaMapping());
+      _petkova.reset(new PetkovaMapping(false)); /* closed form only */
   }
   void free() override {
     _bins.reset();

@@ -372,6 +372,9 @@ class DomainIterationDriver:
         self.nsteps = 0
         self.rounds = 0
         self.flights_exchanged = 0
+        # seconds this rank spent inside the rounds' collectives (waiting for
+        # the slowest rank + the transfer), summed until the caller resets it
+        self.idle_s = 0.
 
     def _exchange(self, rows, counts):
         """One hand-over round: ONE all-gather of every rank's per-owner
@@ -406,10 +409,17 @@ class DomainIterationDriver:
         b.shoot(seed, loop, 0, n_packets)
         self.rounds = 0
         self.flights_exchanged = 0
+        import time
         while True:
             rows, counts = route_flights(self.decomposition, b.take_exports())
             if self.world > 1:
+                # (take_exports waited for this rank's own flights: from here
+                # to the end of the all-to-all the rank waits for the others)
+                t0 = time.perf_counter()
                 incoming, total = self._exchange(rows, counts)
+                if total != 0 and torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                self.idle_s += time.perf_counter() - t0
                 if total == 0:
                     break
             else:

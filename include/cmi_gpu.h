@@ -85,7 +85,13 @@ typedef struct {
   /* optional: caller-allocated device buffer for the CMI_GPU_NACC accumulator
    * fields, contiguous [CMI_GPU_NACC][ncell] doubles (so that the caller can
    * hand it to a collective, e.g. torch.distributed over RCCL); NULL = the
-   * engine allocates it. */
+   * engine allocates it. The engine zeroes it at creation; in hydrogen-only
+   * runs cmi_gpu_reset_grid clears only the fields such a run adds to (J_H,
+   * the heating terms if tracked), so a caller that writes into the block
+   * itself - other than sums of what engines wrote there - declares that
+   * with cmi_gpu_set_tuning("accumulators_dirty", 1): the next reset then
+   * clears the whole block (cmi_gpu_upload_field of an accumulator field
+   * does the same by itself). */
   void *external_accumulators;
   /* optional domain decomposition (replaces DensitySubGridCreator's block
    * decomposition, src/DensitySubGridCreator.hpp:314-396): the engine holds

@@ -147,11 +147,36 @@ def test_eight_ranks_on_one_device():
         assert len(lines) == 1, r.stdout
         return json.loads(lines[0])
 
-    replica = run(8, [])
+    # the driver's command as it stands (no --no-also): the line of N > 1
+    # ranks also carries config 5's shape over torch.distributed and the
+    # native group driver (one process, eight engines) on both shapes
+    small.remove("--no-also")
+    replica = run(8, ["--config5-ncell", "48"])
+    small.append("--no-also")
     assert replica["n_gpus"] == 8 and replica["ranks_in_collective"] == 8
     assert replica["scaling"] == "weak"
     assert replica["packets_per_rank_per_step"] == 2e5
     assert "strong_scaling" in replica
+    c5 = replica["config5"]
+    assert "lexington" in c5["metric"] and "48^3" in c5["metric"]
+    assert c5["scaling"] == "strong" and c5["n_gpus"] == 8
+    assert c5["exchange_rounds_last_step"] >= 2
+    assert c5["flights_exchanged_last_step"] > 0
+    assert len(c5["idle_ms_per_step_by_rank"]) == 8
+    assert all(ms >= 0. for ms in c5["idle_ms_per_step_by_rank"])
+    native = replica["native"]
+    for shape in ("replica", "config5"):
+        assert "error" not in native[shape], native[shape]
+        assert native[shape]["engines"] == 8 and native[shape]["value"] > 0.
+        assert native[shape]["driver"].startswith("native")
+    assert native["config5"]["exchange_rounds_last_step"] >= 2
+    assert native["config5"]["exchange_host_us_per_round"]["whole_round"] > 0.
+    # the same packets through both drivers: the same state
+    assert abs(native["config5"]["ionized_volume_fraction"] -
+               c5["ionized_volume_fraction"]) < \
+        2e-3 * c5["ionized_volume_fraction"]
+    assert abs(native["config5"]["dda_steps_per_packet"] -
+               c5["dda_steps_per_packet"]) < 1e-3 * c5["dda_steps_per_packet"]
     one = run(1, ["--config", "lexington"])
     domain = run(8, ["--config", "lexington", "--decomposition", "domain"])
     assert domain["n_gpus"] == 8 and domain["ranks_in_collective"] == 8

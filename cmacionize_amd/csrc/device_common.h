@@ -116,23 +116,45 @@ struct TileGridDev {
   int32_t ntile[3]; /* tiles per axis (the last one may be clipped) */
   int32_t ntiles;
 };
-/* tile sides (log2) per transport flavour: hydrogen-only 16^3 cells (32 KB of
- * J_H + 32 KB of records in LDS), 14 ions + heating 8^3 (64 KB + 8 KB); the
- * experiment builds of tools/exp_tiles.sh override them */
+/* Tile sides (log2) and workgroup size per transport flavour. What the LDS of
+ * a CU (160 KB) holds decides: hydrogen-only J_H + records of 32 x 16 x 16
+ * cells (64 + 64 KB, one workgroup of 1024 threads per CU); with the heating
+ * term 16^3 cells (3 x 32 KB, 512 threads); 14 ions + heating 8 x 8 x 16
+ * cells (128 KB of accumulators + 16 KB of records, 1024 threads). Measured
+ * on 256^3, ms of transport per iteration (profiles/r05/tile_shapes.txt):
+ * hydrogen-only 16^3 / 512 threads 76.3, 32 x 16 x 16 / 1024 74.3; multi-ion
+ * 8^3 / 512 180.2, 8 x 8 x 16 / 1024 174.9 (16 x 8 x 8: 177.0) - larger
+ * tiles are fewer visits, fewer rounds and above all a smaller tail for the
+ * per-step atomics of the pass kernels. The experiment builds
+ * (`make variant DEFS=-DCMI_TILE_LZ_FULL=3 ...`) override them. */
 #ifndef CMI_TILE_LX_H
-#define CMI_TILE_LX_H 4
+#define CMI_TILE_LX_H 5
 #define CMI_TILE_LY_H 4
 #define CMI_TILE_LZ_H 4
+#define CMI_TILE_THREADS_H 1024
+#endif
+#ifndef CMI_TILE_LX_HHEAT
+#define CMI_TILE_LX_HHEAT 4
+#define CMI_TILE_LY_HHEAT 4
+#define CMI_TILE_LZ_HHEAT 4
+#define CMI_TILE_THREADS_HHEAT 512
 #endif
 #ifndef CMI_TILE_LX_FULL
 #define CMI_TILE_LX_FULL 3
 #define CMI_TILE_LY_FULL 3
-#define CMI_TILE_LZ_FULL 3
+#define CMI_TILE_LZ_FULL 4
+#define CMI_TILE_THREADS_FULL 1024
 #endif
-template <bool FULL> struct TileShape {
-  static constexpr int LX = FULL ? CMI_TILE_LX_FULL : CMI_TILE_LX_H;
-  static constexpr int LY = FULL ? CMI_TILE_LY_FULL : CMI_TILE_LY_H;
-  static constexpr int LZ = FULL ? CMI_TILE_LZ_FULL : CMI_TILE_LZ_H;
+template <bool FULL, bool HEAT> struct TileShape {
+  static constexpr int LX =
+      FULL ? CMI_TILE_LX_FULL : (HEAT ? CMI_TILE_LX_HHEAT : CMI_TILE_LX_H);
+  static constexpr int LY =
+      FULL ? CMI_TILE_LY_FULL : (HEAT ? CMI_TILE_LY_HHEAT : CMI_TILE_LY_H);
+  static constexpr int LZ =
+      FULL ? CMI_TILE_LZ_FULL : (HEAT ? CMI_TILE_LZ_HHEAT : CMI_TILE_LZ_H);
+  static constexpr int THREADS =
+      FULL ? CMI_TILE_THREADS_FULL
+           : (HEAT ? CMI_TILE_THREADS_HHEAT : CMI_TILE_THREADS_H);
   static constexpr int TX = 1 << LX, TY = 1 << LY, TZ = 1 << LZ;
   static constexpr int CELLS = TX * TY * TZ;
   /* index of tile-local coordinates in the tile's LDS arrays */

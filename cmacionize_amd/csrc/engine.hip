@@ -122,6 +122,8 @@ struct cmi_gpu_engine {
   uint32_t temp_pipe_capacity = 0;
   unsigned int *temp_pipe_counts = nullptr;
   uint32_t *tile_ended_slot = nullptr; /* slot of each absorption record */
+  uint32_t *tile_ended_pos = nullptr;  /* its position in the next round */
+  uint32_t *tile_slot_of[2] = {nullptr, nullptr}; /* position -> slot */
   unsigned int *tile_absorbed_count = nullptr; /* [units of work] */
   unsigned int *tile_absorbed_before = nullptr; /* their running totals */
   unsigned int *tile_counts = nullptr; /* [8]: rows, live, nitems, next item,
@@ -181,10 +183,11 @@ struct cmi_gpu_engine {
      * 512: 51.2 / 50.7 / 50.7 / 49.8 - the wide steps are the cheaper way
      * while many slots are left) */
     uint32_t temperature_finish_slots = 1024;
-    /* the free slots are squeezed out once there are this many slots per
-     * flight (measured: 2 beats 4, 8 and never by 1 % - rows in tile order
-     * are read faster than rows scattered among free slots) */
-    int tile_compact_ratio = 2;
+    /* the live rows are copied into fresh rows, in tile order, once the
+     * flights are spread over this many slots per flight; 0: never; -1: 2 for
+     * multi-ion transport (two rows per visit, 25 GB at 1e8 packets: a sparse
+     * footprint costs more than the copies), never for hydrogen-only */
+    int tile_compact_ratio = -1;
   } tune;
 
   /* device timing (HIP events around launches) is opt-in: set_tuning
@@ -1419,7 +1422,7 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
     e->tune.tile_refill_threshold =
         (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
   else if (k == "tile_compact_ratio")
-    e->tune.tile_compact_ratio = (int)(value < 1 ? 1 : value);
+    e->tune.tile_compact_ratio = (int)(value < -1 ? -1 : value);
   else if (k == "accumulators_dirty")
     e->acc_block_dirty = e->acc_block_dirty || value != 0;
   else if (k == "temperature_finish_slots")
@@ -1522,14 +1525,19 @@ __global__ void iota_kernel(uint32_t *out, uint64_t n) {
 /* tiles of the engine's grid for the current transport flavour */
 static TileGridDev tile_grid(const cmi_gpu_engine *e) {
   TileGridDev t;
+  const bool heat = e->config.track_heating != 0;
   if (e->full_ions) {
-    t.log2[0] = TileShape<true>::LX;
-    t.log2[1] = TileShape<true>::LY;
-    t.log2[2] = TileShape<true>::LZ;
+    t.log2[0] = TileShape<true, true>::LX;
+    t.log2[1] = TileShape<true, true>::LY;
+    t.log2[2] = TileShape<true, true>::LZ;
+  } else if (heat) {
+    t.log2[0] = TileShape<false, true>::LX;
+    t.log2[1] = TileShape<false, true>::LY;
+    t.log2[2] = TileShape<false, true>::LZ;
   } else {
-    t.log2[0] = TileShape<false>::LX;
-    t.log2[1] = TileShape<false>::LY;
-    t.log2[2] = TileShape<false>::LZ;
+    t.log2[0] = TileShape<false, false>::LX;
+    t.log2[1] = TileShape<false, false>::LY;
+    t.log2[2] = TileShape<false, false>::LZ;
   }
   int64_t total = 1;
   for (int a = 0; a < 3; ++a) {
@@ -1565,7 +1573,7 @@ static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
   const size_t hist_bytes =
       counting ? sizeof(uint32_t) * (size_t)t.ntiles * CMI_TILE_SORT_BLOCKS : 0;
   const size_t total = 2 * (row_bytes + weight_bytes + key_bytes) +
-                       3 * key_bytes + 2 * begin_bytes + 2 * count_bytes +
+                       6 * key_bytes + 2 * begin_bytes + 2 * count_bytes +
                        item_bytes + hist_bytes;
   HIP_TRY(hipMalloc(&e->tile_block, total));
   if (!e->tile_counts)
@@ -1586,6 +1594,12 @@ static int reserve_tile_buffers(cmi_gpu_engine *e, uint64_t n) {
   at += key_bytes;
   e->tile_ended_slot = (uint32_t *)at;
   at += key_bytes;
+  e->tile_ended_pos = (uint32_t *)at;
+  at += key_bytes;
+  for (int k = 0; k < 2; ++k) {
+    e->tile_slot_of[k] = (uint32_t *)at;
+    at += key_bytes;
+  }
   e->tile_new_slots = (uint32_t *)at;
   at += key_bytes;
   e->tile_begin = (uint32_t *)at;
@@ -1819,13 +1833,8 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     if (rc)
       return rc;
   }
-  /* later generations in tile rounds: needs the incremental marcher (and,
-   * with the heating term of a hydrogen-only run, a tile whose J, heating
-   * and records fit the LDS of a CU together) */
-  constexpr bool HYDROGEN_TILE_HEAT =
-      3 * sizeof(double) * TileShape<false>::CELLS <= 160 * 1024 - 64;
-  const bool tiles = passes && e->tune.tile_rounds && !exact && !tracking &&
-                     (e->full_ions || !heat || HYDROGEN_TILE_HEAT);
+  /* later generations in tile rounds: needs the incremental marcher */
+  const bool tiles = passes && e->tune.tile_rounds && !exact && !tracking;
   void (*tkernel)(const TileArgs) = nullptr;
   int tile_threads = 0, tile_blocks_per_cu = 0;
   if (tiles) {
@@ -1839,9 +1848,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     if (e->full_ions)
       tkernel = heat ? tile_kernel<true, true> : tile_kernel<true, false>;
     else
-      tkernel = heat ? tile_kernel<false, HYDROGEN_TILE_HEAT>
-                     : tile_kernel<false, false>;
-    tile_threads = e->full_ions ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H;
+      tkernel = heat ? tile_kernel<false, true> : tile_kernel<false, false>;
+    tile_threads = e->full_ions
+                       ? TileShape<true, true>::THREADS
+                       : (heat ? TileShape<false, true>::THREADS
+                               : TileShape<false, false>::THREADS);
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &tile_blocks_per_cu, tkernel, tile_threads, 0));
     if (tile_blocks_per_cu < 1)
@@ -2023,6 +2034,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
      * ONE tile with the tile's accumulators in LDS, and collects the flights
      * that go on (into another tile, or re-emitted) for the next round */
     const double *handover = nullptr; /* flights the tile rounds leave over */
+    const uint32_t *handover_slots = nullptr; /* the slots they sit in */
     unsigned int handover_count = 0;
     if (tiles) {
       const TileGridDev tg = tile_grid(e);
@@ -2054,12 +2066,15 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       unsigned int *const d_nlive = e->tile_counts + 1;
       unsigned int *const d_nitems = e->tile_counts + 2;
       unsigned int *const d_next = e->tile_counts + 3;
-      int cur = 0;
       HIP_TRY(hipMemsetAsync(e->tile_counts, 0, 8 * sizeof(unsigned int),
                              e->stream));
       /* the absorbed packets of the first generation -> flights in slots */
-      ia.rows = e->tile_rows[cur];
+      int cur = 0; /* which set of rows holds the flights */
+      FlightRowsDev rows = e->tile_rows[cur];
+      ia.rows = rows;
       ia.rows.count = d_nrows;
+      ia.ended_pos = nullptr;
+      ia.key_out = nullptr;
       {
         const int iblocks = e->num_cu * 8;
         if (e->full_ions && defer)
@@ -2079,15 +2094,15 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         if (rrc)
           return rrc;
       }
-      if (nslots > e->tile_rows[cur].capacity)
+      if (nslots > rows.capacity)
         return fail(CMI_GPU_ENOMEM,
                     "tile rounds: %u flights, room for %u - flights were "
                     "lost, the iteration is invalid",
-                    nslots, e->tile_rows[cur].capacity);
+                    nslots, rows.capacity);
       if (defer && nslots != 0) {
         FlightWeightsArgs wa;
         wa.model = e->model;
-        wa.rows = e->tile_rows[cur];
+        wa.rows = rows;
         wa.slots = nullptr;
         wa.count = nullptr;
         wa.n = nslots;
@@ -2095,13 +2110,29 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                                 0, e->stream>>>(wa);
         HIP_TRY(hipGetLastError());
       }
-      for (int round = 0; nslots != 0; ++round) {
-        /* sort the slots by tile (free slots last), cut the flights into
-         * units of work */
+      /* The flights of a round by position (TileArgs): keys[i] and the slot
+       * of position i < npos. Round 0: the slots as the interaction kernel
+       * filled them, position = slot; every round writes the arrays of the
+       * next one in its tile order, flights only - the rows never move, and
+       * what has ended is gone from the arrays one round later. */
+      uint32_t *keys = rows.keys;
+      uint32_t *keys_next = e->tile_rows[1].keys;
+      const uint32_t *slot_of = nullptr;
+      int next_slot_of = 0;
+      unsigned int npos = nslots;
+      /* slots the flights are spread over (since the last compaction) */
+      unsigned int extent = nslots;
+      const unsigned int compact_ratio =
+          e->tune.tile_compact_ratio >= 0
+              ? (unsigned int)e->tune.tile_compact_ratio
+              : (e->full_ions ? 2u : 0u);
+      for (int round = 0; npos != 0; ++round) {
+        /* the positions in tile order (ended flights last), cut into units
+         * of work */
         TilePlanArgs pa;
         pa.tiles = tg;
         pa.sorted_keys = e->sort_keys[1];
-        pa.nslots = nslots;
+        pa.nslots = npos;
         pa.tile_begin = e->tile_begin;
         pa.item_flights = item_flights;
         pa.items = e->tile_items;
@@ -2110,12 +2141,12 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         pa.nlive = d_nlive;
         if (e->tile_blockhist && e->tune.tile_counting_sort) {
           TileSortArgs sa;
-          sa.keys = e->tile_rows[cur].keys;
-          sa.nslots = nslots;
+          sa.keys = keys;
+          sa.nslots = npos;
           sa.ntiles = (uint32_t)tg.ntiles;
           /* (about a counter per slot and workgroup at least) */
           {
-            uint64_t nb = ((uint64_t)nslots / sa.ntiles + 7) / 8 * 8;
+            uint64_t nb = ((uint64_t)npos / sa.ntiles + 7) / 8 * 8;
             if (nb < 8)
               nb = 8;
             if (nb > CMI_TILE_SORT_BLOCKS)
@@ -2135,11 +2166,10 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                                 e->stream>>>(sa);
           HIP_TRY(hipGetLastError());
         } else {
-          HIP_TRY(cmi_sort_pairs(e->sort_temp, e->sort_temp_bytes,
-                                 e->tile_rows[cur].keys, e->sort_keys[1],
-                                 e->tile_iota, e->sort_ids[1], nslots,
-                                 tile_bits, e->stream));
-          tile_begin_kernel<<<grid_blocks(e, (int64_t)nslots + 1, 8),
+          HIP_TRY(cmi_sort_pairs(e->sort_temp, e->sort_temp_bytes, keys,
+                                 e->sort_keys[1], e->tile_iota,
+                                 e->sort_ids[1], npos, tile_bits, e->stream));
+          tile_begin_kernel<<<grid_blocks(e, (int64_t)npos + 1, 8),
                               CMI_BLOCK, 0, e->stream>>>(pa);
           HIP_TRY(hipGetLastError());
         }
@@ -2154,7 +2184,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         const unsigned int nlive = plan[0];
         if (nlive == 0)
           break;
-        /* a unit of work costs a fixed ~20-40 us (tile records in, tile
+        /* a unit of work costs a fixed ~10-20 us (tile records in, tile
          * accumulators out); measured on MI355X the round beats single
          * atomics while a unit has a few hundred flights to share that */
         const uint64_t per_item =
@@ -2164,30 +2194,48 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         const bool finish = nlive < e->tune.tile_min_flights ||
                             (uint64_t)nlive < per_item * plan[1] ||
                             round >= e->tune.tile_max_rounds;
+        if (finish) {
+          /* too few flights per tile for the LDS accumulators to pay: the
+           * rest goes on as passes of the transport kernel (below), the first
+           * of which resumes the flights from their slots */
+          tile_handover_kernel<<<grid_blocks(e, (int64_t)nlive, 8), CMI_BLOCK,
+                                 0, e->stream>>>(e->sort_ids[1], slot_of,
+                                                 d_nlive, e->tile_new_slots);
+          HIP_TRY(hipGetLastError());
+          handover = rows.rows;
+          handover_slots = e->tile_new_slots;
+          handover_count = nlive;
+          break;
+        }
         const uint32_t *order = e->sort_ids[1];
-        if (finish ||
-            (uint64_t)e->tune.tile_compact_ratio * nlive < nslots) {
-          /* squeeze the free slots out (and put the flights in tile order) */
+        if (compact_ratio != 0 &&
+            (uint64_t)compact_ratio * nlive < (uint64_t)extent) {
+          /* the live rows into the other set of rows, in tile order: position
+           * j of this round is then place j and slot j */
           TileCompactArgs ca;
-          ca.from = e->tile_rows[cur];
+          ca.from = rows;
           ca.to = e->tile_rows[1 - cur];
+          /* (the two key arrays change hands every round, whatever set of
+           * rows is in use: the copies' keys go to the one that is free) */
+          ca.to.keys = keys_next;
           ca.order = e->sort_ids[1];
+          ca.slot_in = slot_of;
+          ca.keys_in = keys;
           ca.nlive = d_nlive;
           ca.with_weights = e->full_ions ? 1 : 0;
           tile_compact_kernel<<<grid_blocks(e, 8ll * nlive, 8), CMI_BLOCK, 0,
                                 e->stream>>>(ca);
           HIP_TRY(hipGetLastError());
           cur = 1 - cur;
-          nslots = nlive;
-          order = nullptr;
-        }
-        if (finish) {
-          /* too few flights per tile for the LDS accumulators to pay: the
-           * rest goes on as passes of the transport kernel (below), the first
-           * of which resumes the flights from their slots */
-          handover = e->tile_rows[cur].rows;
-          handover_count = nlive;
-          break;
+          rows = e->tile_rows[cur];
+          {
+            uint32_t *t = keys;
+            keys = keys_next;
+            keys_next = t;
+          }
+          slot_of = nullptr;
+          order = e->tile_iota;
+          extent = nlive;
         }
         TileArgs ta;
         ta.grid = e->grid;
@@ -2196,13 +2244,17 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         ta.counters = e->counters;
         ta.tiles = tg;
         ta.refill_threshold = e->tune.tile_refill_threshold;
-        ta.rows = e->tile_rows[cur];
+        ta.rows = rows;
         ta.order = order;
+        ta.slot_in = slot_of;
+        ta.keys_out = keys_next;
+        ta.slot_out = e->tile_slot_of[next_slot_of];
         ta.items = e->tile_items;
         ta.nitems = d_nitems;
         ta.next_item = d_next;
         ta.ended = e->ended_queue;
         ta.ended_slot = e->tile_ended_slot;
+        ta.ended_pos = e->tile_ended_pos;
         ta.absorbed_count = e->tile_absorbed_count;
         ta.xout = a.xout;
         /* no more workgroups than units of work can exist */
@@ -2225,8 +2277,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
             return trc;
         }
         ++e->tile_rounds_run;
-        /* the packets absorbed in this round: re-emitted into their slots */
-        ia.rows = e->tile_rows[cur];
+        /* the packets absorbed in this round: re-emitted into their slots,
+         * their new keys at their positions of the next round */
+        ia.rows = rows;
+        ia.ended_pos = e->tile_ended_pos;
+        ia.key_out = keys_next;
         absorbed_scan_kernel<<<1, CMI_TILE_PLAN_THREADS, 0, e->stream>>>(
             d_nitems, e->tile_absorbed_count, e->tile_absorbed_before);
         HIP_TRY(hipGetLastError());
@@ -2239,7 +2294,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
           HIP_TRY(hipGetLastError());
           FlightWeightsArgs wa;
           wa.model = e->model;
-          wa.rows = e->tile_rows[cur];
+          wa.rows = rows;
           wa.slots = e->tile_new_slots;
           wa.count = d_new;
           wa.n = 0;
@@ -2253,6 +2308,15 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
           interaction_slots_kernel<false>
               <<<sblocks, CMI_BLOCK, 0, e->stream>>>(ia);
         HIP_TRY(hipGetLastError());
+        /* the next round: this round's places are its positions */
+        {
+          uint32_t *t = keys;
+          keys = keys_next;
+          keys_next = t;
+        }
+        slot_of = e->tile_slot_of[next_slot_of];
+        next_slot_of = 1 - next_slot_of;
+        npos = nlive;
       }
     }
     /* ... or as passes of the transport kernel: the interaction kernel turns
@@ -2267,6 +2331,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       b.order = nullptr;
       b.xin = handover;
       b.xin_local = 1;
+      b.xin_slots = handover_slots;
       b.n_packets = handover_count;
       b.refill_threshold = e->tune.refill_threshold_reemit;
       b.aggregate = agg_reemit;
@@ -2321,6 +2386,8 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       ia.nitems = nullptr;
       ia.absorbed_before = nullptr;
       ia.ended_slot = nullptr;
+      ia.ended_pos = nullptr;
+      ia.key_out = nullptr;
       if (e->full_ions)
         interaction_kernel<true, false>
             <<<iblocks, CMI_BLOCK, 0, e->stream>>>(ia);

@@ -137,6 +137,8 @@ struct ShootArgs {
   /* xin rows hold the long index of the entered cell in THIS engine's grid
    * (flights left over by the tile rounds) instead of the whole grid's */
   int32_t xin_local;
+  /* ... listed by slot: flight i is row xin_slots[i] (NULL: row i) */
+  const uint32_t *xin_slots = nullptr;
   ExchangeDev xout;
   /* PAD kernels: n x_H of every cell of the grid with CMI_PAD_LAYERS layers
    * of ghost cells around it (pad_record_kernel): -0. marks a vacuum cell
@@ -1116,7 +1118,9 @@ __global__ void
         bool mine = true;
         if (!PRE && a.xin != nullptr) {
           /* a flight handed over by another block of the grid */
-          const double *r = a.xin + (size_t)CMI_FLIGHT_DOUBLES * i;
+          const uint64_t row =
+              (a.xin_local && a.xin_slots) ? (uint64_t)a.xin_slots[i] : i;
+          const double *r = a.xin + (size_t)CMI_FLIGHT_DOUBLES * row;
           int64_t cell_global;
           unsigned long long idmeta;
           if (a.xin_local) {
@@ -1770,6 +1774,10 @@ struct InteractArgs {
   const unsigned int *nitems;
   const unsigned int *absorbed_before; /* running totals of the counts */
   const uint32_t *ended_slot;
+  /* ... whose new keys (or "free") go to the flights' positions in the next
+   * round: key_out[ended_pos[record]] (TileArgs) */
+  const uint32_t *ended_pos;
+  uint32_t *key_out;
   /* DEFER: the accumulation weights (14 Verner cross sections) of the new
    * flights are left to flight_weights_kernel; the slots kernel lists the
    * slots it filled */
@@ -1867,7 +1875,6 @@ interaction_new_flight(const InteractArgs &a, double new_frequency,
                        int32_t type, PacketRng &rng, Packet<FULL> &p,
                        double (&weights)[CMI_NACC], uint32_t &plc,
                        uint32_t &key) {
-  using Shape = TileShape<FULL>;
   p.nu = new_frequency;
   random_direction(p, rng);
   if (!DEFER)
@@ -1877,11 +1884,14 @@ interaction_new_flight(const InteractArgs &a, double new_frequency,
   start_flight<FULL, false>(a.grid, p);
   if (fast_outside(p))
     return false;
-  plc = (uint32_t)(p.index[0] & (Shape::TX - 1)) |
-        ((uint32_t)(p.index[1] & (Shape::TY - 1)) << 8) |
-        ((uint32_t)(p.index[2] & (Shape::TZ - 1)) << 16);
-  key = tile_index(a.tiles, p.index[0] >> Shape::LX, p.index[1] >> Shape::LY,
-                   p.index[2] >> Shape::LZ);
+  /* (the tile sides of this run's tile kernel: TileGridDev) */
+  const int32_t tx = p.index[0] >> a.tiles.log2[0],
+                ty = p.index[1] >> a.tiles.log2[1],
+                tz = p.index[2] >> a.tiles.log2[2];
+  plc = (uint32_t)(p.index[0] - (tx << a.tiles.log2[0])) |
+        ((uint32_t)(p.index[1] - (ty << a.tiles.log2[1])) << 8) |
+        ((uint32_t)(p.index[2] - (tz << a.tiles.log2[2])) << 16);
+  key = tile_index(a.tiles, tx, ty, tz);
   return true;
 }
 
@@ -2056,7 +2066,7 @@ __global__ void __launch_bounds__(CMI_BLOCK,
         if (q < a.rows.capacity) {
           if (fly)
             write_flight_row<FULL, DEFER>(
-                a.rows, q, p, plc, key, packet,
+                a.rows, q, a.rows.keys + q, p, plc, key, packet,
                 cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin),
                 weights);
           else /* its row stays a free slot */
@@ -2149,6 +2159,7 @@ __global__ void __launch_bounds__(CMI_BLOCK,
   constexpr unsigned int BATCH = TRIPS * CMI_BLOCK;
   __shared__ InteractStage<BATCH> stage;
   __shared__ uint32_t s_slot[BATCH];
+  __shared__ uint32_t s_place[BATCH];
   __shared__ uint32_t s_before[CMI_SLOTS_WINDOW + 1];
   const int lane = threadIdx.x & 63;
   const uint32_t key_dead = CMI_TILE_KEY_DEAD(a.tiles);
@@ -2178,6 +2189,7 @@ __global__ void __launch_bounds__(CMI_BLOCK,
     __syncthreads();
     for (int k0 = 0; k0 < TRIPS; k0 += GROUP) {
       uint32_t record[GROUP], slot[GROUP], meta[GROUP], id[GROUP];
+      uint32_t place[GROUP];
       int32_t cell[GROUP];
       double nu[GROUP];
       InteractCell at_cell[GROUP];
@@ -2208,12 +2220,13 @@ __global__ void __launch_bounds__(CMI_BLOCK,
       for (int g = 0; g < GROUP; ++g) {
         const uint64_t j =
             base + (unsigned int)(k0 + g) * CMI_BLOCK + threadIdx.x;
-        slot[g] = meta[g] = id[g] = 0;
+        slot[g] = meta[g] = id[g] = place[g] = 0;
         cell[g] = 0;
         nu[g] = 0.;
         if (j < total) {
           const uint32_t i = record[g];
           slot[g] = a.ended_slot[i];
+          place[g] = a.ended_pos[i];
           meta[g] = a.qin.meta[i];
           id[g] = a.qin.id[i];
           cell[g] = a.qin.cell[i];
@@ -2243,6 +2256,7 @@ __global__ void __launch_bounds__(CMI_BLOCK,
         if (again) {
           stage.item[at] = record[g];
           s_slot[at] = slot[g];
+          s_place[at] = place[g];
           stage.state[at] =
               cmi_pack_meta(rng.block, rng.have, (uint32_t)kind, origin);
           stage.T[at] = at_cell[g].T;
@@ -2251,7 +2265,7 @@ __global__ void __launch_bounds__(CMI_BLOCK,
           const double w = a.model.photon_weight[origin];
           tw += w;
           tc3 += w;
-          a.rows.keys[slot[g]] = key_dead;
+          a.key_out[place[g]] = key_dead;
         }
       }
     }
@@ -2287,12 +2301,12 @@ __global__ void __launch_bounds__(CMI_BLOCK,
       if (interaction_new_flight<FULL, DEFER>(a, new_frequency, type, rng, p,
                                               weights, plc, key)) {
         write_flight_row<FULL, DEFER>(
-            a.rows, to, p, plc, key, packet,
+            a.rows, to, a.key_out + s_place[j], p, plc, key, packet,
             cmi_pack_meta(rng.block, rng.have, (uint32_t)type, origin),
             weights);
       } else {
         const double w = a.model.photon_weight[origin];
-        a.rows.keys[to] = key_dead;
+        a.key_out[s_place[j]] = key_dead;
         tw += w;
         tc1 += (type == TYPE_DIFFUSE_HI) ? w : 0.;
         tc2 += (type == TYPE_DIFFUSE_HeI) ? w : 0.;

@@ -43,14 +43,8 @@
 #include "device_reemit.h"
 #include "device_transport.h"
 
-/* workgroup size per transport flavour (the tile sides: TileShape,
- * device_common.h) and waves per SIMD the kernels are built for */
-#ifndef CMI_TILE_THREADS_H
-#define CMI_TILE_THREADS_H 512
-#endif
-#ifndef CMI_TILE_THREADS_FULL
-#define CMI_TILE_THREADS_FULL 512
-#endif
+/* waves per SIMD the tile kernels are built for (tile sides and workgroup
+ * sizes: TileShape, device_common.h) */
 #ifndef CMI_TILE_WAVES
 #define CMI_TILE_WAVES 4
 #endif
@@ -78,7 +72,19 @@ struct TileArgs {
    * CMI_TILE_KEY_DEAD; the slot of an absorbed packet is rewritten by the
    * interaction kernel of the round) - no output queue, no shared counter */
   FlightRowsDev rows;
-  const uint32_t *order; /* slots sorted by tile; NULL = identity */
+  /* The flights of a round are known by POSITION: position i < n has the key
+   * keys[i] and sits in slot slot_in[i] (NULL: slot i) of the rows. `order`
+   * lists the positions by tile; the flight at place j of that list gets
+   * position j of the NEXT round: its new key goes to keys_out[j], its slot
+   * to slot_out[j] - dense, coalesced writes (a 4-B key written into the
+   * slot's place of a key array is one more scattered partial-line write per
+   * visit: 8 ps of 60, tools/microbench/row_gather.hip), the flights that
+   * ended drop out of the next round's arrays by themselves (their keys sort
+   * last), and the rows never move. */
+  const uint32_t *order;
+  const uint32_t *slot_in;
+  uint32_t *keys_out;
+  uint32_t *slot_out;
   const TileItemDev *items;
   const unsigned int *nitems;
   unsigned int *next_item;
@@ -88,6 +94,7 @@ struct TileArgs {
    * these arrays and n_k in absorbed_count[k] */
   QueueDev ended;
   uint32_t *ended_slot;
+  uint32_t *ended_pos; /* its position in the next round (keys_out) */
   unsigned int *absorbed_count;
   ExchangeDev xout; /* decomposed grids: flights that leave the block */
 };
@@ -329,11 +336,18 @@ __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
   }
 }
 
-/* squeeze the dead slots out: slot j of `to` = slot order[j] of `from`
- * (afterwards the slots are in tile order and the order is the identity) */
+/* The rows of the live flights into fresh rows in tile order: row j of `to` =
+ * the flight at place j of the tile order (afterwards position j sits in slot
+ * j). The rows of a round's flights lie scattered among the rows of all that
+ * have ended since; multi-ion transport reads two of them per visit (slot and
+ * weights, 25 GB at 1e8 packets), and once most slots are dead the visits pay
+ * for the sparse footprint (measured without any compaction: the rounds of
+ * 1e7 ... 2e7 flights 2.0 ... 2.7 ms instead of 1.5 ... 2.2). */
 struct TileCompactArgs {
   FlightRowsDev from, to;
-  const uint32_t *order;
+  const uint32_t *order;   /* positions by tile */
+  const uint32_t *slot_in; /* position -> slot of `from` (NULL: identity) */
+  const uint32_t *keys_in; /* by position */
   const unsigned int *nlive;
   int32_t with_weights;
 };
@@ -346,7 +360,8 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   const int part = threadIdx.x & 7;
   for (uint64_t j = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
        j < n; j += stride) {
-    const uint32_t src = a.order[j];
+    const uint32_t i = a.order[j];
+    const uint32_t src = a.slot_in ? a.slot_in[i] : i;
     const double2 *r = reinterpret_cast<const double2 *>(
         a.from.rows + (size_t)CMI_FLIGHT_DOUBLES * src);
     reinterpret_cast<double2 *>(a.to.rows +
@@ -358,14 +373,28 @@ __global__ void __launch_bounds__(CMI_BLOCK)
           w[part];
     }
     if (part == 0)
-      a.to.keys[j] = a.from.keys[src];
+      a.to.keys[j] = a.keys_in[i];
+  }
+}
+
+/* the slots of the flights that the tile rounds leave to the pass kernels:
+ * slots[j] = slot of the flight at place j of the tile order */
+__global__ void __launch_bounds__(CMI_BLOCK)
+    tile_handover_kernel(const uint32_t *order, const uint32_t *slot_in,
+                         const unsigned int *nlive, uint32_t *slots) {
+  const uint64_t n = *nlive;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+       j += stride) {
+    const uint32_t i = order[j];
+    slots[j] = slot_in ? slot_in[i] : i;
   }
 }
 
 /* a new flight into slot q (interaction kernel) */
 template <bool FULL, bool DEFER = false>
 __device__ __forceinline__ void
-write_flight_row(const FlightRowsDev &out, unsigned int q,
+write_flight_row(const FlightRowsDev &out, unsigned int q, uint32_t *key_out,
                  const Packet<FULL> &p, uint32_t packed_lc, uint32_t key,
                  uint32_t packet_id, uint32_t meta,
                  const double (&weights)[CMI_NACC]) {
@@ -382,7 +411,7 @@ write_flight_row(const FlightRowsDev &out, unsigned int q,
       __longlong_as_double((long long)(((unsigned long long)packed_lc << 32) |
                                        (uint32_t)p.cell)),
       p.tdelta[0], p.tdelta[1]);
-  out.keys[q] = key;
+  *key_out = key;
   if (FULL && !DEFER) {
     double4 *w = reinterpret_cast<double4 *>(out.weights + (size_t)CMI_NACC * q);
 #pragma unroll
@@ -403,16 +432,15 @@ write_flight_row(const FlightRowsDev &out, unsigned int q,
  * memory.
  */
 template <bool FULL, bool HEAT>
-__global__ void
-__launch_bounds__(FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H,
-                  (!FULL && HEAT) ? 2 : CMI_TILE_WAVES)
+__global__ void __launch_bounds__((TileShape<FULL, HEAT>::THREADS),
+                                  (!FULL && HEAT) ? 2 : CMI_TILE_WAVES)
     tile_kernel(const TileArgs a) {
-  using Shape = TileShape<FULL>;
+  using Shape = TileShape<FULL, HEAT>;
   constexpr int LX = Shape::LX, LY = Shape::LY, LZ = Shape::LZ;
   constexpr int TX = Shape::TX, TY = Shape::TY, TZ = Shape::TZ;
   constexpr int TC = Shape::CELLS;
   constexpr int NV = FULL ? CMI_NACC : (HEAT ? 2 : 1);
-  constexpr int NT = FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H;
+  constexpr int NT = Shape::THREADS;
   /* value v of tile cell k lives at acc[v * TC + k]: neighbouring cells in
    * neighbouring banks whatever the value */
   __shared__ double acc[NV * TC];
@@ -431,7 +459,7 @@ __launch_bounds__(FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H,
   double weights[CMI_NACC];
   int32_t lc[3] = {0, 0, 0}, lsgn[3] = {0, 0, 0};
   int32_t type = 0;
-  uint32_t packet_id = 0, lane_meta = 0, slot = 0;
+  uint32_t packet_id = 0, lane_meta = 0, slot = 0, place = 0;
   double tc0 = 0., tc1 = 0., tc2 = 0., tc3 = 0.; /* sums of packet weights */
   unsigned int nsteps = 0, natomics = 0, nwavesteps = 0;
 #pragma unroll
@@ -447,15 +475,14 @@ __launch_bounds__(FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H,
    * after the other, each unit cost ~18 us of dependent latencies (returning
    * atomic -> descriptor -> records -> order -> rows) whatever its flights -
    * 1.2 ms per round of a 256^3 grid's 32768 multi-ion tiles, half the tile
-   * kernel's time in lexingtonHII40. */
+   * kernel's time in lexingtonHII40 (49.9 -> 43.3 ms per iteration with the
+   * units fetched ahead).
+   * (Hydrogen-only tiles - eight records per thread, a tenth as many units -
+   * claim, describe and load a unit when they get to it: measured with the
+   * descriptor alone fetched ahead, 76.4 -> 78.2 ms per diffuse iteration.) */
   constexpr bool PREFETCH = (TC <= NT); /* one record per thread */
   const unsigned int nitems = *a.nitems;
-  if (threadIdx.x == 0) {
-    s_ring[0] = atomicAdd(a.next_item, 1u);
-    s_ring[1] = atomicAdd(a.next_item, 1u);
-  }
-  __syncthreads();
-  unsigned int item = s_ring[0], item_next = s_ring[1];
+  unsigned int item = 0, item_next = 0;
   TileItemDev it;
   it.tile = it.begin = it.end = it.pad = 0;
   double2 rec_ahead = make_double2(-1., 0.);
@@ -484,9 +511,16 @@ __launch_bounds__(FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H,
                              ly) * a.grid.ncell[2] + o[2] + lz];
     return rec;
   };
-  if (item < nitems) {
-    it = a.items[item];
-    if (PREFETCH) {
+  if (PREFETCH) {
+    if (threadIdx.x == 0) {
+      s_ring[0] = atomicAdd(a.next_item, 1u);
+      s_ring[1] = atomicAdd(a.next_item, 1u);
+    }
+    __syncthreads();
+    item = s_ring[0];
+    item_next = s_ring[1];
+    if (item < nitems) {
+      it = a.items[item];
       int32_t o[3], td[3];
       tile_origin(it, o, td);
       if ((int)threadIdx.x < TC)
@@ -495,17 +529,29 @@ __launch_bounds__(FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H,
   }
 
   for (int trip = 0; item < nitems; ++trip) {
+    if (!PREFETCH) {
+      if (threadIdx.x == 0)
+        s_ring[0] = atomicAdd(a.next_item, 1u);
+      for (int k = threadIdx.x; k < NV * TC; k += NT)
+        acc[k] = 0.;
+      __syncthreads();
+      item = s_ring[0];
+      if (item >= nitems)
+        break;
+      it = a.items[item];
+    }
     if (threadIdx.x == 0) {
-      s_ring[trip & 1] = atomicAdd(a.next_item, 1u); /* the unit after next */
+      if (PREFETCH)
+        s_ring[trip & 1] = atomicAdd(a.next_item, 1u); /* the one after next */
       s_nabs = 0;
       s_next = it.begin;
     }
-    for (int k = threadIdx.x; k < NV * TC; k += NT)
-      acc[k] = 0.;
     int32_t o[3], td[3];
     tile_origin(it, o, td);
     const bool clipped = td[0] != TX || td[1] != TY || td[2] != TZ;
     if (PREFETCH) {
+      for (int k = threadIdx.x; k < NV * TC; k += NT)
+        acc[k] = 0.;
       if ((int)threadIdx.x < TC) {
         opac[threadIdx.x] = rec_ahead.x;
         if (FULL)
@@ -522,14 +568,12 @@ __launch_bounds__(FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H,
     __syncthreads();
     /* the next unit's descriptor and records: needed after this unit's march */
     TileItemDev it_ahead = it;
-    if (item_next < nitems) {
+    if (PREFETCH && item_next < nitems) {
       it_ahead = a.items[item_next];
-      if (PREFETCH) {
-        int32_t on[3], tdn[3];
-        tile_origin(it_ahead, on, tdn);
-        if ((int)threadIdx.x < TC)
-          rec_ahead = load_record(on, tdn, threadIdx.x);
-      }
+      int32_t on[3], tdn[3];
+      tile_origin(it_ahead, on, tdn);
+      if ((int)threadIdx.x < TC)
+        rec_ahead = load_record(on, tdn, threadIdx.x);
     }
 
     bool active = false;
@@ -565,7 +609,10 @@ __launch_bounds__(FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H,
         base = __shfl(base, 0, 64);
         const unsigned int i = base + __popcll(idle_mask & lane_lt);
         if (!active && i < it.end) {
-          slot = a.order ? a.order[i] : i;
+          place = i;
+          const uint32_t from = a.order[i];
+          slot = a.slot_in ? a.slot_in[from] : from;
+          a.slot_out[i] = slot;
           const double4 *r = reinterpret_cast<const double4 *>(
               a.rows.rows + (size_t)CMI_FLIGHT_DOUBLES * slot);
           const double4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
@@ -843,9 +890,10 @@ __launch_bounds__(FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H,
           a.ended.id[q] = packet_id;
           a.ended.meta[q] = lane_meta;
           a.ended_slot[q] = slot;
+          a.ended_pos[q] = place;
         }
         if (!absorbed)
-          a.rows.keys[slot] = key;
+          a.keys_out[place] = key;
         if (done) {
           const double w = a.model.photon_weight[cmi_meta_origin(lane_meta)];
           tc0 += (type == TYPE_PRIMARY) ? w : 0.;
@@ -902,9 +950,11 @@ __launch_bounds__(FULL ? CMI_TILE_THREADS_FULL : CMI_TILE_THREADS_H,
       }
     }
     __syncthreads();
-    item = item_next;
-    item_next = s_ring[trip & 1];
-    it = it_ahead;
+    if (PREFETCH) {
+      item = item_next;
+      item_next = s_ring[trip & 1];
+      it = it_ahead;
+    }
   }
 
   const double s0 = wave_sum(tc0);

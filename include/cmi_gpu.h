@@ -510,8 +510,11 @@ int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);
  *                           flights of one tile), are left
  *   "tile_refill_threshold" (48)  idle lanes of a wave that trigger a refill
  *                           in the tile kernel
- *   "tile_compact_ratio" (2)  free slots are squeezed out of the flight rows
- *                           once there are this many slots per flight
+ *   "tile_compact_ratio" (-1)  the rows of the live flights are copied into
+ *                           fresh rows, in tile order, once the flights are
+ *                           spread over this many slots per flight; 0: never;
+ *                           -1: 2 for multi-ion transport, never for
+ *                           hydrogen-only
  *   "temperature_pipeline" (1)  the temperature solve as one kernel per stage
  *                           of a secant step (ionization balance / line
  *                           cooling / update), each dense in like work -

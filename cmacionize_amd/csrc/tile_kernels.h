@@ -50,10 +50,16 @@
 #endif
 /* flights per unit of work: a tile with more is shared by several workgroups
  * (each with its own LDS copy, all written back with atomics); measured on
- * 256^3: half as many cost 1 ms (H-only) / 3 ms (multi-ion) per iteration,
- * twice as many gain nothing */
-#define CMI_TILE_ITEM_FLIGHTS_H 8192
-#define CMI_TILE_ITEM_FLIGHTS_FULL 4096
+ * 256^3 with the round-5 tiles (32 x 16 x 16 / 8 x 8 x 16), ms of transport
+ * per diffuse / lexington iteration: 4096 / 2048 flights 74.4 / 179.3,
+ * 8192 / 4096 72.8 / 174.7, 16384 / 8192 71.9 / 172.9, 32768 / 16384 72.1 /
+ * 173.2 */
+#ifndef CMI_TILE_ITEM_FLIGHTS_H
+#define CMI_TILE_ITEM_FLIGHTS_H 16384
+#endif
+#ifndef CMI_TILE_ITEM_FLIGHTS_FULL
+#define CMI_TILE_ITEM_FLIGHTS_FULL 8192
+#endif
 #define CMI_TILE_PLAN_THREADS 1024
 
 /* key of a slot that holds no flight (tiles have keys < ntiles): sorts behind

@@ -11,26 +11,30 @@
 set -u
 REPO=$(pwd)
 OUT=$REPO/$1
-ROUND=${2:-r04}
+ROUND=${2:-r05}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # (SKIP_PMC=1: keep profiles/rNN/counters.json as it is)
 if [ -z "${SKIP_PMC:-}" ]; then
   for CFG in stromgren stromgren_diffuse lexington; do
-    tools/pmc_profile.sh "$1/pmc_$CFG" -- bench.py --config $CFG --steps 3 --warmup 0 --no-cpu-baseline
+    tools/pmc_profile.sh "$1/pmc_$CFG" -- bench.py --config $CFG --steps 3 --warmup 0 --no-cpu-baseline --no-also
   done
   python3 tools/pmc_rooflines.py "$OUT" 3 > "$OUT/counters.json" || exit 1
   mkdir -p "$REPO/profiles/$ROUND"
   cp "$OUT/counters.json" "$REPO/profiles/$ROUND/counters.json"
 fi
 for CFG in stromgren stromgren_diffuse lexington; do
-  python3 bench.py --config $CFG > "$OUT/bench_$CFG.json" 2> "$OUT/bench_$CFG.err"
+  python3 bench.py --config $CFG --no-also > "$OUT/bench_$CFG.json" 2> "$OUT/bench_$CFG.err"
   echo "bench $CFG rc=$?"
 done
+# the round driver's own command: the headline line with the other two
+# single-GPU configs under "also"
+( time python3 bench.py --gpus 1 --steps 20 --warmup 5 ) > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+echo "bench default rc=$?"
 cd /tmp
 for CFG in stromgren stromgren_diffuse lexington; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$CFG" -- \
-    python3 "$REPO/bench.py" --config $CFG --no-cpu-baseline > "$OUT/stats_$CFG.log" 2>&1
+    python3 "$REPO/bench.py" --config $CFG --no-cpu-baseline --no-also > "$OUT/stats_$CFG.log" 2>&1
   echo "stats $CFG rc=$?"
   python3 "$REPO/tools/profile_summary.py" "$OUT/stats_$CFG" "$OUT/stats_$CFG.log" \
     > "$OUT/bench_${CFG}_kernel_stats.txt"

@@ -2034,7 +2034,6 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
      * ONE tile with the tile's accumulators in LDS, and collects the flights
      * that go on (into another tile, or re-emitted) for the next round */
     const double *handover = nullptr; /* flights the tile rounds leave over */
-    const uint32_t *handover_slots = nullptr; /* the slots they sit in */
     unsigned int handover_count = 0;
     if (tiles) {
       const TileGridDev tg = tile_grid(e);
@@ -2194,22 +2193,9 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         const bool finish = nlive < e->tune.tile_min_flights ||
                             (uint64_t)nlive < per_item * plan[1] ||
                             round >= e->tune.tile_max_rounds;
-        if (finish) {
-          /* too few flights per tile for the LDS accumulators to pay: the
-           * rest goes on as passes of the transport kernel (below), the first
-           * of which resumes the flights from their slots */
-          tile_handover_kernel<<<grid_blocks(e, (int64_t)nlive, 8), CMI_BLOCK,
-                                 0, e->stream>>>(e->sort_ids[1], slot_of,
-                                                 d_nlive, e->tile_new_slots);
-          HIP_TRY(hipGetLastError());
-          handover = rows.rows;
-          handover_slots = e->tile_new_slots;
-          handover_count = nlive;
-          break;
-        }
         const uint32_t *order = e->sort_ids[1];
-        if (compact_ratio != 0 &&
-            (uint64_t)compact_ratio * nlive < (uint64_t)extent) {
+        if (finish || (compact_ratio != 0 &&
+                       (uint64_t)compact_ratio * nlive < (uint64_t)extent)) {
           /* the live rows into the other set of rows, in tile order: position
            * j of this round is then place j and slot j */
           TileCompactArgs ca;
@@ -2236,6 +2222,14 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
           slot_of = nullptr;
           order = e->tile_iota;
           extent = nlive;
+        }
+        if (finish) {
+          /* too few flights per tile for the LDS accumulators to pay: the
+           * rest goes on as passes of the transport kernel (below), the first
+           * of which resumes the flights from their (fresh, dense) rows */
+          handover = rows.rows;
+          handover_count = nlive;
+          break;
         }
         TileArgs ta;
         ta.grid = e->grid;
@@ -2331,7 +2325,6 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       b.order = nullptr;
       b.xin = handover;
       b.xin_local = 1;
-      b.xin_slots = handover_slots;
       b.n_packets = handover_count;
       b.refill_threshold = e->tune.refill_threshold_reemit;
       b.aggregate = agg_reemit;

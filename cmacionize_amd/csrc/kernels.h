@@ -137,8 +137,6 @@ struct ShootArgs {
   /* xin rows hold the long index of the entered cell in THIS engine's grid
    * (flights left over by the tile rounds) instead of the whole grid's */
   int32_t xin_local;
-  /* ... listed by slot: flight i is row xin_slots[i] (NULL: row i) */
-  const uint32_t *xin_slots = nullptr;
   ExchangeDev xout;
   /* PAD kernels: n x_H of every cell of the grid with CMI_PAD_LAYERS layers
    * of ghost cells around it (pad_record_kernel): -0. marks a vacuum cell
@@ -1118,9 +1116,7 @@ __global__ void
         bool mine = true;
         if (!PRE && a.xin != nullptr) {
           /* a flight handed over by another block of the grid */
-          const uint64_t row =
-              (a.xin_local && a.xin_slots) ? (uint64_t)a.xin_slots[i] : i;
-          const double *r = a.xin + (size_t)CMI_FLIGHT_DOUBLES * row;
+          const double *r = a.xin + (size_t)CMI_FLIGHT_DOUBLES * i;
           int64_t cell_global;
           unsigned long long idmeta;
           if (a.xin_local) {

@@ -383,20 +383,6 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   }
 }
 
-/* the slots of the flights that the tile rounds leave to the pass kernels:
- * slots[j] = slot of the flight at place j of the tile order */
-__global__ void __launch_bounds__(CMI_BLOCK)
-    tile_handover_kernel(const uint32_t *order, const uint32_t *slot_in,
-                         const unsigned int *nlive, uint32_t *slots) {
-  const uint64_t n = *nlive;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-       j += stride) {
-    const uint32_t i = order[j];
-    slots[j] = slot_in ? slot_in[i] : i;
-  }
-}
-
 /* a new flight into slot q (interaction kernel) */
 template <bool FULL, bool DEFER = false>
 __device__ __forceinline__ void

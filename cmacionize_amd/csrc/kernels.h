@@ -21,7 +21,18 @@
 /* slots of a block's combining table (aggregate mode 3) */
 #define CMI_TABLE_BITS 10
 #define CMI_TABLE_SLOTS (1 << CMI_TABLE_BITS)
-#define CMI_TABLE_PROBES 4
+/* (measured in round 5, ms per iteration of config 2: 2 probes 35.1, 4: 34.5,
+ * 8: 34.2) */
+#ifndef CMI_TABLE_PROBES
+#define CMI_TABLE_PROBES 8
+#endif
+/* experiment: look at a slot's tag with a plain LDS read before trying the
+ * compare-and-swap (a hit then costs no LDS atomic; measured: 39.0 instead of
+ * 34.5 ms - the second round trip of every first visit costs more than the
+ * atomics of the hits) */
+#ifndef CMI_TABLE_READ_FIRST
+#define CMI_TABLE_READ_FIRST 0
+#endif
 /* run sums in front of the table cover groups of 2^this lanes */
 #ifndef CMI_TABLE_SCAN_ROUNDS
 #define CMI_TABLE_SCAN_ROUNDS 2
@@ -1067,10 +1078,24 @@ __global__ void
        * masked out below) */
       int32_t was;
       asm volatile("" : "=v"(was));
-      if (lanes_of(looking))
-        was = atomicCAS(&lds_tag[slot], -1, cell);
-      const unsigned long long found =
-          looking & (mask_eq(was, -1) | mask_eq(was, cell));
+      unsigned long long found;
+      if (CMI_TABLE_READ_FIRST) {
+        if (lanes_of(looking))
+          was = *(volatile int32_t *)&lds_tag[slot];
+        found = looking & mask_eq(was, cell);
+        const unsigned long long vacant = looking & mask_eq(was, -1);
+        if (vacant != 0ull) {
+          int32_t got;
+          asm volatile("" : "=v"(got));
+          if (lanes_of(vacant))
+            got = atomicCAS(&lds_tag[slot], -1, cell);
+          found |= vacant & (mask_eq(got, -1) | mask_eq(got, cell));
+        }
+      } else {
+        if (lanes_of(looking))
+          was = atomicCAS(&lds_tag[slot], -1, cell);
+        found = looking & (mask_eq(was, -1) | mask_eq(was, cell));
+      }
       if (lanes_of(found)) {
         atomicAdd(&lds_val[slot], v0); /* ds_add_f64 */
         if (HEAT)

@@ -948,25 +948,46 @@ def native_devices(n):
     return [r % max(have, 1) for r in range(n)]
 
 
-def native_child(args, config, ncell, domain, steps, warmup, timeout=900.):
-    """run_native in a process of its own (started by rank 0 once the ranks'
-    engines are closed): whatever happens to it - RCCL inside one process
-    next to torch's, peer access that the box refuses - the line of the torch
-    driver survives; what went wrong is recorded instead."""
+def child_line(args, config, ncell, domain, steps, warmup, driver,
+               timeout=900.):
+    """One more leg of an N > 1 run as a job of its own, started by rank 0 once
+    the ranks' engines are closed (the other ranks wait on the rendezvous
+    store): `driver` "native" - this script with --driver native, one process
+    for all GPUs - or "torch" - this script under torch.distributed.run, N
+    fresh ranks on a port of their own. Whatever happens to that job - RCCL
+    inside one process next to torch's, peer access that the box refuses, a
+    rank that dies in a collective - the headline line survives; what went
+    wrong is recorded instead."""
+    import socket
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--driver", "native",
-           "--gpus", str(args.gpus), "--steps", str(steps), "--warmup",
-           str(warmup), "--config", config, "--ncell", str(ncell),
-           "--packets", repr(float(args.packets)), "--converge-packets",
-           repr(float(args.converge_packets)), "--decomposition",
-           "domain" if domain else "replica", "--no-cpu-baseline",
-           "--no-also"]
+    tail = ["--gpus", str(args.gpus), "--steps", str(steps), "--warmup",
+            str(warmup), "--config", config, "--ncell", str(ncell),
+            "--packets", repr(float(args.packets)), "--converge-packets",
+            repr(float(args.converge_packets)), "--decomposition",
+            "domain" if domain else "replica", "--no-cpu-baseline",
+            "--no-also", "--no-strong"]
     if args.converge_iterations is not None:
-        cmd += ["--converge-iterations", str(args.converge_iterations)]
+        tail += ["--converge-iterations", str(args.converge_iterations)]
+    if driver == "native":
+        cmd = [sys.executable, os.path.abspath(__file__), "--driver",
+               "native"] + tail
+    else:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + tail
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT",
                         "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
-                        "TORCHELASTIC_RUN_ID")}
+                        "ROLE_NAME", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
+                        "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
+                        "TORCHELASTIC_MAX_RESTARTS",
+                        "TORCHELASTIC_USE_AGENT_STORE",
+                        "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True,
                            timeout=timeout)
@@ -1046,38 +1067,37 @@ def main():
     if extras:
         # N > 1, the driver's command: the line also carries config 5's shape
         # (lexingtonHII40 in one block per GPU, flights exchanged over RCCL)
-        # and the product's own multi-GPU path (the group API) on both shapes
-        import copy
-        steps = args.also_steps or min(args.steps, 20)
-        a5 = copy.copy(args)
-        a5.decomposition = "domain"
-        a5.ncell = args.config5_ncell or (512 if ranks.world == 8 else 256)
-        leg = run_leg(a5, ranks, "lexington", steps, args.warmup)
-        if ranks.rank == 0:
-            rec = {k: leg[k] for k in ALSO_KEYS + (
-                "n_gpus", "ranks_in_collective", "packets_per_rank_per_step",
-                "scaling", "exchange_rounds_last_step",
-                "flights_exchanged_last_step", "idle_ms_per_step_by_rank")
-                if k in leg}
-            rec["iterations_to_converge"] = \
-                leg["iterations_to_converge"]["value"]
-            out["config5"] = rec
-        # the native driver needs the GPUs to itself: the other ranks wait on
-        # the rendezvous store (a host-side wait: a collective would spin on
-        # their devices)
+        # and the product's own multi-GPU path (the group API) on both
+        # shapes - each as a job of its own (child_line), so that nothing
+        # that happens there can take the headline line with it. They need
+        # the GPUs to themselves: the other ranks wait on the rendezvous
+        # store (a host-side wait: a collective would spin on their devices).
         from datetime import timedelta
+        steps = args.also_steps or min(args.steps, 20)
+        ncell5 = args.config5_ncell or (512 if ranks.world == 8 else 256)
         store = ranks.dist.distributed_c10d._get_default_store()
         if ranks.rank == 0:
+            leg = child_line(args, "lexington", ncell5, True, steps,
+                             args.warmup, "torch")
+            keep = ALSO_KEYS + (
+                "n_gpus", "ranks_in_collective", "packets_per_rank_per_step",
+                "scaling", "exchange_rounds_last_step",
+                "flights_exchanged_last_step", "idle_ms_per_step_by_rank",
+                "error")
+            rec = {k: leg[k] for k in keep if k in leg}
+            if "iterations_to_converge" in leg:
+                rec["iterations_to_converge"] = \
+                    leg["iterations_to_converge"]["value"]
+            out["config5"] = rec
             out["native"] = {
-                "replica": native_child(args, "stromgren", args.ncell, False,
-                                        steps, args.warmup),
-                "config5": native_child(args, "lexington", a5.ncell, True,
-                                        steps, args.warmup)}
-            store.set("cmi_bench_native_done", "1")
-        else:
-            store.wait(["cmi_bench_native_done"], timedelta(minutes=45))
-        if ranks.rank == 0:
+                "replica": child_line(args, "stromgren", args.ncell, False,
+                                      steps, args.warmup, "native"),
+                "config5": child_line(args, "lexington", ncell5, True, steps,
+                                      args.warmup, "native")}
             out["bench_wall_s"] = time.perf_counter() - t_start
+            store.set("cmi_bench_extras_done", "1")
+        else:
+            store.wait(["cmi_bench_extras_done"], timedelta(minutes=60))
     if ranks.rank == 0:
         print(json.dumps(out))
     if ranks.world > 1:

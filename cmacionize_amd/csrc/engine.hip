@@ -1873,8 +1873,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     else
       /* measured on 256^3: the classes pay off once a direction bin of
        * 64 x 2^bits packets is still narrower than a few cells */
-      tau_bits = per_source >= (1ull << 24) ? 3u
-                                            : (per_source >= (1ull << 22) ? 2u : 0u);
+      /* (multi-ion runs since round 5's cell-by-cell sums: 0 / 1 / 2 / 3 /
+       * 4 class bits 71.8 / 70.0 / 66.3 / 68.0 / 68.0 ms per 1e8 packets) */
+      tau_bits = per_source >= (1ull << 24)
+                     ? (e->full_ions ? 2u : 3u)
+                     : (per_source >= (1ull << 22) ? 2u : 0u);
   }
   double sigma_ref = 1.;
   if (e->full_ions) {

@@ -188,6 +188,9 @@ struct cmi_gpu_engine {
      * multi-ion transport (two rows per visit, 25 GB at 1e8 packets: a sparse
      * footprint costs more than the copies), never for hydrogen-only */
     int tile_compact_ratio = -1;
+    /* the first generation parks an absorbed packet at the place of its
+     * position in the launch's order (no queue counter) */
+    bool park_in_place = true;
   } tune;
 
   /* device timing (HIP events around launches) is opt-in: set_tuning
@@ -1423,6 +1426,8 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
         (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
   else if (k == "tile_compact_ratio")
     e->tune.tile_compact_ratio = (int)(value < -1 ? -1 : value);
+  else if (k == "park_in_place")
+    e->tune.park_in_place = value != 0;
   else if (k == "accumulators_dirty")
     e->acc_block_dirty = e->acc_block_dirty || value != 0;
   else if (k == "temperature_finish_slots")
@@ -1956,10 +1961,17 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     a.aggregate = flights ? agg_reemit : agg;
     a.qin = no_queue;
     a.qout = no_queue;
+    a.park_in_place = 0;
     if (passes) {
       HIP_TRY(hipMemsetAsync(e->queue_counts, 0, 2 * sizeof(unsigned int),
                              e->stream));
       a.qout = e->ended_queue;
+      if (!flights && e->tune.park_in_place) {
+        /* new packets: parked at their place in the launch's order */
+        a.park_in_place = 1;
+        HIP_TRY(hipMemsetAsync(e->ended_queue.id, 0xff,
+                               sizeof(uint32_t) * (size_t)n, e->stream));
+      }
     }
 
     EventPair ev;
@@ -2051,6 +2063,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       ia.seed = seed;
       ia.iteration = iteration;
       ia.qin = e->ended_queue;
+      ia.n_in = a.park_in_place ? (uint32_t)n : 0u;
       ia.qout = no_queue;
       ia.grid = e->grid;
       ia.tiles = tg;
@@ -2325,6 +2338,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
        * ones are parked for the interaction kernel as in every pass */
       const bool last = handover_count < e->tune.reemit_inline_below;
       ShootArgs b = a;
+      b.park_in_place = 0;
       b.order = nullptr;
       b.xin = handover;
       b.xin_local = 1;
@@ -2371,6 +2385,8 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       ia.seed = seed;
       ia.iteration = iteration;
       ia.qin = e->ended_queue;
+      /* (the first pass reads what the first generation parked) */
+      ia.n_in = (gen == 0 && !tiles && a.park_in_place) ? (uint32_t)n : 0u;
       ia.qout = e->ready_queue;
       HIP_TRY(hipMemsetAsync(e->ready_queue.count, 0, sizeof(unsigned int),
                              e->stream));
@@ -2402,6 +2418,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       const bool last = count < e->tune.reemit_inline_below ||
                         gen + 2 >= e->tune.reemit_max_passes;
       ShootArgs b = a;
+      b.park_in_place = 0;
       b.order = nullptr;
       b.xin = nullptr;
       b.n_packets = count;

@@ -109,6 +109,10 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+/* id of a place of the ended queue that holds no flight
+ * (ShootArgs::park_in_place; packet ids of a call are < 2^32 - 1) */
+#define CMI_QUEUE_HOLE 0xffffffffu
+
 struct ShootArgs {
   GridDev grid;
   ModelDev model;
@@ -141,6 +145,14 @@ struct ShootArgs {
    * its re-emission; otherwise it is re-emitted in place (REEMIT variants) or
    * counted as absorbed. */
   QueueDev qin, qout;
+  /* qout of a launch of NEW packets: an absorbed packet is parked at the
+   * place of its position in the launch's order (qout.id is pre-set to
+   * CMI_QUEUE_HOLE; the interaction kernel runs over all n_packets places and
+   * skips the holes) instead of at a place claimed from the queue's counter -
+   * the bundles of a launch end one after the other, 1.6e6 returning atomics
+   * on one word per 1e8 packets, ~3 ms of the first generation of configs 3
+   * and 4 */
+  int32_t park_in_place;
   /* decomposed grids: xin != NULL: this launch continues the flights handed
    * over by other blocks (CMI_FLIGHT_DOUBLES doubles each); packets that
    * leave this block into another one are appended to xout */
@@ -924,7 +936,18 @@ __global__ void
   p.nu = 0.;
   p.weight = 1.;
   PacketRng rng;
+  /* (park_in_place launches: the packet's POSITION in the launch's order
+   * instead - the id follows from it, id_of() below - so that parking at the
+   * position costs no register across the march: a second value did cost the
+   * hydrogen-only first generation, whose 64 are all taken, 0.3 of 34.6 ms,
+   * and a build without the parking code, of all things, spilled the cross
+   * section inside the march loop: 38.5 ms) */
   uint32_t packet_id = 0;
+  auto id_of = [&](uint32_t held) -> uint32_t {
+    return a.park_in_place
+               ? (uint32_t)a.batch_offset + (a.order ? a.order[held] : held)
+               : held;
+  };
   uint32_t lane_meta = 0; /* rng position of the lane's packet (cmi_pack_meta) */
   bool active = false;
   int32_t last_cell = -1; /* EXACT marcher on grids >= 2^31 cells: see below */
@@ -1299,6 +1322,8 @@ __global__ void
               emit_physics<FULL>(a.model, rng, p, weights, origin);
             lane_meta = cmi_pack_meta(rng.block, rng.have, 0, origin);
           }
+          if (a.park_in_place)
+            packet_id = (uint32_t)i; /* the position; the id: id_of() */
         }
         if (FULL) {
 #pragma unroll
@@ -1663,7 +1688,7 @@ __global__ void
                         : ((lane_meta & CMI_META_KEEP_MASK) |
                            ((uint32_t)p.type << 28));
                 r[13] = __longlong_as_double((long long)(
-                    ((unsigned long long)meta << 32) | packet_id));
+                    ((unsigned long long)meta << 32) | id_of(packet_id)));
                 r[14] = 0.;
                 r[15] = 0.;
               }
@@ -1677,19 +1702,22 @@ __global__ void
            * happens there): wave-level compaction into the queue */
           if (!EXACT)
             end_flight(p); /* position of the absorption */
-          const unsigned long long parked = __ballot(true);
-          unsigned int base = 0;
-          const int first = __ffsll((long long)parked) - 1;
-          if (lane == first)
-            base = atomicAdd(a.qout.count, (unsigned int)__popcll(parked));
-          base = __shfl(base, first, 64);
-          const unsigned int q = base + __popcll(parked & lane_lt);
+          unsigned int q = packet_id; /* park_in_place: the position */
+          if (!a.park_in_place) {
+            const unsigned long long parked = __ballot(true);
+            unsigned int base = 0;
+            const int first = __ffsll((long long)parked) - 1;
+            if (lane == first)
+              base = atomicAdd(a.qout.count, (unsigned int)__popcll(parked));
+            base = __shfl(base, first, 64);
+            q = base + __popcll(parked & lane_lt);
+          }
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax)
             a.qout.pos[ax][q] = p.pos[ax];
           a.qout.nu[q] = p.nu;
           a.qout.cell[q] = (int32_t)cell_now;
-          a.qout.id[q] = packet_id;
+          a.qout.id[q] = id_of(packet_id);
           a.qout.meta[q] =
               REEMIT ? cmi_pack_meta(rng.block, rng.have, (uint32_t)p.type,
                                      cmi_meta_origin(lane_meta))
@@ -1783,6 +1811,9 @@ struct InteractArgs {
   uint32_t seed;
   uint32_t iteration;
   QueueDev qin;  /* ended flights */
+  /* not 0: the places [0, n_in) of qin, holes (id CMI_QUEUE_HOLE) among them
+   * (ShootArgs::park_in_place), instead of *qin.count dense entries */
+  uint32_t n_in;
   QueueDev qout; /* ready flights */
   /* ROWS: the survivors become flight rows of the tile rounds instead - the
    * new flight is set up here (cell, wall parameters, cross sections) and
@@ -1981,7 +2012,7 @@ __global__ void __launch_bounds__(CMI_BLOCK,
   constexpr unsigned int BATCH = TRIPS * CMI_BLOCK;
   __shared__ InteractStage<BATCH> stage;
   const int lane = threadIdx.x & 63;
-  const uint64_t count = *a.qin.count;
+  const uint64_t count = a.n_in ? (uint64_t)a.n_in : (uint64_t)*a.qin.count;
   const uint64_t stride = (uint64_t)gridDim.x * BATCH;
   double tw = 0., tc3 = 0.;
   double tc1 = 0., tc2 = 0.; /* ROWS: re-emitted outside the box (rounding) */
@@ -1998,6 +2029,7 @@ __global__ void __launch_bounds__(CMI_BLOCK,
       uint32_t meta[GROUP], id[GROUP];
       int32_t cell[GROUP];
       double nu[GROUP];
+      bool there[GROUP];
       InteractCell at_cell[GROUP];
 #pragma unroll
       for (int g = 0; g < GROUP; ++g) {
@@ -2006,9 +2038,13 @@ __global__ void __launch_bounds__(CMI_BLOCK,
         meta[g] = id[g] = 0;
         cell[g] = 0;
         nu[g] = 0.;
+        there[g] = false;
         if (i < count) {
-          meta[g] = a.qin.meta[i];
           id[g] = a.qin.id[i];
+          there[g] = id[g] != CMI_QUEUE_HOLE;
+        }
+        if (there[g]) {
+          meta[g] = a.qin.meta[i];
           cell[g] = a.qin.cell[i];
           if (FULL)
             nu[g] = a.qin.nu[i];
@@ -2016,14 +2052,12 @@ __global__ void __launch_bounds__(CMI_BLOCK,
       }
 #pragma unroll
       for (int g = 0; g < GROUP; ++g)
-        at_cell[g] = interaction_gather<FULL>(
-            a, cell[g],
-            base + (unsigned int)(k0 + g) * CMI_BLOCK + threadIdx.x < count);
+        at_cell[g] = interaction_gather<FULL>(a, cell[g], there[g]);
 #pragma unroll
       for (int g = 0; g < GROUP; ++g) {
         const unsigned int local =
             (unsigned int)(k0 + g) * CMI_BLOCK + threadIdx.x;
-        const bool valid = base + local < count;
+        const bool valid = there[g];
         const uint32_t origin = cmi_meta_origin(meta[g]);
         int32_t kind = CMI_REEMIT_ABSORBED;
         PacketRng rng;

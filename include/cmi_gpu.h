@@ -510,6 +510,12 @@ int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);
  *                           flights of one tile), are left
  *   "tile_refill_threshold" (48)  idle lanes of a wave that trigger a refill
  *                           in the tile kernel
+ *   "park_in_place" (1)     runs with re-emission in passes / tile rounds: the
+ *                           first generation leaves an absorbed packet's
+ *                           record at the place of its position in the
+ *                           launch's order instead of claiming a place from
+ *                           the queue's counter (one returning atomic per
+ *                           bundle on one word)
  *   "tile_compact_ratio" (-1)  the rows of the live flights are copied into
  *                           fresh rows, in tile order, once the flights are
  *                           spread over this many slots per flight; 0: never;

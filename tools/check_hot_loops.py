@@ -16,14 +16,14 @@ import sys
 path = sys.argv[1] if len(sys.argv) > 1 else "cmacionize_amd/csrc/engine.s"
 text = open(path).read().split("\n")
 starts = [i for i, l in enumerate(text)
-          if re.match(r"^_Z12shoot_kernelI(Lb[01]E){6,8}Ev9ShootArgs:", l)]
+          if re.match(r"^_Z12shoot_kernelI(Lb[01]E){6,9}Ev9ShootArgs:", l)]
 bad = 0
-print("%-22s %6s %6s %6s %6s %8s" % ("variant <F,H,R,X,T,P,PAD,TRK>", "lines", "valu",
+print("%-22s %6s %6s %6s %6s %8s" % ("variant <F,H,R,X,T,P,PAD,TRK,Q>", "lines", "valu",
                                      "salu", "lds", "scratch"))
 for s in starts:
     e = next(i for i in range(s, len(text)) if "s_endpgm" in text[i])
     body = text[s:e]
-    flags = re.findall(r"Lb([01])E", text[s].split("Ev9ShootArgs")[0])[:8]
+    flags = re.findall(r"Lb([01])E", text[s].split("Ev9ShootArgs")[0])[:9]
     cas = [i for i, l in enumerate(body) if "ds_cmpst" in l]
     if not cas:
         continue

@@ -24,8 +24,8 @@ import sys
 from collections import defaultdict
 
 root, steps = sys.argv[1], int(sys.argv[2])
-# (template arguments: FULL, HEAT, REEMIT, EXACT, TABLE, PRE, PAD, TRACK - the first
-# generation of an iteration runs the TABLE variant)
+# (template arguments: FULL, HEAT, REEMIT, EXACT, TABLE, PRE, PAD, TRACK -
+# the first generation of an iteration runs the TABLE variant)
 DOMINANT = {"stromgren":
                 "shoot_kernel<false, false, false, false, true, false, true, false>",
             "stromgren_diffuse":

@@ -154,6 +154,17 @@ def test_temperature_solve_fixture(oracle):
     dict(reemit_passes=1, reemit_inline_below=0, reemit_max_passes=3,
          refill_threshold_reemit=1, max_packets_per_launch=25000),
     dict(reemit_passes=1, exact_dda=1, aggregate=0, sort_packets=0),
+    # round 5: absorbed packets parked through the queue's counter instead of
+    # at their position; parked at their position with lane-by-lane refills
+    # and split launches; the rows of the live flights copied into fresh rows
+    # whenever there is a dead slot (default for these runs: never)
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0,
+         park_in_place=0),
+    dict(tile_rounds=1, tile_min_flights=500, tile_min_per_item=0,
+         refill_threshold=5, max_packets_per_launch=17000),
+    dict(tile_rounds=0, refill_threshold=20, sort_packets=0),
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0,
+         tile_compact_ratio=1),
 ])
 def test_diffuse_stromgren_shoot_matches_oracle(oracle, tuning):
     """benchmarks/stromgren_diffuse.param: physical re-emission with fixed
@@ -204,6 +215,12 @@ def test_diffuse_stromgren_shoot_matches_oracle(oracle, tuning):
          defer_weights=0),
     dict(pre_emission=0, defer_weights=0),
     dict(tile_rounds=0),
+    # round 5: rows never copied / copied at every dead slot; absorbed
+    # packets parked through the queue's counter
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0,
+         tile_compact_ratio=0),
+    dict(tile_rounds=1, tile_min_flights=0, tile_min_per_item=0,
+         tile_compact_ratio=1, park_in_place=0),
     # range classes in the sort key, as at 1e8 packets
     dict(sort_tau_bits=3),
     dict(sort_tau_bits=2, tile_rounds=0),

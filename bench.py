@@ -949,7 +949,7 @@ def native_devices(n):
 
 
 def child_line(args, config, ncell, domain, steps, warmup, driver,
-               timeout=900.):
+               timeout=300.):
     """One more leg of an N > 1 run as a job of its own, started by rank 0 once
     the ranks' engines are closed (the other ranks wait on the rendezvous
     store): `driver` "native" - this script with --driver native, one process
@@ -957,7 +957,9 @@ def child_line(args, config, ncell, domain, steps, warmup, driver,
     fresh ranks on a port of their own. Whatever happens to that job - RCCL
     inside one process next to torch's, peer access that the box refuses, a
     rank that dies in a collective - the headline line survives; what went
-    wrong is recorded instead."""
+    wrong is recorded instead. (A leg takes 1-2 minutes at 8 ranks; after 5
+    it is given up so that three hanging legs cannot hold the line back for
+    longer than a scaling run may take.)"""
     import socket
     import subprocess
     tail = ["--gpus", str(args.gpus), "--steps", str(steps), "--warmup",
@@ -1097,7 +1099,7 @@ def main():
             out["bench_wall_s"] = time.perf_counter() - t_start
             store.set("cmi_bench_extras_done", "1")
         else:
-            store.wait(["cmi_bench_extras_done"], timedelta(minutes=60))
+            store.wait(["cmi_bench_extras_done"], timedelta(minutes=20))
     if ranks.rank == 0:
         print(json.dumps(out))
     if ranks.world > 1:

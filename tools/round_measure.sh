@@ -14,6 +14,8 @@ OUT=$REPO/$1
 ROUND=${2:-r05}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# (the GPU box has no .git: pass the commit the counters belong to, e.g.
+#  CMI_PROFILE_COMMIT=$(git rev-parse --short HEAD) in the gpurun command)
 # (SKIP_PMC=1: keep profiles/rNN/counters.json as it is)
 if [ -z "${SKIP_PMC:-}" ]; then
   for CFG in stromgren stromgren_diffuse lexington; do

@@ -1117,3 +1117,62 @@ def test_copies_cascade_is_cut_back_to_the_group_limit(exe, tmp_path):
     rel = np.abs(blocks[:, 5] - x) / x
     assert np.median(rel) < 1e-5
     assert (rel < 1e-2).mean() > 0.97, (rel > 1e-2).sum()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,flags,prefix,ncell,nphoton,niter", [
+    ("test_ionizationsimulation.param", [], "test_ionizationsimulation",
+     32, 50000, 4),
+    ("test_taskbasedionizationsimulation.param", ["--task-based"],
+     "test_taskbasedionizationsimulation", 16, 100000, 10),
+])
+def test_reference_integration_inputs_run_unchanged(exe, tmp_path, oracle,
+                                                    name, flags, prefix,
+                                                    ncell, nphoton, niter):
+    """test/testIonizationSimulation.cpp and
+    test/testTaskBasedIonizationSimulation.cpp construct a simulation from
+    their parameter file, initialize and run it - nothing else. The same two
+    files (tests/golden/, byte for byte; the second holds two
+    PhotonSourceSpectrum blocks, the later one counts) through the executable:
+    it runs to the end, writes the reference's snapshots, and the final
+    neutral fractions are the oracle's for the lowered values."""
+    import shutil
+    src = os.path.join(ROOT, "tests", "golden", name)
+    p = tmp_path / name
+    shutil.copy(src, p)
+    r = subprocess.run([exe, "--params", str(p)] + flags,
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(src, "rb").read() == open(p, "rb").read()  # unchanged
+    first = np.loadtxt(tmp_path / (prefix + "000.txt"))
+    last = np.loadtxt(tmp_path / (prefix + "%03d.txt" % niter))
+    n = ncell ** 3
+    assert first.shape == (n, 6) and last.shape == (n, 6)
+    d = describe(exe, str(p), str(tmp_path))
+    assert d["number_of_photons"] == nphoton
+    assert d["number_of_iterations"] == niter
+    sim = oracle.OracleSimulation((ncell,) * 3, d["anchor"], d["sides"])
+    sim.set_sources([[0., 0., 0.]], [1.], d["total_luminosity"])
+    sim.set_homogeneous(100. * (1. / 0.01 / 0.01 / 0.01), 8000.)
+    m = sim.model
+    if d["spectrum"]["type"] == "Planck":
+        m.spectrum_type = oracle.SPECTRUM_PLANCK
+        m.planck_temperature = d["spectrum"]["temperature"]
+    else:
+        m.spectrum_type = oracle.SPECTRUM_MONOCHROMATIC
+        m.mono_frequency = d["spectrum"]["frequency"]
+    if d["cross_sections"] == "Verner":
+        m.xsec_type = oracle.XSEC_VERNER
+        m.recomb_type = oracle.RECOMB_VERNER
+    else:
+        m.xsec_type = oracle.XSEC_FIXED
+        m.recomb_type = oracle.RECOMB_FIXED
+        for i in range(14):
+            m.xsec_fixed[i] = d["cross_sections"][i]
+            m.recomb_fixed[i] = d["recombination_rates"][i]
+    sim.run(nphoton, niter, seed=42)
+    # (text output has 6 significant digits; the iterations feed the rounded
+    # state back - as in test_cmi_gpu_executable_end_to_end)
+    ionized = np.asarray(sim.x[0]) < 0.5
+    assert 0.2 < ionized.mean() < 0.6
+    assert np.allclose(last[:, 5], sim.x[0], rtol=5e-3, atol=0.)

@@ -347,3 +347,37 @@ def test_c_caller_typed_from_the_reference_header(library, tmp_path):
         near = nH[radius < 2.]
         assert np.abs(near[:, 1] - near[:, 0]).max() < \
             0.25 * np.abs(near[:, 0]).max(), mapping
+
+
+@pytest.mark.gpu
+def test_the_references_library_test_input_runs_unchanged(tmp_path):
+    """test/testCMICLibrary.c initialises the library with
+    test_CMI_library.param (tests/golden/, byte for byte) and the "Petkova"
+    mapping on a lattice of particles in its box, computes the neutral
+    fractions and destroys it: the same through libcmi_gpu_library.so with
+    the gcc-compiled caller (6^3 particles) - every buffer intact, every
+    value finite, the particles near the star more ionized than the far
+    ones."""
+    import shutil
+    exe = tmp_path / "cmi_library_caller"
+    subprocess.run(["gcc", "-O1", "-Wall", "-Wextra", "-o", str(exe),
+                    os.path.join(ROOT, "tests", "support",
+                                 "cmi_library_caller.c"),
+                    "-L" + os.path.join(ROOT, "cmacionize_amd"),
+                    "-lcmi_gpu_library", "-lcmi_gpu",
+                    "-Wl,-rpath," + os.path.join(ROOT, "cmacionize_amd"),
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    src = os.path.join(ROOT, "tests", "golden", "test_CMI_library.param")
+    p = tmp_path / "test_CMI_library.param"
+    shutil.copy(src, p)
+    out = tmp_path / "caller.txt"
+    run = subprocess.run([str(exe), str(p), "Petkova", str(out)],
+                         cwd=tmp_path, capture_output=True, text=True,
+                         timeout=600)
+    assert run.returncode == 0, (run.returncode, run.stderr)
+    assert open(src, "rb").read() == open(p, "rb").read()
+    data = np.loadtxt(out)
+    pos, nH = data[:, :3], data[:, 3:]
+    assert nH.shape[0] == 216 and np.all(np.isfinite(nH))
+    radius = np.linalg.norm(pos, axis=1)
+    assert nH[radius < 1.5][:, 0].mean() < nH[radius > 6.5][:, 0].mean()

@@ -66,18 +66,42 @@ __device__ inline bool solve_5x5(double (&A)[5][5], double (&B)[5]) {
   return true;
 }
 
+/* exp(x) for |x| <= 0.01 to the last bit or two: the series to x^7 (the next
+ * term is 2.5e-21), seven fused multiply-adds instead of the ~30 instructions
+ * of exp() */
+__device__ __forceinline__ double lc_exp_small(double x) {
+  double q = 1. / 5040.;
+  q = __fma_rn(q, x, 1. / 720.);
+  q = __fma_rn(q, x, 1. / 120.);
+  q = __fma_rn(q, x, 1. / 24.);
+  q = __fma_rn(q, x, 1. / 6.);
+  q = __fma_rn(q, x, 0.5);
+  q = __fma_rn(q, x, 1.);
+  return __fma_rn(q, x, 1.);
+}
+
 /* collision strength fit, src/LineCoolingData.cpp:1590-1601. The two powers
  * of T are taken as exp(y ln T) with the logarithm the fit needs anyway: a
  * balance evaluation has 206 of them, and the general pow() is 4-5x the
  * instructions of exp(). Relative difference to pow(): ~|y ln T| ulp ~ 2e-15,
- * far inside the 1e-6 of the reference's own line-cooling test. */
+ * far inside the 1e-6 of the reference's own line-cooling test.
+ *
+ * The fit's last term, a4 T (1 + (a5 - 1) T^a6): a4 is zero for 20 of the 103
+ * transitions (the term is then skipped: x + 0 = x), and of the others all
+ * but two have |a6| < 3.7e-4, i.e. |a6 ln T| < 0.0086 up to the solve's limit
+ * of 1.1e10 K - the series above instead of exp(). The coefficients of a
+ * transition are the same for every lane: both tests are scalar branches. */
 __device__ __forceinline__ double lc_collision_strength(const double *a,
                                                         double prefactor,
                                                         double T, double Tinv,
                                                         double logT) {
-  return prefactor * exp((1. + a[0]) * logT) *
-         (a[1] + a[2] * Tinv + a[3] * logT +
-          a[4] * T * (1. + (a[5] - 1.) * exp(a[6] * logT)));
+  double fit = a[1] + a[2] * Tinv + a[3] * logT;
+  if (a[4] != 0.) {
+    const double x = a[6] * logT;
+    const double power = fabs(a[6]) < 4.e-4 ? lc_exp_small(x) : exp(x);
+    fit += a[4] * T * (1. + (a[5] - 1.) * power);
+  }
+  return prefactor * exp((1. + a[0]) * logT) * fit;
 }
 
 /* LineCoolingData::get_cooling, src/LineCoolingData.cpp:1767-1847 with
@@ -103,6 +127,20 @@ lc_five_level_cooling(const LineCoolingDev &lc, int e, double prefactor,
   double M[5][5];
   double pop[5] = {1., 0., 0., 0., 0.};
   double sumC[5] = {0., 0., 0., 0., 0.}; /* collisions out of each level */
+  /* the Boltzmann factor of transition (lo, hi), exp(-(E_hi - E_lo) / T), as
+   * the quotient of the levels' factors: four exponentials and three
+   * reciprocals per ion instead of ten exponentials (the transition energies
+   * ARE differences of level energies, src/LineCoolingData.cpp:76-97 and
+   * likewise for every ion;
+   * relative difference ~E / T x 1e-16) */
+  double level[5], level_inv[4];
+  level[0] = level_inv[0] = 1.;
+#pragma unroll
+  for (int k = 1; k < 5; ++k) {
+    level[k] = exp(-lc.energy[e][lc_tr(0, k)] * Tinv);
+    if (k < 4)
+      level_inv[k] = 1. / level[k];
+  }
 #pragma unroll
   for (int lo = 0; lo < 4; ++lo) {
 #pragma unroll
@@ -110,7 +148,8 @@ lc_five_level_cooling(const LineCoolingDev &lc, int e, double prefactor,
       const int t = lc_tr(lo, hi);
       const double down = lc_collision_strength(lc.cs[e][t], prefactor,
                                                 temperature, Tinv, logT);
-      const double up = down * exp(-lc.energy[e][t] * Tinv);
+      const double up =
+          down * (lo == 0 ? level[hi] : level[hi] * level_inv[lo]);
       /* level hi is fed from lo, level lo from hi (row 0 is replaced by
        * the normalisation below) */
       M[hi][lo] = up * w[lo];

@@ -175,6 +175,64 @@ def test_fullsize_reemission_decomposition_invariance(converged):
         b.engine.close()
 
 
+def test_fullsize_cell_update_invariance(converged):
+    """the 256^3 cell update - for lexingtonHII40 the temperature solve of
+    ~7e6 cells with its ~1e3 stragglers - gives the same state, bit for bit,
+    as one kernel, as the pipeline of kernels (the default), with all slots
+    finished by the one-wave-per-slot kernel from 4096 on, and solved in
+    three slabs of cells (cmi_gpu_update_cells_range, what the copies of a
+    block do); the inputs are restored afterwards."""
+    from cmacionize_amd import engine as E
+    model, eng = converged
+    n = 3000000
+    eng.reset_grid()
+    eng.shoot(13, 80, 0, n)
+    tw, _, _ = eng.get_counters()
+    nacc = 16 if model == "lexington" else 1
+    state = [E.FIELD_TEMPERATURE] + \
+        [E.FIELD_IONIC_FRACTION + i for i in range(14)]
+    inputs = state + [E.FIELD_MEAN_INTENSITY + i for i in range(nacc)]
+    before = {f: eng.download_field(f) for f in inputs}
+
+    def restore():
+        for f in inputs:
+            eng.upload_field(f, before[f])
+
+    ncells = NCELL ** 3
+    ways = [dict(temperature_pipeline=1, temperature_finish_slots=1024)]
+    if model == "lexington":
+        ways += [dict(temperature_pipeline=0),
+                 dict(temperature_pipeline=1, temperature_finish_slots=0),
+                 dict(temperature_pipeline=1, temperature_finish_slots=4096)]
+    ways.append("slabs")
+    reference = None
+    for way in ways:
+        restore()
+        if way == "slabs":
+            eng.set_tuning(**ways[0])
+            cuts = [0, ncells // 3 + 5, 2 * (ncells // 3) - 7, ncells]
+            for a, b in zip(cuts, cuts[1:]):
+                eng.update_cells_range(9, tw, a, b - a)
+        else:
+            eng.set_tuning(**way)
+            eng.update_cells(9, tw)
+        if reference is None:
+            reference = {f: eng.download_field(f) for f in state}
+            T = reference[E.FIELD_TEMPERATURE]
+            xH = reference[E.FIELD_IONIC_FRACTION]
+            assert np.isfinite(T).all() and (xH != before[state[1]]).any()
+            if model == "lexington":
+                solved = T != before[E.FIELD_TEMPERATURE]
+                assert solved.sum() > 1000000
+                assert 6000. < T[xH < 0.1].mean() < 12000.
+            continue
+        for f in state:
+            assert np.array_equal(eng.download_field(f), reference[f]), \
+                (way, f)
+    eng.set_tuning(**ways[0])
+    restore()
+
+
 def test_config5_512_cubed_in_blocks_equals_whole_grid():
     """BASELINE config 5 at its full size: lexingtonHII40 on 512^3 as
     2 x 2 x 2 blocks of 256^3 (the 8-GPU decomposition, all eight engines on

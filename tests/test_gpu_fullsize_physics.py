@@ -227,8 +227,10 @@ def test_fullsize_cell_update_invariance(converged):
                 assert 6000. < T[xH < 0.1].mean() < 12000.
             continue
         for f in state:
-            assert np.array_equal(eng.download_field(f), reference[f]), \
-                (way, f)
+            # (H-only models: the metals' balance is 0 / 0 in ionized cells,
+            # as in the reference - NaN in the same cells either way)
+            assert np.array_equal(eng.download_field(f), reference[f],
+                                  equal_nan=True), (way, f)
     eng.set_tuning(**ways[0])
     restore()
 

@@ -119,9 +119,10 @@ __device__ __forceinline__ double lc_collision_strength(const double *a,
  * run in a different order than the reference's sumC (same terms). */
 /* the cooling of five-level ion e per unit of abundance and kb:
  * sum_i pop_i sum_j A_ji E_ji (the body of line_cooling's first loop) */
+template <bool COLD>
 __device__ __forceinline__ double
-lc_five_level_cooling(const LineCoolingDev &lc, int e, double prefactor,
-                      double temperature, double Tinv, double logT) {
+lc_five_level_cooling_at(const LineCoolingDev &lc, int e, double prefactor,
+                         double temperature, double Tinv, double logT) {
   const double *A = lc.A[e];
   const double *w = lc.inv_weight[e];
   double M[5][5];
@@ -135,11 +136,13 @@ lc_five_level_cooling(const LineCoolingDev &lc, int e, double prefactor,
    * relative difference ~E / T x 1e-16) */
   double level[5], level_inv[4];
   level[0] = level_inv[0] = 1.;
+  if (!COLD) {
 #pragma unroll
-  for (int k = 1; k < 5; ++k) {
-    level[k] = exp(-lc.energy[e][lc_tr(0, k)] * Tinv);
-    if (k < 4)
-      level_inv[k] = 1. / level[k];
+    for (int k = 1; k < 5; ++k) {
+      level[k] = exp(-lc.energy[e][lc_tr(0, k)] * Tinv);
+      if (k < 4)
+        level_inv[k] = 1. / level[k];
+    }
   }
 #pragma unroll
   for (int lo = 0; lo < 4; ++lo) {
@@ -148,8 +151,10 @@ lc_five_level_cooling(const LineCoolingDev &lc, int e, double prefactor,
       const int t = lc_tr(lo, hi);
       const double down = lc_collision_strength(lc.cs[e][t], prefactor,
                                                 temperature, Tinv, logT);
-      const double up =
-          down * (lo == 0 ? level[hi] : level[hi] * level_inv[lo]);
+      const double boltzmann =
+          COLD ? exp(-lc.energy[e][t] * Tinv)
+               : (lo == 0 ? level[hi] : level[hi] * level_inv[lo]);
+      const double up = down * boltzmann;
       /* level hi is fed from lo, level lo from hi (row 0 is replaced by
        * the normalisation below) */
       M[hi][lo] = up * w[lo];
@@ -185,6 +190,26 @@ lc_five_level_cooling(const LineCoolingDev &lc, int e, double prefactor,
     cl[i] = pop[i] * s;
   }
   return cl[1] + cl[2] + cl[3] + cl[4];
+}
+
+/* (COLD: a temperature so low that a level's factor leaves the normal range
+ * - below ~130 K, never reached by the solve, possible through the probes and
+ * with a t_min_ionized set that low -: every transition's own exponential, as
+ * the reference has it; a path of its own so that the other stays short) */
+__device__ __attribute__((noinline)) double
+lc_five_level_cooling_cold(const LineCoolingDev &lc, int e, double prefactor,
+                           double temperature, double Tinv, double logT) {
+  return lc_five_level_cooling_at<true>(lc, e, prefactor, temperature, Tinv,
+                                        logT);
+}
+__device__ __forceinline__ double
+lc_five_level_cooling(const LineCoolingDev &lc, int e, double prefactor,
+                      double temperature, double Tinv, double logT) {
+  if (__builtin_expect(lc.energy[e][lc_tr(0, 4)] * Tinv > 600., 0))
+    return lc_five_level_cooling_cold(lc, e, prefactor, temperature, Tinv,
+                                      logT);
+  return lc_five_level_cooling_at<false>(lc, e, prefactor, temperature, Tinv,
+                                         logT);
 }
 
 /* two-level ion i: the population of its upper level (the body of

@@ -3,6 +3,8 @@ on the DEVICE functions through cmi_gpu_physics_probe, and h0 through the
 cell update itself (the other fixtures - ioneng, tbal - run on the device in
 test_gpu_physics.py, hiilines and bjump in test_gpu_emissivity.py). Same data files, same tolerances as the reference's
 tests; the device's pow/exp/log differ from libm by ulps only."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -85,6 +87,30 @@ def test_line_cooling_on_device(engine):
         assert rel_ok(c * 1.e7, row[15], 1.e-6), (row[0], c)
     zero = engine.physics_probe(2, [[8000., 0.] + [1.] * 13])
     assert zero[0, 0] == 1.e-99
+
+
+def test_line_cooling_over_the_temperature_range(engine, oracle):
+    """the device's line cooling (Boltzmann factors as quotients of level
+    factors, T^a6 from its series) against the oracle's plain restatement of
+    LineCoolingData::get_cooling from 10 K - where the level factors
+    underflow and the transitions' own exponentials take over - to the
+    solve's upper limit of 1.1e10 K, at densities from 1 to 1e6 cm^-3"""
+    rng = np.random.default_rng(5)
+    T = np.concatenate([[10., 30., 60., 100., 130., 200., 450., 500.],
+                        np.logspace(2.7, 10.04, 40)])
+    rows, expect = [], []
+    for t in T:
+        for ne in (1.e6, 1.e9, 1.e12):
+            ab = rng.uniform(1.e-6, 1.e-3, 13)
+            rows.append([t, ne] + list(ab))
+            expect.append(oracle.lib().cmio_line_cooling(
+                t, ne, ab.ctypes.data_as(C.POINTER(C.c_double))))
+    cool = engine.physics_probe(2, rows)[:, 0]
+    expect = np.array(expect)
+    # (the fits are extrapolated far beyond their range: no sign is asserted)
+    assert np.isfinite(cool).all() and np.isfinite(expect).all()
+    assert np.allclose(cool, expect, rtol=1e-11, atol=0.), \
+        np.abs(cool / expect - 1.).max()
 
 
 def test_reemission_probabilities_on_device(engine):

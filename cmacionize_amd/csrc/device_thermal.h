@@ -228,10 +228,12 @@ lc_two_level_cooling(const LineCoolingDev &lc, int i, double prefactor,
   return pop;
 }
 
-__device__ inline double line_cooling(const LineCoolingDev &lc,
-                                      double temperature,
-                                      double electron_density,
-                                      const double *abund, int abund_stride) {
+/* (the body, for a kernel that wants it in its own register budget:
+ * temp_linecool_kernel; everybody else calls line_cooling below) */
+__device__ __forceinline__ double
+line_cooling_inlined(const LineCoolingDev &lc, double temperature,
+                     double electron_density, const double *abund,
+                     int abund_stride) {
   if (electron_density == 0.)
     return 1.e-99;
   const double kb = CMI_BOLTZMANN;
@@ -254,6 +256,14 @@ __device__ inline double line_cooling(const LineCoolingDev &lc,
                lc.two_energy[i] * lc.two_A[i] *
                lc_two_level_cooling(lc, i, prefactor, temperature, Tinv, logT);
   return cooling;
+}
+
+__device__ inline double line_cooling(const LineCoolingDev &lc,
+                                      double temperature,
+                                      double electron_density,
+                                      const double *abund, int abund_stride) {
+  return line_cooling_inlined(lc, temperature, electron_density, abund,
+                              abund_stride);
 }
 
 /* the integrals of a cell as the solve reads them: J[k * stride], normalised

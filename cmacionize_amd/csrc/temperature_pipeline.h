@@ -291,7 +291,14 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   }
 }
 
-__global__ void __launch_bounds__(CMI_BLOCK)
+/* waves per SIMD temp_linecool_kernel is built for, with the line cooling
+ * inlined (measured, ms per launch of a 256^3 lexington update: the function
+ * called, 246 VGPRs / 2 waves 7.10; inlined at 2 / 3 / 4 waves per SIMD 6.90 /
+ * 6.25 / 8.70) */
+#ifndef CMI_LINECOOL_WAVES
+#define CMI_LINECOOL_WAVES 3
+#endif
+__global__ void __launch_bounds__(CMI_BLOCK, CMI_LINECOOL_WAVES)
     temp_linecool_kernel(const TempPipeArgs a) {
   __shared__ LineCoolingDev lds_lc;
   {
@@ -312,7 +319,7 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     const uint32_t i = (uint32_t)(t % a.nactive);
     double *e = a.eval + (size_t)k * a.capacity + i;
     e[(size_t)TE_LINES * estride] =
-        line_cooling(lds_lc, e[(size_t)TE_T * estride],
+        line_cooling_inlined(lds_lc, e[(size_t)TE_T * estride],
                      e[(size_t)TE_NE * estride],
                      e + (size_t)TE_ABUND * estride, (int)estride);
   }

@@ -887,12 +887,18 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
  * non-periodic grid (the first generation of every benchmark config): those
  * choices are compile-time constants and the code of the other aggregation
  * modes and of the periodic wrap is not in the march loop at all. */
+/* waves per SIMD of the multi-ion kernels without the cell-by-cell sums (the
+ * pass kernels of the tail) */
+#ifndef CMI_FULL_PASS_WAVES
+#define CMI_FULL_PASS_WAVES 3
+#endif
 template <bool FULL, bool HEAT, bool REEMIT, bool EXACT, bool TABLE = false,
           bool PRE = false, bool PAD = false, bool TRACK = false>
 __global__ void
     __launch_bounds__(CMI_BLOCK,
                       REEMIT ? 1
-                             : (FULL ? (TABLE ? CMI_FULL_WAVES : 3)
+                             : (FULL ? (TABLE ? CMI_FULL_WAVES
+                                              : CMI_FULL_PASS_WAVES)
                                     : ((PAD && !HEAT) ? CMI_PAD_WAVES : 6)))
         shoot_kernel(const ShootArgs a) {
   /* PAD: the hydrogen-only first generation on a whole, non-periodic grid,
@@ -1980,9 +1986,13 @@ block_reserve(bool mine, unsigned int *counter, unsigned int *s_count,
 #endif
 /* multi-ion transport with deferred weights: the two Verner cross sections of
  * the decision and the new flight want ~150 registers; at 4 waves per SIMD
- * (128) they spill 70-110 bytes per lane */
+ * (128) they spill 70-110 bytes per lane - and are the faster all the same
+ * (round 5, ms per lexington iteration, first-generation kernel / all rounds'
+ * slots kernels: 2 waves 9.14 / 7.1, 3: 9.33 / 7.2, 4: 8.31 / 6.8, 5: 9.63 /
+ * 7.1, 6: 10.46 / 7.1; the hydrogen-only kernels: 3: 4.03, 4: 3.64, 6: 5.88,
+ * 8: 4.03) */
 #ifndef CMI_INTERACT_WAVES_FULL
-#define CMI_INTERACT_WAVES_FULL 3
+#define CMI_INTERACT_WAVES_FULL 4
 #endif
 /* trips of a batch whose loads are issued together (multi-ion transport) */
 #ifndef CMI_INTERACT_GROUP_FULL
@@ -2410,7 +2420,10 @@ order_by_verner_class(const uint32_t (&cls)[TRIPS], unsigned int n,
 #ifndef CMI_WEIGHTS_BATCH
 #define CMI_WEIGHTS_BATCH 4
 #endif
-__global__ void __launch_bounds__(CMI_BLOCK)
+#ifndef CMI_WEIGHTS_WAVES
+#define CMI_WEIGHTS_WAVES 1
+#endif
+__global__ void __launch_bounds__(CMI_BLOCK, CMI_WEIGHTS_WAVES)
     flight_weights_kernel(const FlightWeightsArgs a) {
   constexpr int TRIPS = CMI_WEIGHTS_BATCH;
   constexpr unsigned int BATCH = TRIPS * CMI_BLOCK;
@@ -2761,8 +2774,13 @@ struct UpdateArgs {
 /* HEATING = false: a hydrogen-only run that does not track the heating terms
  * (no transport kernel adds to them, no temperature solve reads them): their
  * two fields are neither read nor normalised. */
+/* (hydrogen-only update of 256^3 cells, ms: the compiler's choice - 3 waves
+ * per SIMD - 1.92, built for 4: 1.80, for 6: 3.42) */
+#ifndef CMI_IONIZATION_WAVES
+#define CMI_IONIZATION_WAVES 4
+#endif
 template <bool FULL, bool HEATING = true>
-__global__ void __launch_bounds__(CMI_BLOCK)
+__global__ void __launch_bounds__(CMI_BLOCK, FULL ? 2 : CMI_IONIZATION_WAVES)
     ionization_kernel(const UpdateArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t c = a.first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -363,7 +363,12 @@ temperature_step_finish(const ModelDev &m, TemperatureSolve &s, double T0,
   }
 }
 
-__global__ void __launch_bounds__(CMI_BLOCK)
+/* (measured, ms per launch of a 256^3 lexington update: the compiler's choice
+ * 1.50, built for 3 waves per SIMD 1.34, for 4 1.44) */
+#ifndef CMI_SECANT_WAVES
+#define CMI_SECANT_WAVES 3
+#endif
+__global__ void __launch_bounds__(CMI_BLOCK, CMI_SECANT_WAVES)
     temp_secant_kernel(const TempPipeArgs a_in) {
   __shared__ unsigned int s_count[CMI_BLOCK / 64], s_base;
   __shared__ TablesDev lds_tables;

@@ -1797,10 +1797,15 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
         heat ? shoot_kernel<true, true, false, false, true, true>
              : shoot_kernel<true, false, false, false, true, true>;
 
-  auto occupancy = [&](void (*k)(const ShootArgs), int &blocks_per_cu) -> int {
+  /* (the hydrogen-only kernels built for the table run in larger blocks) */
+  const int first_threads = (kernel_first != kernel && !e->full_ions)
+                                ? shoot_block_threads<false, true>()
+                                : CMI_BLOCK;
+  auto occupancy = [&](void (*k)(const ShootArgs), int &blocks_per_cu,
+                       int threads = CMI_BLOCK) -> int {
     blocks_per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k,
-                                                         CMI_BLOCK, 0));
+                                                         threads, 0));
     if (blocks_per_cu < 1)
       blocks_per_cu = 1;
     if (blocks_per_cu > e->tune.max_blocks_per_cu)
@@ -1821,7 +1826,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   int blocks_per_cu_first = blocks_per_cu;
   if (kernel_first != kernel) {
     int rc = occupancy(kernel_first_pre ? kernel_first_pre : kernel_first,
-                       blocks_per_cu_first);
+                       blocks_per_cu_first, first_threads);
     if (rc)
       return rc;
   }
@@ -2021,8 +2026,8 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     /* enough chunks for every wave of a full grid, else fewer blocks */
     const uint64_t nchunks = (n + a.chunk - 1) / a.chunk;
     int64_t blocks = (int64_t)e->num_cu * blocks_per_cu_first;
-    const int64_t need = (int64_t)((nchunks + (CMI_BLOCK / 64) - 1) /
-                                   (CMI_BLOCK / 64));
+    const int64_t need = (int64_t)((nchunks + (first_threads / 64) - 1) /
+                                   (first_threads / 64));
     if (blocks > need)
       blocks = need;
     if (blocks < 1)
@@ -2036,7 +2041,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     if (sorted && kernel_first_pre)
       kernel_first_pre<<<(unsigned)blocks, CMI_BLOCK, 0, e->stream>>>(a);
     else
-      kernel_first<<<(unsigned)blocks, CMI_BLOCK, 0, e->stream>>>(a);
+      kernel_first<<<(unsigned)blocks, first_threads, 0, e->stream>>>(a);
     HIP_TRY(hipGetLastError());
     {
       int trc = timer_end(e, e->kernel_events, kev, n);

@@ -9,7 +9,9 @@
 #include "device_thermal.h"
 #include "device_emissivity.h"
 
+#ifndef CMI_BLOCK
 #define CMI_BLOCK 256
+#endif
 /* the "exp_no_atomics" experiments (results are wrong by design) exist only in
  * builds with -DCMI_EXPERIMENTS (make variant ...); the product kernels carry
  * none of their branches */
@@ -19,8 +21,27 @@
 #define CMI_EXP(a) 0
 #endif
 /* slots of a block's combining table (aggregate mode 3) */
+#ifndef CMI_TABLE_BITS
 #define CMI_TABLE_BITS 10
+#endif
 #define CMI_TABLE_SLOTS (1 << CMI_TABLE_BITS)
+/* threads per block and table slots of the hydrogen-only kernels that are
+ * BUILT for the table (TABLE: the first generation). The waves of a block share
+ * the table and meet at a barrier between two bundles: 8 waves with 2048 slots
+ * combine more than 4 with 1024 and wait no longer for each other (measured,
+ * key + sort + kernel of config 2 in ms: 128 threads / 512 slots 47.3, 256 /
+ * 1024 34.4, 512 / 2048 33.4, 1024 / 4096 34.6; 256 / 512 37.1, 256 / 2048
+ * 56.1, 512 / 1024 34.8, 512 / 4096 54.5 - LDS then limits the waves per CU).
+ * Every other kernel is slower with 512 threads (CMI_BLOCK). */
+#ifndef CMI_TABLE_BLOCK
+#define CMI_TABLE_BLOCK 512
+#endif
+#ifndef CMI_TABLE_BLOCK_BITS
+#define CMI_TABLE_BLOCK_BITS 11
+#endif
+template <bool FULL, bool TABLE> constexpr int shoot_block_threads() {
+  return (TABLE && !FULL) ? CMI_TABLE_BLOCK : CMI_BLOCK;
+}
 /* (measured in round 5, ms per iteration of config 2: 2 probes 35.1, 4: 34.5,
  * 8: 34.2) */
 #ifndef CMI_TABLE_PROBES
@@ -895,12 +916,17 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
 template <bool FULL, bool HEAT, bool REEMIT, bool EXACT, bool TABLE = false,
           bool PRE = false, bool PAD = false, bool TRACK = false>
 __global__ void
-    __launch_bounds__(CMI_BLOCK,
+    __launch_bounds__((shoot_block_threads<FULL, TABLE>()),
                       REEMIT ? 1
                              : (FULL ? (TABLE ? CMI_FULL_WAVES
                                               : CMI_FULL_PASS_WAVES)
                                     : ((PAD && !HEAT) ? CMI_PAD_WAVES : 6)))
         shoot_kernel(const ShootArgs a) {
+  constexpr int BLOCK = shoot_block_threads<FULL, TABLE>();
+  /* (hydrogen-only table: slots = 2^TBITS) */
+  constexpr int TBITS =
+      (TABLE && !FULL) ? CMI_TABLE_BLOCK_BITS : CMI_TABLE_BITS;
+  constexpr int TSLOTS = 1 << TBITS;
   /* PAD: the hydrogen-only first generation on a whole, non-periodic grid,
    * marching through the padded records (ShootArgs::pad_H) */
   static_assert(!PAD || (TABLE && !FULL && !REEMIT && !EXACT && !PRE),
@@ -919,9 +945,9 @@ __global__ void
     block = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) +
             (block >> 3);
   }
-  const uint64_t wave = (uint64_t)block * (CMI_BLOCK / 64) +
+  const uint64_t wave = (uint64_t)block * (BLOCK / 64) +
                         (threadIdx.x >> 6);
-  const uint64_t nwaves = (uint64_t)gridDim.x * (CMI_BLOCK / 64);
+  const uint64_t nwaves = (uint64_t)gridDim.x * (BLOCK / 64);
   const uint64_t chunk = a.chunk;
 
   /* wave-uniform cursor into the launch's position range */
@@ -963,7 +989,7 @@ __global__ void
    * src/IonizationPhotonShootJob.hpp:143-144); those that came from the
    * continuous source are counted a second time, per wave, in LDS */
   unsigned int tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
-  __shared__ unsigned int s_continuous[CMI_BLOCK / 64][4];
+  __shared__ unsigned int s_continuous[BLOCK / 64][4];
   if (lane < 4)
     s_continuous[threadIdx.x >> 6][lane] = 0;
   unsigned int nsteps = 0, natomics = 0; /* per lane and launch: < 2^32 */
@@ -1001,15 +1027,15 @@ __global__ void
    * no table: accumulate_full_grouped) */
   constexpr bool GROUPED = FULL && TABLE;
   constexpr int lds_slots =
-      GROUPED ? 1 : (FULL ? CMI_FTABLE_SLOTS : CMI_TABLE_SLOTS);
+      GROUPED ? 1 : (FULL ? CMI_FTABLE_SLOTS : TSLOTS);
   constexpr int lds_values = FULL ? CMI_NACC : (HEAT ? 2 : 1);
   __shared__ int32_t lds_tag[lds_slots];
   /* FULL: one more row, the sink of table_row() for lanes without a slot */
   __shared__ double lds_val[lds_values * (lds_slots + (FULL ? 1 : 0))];
-  __shared__ int32_t block_has_work[CMI_BLOCK / 64];
+  __shared__ int32_t block_has_work[BLOCK / 64];
   const int wib = threadIdx.x >> 6;
   /* FULL: per-wave accumulation weights and per-step scratch in LDS */
-  __shared__ FullStage full_stage[FULL ? CMI_BLOCK / 64 : 1];
+  __shared__ FullStage full_stage[FULL ? BLOCK / 64 : 1];
   FullStage &stage = full_stage[FULL ? wib : 0];
   double weights[CMI_NACC];
   double wq[CMI_NACC]; /* FULL: transposed weights of the lane's quarter */
@@ -1030,9 +1056,9 @@ __global__ void
   const bool use_table =
       !GROUPED && (TABLE || a.aggregate == CMI_AGG_BLOCK);
   if (use_table) {
-    for (int k = threadIdx.x; k < lds_slots; k += CMI_BLOCK)
+    for (int k = threadIdx.x; k < lds_slots; k += BLOCK)
       lds_tag[k] = -1;
-    for (int k = threadIdx.x; k < lds_values * lds_slots; k += CMI_BLOCK)
+    for (int k = threadIdx.x; k < lds_values * lds_slots; k += BLOCK)
       lds_val[k] = 0.;
     __syncthreads();
   }
@@ -1047,7 +1073,7 @@ __global__ void
     __syncthreads();
     if (FULL) {
       const int i = threadIdx.x & 15;
-      for (int k = threadIdx.x >> 4; k < lds_slots; k += CMI_BLOCK / 16) {
+      for (int k = threadIdx.x >> 4; k < lds_slots; k += BLOCK / 16) {
         const int32_t t = lds_tag[k];
         if (t >= 0) {
           /* (table rows are in column order, like the cells' rows) */
@@ -1062,7 +1088,7 @@ __global__ void
         }
       }
     } else {
-      for (int k = threadIdx.x; k < lds_slots; k += CMI_BLOCK) {
+      for (int k = threadIdx.x; k < lds_slots; k += BLOCK) {
         const int32_t t = lds_tag[k];
         if (t >= 0) {
           const int32_t c = PAD ? cmi_unpad_cell(a, a.grid, t) : t;
@@ -1080,7 +1106,7 @@ __global__ void
     }
     int any_work = 0;
 #pragma unroll
-    for (int w = 0; w < CMI_BLOCK / 64; ++w)
+    for (int w = 0; w < BLOCK / 64; ++w)
       any_work |= block_has_work[w];
     __syncthreads();
     return any_work != 0;
@@ -1098,9 +1124,9 @@ __global__ void
        * v_mul_lo_u32) */
       uint32_t product;
       asm("v_mul_u32_u24 %0, 0x9e3779, %1" : "=v"(product) : "v"(cell));
-      slot = (product >> (24 - CMI_TABLE_BITS)) & (CMI_TABLE_SLOTS - 1);
+      slot = (product >> (24 - TBITS)) & (TSLOTS - 1);
     } else {
-      slot = ((uint32_t)cell * 0x9E3779B1u) >> (32 - CMI_TABLE_BITS);
+      slot = ((uint32_t)cell * 0x9E3779B1u) >> (32 - TBITS);
     }
     for (int probe = 0; probe < CMI_TABLE_PROBES; ++probe) {
       /* (lanes that are not looking: whatever the register holds, they are
@@ -1128,11 +1154,11 @@ __global__ void
       if (lanes_of(found)) {
         atomicAdd(&lds_val[slot], v0); /* ds_add_f64 */
         if (HEAT)
-          atomicAdd(&lds_val[CMI_TABLE_SLOTS + slot], v1);
+          atomicAdd(&lds_val[TSLOTS + slot], v1);
       }
       looking &= ~found;
       if (lanes_of(looking))
-        slot = (slot + 1) & (CMI_TABLE_SLOTS - 1);
+        slot = (slot + 1) & (TSLOTS - 1);
       if (looking == 0ull)
         return;
     }

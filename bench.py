@@ -56,15 +56,15 @@ CONFIGS = {
     "stromgren": dict(
         name="stromgren.param", bytes_per_step=16. + 16. * 1, diffuse=False,
         lexington=False, converge_iterations=20,
-        kernel="shoot_kernel<false, false, false, false, true, false, true, false>"),
+        kernel="shoot_kernel<false, false, false, false, true, false, true, false, false>"),
     "stromgren_diffuse": dict(
         name="stromgren_diffuse.param", bytes_per_step=16. + 16. * 1,
         diffuse=True, lexington=False, converge_iterations=20,
-        kernel="shoot_kernel<false, false, false, false, true, false, true, false>"),
+        kernel="shoot_kernel<false, false, false, false, true, false, true, false, false>"),
     "lexington": dict(
         name="lexingtonHII40.param", bytes_per_step=24. + 16. * 16,
         diffuse=True, lexington=True, converge_iterations=20,
-        kernel="shoot_kernel<true, true, false, false, true, true, false, false>"),
+        kernel="shoot_kernel<true, true, false, false, true, true, false, false, false>"),
 }
 
 # The CPU baseline (oracle/cmio_transport_fast.c) against the REFERENCE on the

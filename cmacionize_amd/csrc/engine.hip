@@ -1782,7 +1782,13 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                    e->tune.pad_march && !e->grid.decomposed &&
                    e->grid.copy_count <= 1 &&
                    padded_cells < ((int64_t)1 << 29);
-  if (pad)
+  const bool pad_big = pad && e->ncell > CMI_TABLE_BIG_CELLS;
+  if (pad_big)
+    kernel_first = heat ? shoot_kernel<false, true, false, false, true, false,
+                                       true, false, true>
+                        : shoot_kernel<false, false, false, false, true, false,
+                                       true, false, true>;
+  else if (pad)
     kernel_first =
         heat ? shoot_kernel<false, true, false, false, true, false, true>
              : shoot_kernel<false, false, false, false, true, false, true>;
@@ -1798,9 +1804,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
              : shoot_kernel<true, false, false, false, true, true>;
 
   /* (the hydrogen-only kernels built for the table run in larger blocks) */
-  const int first_threads = (kernel_first != kernel && !e->full_ions)
-                                ? shoot_block_threads<false, true>()
-                                : CMI_BLOCK;
+  const int first_threads =
+      (kernel_first != kernel && !e->full_ions)
+          ? (pad_big ? shoot_block_threads<false, true, true>()
+                     : shoot_block_threads<false, true>())
+          : CMI_BLOCK;
   auto occupancy = [&](void (*k)(const ShootArgs), int &blocks_per_cu,
                        int threads = CMI_BLOCK) -> int {
     blocks_per_cu = 0;

@@ -39,8 +39,17 @@
 #ifndef CMI_TABLE_BLOCK_BITS
 #define CMI_TABLE_BLOCK_BITS 11
 #endif
-template <bool FULL, bool TABLE> constexpr int shoot_block_threads() {
-  return (TABLE && !FULL) ? CMI_TABLE_BLOCK : CMI_BLOCK;
+/* ... and on grids of more than 2^25 cells (BIG: engine.hip picks the build),
+ * where a bundle crosses more cells than the smaller table holds: 1024
+ * threads with 4096 slots (measured, key + sort + kernel in ms, 512 / 1024
+ * threads: 256^3 33.4 / 34.6, 384^3 49.3 / 48.4, 512^3 73.0 / 66.5) */
+#define CMI_TABLE_BLOCK_BIG 1024
+#define CMI_TABLE_BLOCK_BIG_BITS 12
+#define CMI_TABLE_BIG_CELLS (1ll << 25)
+template <bool FULL, bool TABLE, bool BIG = false>
+constexpr int shoot_block_threads() {
+  return (TABLE && !FULL) ? (BIG ? CMI_TABLE_BLOCK_BIG : CMI_TABLE_BLOCK)
+                          : CMI_BLOCK;
 }
 /* (measured in round 5, ms per iteration of config 2: 2 probes 35.1, 4: 34.5,
  * 8: 34.2) */
@@ -914,18 +923,24 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
 #define CMI_FULL_PASS_WAVES 3
 #endif
 template <bool FULL, bool HEAT, bool REEMIT, bool EXACT, bool TABLE = false,
-          bool PRE = false, bool PAD = false, bool TRACK = false>
+          bool PRE = false, bool PAD = false, bool TRACK = false,
+          bool BIG = false>
 __global__ void
-    __launch_bounds__((shoot_block_threads<FULL, TABLE>()),
+    __launch_bounds__((shoot_block_threads<FULL, TABLE, BIG>()),
                       REEMIT ? 1
                              : (FULL ? (TABLE ? CMI_FULL_WAVES
                                               : CMI_FULL_PASS_WAVES)
-                                    : ((PAD && !HEAT) ? CMI_PAD_WAVES : 6)))
+                                    : ((PAD && !HEAT) ? CMI_PAD_WAVES
+                                       : BIG          ? 4
+                                                      : 6)))
         shoot_kernel(const ShootArgs a) {
-  constexpr int BLOCK = shoot_block_threads<FULL, TABLE>();
+  static_assert(!BIG || PAD, "BIG: the padded march on large grids");
+  constexpr int BLOCK = shoot_block_threads<FULL, TABLE, BIG>();
   /* (hydrogen-only table: slots = 2^TBITS) */
   constexpr int TBITS =
-      (TABLE && !FULL) ? CMI_TABLE_BLOCK_BITS : CMI_TABLE_BITS;
+      (TABLE && !FULL)
+          ? (BIG ? CMI_TABLE_BLOCK_BIG_BITS : CMI_TABLE_BLOCK_BITS)
+          : CMI_TABLE_BITS;
   constexpr int TSLOTS = 1 << TBITS;
   /* PAD: the hydrogen-only first generation on a whole, non-periodic grid,
    * marching through the padded records (ShootArgs::pad_H) */

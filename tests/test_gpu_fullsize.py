@@ -93,6 +93,42 @@ def test_fullsize_reordering_invariance(converged):
     assert abs(J.sum() - J0.sum()) <= 1e-9 * J0.sum()
 
 
+@pytest.mark.parametrize("heating", [False, True])
+def test_large_grid_reordering_invariance(heating):
+    """beyond 2^25 cells the padded march runs in blocks of 1024 threads with
+    a table of 4096 slots (shoot_kernel<..., PAD, ..., BIG>): 336^3, the same
+    packets through that kernel, through the march on the plain records and
+    one packet per lane with single atomics - the same tallies."""
+    from cmacionize_amd import engine as E
+    from test_gpu_transport import make_engine
+    ncell, n = 336, 3000000
+    assert ncell ** 3 > 1 << 25
+    eng = make_engine(ncell, track_heating=heating)
+    for loop in range(4):
+        eng.reset_grid()
+        eng.shoot(42, loop, 0, 3000000)
+        tw, _, _ = eng.get_counters()
+        eng.update_cells(loop, tw)
+    fields = [E.FIELD_MEAN_INTENSITY] + ([E.FIELD_HEATING] if heating else [])
+    results = []
+    default = dict(sort_packets=1, aggregate=2, pad_march=1)
+    for kw in (dict(), dict(pad_march=0), dict(sort_packets=0, aggregate=0)):
+        tuning = dict(default)
+        tuning.update(kw)
+        eng.set_tuning(**tuning)
+        eng.reset_grid()
+        eng.shoot(11, 60, 5, n)
+        results.append((eng.get_counters(),
+                        [eng.download_field(f) for f in fields]))
+    eng.close()
+    (tw0, tc0, ns0), J0 = results[0]
+    assert tw0 == n and 100. < ns0 / n < 300.
+    for (tw, tc, ns), J in results[1:]:
+        assert tw == tw0 and np.array_equal(tc, tc0) and ns == ns0
+        for a, b in zip(J, J0):
+            assert np.allclose(a, b, rtol=1e-10, atol=1e-13 * np.abs(b).max())
+
+
 def test_fullsize_decomposition_invariance(converged):
     """256^3 as 2 x 2 x 2 blocks of 128^3 (config 5's shape at half the
     linear size) against the undivided grid, same state, same packets."""

@@ -27,11 +27,11 @@ root, steps = sys.argv[1], int(sys.argv[2])
 # (template arguments: FULL, HEAT, REEMIT, EXACT, TABLE, PRE, PAD, TRACK -
 # the first generation of an iteration runs the TABLE variant)
 DOMINANT = {"stromgren":
-                "shoot_kernel<false, false, false, false, true, false, true, false>",
+                "shoot_kernel<false, false, false, false, true, false, true, false, false>",
             "stromgren_diffuse":
-                "shoot_kernel<false, false, false, false, true, false, true, false>",
+                "shoot_kernel<false, false, false, false, true, false, true, false, false>",
             "lexington":
-                "shoot_kernel<true, true, false, false, true, true, false, false>"}
+                "shoot_kernel<true, true, false, false, true, true, false, false, false>"}
 N_SIMD, N_CU, MAXCLK = 1024, 256, 2.4e9
 
 

@@ -2254,13 +2254,18 @@ __global__ void __launch_bounds__(CMI_TILE_PLAN_THREADS)
  * half ends with 14 Verner cross sections unless they are deferred). The
  * running totals of the units around the batch are searched in LDS. */
 #define CMI_SLOTS_WINDOW 128
+/* (hydrogen-only rounds, x 256 ended flights per batch; ms per launch of
+ * stromgren_diffuse's rounds: 1: 0.153, 2: 0.131, 4: 0.152, 8: 0.167) */
+#ifndef CMI_SLOTS_BATCH_H
+#define CMI_SLOTS_BATCH_H 2
+#endif
 template <bool FULL, bool DEFER = false>
 __global__ void __launch_bounds__(CMI_BLOCK,
                                   (FULL && !DEFER) ? 1
                                   : FULL           ? CMI_INTERACT_WAVES_FULL
                                                    : CMI_INTERACT_WAVES_H)
     interaction_slots_kernel(const InteractArgs a) {
-  constexpr int TRIPS = CMI_INTERACT_BATCH;
+  constexpr int TRIPS = FULL ? CMI_INTERACT_BATCH : CMI_SLOTS_BATCH_H;
   constexpr int GROUP = FULL ? CMI_INTERACT_GROUP_FULL : TRIPS;
   constexpr unsigned int BATCH = TRIPS * CMI_BLOCK;
   __shared__ InteractStage<BATCH> stage;

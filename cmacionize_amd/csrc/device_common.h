@@ -284,6 +284,23 @@ struct SpectraDev {
   uint16_t lyc_guide[2][CMI_NTEMP][CMI_NGUIDE + 2];
 };
 
+/* A caller-supplied table (cmi_gpu_set_spectrum_table,
+ * cmi_gpu_set_cross_sections_table, cmi_gpu_set_recombination_rates_table):
+ * the generic lowering of a plugin that is known only through the reference's
+ * per-packet / per-cell virtual ("sample the virtual on the host
+ * into a table"). n abscissae x[] in ascending order and the values y[] - one
+ * row of n for a spectrum, CMI_NION rows of n for cross sections and
+ * recombination rates. Device pointers in the kernels' copy of the model,
+ * host pointers in the host's. */
+struct TableDev {
+  const double *x;
+  const double *y;
+  int32_t n;
+  int32_t interpolation; /* CMI_GPU_TABLE_LINEAR / CMI_GPU_TABLE_LOGLOG */
+};
+#define CMI_TABLE_LINEAR 0
+#define CMI_TABLE_LOGLOG 1
+
 /* Physics set-up passed by value to the kernels */
 struct ModelDev {
   /* sources */
@@ -334,6 +351,14 @@ struct ModelDev {
   int32_t pad2;
   double continuous_intercept;
   double continuous_anchor[2], continuous_side[2];
+  /* generic lowering: spectrum_type / continuous_spectrum_type == 2 sample
+   * spectrum_table[0] / [1] (x = cumulative distribution, y = frequency in
+   * Hz); xsec_verner == 2 interpolates xsec_table (x = frequency in Hz, y =
+   * sigma[14][n] in m^2); recomb_verner == 2 interpolates recomb_table (x =
+   * temperature in K, y = alpha[14][n] in m^3 s^-1) */
+  TableDev spectrum_table[2];
+  TableDev xsec_table;
+  TableDev recomb_table;
 };
 
 /* SoA cell state, all device pointers to [ncell] doubles */

@@ -134,6 +134,39 @@ cmi_locate_linear(double x, const double *arr, uint32_t length) {
   return (g == length - 1) ? g - 1 : g;
 }
 
+/* ------------------------------------------- caller-supplied tables ---- */
+
+/* Row `row` of a table at abscissa x: Utilities::locate's interval
+ * (src/Utilities.hpp:726-742), linear interpolation in (x, y) or in
+ * (log x, log y) - a power law between two samples, the form the reference's
+ * Planck table is sampled in (src/PlanckPhotonSourceSpectrum.cpp:149-165) -;
+ * outside [x[0], x[n - 1]] the end values (no extrapolation). A log-log
+ * interval with a sample that is not positive falls back to linear. */
+__host__ __device__ inline double cmi_table_value(const TableDev &t, int row,
+                                                 double x) {
+  const double *xs = t.x;
+  const double *ys = t.y + (size_t)row * (size_t)t.n;
+  const uint32_t n = (uint32_t)t.n;
+  if (!(x > xs[0]))
+    return ys[0];
+  if (!(x < xs[n - 1]))
+    return ys[n - 1];
+  uint32_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (x > xs[mid])
+      lo = mid;
+    else
+      hi = mid;
+  }
+  if (lo == n - 1)
+    --lo;
+  const double x0 = xs[lo], x1 = xs[lo + 1], y0 = ys[lo], y1 = ys[lo + 1];
+  if (t.interpolation == CMI_TABLE_LOGLOG && y0 > 0. && y1 > 0. && x0 > 0.)
+    return y0 * exp(log(y1 / y0) * (log(x / x0) / log(x1 / x0)));
+  return y0 + (y1 - y0) * ((x - x0) / (x1 - x0));
+}
+
 /* ------------------------------------------------ Verner cross section -- */
 
 /* VernerCrossSections::get_cross_section_verner,
@@ -185,6 +218,19 @@ __host__ __device__ inline void cmi_cross_sections(const ModelDev &m, double nu,
       sigma[i] = m.xsec_fixed[i];
     return;
   }
+  if (m.xsec_verner == 2) {
+    /* a plugin known only through CrossSections::get_cross_section
+     * (src/CrossSections.hpp:49-50), sampled into a table by the host */
+#pragma unroll 1
+    for (int k = 0; k < CMI_NION; ++k) {
+      const double s = cmi_table_value(m.xsec_table, k, nu);
+#pragma unroll
+      for (int i = 0; i < CMI_NION; ++i)
+        if (i == k)
+          sigma[i] = s;
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < CMI_NION; ++i)
     sigma[i] = 0.;
@@ -217,7 +263,7 @@ __host__ __device__ inline void cmi_cross_sections(const ModelDev &m, double nu,
 /* how many of the fits' thresholds a photon lies above: photons of a class
  * skip the same terms */
 __device__ inline uint32_t verner_class(const ModelDev &m, double nu) {
-  if (!m.xsec_verner)
+  if (m.xsec_verner != 1)
     return 0;
   const VernerTermDev *terms = m.tables->verner;
   uint32_t c = 0;
@@ -235,6 +281,11 @@ __host__ __device__ inline void cmi_cross_sections_H_He(const ModelDev &m, doubl
   if (!m.xsec_verner) {
     sigma_H = m.xsec_fixed[ION_H_n];
     sigma_He = m.xsec_fixed[ION_He_n];
+    return;
+  }
+  if (m.xsec_verner == 2) {
+    sigma_H = cmi_table_value(m.xsec_table, ION_H_n, nu);
+    sigma_He = cmi_table_value(m.xsec_table, ION_He_n, nu);
     return;
   }
   sigma_H = 0.;
@@ -259,6 +310,10 @@ __device__ inline double cmi_recombination_rate(const ModelDev &m, int ion,
                                                 double temperature) {
   if (!m.recomb_verner)
     return m.recomb_fixed[ion];
+  if (m.recomb_verner == 2)
+    /* RecombinationRates::get_recombination_rate
+     * (src/RecombinationRates.hpp:49) sampled into a table by the host */
+    return cmi_table_value(m.recomb_table, ion, temperature);
   const VernerRecDev &r = m.tables->verner_rec[ion];
   /* powers as exp(y ln x) and x^-1.5 as 1 / (x sqrt x): a few 1e-16 from
    * pow() (the reference's test of these fits passes at 1e-13 here), a

@@ -62,6 +62,17 @@ __device__ inline double sample_he_two_photon(const SpectraDev *s,
                                   (s->he2pc_cdf[inu + 1] - s->he2pc_cdf[inu]);
 }
 
+/* A spectrum known only through PhotonSourceSpectrum::get_random_frequency
+ * (src/PhotonSourceSpectrum.hpp:48-50), lowered by the host into its quantile
+ * function: one uniform, located in the cumulative distribution x[], the
+ * frequency interpolated between y[i] and y[i + 1] - linearly (the form of
+ * src/HeliumTwoPhotonContinuumSpectrum.cpp:167-180) or log-log (the form of
+ * src/PlanckPhotonSourceSpectrum.cpp:149-165). */
+__device__ inline double sample_spectrum_table(const TableDev &t,
+                                               PacketRng &rng) {
+  return cmi_table_value(t, 0, rng.next());
+}
+
 /* PhotonSourceSpectrum::get_random_frequency of the discrete sources
  * (origin 0) or of the continuous source (origin 1) */
 __device__ inline double sample_source_spectrum(const ModelDev &m,
@@ -70,6 +81,8 @@ __device__ inline double sample_source_spectrum(const ModelDev &m,
   if (origin != 0) {
     if (m.continuous_spectrum_type == 0)
       return m.continuous_mono_frequency;
+    if (m.continuous_spectrum_type == 2)
+      return sample_spectrum_table(m.spectrum_table[1], rng);
     return sample_planck_table(m.spectra->planck2_cdf, m.spectra->planck2_logcdf,
                                m.spectra->planck2_logfreq,
                                m.spectra->planck2_guide, rng);
@@ -79,6 +92,8 @@ __device__ inline double sample_source_spectrum(const ModelDev &m,
      * (src/MonochromaticPhotonSourceSpectrum.hpp:97-100) */
     return m.mono_frequency;
   }
+  if (m.spectrum_type == 2)
+    return sample_spectrum_table(m.spectrum_table[0], rng);
   return sample_planck(m.spectra, rng);
 }
 

@@ -69,6 +69,11 @@ struct cmi_gpu_engine {
   TablesDev *host_tables = nullptr; /* host copy, for host-side tabulation */
   SpectraDev *spectra = nullptr;
   bool spectra_dirty = true; /* cross sections / spectrum changed */
+  /* caller-supplied tables (cmi_gpu_set_*_table): [0], [1] the spectra of the
+   * discrete / continuous sources, [2] cross sections, [3] recombination
+   * rates - device copy {x[n], y[rows][n]} and the host's */
+  double *user_table[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<double> user_table_host[4];
   /* counters the host needs between launches: pinned host memory, mapped */
   unsigned int *mailbox = nullptr, *mailbox_dev = nullptr;
   double *source_position = nullptr;
@@ -569,6 +574,54 @@ void build_tables(TablesDev &t) {
                   std::pow(2. * M_PI * CMI_ELECTRON_MASS, 1.5));
 }
 
+/* the model as the HOST evaluates it (tabulating spectra, the reference cross
+ * section of the sort key): the tables' host copies instead of the device's */
+ModelDev host_model_of(const cmi_gpu_engine *e) {
+  ModelDev m = e->model;
+  m.tables = e->host_tables;
+  TableDev *t[4] = {&m.spectrum_table[0], &m.spectrum_table[1], &m.xsec_table,
+                    &m.recomb_table};
+  for (int k = 0; k < 4; ++k) {
+    if (t[k]->n > 0) {
+      t[k]->x = e->user_table_host[k].data();
+      t[k]->y = e->user_table_host[k].data() + t[k]->n;
+    }
+  }
+  return m;
+}
+
+/* store a caller-supplied table: n abscissae and rows x n values */
+int store_user_table(cmi_gpu_engine *e, int which, TableDev &t, int32_t n,
+                     int rows, const double *x, const double *y,
+                     int32_t interpolation) {
+  HIP_TRY(hipSetDevice(e->device));
+  /* (kernels of an earlier call may still read the old table) */
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::vector<double> &h = e->user_table_host[which];
+  h.assign(x, x + n);
+  h.insert(h.end(), y, y + (size_t)rows * (size_t)n);
+  (void)hipFree(e->user_table[which]);
+  e->user_table[which] = nullptr;
+  HIP_TRY(hipMalloc(&e->user_table[which], sizeof(double) * h.size()));
+  HIP_TRY(hipMemcpy(e->user_table[which], h.data(), sizeof(double) * h.size(),
+                    hipMemcpyHostToDevice));
+  t.x = e->user_table[which];
+  t.y = e->user_table[which] + n;
+  t.n = n;
+  t.interpolation = interpolation;
+  return CMI_GPU_OK;
+}
+
+/* n >= 2 abscissae, finite and in strictly ascending order */
+bool table_abscissae_ok(int32_t n, const double *x) {
+  if (n < 2 || !x)
+    return false;
+  for (int32_t i = 0; i < n; ++i)
+    if (!std::isfinite(x[i]) || (i > 0 && !(x[i] > x[i - 1])))
+      return false;
+  return true;
+}
+
 /* the guide table of a cumulative distribution (SpectraDev) */
 void build_guide(const double *cdf, uint16_t *guide) {
   uint32_t last = 0; /* last entry below the current k / G */
@@ -725,8 +778,7 @@ int ensure_spectra(cmi_gpu_engine *e) {
     return CMI_GPU_OK;
   if (!e->spectra)
     HIP_TRY(hipMalloc(&e->spectra, sizeof(SpectraDev)));
-  ModelDev host_model = e->model;
-  host_model.tables = e->host_tables;
+  const ModelDev host_model = host_model_of(e);
   SpectraDev *host = new SpectraDev;
   build_spectra(host_model, *host);
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -977,6 +1029,8 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->temp_pipe_counts);
   (void)hipFree(e->tables);
   (void)hipFree(e->spectra);
+  for (int k = 0; k < 4; ++k)
+    (void)hipFree(e->user_table[k]);
   delete e->host_tables;
   (void)hipFree(e->source_position);
   (void)hipFree(e->source_cumulative);
@@ -1157,6 +1211,96 @@ int cmi_gpu_set_spectrum_planck(cmi_gpu_engine *e, double temperature) {
   e->model.planck_temperature = temperature;
   e->have_spectrum = true;
   e->spectra_dirty = true;
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_spectrum_table(cmi_gpu_engine *e, int32_t role, int32_t n,
+                               const double *frequency,
+                               const double *cumulative,
+                               int32_t interpolation) {
+  if (!e || (role != CMI_GPU_ROLE_SOURCE && role != CMI_GPU_ROLE_CONTINUOUS) ||
+      !frequency || !table_abscissae_ok(n, cumulative) ||
+      (interpolation != CMI_GPU_TABLE_LINEAR &&
+       interpolation != CMI_GPU_TABLE_LOGLOG))
+    return fail(CMI_GPU_EINVAL,
+                "cmi_gpu_set_spectrum_table: needs n >= 2 frequencies and a "
+                "strictly ascending cumulative distribution");
+  if (cumulative[0] < 0. || cumulative[0] > 1.e-9 ||
+      std::abs(cumulative[n - 1] - 1.) > 1.e-9)
+    return fail(CMI_GPU_EINVAL,
+                "cmi_gpu_set_spectrum_table: the cumulative distribution must "
+                "run from 0 to 1 (%g ... %g)",
+                cumulative[0], cumulative[n - 1]);
+  for (int32_t i = 0; i < n; ++i)
+    if (!(frequency[i] > 0.) || !std::isfinite(frequency[i]))
+      return fail(CMI_GPU_EINVAL,
+                  "cmi_gpu_set_spectrum_table: frequency %d is not positive",
+                  i);
+  int rc = store_user_table(e, role, e->model.spectrum_table[role], n, 1,
+                            cumulative, frequency, interpolation);
+  if (rc)
+    return rc;
+  if (role == CMI_GPU_ROLE_SOURCE) {
+    e->model.spectrum_type = CMI_GPU_SPECTRUM_TABLE;
+    e->have_spectrum = true;
+  } else {
+    e->model.continuous_spectrum_type = CMI_GPU_SPECTRUM_TABLE;
+    e->have_continuous_spectrum = true;
+  }
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_cross_sections_table(cmi_gpu_engine *e, int32_t n,
+                                     const double *frequency,
+                                     const double *sigma,
+                                     int32_t interpolation) {
+  if (!e || !sigma || !table_abscissae_ok(n, frequency) ||
+      !(frequency[0] > 0.) ||
+      (interpolation != CMI_GPU_TABLE_LINEAR &&
+       interpolation != CMI_GPU_TABLE_LOGLOG))
+    return fail(CMI_GPU_EINVAL,
+                "cmi_gpu_set_cross_sections_table: needs n >= 2 positive, "
+                "strictly ascending frequencies and sigma[14][n]");
+  for (size_t i = 0; i < (size_t)CMI_NION * (size_t)n; ++i)
+    if (!(sigma[i] >= 0.) || !std::isfinite(sigma[i]))
+      return fail(CMI_GPU_EINVAL,
+                  "cmi_gpu_set_cross_sections_table: cross section %zu of ion "
+                  "%zu is negative or not finite",
+                  i % (size_t)n, i / (size_t)n);
+  int rc = store_user_table(e, 2, e->model.xsec_table, n, CMI_NION, frequency,
+                            sigma, interpolation);
+  if (rc)
+    return rc;
+  e->model.xsec_verner = 2;
+  e->have_xsec = true;
+  e->spectra_dirty = true;
+  update_full_flag(e);
+  return CMI_GPU_OK;
+}
+
+int cmi_gpu_set_recombination_rates_table(cmi_gpu_engine *e, int32_t n,
+                                          const double *temperature,
+                                          const double *alpha,
+                                          int32_t interpolation) {
+  if (!e || !alpha || !table_abscissae_ok(n, temperature) ||
+      !(temperature[0] > 0.) ||
+      (interpolation != CMI_GPU_TABLE_LINEAR &&
+       interpolation != CMI_GPU_TABLE_LOGLOG))
+    return fail(CMI_GPU_EINVAL,
+                "cmi_gpu_set_recombination_rates_table: needs n >= 2 positive, "
+                "strictly ascending temperatures and alpha[14][n]");
+  for (size_t i = 0; i < (size_t)CMI_NION * (size_t)n; ++i)
+    if (!(alpha[i] >= 0.) || !std::isfinite(alpha[i]))
+      return fail(CMI_GPU_EINVAL,
+                  "cmi_gpu_set_recombination_rates_table: rate %zu of ion %zu "
+                  "is negative or not finite",
+                  i % (size_t)n, i / (size_t)n);
+  int rc = store_user_table(e, 3, e->model.recomb_table, n, CMI_NION,
+                            temperature, alpha, interpolation);
+  if (rc)
+    return rc;
+  e->model.recomb_verner = 2;
+  e->have_recomb = true;
   return CMI_GPU_OK;
 }
 
@@ -1900,8 +2044,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   double sigma_ref = 1.;
   if (e->full_ions) {
     double sigma_He;
-    ModelDev host_model = e->model;
-    host_model.tables = e->host_tables;
+    const ModelDev host_model = host_model_of(e);
     cmi_cross_sections_H_He(host_model, 1.0001 * e->model.nu_H, sigma_ref,
                             sigma_He);
   }

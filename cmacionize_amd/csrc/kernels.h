@@ -190,6 +190,12 @@ struct ShootArgs {
   /* xin rows hold the long index of the entered cell in THIS engine's grid
    * (flights left over by the tile rounds) instead of the whole grid's */
   int32_t xin_local;
+#ifdef CMI_DBG_XIN_SLOTS
+  /* (the episode of DESIGN_LOG.md "A result that changed with one more kernel
+   * argument": the member and the indirection of commit 3e4ff5c, for
+   * tools/debug/episode.sh) */
+  const uint32_t *xin_slots = nullptr;
+#endif
   ExchangeDev xout;
   /* PAD kernels: n x_H of every cell of the grid with CMI_PAD_LAYERS layers
    * of ghost cells around it (pad_record_kernel): -0. marks a vacuum cell
@@ -1211,7 +1217,13 @@ __global__ void
         bool mine = true;
         if (!PRE && a.xin != nullptr) {
           /* a flight handed over by another block of the grid */
+#ifdef CMI_DBG_XIN_SLOTS
+          const uint64_t row =
+              (a.xin_local && a.xin_slots) ? (uint64_t)a.xin_slots[i] : i;
+          const double *r = a.xin + (size_t)CMI_FLIGHT_DOUBLES * row;
+#else
           const double *r = a.xin + (size_t)CMI_FLIGHT_DOUBLES * i;
+#endif
           int64_t cell_global;
           unsigned long long idmeta;
           if (a.xin_local) {
@@ -2572,6 +2584,10 @@ __device__ inline float approximate_opacity_cross_section(const ModelDev &m,
   if (!m.xsec_verner)
     return (float)(m.xsec_fixed[ION_H_n] +
                    m.abundance[0] * m.xsec_fixed[ION_He_n]);
+  if (m.xsec_verner == 2)
+    return (float)(cmi_table_value(m.xsec_table, ION_H_n, nu) +
+                   m.abundance[0] *
+                       cmi_table_value(m.xsec_table, ION_He_n, nu));
   const VernerTermDev *terms = m.tables->verner;
   float sum = 0.f;
   for (int k = 0; k < CMI_VERNER_NTERM_DEV; ++k) {

@@ -27,6 +27,9 @@ FIELD_HEATING = 30
 
 REEMIT_NONE, REEMIT_PHYSICAL, REEMIT_FIXED = 0, 1, 2
 CONTINUOUS_NONE, CONTINUOUS_ISOTROPIC, CONTINUOUS_PLANAR = 0, 1, 2
+# cmi_gpu_set_*_table (the generic lowering of a plugin into a table)
+ROLE_SOURCE, ROLE_CONTINUOUS = 0, 1
+TABLE_LINEAR, TABLE_LOGLOG = 0, 1
 
 _dp = C.POINTER(C.c_double)
 
@@ -66,6 +69,8 @@ EXPORTED_SYMBOLS = [
     "cmi_gpu_set_continuous_spectrum_monochromatic",
     "cmi_gpu_set_continuous_spectrum_planck",
     "cmi_gpu_set_cross_sections_fixed", "cmi_gpu_set_cross_sections_verner",
+    "cmi_gpu_set_spectrum_table", "cmi_gpu_set_cross_sections_table",
+    "cmi_gpu_set_recombination_rates_table",
     "cmi_gpu_set_recombination_rates_fixed",
     "cmi_gpu_set_recombination_rates_verner", "cmi_gpu_set_abundances",
     "cmi_gpu_set_reemission", "cmi_gpu_set_temperature_params",
@@ -145,6 +150,12 @@ def load_library():
     L.cmi_gpu_set_continuous_spectrum_monochromatic.argtypes = [vp, C.c_double]
     L.cmi_gpu_set_continuous_spectrum_planck.argtypes = [vp, C.c_double]
     L.cmi_gpu_set_cross_sections_fixed.argtypes = [vp, _dp]
+    L.cmi_gpu_set_spectrum_table.argtypes = [vp, C.c_int32, C.c_int32, _dp,
+                                             _dp, C.c_int32]
+    L.cmi_gpu_set_cross_sections_table.argtypes = [vp, C.c_int32, _dp, _dp,
+                                                   C.c_int32]
+    L.cmi_gpu_set_recombination_rates_table.argtypes = [vp, C.c_int32, _dp,
+                                                        _dp, C.c_int32]
     L.cmi_gpu_set_cross_sections_verner.argtypes = [vp]
     L.cmi_gpu_set_recombination_rates_fixed.argtypes = [vp, _dp]
     L.cmi_gpu_set_recombination_rates_verner.argtypes = [vp]
@@ -387,6 +398,33 @@ class GpuEngine:
     def set_spectrum_planck(self, temperature):
         self._check(self._lib.cmi_gpu_set_spectrum_planck(self._h,
                                                           temperature))
+
+    def set_spectrum_table(self, frequency, cumulative, role=ROLE_SOURCE,
+                           interpolation=TABLE_LINEAR):
+        """Generic lowering of a PhotonSourceSpectrum: its quantile function
+        (cumulative[n] from 0 to 1 -> frequency[n] in Hz)."""
+        f, c = _f64(frequency), _f64(cumulative)
+        assert f.shape == c.shape and f.ndim == 1
+        self._check(self._lib.cmi_gpu_set_spectrum_table(
+            self._h, role, len(f), _p(f), _p(c), interpolation))
+
+    def set_cross_sections_table(self, frequency, sigma,
+                                 interpolation=TABLE_LINEAR):
+        """Generic lowering of CrossSections: sigma[14][n] (m^2) on the
+        frequencies frequency[n] (Hz)."""
+        f, s = _f64(frequency), _f64(sigma)
+        assert s.shape == (NION, len(f))
+        self._check(self._lib.cmi_gpu_set_cross_sections_table(
+            self._h, len(f), _p(f), _p(s), interpolation))
+
+    def set_recombination_rates_table(self, temperature, alpha,
+                                      interpolation=TABLE_LOGLOG):
+        """Generic lowering of RecombinationRates: alpha[14][n] (m^3 s^-1) on
+        the temperatures temperature[n] (K)."""
+        t, a = _f64(temperature), _f64(alpha)
+        assert a.shape == (NION, len(t))
+        self._check(self._lib.cmi_gpu_set_recombination_rates_table(
+            self._h, len(t), _p(t), _p(a), interpolation))
 
     def set_cross_sections_fixed(self, sigma):
         s = _f64(sigma)

@@ -7,8 +7,15 @@
  * virtual functions. Here they run on the host once, at initialisation, and
  * are LOWERED into the flat descriptors of the C ABI (include/cmi_gpu.h):
  * every concrete class below has a lower() that makes the matching
- * cmi_gpu_set_* call. A third-party plugin ports by recompiling against these
- * headers and adding its lower().
+ * cmi_gpu_set_* call. A plugin that implements ONLY the reference's virtuals
+ * - a third-party class recompiled against these headers - inherits the
+ * generic lower() of its base class: the virtual is sampled on the host into a
+ * table (tabulate_spectrum / tabulate_cross_sections /
+ * tabulate_recombination_rates) that goes to the device through
+ * cmi_gpu_set_spectrum_table / cmi_gpu_set_cross_sections_table /
+ * cmi_gpu_set_recombination_rates_table, and is made known to the factories
+ * with register_photon_source_spectrum() / register_cross_sections() /
+ * register_recombination_rates().
  *
  * Reference interfaces mirrored (signatures kept):
  *   Cell                         src/Cell.hpp
@@ -29,9 +36,12 @@
 #include "Hdf5Reader.hpp"
 #include "ParameterFile.hpp"
 
+#include <algorithm>
 #include <array>
 #include <cfloat>
 #include <cmath>
+#include <functional>
+#include <map>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -1393,20 +1403,195 @@ generate_photon_source_distribution(ParameterFile &params) {
 
 /* -------------------------------------------------- PhotonSourceSpectrum */
 
-class RandomGenerator; /* per-packet streams live on the device */
+/* RandomGenerator with the interface of src/RandomGenerator.hpp:207-236. On
+ * this path the per-packet streams live on the device; the host's generator
+ * exists for plugins that are known only through
+ * PhotonSourceSpectrum::get_random_frequency: the generic lowering hands them
+ * a generator whose NEXT uniform it dictates (script()) and counts the draws
+ * (draws()), or lets it run free (a SplitMix64 stream: the reference's ranlxd
+ * is not reproduced, nothing depends on the host stream's values). */
+class RandomGenerator {
+  uint64_t _state;
+  int_fast32_t _seed;
+  bool _scripted = false;
+  double _script_value = 0.5;
+  uint64_t _draws = 0;
+
+  uint64_t next_bits() {
+    uint64_t z = (_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+
+public:
+  RandomGenerator(int_fast32_t seed = 42) { set_seed(seed); }
+  void set_seed(int_fast32_t seed) {
+    _seed = seed;
+    _state = (uint64_t)seed * 0xD1342543DE82EF95ull + 1ull;
+  }
+  int_fast32_t get_seed() const { return _seed; }
+  /* uniform in the open interval (0, 1) */
+  double get_uniform_random_double() {
+    ++_draws;
+    if (_scripted)
+      return _script_value;
+    return ((double)(next_bits() >> 12) + 0.5) * 0x1.0p-52;
+  }
+  int_fast32_t get_random_integer() {
+    ++_draws;
+    return (int_fast32_t)(next_bits() >> 33);
+  }
+  /* every following draw returns `value` (until unscript()) */
+  void script(double value) {
+    _scripted = true;
+    _script_value = value;
+    _draws = 0;
+  }
+  void unscript() {
+    _scripted = false;
+    _draws = 0;
+  }
+  uint64_t draws() const { return _draws; }
+};
+
+class PhotonSourceSpectrum;
+/* a spectrum as its quantile function: cumulative[k] -> frequency[k] */
+struct SpectrumTable {
+  std::vector<double> frequency, cumulative;
+  int32_t interpolation = CMI_GPU_TABLE_LINEAR;
+  /* how the table was obtained: "scripted" (the virtual is a monotone
+   * function of ONE uniform - every sampler of the reference is - and was
+   * evaluated on a grid of it) or "empirical" (quantiles of 2^20 draws) */
+  const char *method = "";
+};
+inline SpectrumTable tabulate_spectrum(const PhotonSourceSpectrum &spectrum,
+                                       size_t n = 8193);
 
 class PhotonSourceSpectrum {
 public:
   virtual ~PhotonSourceSpectrum() {}
-  /* per-packet virtual of the reference; on this path spectra are sampled on
-   * the device from the descriptor set by lower() */
+  /* per-packet virtual of the reference (src/PhotonSourceSpectrum.hpp:48-50);
+   * on this path spectra are sampled on the device from the descriptor set by
+   * lower() */
   virtual double get_random_frequency(RandomGenerator &random_generator,
                                       double temperature = 0.) const = 0;
   virtual double get_total_flux() const = 0;
-  virtual int lower(cmi_gpu_engine *engine) const = 0;
+  /* Generic lowering: a class that implements only the two
+   * virtuals above is sampled on the host into its quantile function, which
+   * the device reads with one uniform per packet - the reference's own table
+   * samplers do the same with their own tables. Classes the device knows in
+   * closed form override this. */
+  virtual int lower(cmi_gpu_engine *engine) const {
+    const SpectrumTable t = tabulate_spectrum(*this);
+    return cmi_gpu_set_spectrum_table(engine, CMI_GPU_ROLE_SOURCE,
+                                      (int32_t)t.frequency.size(),
+                                      t.frequency.data(), t.cumulative.data(),
+                                      t.interpolation);
+  }
   /* the same spectrum in the role of ContinuousPhotonSourceSpectrum */
-  virtual int lower_continuous(cmi_gpu_engine *engine) const = 0;
+  virtual int lower_continuous(cmi_gpu_engine *engine) const {
+    const SpectrumTable t = tabulate_spectrum(*this);
+    return cmi_gpu_set_spectrum_table(engine, CMI_GPU_ROLE_CONTINUOUS,
+                                      (int32_t)t.frequency.size(),
+                                      t.frequency.data(), t.cumulative.data(),
+                                      t.interpolation);
+  }
+  /* --describe */
+  virtual std::string describe() const { return "\"Table\""; }
 };
+
+/* The quantile function of a spectrum from get_random_frequency alone. First
+ * with dictated uniforms u_k = k / (n - 1) (the ends moved half an ulp into
+ * the open interval): if every call consumes exactly one uniform and the
+ * frequencies are monotone in it, they ARE the quantile function on that grid
+ * (ascending as they are, or read backwards for a sampler that uses 1 - u).
+ * Otherwise (rejection samplers, several uniforms) the quantiles of 2^20 free
+ * draws. */
+inline SpectrumTable tabulate_spectrum(const PhotonSourceSpectrum &spectrum,
+                                       size_t n) {
+  SpectrumTable t;
+  t.frequency.resize(n);
+  t.cumulative.resize(n);
+  for (size_t k = 0; k < n; ++k)
+    t.cumulative[k] = (double)k / (double)(n - 1);
+  RandomGenerator rg(42);
+  bool one_draw = true, ascending = true, descending = true;
+  for (size_t k = 0; k < n && one_draw; ++k) {
+    const double u = std::min(std::max(t.cumulative[k], 0x1.0p-53),
+                              1. - 0x1.0p-53);
+    rg.script(u);
+    t.frequency[k] = spectrum.get_random_frequency(rg, 0.);
+    one_draw = rg.draws() == 1 || (rg.draws() == 0 && k > 0 &&
+                                   t.frequency[k] == t.frequency[0]);
+    if (rg.draws() == 0 && k == 0) {
+      /* no uniform at all: a line spectrum */
+      std::fill(t.frequency.begin(), t.frequency.end(), t.frequency[0]);
+      t.method = "scripted";
+      return t;
+    }
+    if (k > 0) {
+      ascending &= t.frequency[k] >= t.frequency[k - 1];
+      descending &= t.frequency[k] <= t.frequency[k - 1];
+    }
+  }
+  if (one_draw && (ascending || descending)) {
+    if (!ascending)
+      std::reverse(t.frequency.begin(), t.frequency.end());
+    t.method = "scripted";
+    return t;
+  }
+  rg.unscript();
+  const size_t ndraw = (size_t)1 << 20;
+  std::vector<double> draws(ndraw);
+  for (double &d : draws)
+    d = spectrum.get_random_frequency(rg, 0.);
+  std::sort(draws.begin(), draws.end());
+  for (size_t k = 0; k < n; ++k)
+    t.frequency[k] = draws[(size_t)((double)k / (double)(n - 1) *
+                                    (double)(ndraw - 1))];
+  t.method = "empirical";
+  return t;
+}
+
+/* src/UniformPhotonSourceSpectrum.hpp:36-73: flat between 13.6 and 54.4 eV -
+ * the reference's class as it stands, known to this path through its virtuals
+ * alone (it goes to the device by the generic lowering above) */
+class UniformPhotonSourceSpectrum : public PhotonSourceSpectrum {
+public:
+  double get_random_frequency(RandomGenerator &random_generator,
+                              double = 0.) const override {
+    return (1. + 3. * random_generator.get_uniform_random_double()) * 3.289e15;
+  }
+  double get_total_flux() const override {
+    throw ParameterError("This function should not be used!");
+  }
+  std::string describe() const override { return "\"Uniform\""; }
+};
+
+/* plugins from outside this header: name -> constructor, consulted by the
+ * factories for any "<Block>:type" they do not know themselves (the
+ * reference's factories are if-chains one adds a branch to,
+ * src/PhotonSourceSpectrumFactory.hpp:93-113) */
+template <typename Plugin, typename... Args> class PluginRegistry {
+public:
+  typedef std::function<Plugin *(Args...)> Constructor;
+  static std::map<std::string, Constructor> &table() {
+    static std::map<std::string, Constructor> t;
+    return t;
+  }
+  static Plugin *create(const std::string &type, Args... args) {
+    auto it = table().find(type);
+    return it == table().end() ? nullptr : it->second(args...);
+  }
+};
+typedef PluginRegistry<PhotonSourceSpectrum, const std::string &,
+                       ParameterFile &>
+    PhotonSourceSpectrumRegistry;
+inline void register_photon_source_spectrum(
+    const std::string &type, PhotonSourceSpectrumRegistry::Constructor make) {
+  PhotonSourceSpectrumRegistry::table()[type] = make;
+}
 
 /* src/MonochromaticPhotonSourceSpectrum.hpp:40-113 */
 class MonochromaticPhotonSourceSpectrum : public PhotonSourceSpectrum {
@@ -1486,8 +1671,17 @@ generate_photon_source_spectrum(const std::string &role,
     return new MonochromaticPhotonSourceSpectrum(role, params);
   if (type == "Planck")
     return new PlanckPhotonSourceSpectrum(role, params);
+  if (type == "Uniform")
+    return new UniformPhotonSourceSpectrum();
   if (type == "None")
     return nullptr;
+  if (PhotonSourceSpectrum *plugin =
+          PhotonSourceSpectrumRegistry::create(type, role, params))
+    return plugin;
+  /* (the reference's other five - FaucherGiguere, Pegase3, PopStar, WMBasic,
+   * CastelliKurucz, Masked - read data files the reference ships under
+   * data/, which are not part of this path; a class that reads them and
+   * implements get_random_frequency plugs in through the registry) */
   throw ParameterError("Unknown PhotonSourceSpectrum type: \"" + type + "\"");
 }
 
@@ -1590,13 +1784,88 @@ generate_continuous_photon_source(const double box_sides[3],
 
 /* -------------------------------------- CrossSections / RecombinationRates */
 
+/* 14 functions of one argument sampled on a common grid */
+struct IonTable {
+  std::vector<double> x;
+  std::vector<double> y; /* [NUMBER_OF_IONNAMES][x.size()] */
+  int32_t interpolation = CMI_GPU_TABLE_LOGLOG;
+};
+/* f(ion, x) for the 14 ions on n logarithmically spaced points of
+ * [lo, hi], plus - where a function jumps between two neighbouring points
+ * (from zero to a finite value, or by more than a factor of 2: an ionization
+ * threshold) - the two sides of the jump, found by bisection down to one ulp:
+ * the table then has the jump between two adjacent samples */
+template <typename F>
+inline IonTable tabulate_ions(F f, double lo, double hi, size_t n) {
+  std::vector<double> x(n);
+  for (size_t k = 0; k < n; ++k)
+    x[k] = lo * std::exp(std::log(hi / lo) * (double)k / (double)(n - 1));
+  x[n - 1] = hi;
+  auto jumps = [&](double a, double b) {
+    for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion) {
+      const double fa = f(ion, a), fb = f(ion, b);
+      if ((fa == 0.) != (fb == 0.) || fa > 2. * fb || fb > 2. * fa)
+        return true;
+    }
+    return false;
+  };
+  std::vector<double> extra;
+  for (size_t k = 0; k + 1 < n; ++k) {
+    if (!jumps(x[k], x[k + 1]))
+      continue;
+    double a = x[k], b = x[k + 1];
+    for (int step = 0; step < 80 && std::nextafter(a, b) < b; ++step) {
+      const double mid = 0.5 * (a + b);
+      if (jumps(a, mid))
+        b = mid;
+      else
+        a = mid;
+    }
+    if (a > x[k])
+      extra.push_back(a);
+    if (b < x[k + 1])
+      extra.push_back(b);
+  }
+  x.insert(x.end(), extra.begin(), extra.end());
+  std::sort(x.begin(), x.end());
+  x.erase(std::unique(x.begin(), x.end()), x.end());
+  IonTable t;
+  t.x = x;
+  t.y.resize((size_t)NUMBER_OF_IONNAMES * x.size());
+  for (int ion = 0; ion < NUMBER_OF_IONNAMES; ++ion)
+    for (size_t k = 0; k < x.size(); ++k)
+      t.y[(size_t)ion * x.size() + k] = f(ion, x[k]);
+  return t;
+}
+
 class CrossSections {
 public:
   virtual ~CrossSections() {}
+  /* src/CrossSections.hpp:49-50 (energy: the photon's frequency in Hz) */
   virtual double get_cross_section(const int_fast32_t ion,
                                    const double energy) const = 0;
-  virtual int lower(cmi_gpu_engine *engine) const = 0;
+  /* the virtual on 4096 frequencies between 1e15 Hz (4.1 eV) and 1e17 Hz
+   * (414 eV) - every spectrum of this path lies in [13.6, 54.4] eV - with the
+   * thresholds resolved (tabulate_ions) */
+  IonTable tabulate() const {
+    return tabulate_ions(
+        [this](int ion, double nu) { return get_cross_section(ion, nu); },
+        1.e15, 1.e17, 4096);
+  }
+  /* generic lowering: a class that implements only get_cross_section */
+  virtual int lower(cmi_gpu_engine *engine) const {
+    const IonTable t = tabulate();
+    return cmi_gpu_set_cross_sections_table(engine, (int32_t)t.x.size(),
+                                            t.x.data(), t.y.data(),
+                                            t.interpolation);
+  }
+  virtual std::string describe() const { return "\"Table\""; }
 };
+typedef PluginRegistry<CrossSections, ParameterFile &> CrossSectionsRegistry;
+inline void register_cross_sections(const std::string &type,
+                                    CrossSectionsRegistry::Constructor make) {
+  CrossSectionsRegistry::table()[type] = make;
+}
 
 /* parameter key of an ion's cross section / of the ion that recombines INTO
  * it (src/FixedValueCrossSections.hpp:113-146,
@@ -1652,16 +1921,38 @@ inline CrossSections *generate_cross_sections(ParameterFile &params) {
     return new FixedValueCrossSections(params);
   if (type == "Verner")
     return new VernerCrossSections();
+  if (CrossSections *plugin = CrossSectionsRegistry::create(type, params))
+    return plugin;
   throw ParameterError("Unknown CrossSections type: \"" + type + "\"");
 }
 
 class RecombinationRates {
 public:
   virtual ~RecombinationRates() {}
+  /* src/RecombinationRates.hpp:49 */
   virtual double get_recombination_rate(const int_fast32_t ion,
                                         const double temperature) const = 0;
-  virtual int lower(cmi_gpu_engine *engine) const = 0;
+  /* the virtual on 2048 temperatures between 10 K and 1e9 K */
+  IonTable tabulate() const {
+    return tabulate_ions(
+        [this](int ion, double T) { return get_recombination_rate(ion, T); },
+        10., 1.e9, 2048);
+  }
+  /* generic lowering: a class that implements only get_recombination_rate */
+  virtual int lower(cmi_gpu_engine *engine) const {
+    const IonTable t = tabulate();
+    return cmi_gpu_set_recombination_rates_table(
+        engine, (int32_t)t.x.size(), t.x.data(), t.y.data(), t.interpolation);
+  }
+  virtual std::string describe() const { return "\"Table\""; }
 };
+typedef PluginRegistry<RecombinationRates, ParameterFile &>
+    RecombinationRatesRegistry;
+inline void
+register_recombination_rates(const std::string &type,
+                             RecombinationRatesRegistry::Constructor make) {
+  RecombinationRatesRegistry::table()[type] = make;
+}
 
 class FixedValueRecombinationRates : public RecombinationRates {
   double _rates[NUMBER_OF_IONNAMES];
@@ -1702,6 +1993,9 @@ inline RecombinationRates *generate_recombination_rates(ParameterFile &params) {
     return new FixedValueRecombinationRates(params);
   if (type == "Verner")
     return new VernerRecombinationRates();
+  if (RecombinationRates *plugin =
+          RecombinationRatesRegistry::create(type, params))
+    return plugin;
   throw ParameterError("Unknown RecombinationRates type: \"" + type + "\"");
 }
 

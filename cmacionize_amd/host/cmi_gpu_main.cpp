@@ -63,6 +63,16 @@ static void describe(GpuIonizationSimulation &sim) {
                dynamic_cast<PlanckPhotonSourceSpectrum *>(sim.spectrum()))
     std::cout << "  \"spectrum\": {\"type\": \"Planck\", \"temperature\": "
               << pl->get_temperature() << "},\n";
+  else if (sim.spectrum()) {
+    /* known through its virtuals alone: what the generic lowering made of it */
+    const SpectrumTable table = tabulate_spectrum(*sim.spectrum());
+    std::cout << "  \"spectrum\": {\"type\": " << sim.spectrum()->describe()
+              << ", \"lowering\": \"" << table.method
+              << "\", \"samples\": " << table.frequency.size()
+              << ", \"minimum_frequency\": " << table.frequency.front()
+              << ", \"maximum_frequency\": " << table.frequency.back()
+              << "},\n";
+  }
   std::cout << "  \"cross_sections\": ";
   if (dynamic_cast<FixedValueCrossSections *>(sim.cross_sections())) {
     std::cout << "[";
@@ -70,8 +80,12 @@ static void describe(GpuIonizationSimulation &sim) {
       std::cout << (ion ? ", " : "")
                 << sim.cross_sections()->get_cross_section(ion, 0.);
     std::cout << "],\n";
-  } else {
+  } else if (dynamic_cast<VernerCrossSections *>(sim.cross_sections())) {
     std::cout << "\"Verner\",\n";
+  } else {
+    std::cout << "{\"type\": " << sim.cross_sections()->describe()
+              << ", \"samples\": " << sim.cross_sections()->tabulate().x.size()
+              << "},\n";
   }
   std::cout << "  \"recombination_rates\": ";
   if (dynamic_cast<FixedValueRecombinationRates *>(sim.recombination_rates())) {
@@ -80,8 +94,13 @@ static void describe(GpuIonizationSimulation &sim) {
       std::cout << (ion ? ", " : "")
                 << sim.recombination_rates()->get_recombination_rate(ion, 0.);
     std::cout << "],\n";
-  } else {
+  } else if (dynamic_cast<VernerRecombinationRates *>(
+                 sim.recombination_rates())) {
     std::cout << "\"Verner\",\n";
+  } else {
+    std::cout << "{\"type\": " << sim.recombination_rates()->describe()
+              << ", \"samples\": "
+              << sim.recombination_rates()->tabulate().x.size() << "},\n";
   }
   std::cout << "  \"abundances\": [";
   for (int i = 0; i < 6; ++i)

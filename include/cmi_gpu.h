@@ -61,7 +61,18 @@ enum {
   CMI_GPU_NFIELD = 32
 };
 
-enum { CMI_GPU_SPECTRUM_MONOCHROMATIC = 0, CMI_GPU_SPECTRUM_PLANCK = 1 };
+enum {
+  CMI_GPU_SPECTRUM_MONOCHROMATIC = 0,
+  CMI_GPU_SPECTRUM_PLANCK = 1,
+  CMI_GPU_SPECTRUM_TABLE = 2 /* cmi_gpu_set_spectrum_table */
+};
+/* which PhotonSourceSpectrum of the run a table stands for
+ * (src/IonizationSimulation.cpp:155-168: role "PhotonSourceSpectrum" of the
+ * discrete sources, role "ContinuousPhotonSourceSpectrum") */
+enum { CMI_GPU_ROLE_SOURCE = 0, CMI_GPU_ROLE_CONTINUOUS = 1 };
+/* how a table is read between two of its samples: linearly, or linearly in
+ * the logarithms (a power law through the two samples) */
+enum { CMI_GPU_TABLE_LINEAR = 0, CMI_GPU_TABLE_LOGLOG = 1 };
 enum { CMI_GPU_REEMIT_NONE = 0, CMI_GPU_REEMIT_PHYSICAL = 1,
        CMI_GPU_REEMIT_FIXED = 2 };
 
@@ -167,6 +178,49 @@ int cmi_gpu_set_spectrum_monochromatic(cmi_gpu_engine *engine,
                                        double frequency);
 /* ... for PlanckPhotonSourceSpectrum (src/PlanckPhotonSourceSpectrum.cpp:53-113,149-165) */
 int cmi_gpu_set_spectrum_planck(cmi_gpu_engine *engine, double temperature);
+
+/* GENERIC LOWERING ("unknown plugin => sample the virtual on the
+ * host into a table"). A PhotonSourceSpectrum, CrossSections or
+ * RecombinationRates implementation that is known only through the
+ * reference's virtual - a third-party plugin, or one of the reference's
+ * data-file spectra - is evaluated by the host ONCE, at initialisation, on a
+ * grid of its argument, and the device reads the table. The three entry
+ * points below take such tables (host arrays, copied); host/Plugins.hpp's base
+ * classes build them by default from the virtuals alone.
+ *
+ * replaces: PhotonSourceSpectrum::get_random_frequency
+ * (src/PhotonSourceSpectrum.hpp:48-50) of ANY spectrum, given as its quantile
+ * function: cumulative[n] strictly ascending from 0 to 1, frequency[n] (Hz)
+ * the frequency below which that fraction of the photons lies. A packet draws
+ * one uniform x, Utilities::locate finds its interval of cumulative[]
+ * (src/Utilities.hpp:726-742) and the frequency is interpolated between the
+ * interval's ends - CMI_GPU_TABLE_LINEAR as
+ * src/HeliumTwoPhotonContinuumSpectrum.cpp:167-180 does, CMI_GPU_TABLE_LOGLOG
+ * as src/PlanckPhotonSourceSpectrum.cpp:149-165 does. role: CMI_GPU_ROLE_*. */
+int cmi_gpu_set_spectrum_table(cmi_gpu_engine *engine, int32_t role, int32_t n,
+                               const double *frequency,
+                               const double *cumulative,
+                               int32_t interpolation);
+/* replaces: CrossSections::get_cross_section (src/CrossSections.hpp:49-50) of
+ * ANY implementation: frequency[n] (Hz, strictly ascending) and
+ * sigma[14][n] (m^2; ion-major, the ions in the order of
+ * src/ElementNames.hpp:101-154). Between two samples the cross section is
+ * interpolated (CMI_GPU_TABLE_*; a log-log interval with a zero in it falls
+ * back to linear), outside the table it keeps the end values: a jump at an
+ * ionization threshold is two neighbouring samples. The run then carries all
+ * 14 cross sections per packet, as with VernerCrossSections. */
+int cmi_gpu_set_cross_sections_table(cmi_gpu_engine *engine, int32_t n,
+                                     const double *frequency,
+                                     const double *sigma,
+                                     int32_t interpolation);
+/* replaces: RecombinationRates::get_recombination_rate
+ * (src/RecombinationRates.hpp:49) of ANY implementation: temperature[n] (K,
+ * strictly ascending), alpha[14][n] (m^3 s^-1, indexed by the recombined
+ * ion). */
+int cmi_gpu_set_recombination_rates_table(cmi_gpu_engine *engine, int32_t n,
+                                          const double *temperature,
+                                          const double *alpha,
+                                          int32_t interpolation);
 
 /* replaces: CrossSections::get_cross_section for FixedValueCrossSections
  * (src/FixedValueCrossSections.hpp:151-154); sigma: host [14] (m^2) */

@@ -79,9 +79,31 @@ enum {
   CMIO_NTYPE = 4
 };
 
-enum { CMIO_SPECTRUM_MONOCHROMATIC = 0, CMIO_SPECTRUM_PLANCK = 1 };
-enum { CMIO_XSEC_FIXED = 0, CMIO_XSEC_VERNER = 1 };
-enum { CMIO_RECOMB_FIXED = 0, CMIO_RECOMB_VERNER = 1 };
+enum {
+  CMIO_SPECTRUM_MONOCHROMATIC = 0,
+  CMIO_SPECTRUM_PLANCK = 1,
+  CMIO_SPECTRUM_TABLE = 2
+};
+enum { CMIO_XSEC_FIXED = 0, CMIO_XSEC_VERNER = 1, CMIO_XSEC_TABLE = 2 };
+enum { CMIO_RECOMB_FIXED = 0, CMIO_RECOMB_VERNER = 1, CMIO_RECOMB_TABLE = 2 };
+enum { CMIO_TABLE_LINEAR = 0, CMIO_TABLE_LOGLOG = 1 };
+
+/* A plugin that is known only through the reference's virtual
+ * (PhotonSourceSpectrum::get_random_frequency, src/PhotonSourceSpectrum.hpp:
+ * 48-50; CrossSections::get_cross_section, src/CrossSections.hpp:49-50;
+ * RecombinationRates::get_recombination_rate, src/RecombinationRates.hpp:49),
+ * sampled on a grid of its argument: n abscissae x[] in ascending order and
+ * rows of n values y[] (1 row for a spectrum - x = cumulative distribution, y
+ * = frequency -, 14 for cross sections / rates). cmio_table_value reads it
+ * with Utilities::locate (src/Utilities.hpp:726-742) and linear or log-log
+ * interpolation, end values outside. The arrays stay the caller's. */
+typedef struct {
+  const double *x;
+  const double *y;
+  int32_t n;
+  int32_t interpolation;
+} cmio_table;
+double cmio_table_value(const cmio_table *table, int row, double x);
 enum { CMIO_REEMIT_NONE = 0, CMIO_REEMIT_PHYSICAL = 1, CMIO_REEMIT_FIXED = 2 };
 
 /* ---------------------------------------------------------------- RNG -- */
@@ -194,6 +216,11 @@ typedef struct {
   int32_t continuous_axis;
   double continuous_intercept;
   double continuous_anchor[2], continuous_side[2];
+  /* the *_TABLE types: [0] the discrete sources' spectrum, [1] the continuous
+   * source's */
+  cmio_table spectrum_table[2];
+  cmio_table xsec_table;
+  cmio_table recomb_table;
 } cmio_model;
 
 /* PhotonSource ctor, src/PhotonSource.cpp:104-130: total_luminosity,

@@ -118,9 +118,31 @@ double cmio_verner_cross_section(int ion, double energy) {
   return sigma;
 }
 
+/* a sampled plugin (cmio.h): Utilities::locate's interval
+ * (src/Utilities.hpp:726-742), linear or log-log interpolation (the forms of
+ * src/HeliumTwoPhotonContinuumSpectrum.cpp:167-180 and
+ * src/PlanckPhotonSourceSpectrum.cpp:149-165), the end values outside */
+double cmio_table_value(const cmio_table *t, int row, double x) {
+  const double *xs = t->x;
+  const double *ys = t->y + (size_t)row * (size_t)t->n;
+  const uint32_t n = (uint32_t)t->n;
+  if (!(x > xs[0]))
+    return ys[0];
+  if (!(x < xs[n - 1]))
+    return ys[n - 1];
+  const uint32_t lo = (uint32_t)cmio_locate(x, xs, n);
+  const double x0 = xs[lo], x1 = xs[lo + 1], y0 = ys[lo], y1 = ys[lo + 1];
+  if (t->interpolation == CMIO_TABLE_LOGLOG && y0 > 0. && y1 > 0. && x0 > 0.)
+    return y0 * exp(log(y1 / y0) * (log(x / x0) / log(x1 / x0)));
+  return y0 + (y1 - y0) * ((x - x0) / (x1 - x0));
+}
+
 double cmio_cross_section(const cmio_model *model, int ion, double frequency) {
   if (model->xsec_type == CMIO_XSEC_FIXED) {
     return model->xsec_fixed[ion];
+  }
+  if (model->xsec_type == CMIO_XSEC_TABLE) {
+    return cmio_table_value(&model->xsec_table, ion, frequency);
   }
   return cmio_verner_cross_section(ion, frequency);
 }
@@ -276,6 +298,9 @@ double cmio_verner_recombination_rate(int ion, double temperature) {
 double cmio_recombination_rate(const cmio_model *model, int ion, double T) {
   if (model->recomb_type == CMIO_RECOMB_FIXED) {
     return model->recomb_fixed[ion];
+  }
+  if (model->recomb_type == CMIO_RECOMB_TABLE) {
+    return cmio_table_value(&model->recomb_table, ion, T);
   }
   return cmio_verner_recombination_rate(ion, T);
 }

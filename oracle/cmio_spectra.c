@@ -196,6 +196,9 @@ double cmio_spectrum_sample(const cmio_model *model, cmio_rng *rng) {
   if (model->spectrum_type == CMIO_SPECTRUM_MONOCHROMATIC) {
     return model->mono_frequency; /* no random number drawn */
   }
+  if (model->spectrum_type == CMIO_SPECTRUM_TABLE) {
+    return cmio_table_value(&model->spectrum_table[0], 0, cmio_rng_next(rng));
+  }
   if (!model->tables) {
     cmio_set_error("cmio: Planck spectrum needs cmio_tables_create");
     return NAN;
@@ -208,6 +211,9 @@ double cmio_continuous_spectrum_sample(const cmio_model *model,
                                        cmio_rng *rng) {
   if (model->continuous_spectrum_type == CMIO_SPECTRUM_MONOCHROMATIC) {
     return model->continuous_mono_frequency;
+  }
+  if (model->continuous_spectrum_type == CMIO_SPECTRUM_TABLE) {
+    return cmio_table_value(&model->spectrum_table[1], 0, cmio_rng_next(rng));
   }
   if (!model->tables) {
     cmio_set_error("cmio: Planck spectrum needs cmio_tables_create");

@@ -19,9 +19,10 @@ NTYPE = 4
 ION_NAMES = ["H_n", "He_n", "C_p1", "C_p2", "N_n", "N_p1", "N_p2", "O_n",
              "O_p1", "Ne_n", "Ne_p1", "S_p1", "S_p2", "S_p3"]
 
-SPECTRUM_MONOCHROMATIC, SPECTRUM_PLANCK = 0, 1
-XSEC_FIXED, XSEC_VERNER = 0, 1
-RECOMB_FIXED, RECOMB_VERNER = 0, 1
+SPECTRUM_MONOCHROMATIC, SPECTRUM_PLANCK, SPECTRUM_TABLE = 0, 1, 2
+XSEC_FIXED, XSEC_VERNER, XSEC_TABLE = 0, 1, 2
+RECOMB_FIXED, RECOMB_VERNER, RECOMB_TABLE = 0, 1, 2
+TABLE_LINEAR, TABLE_LOGLOG = 0, 1
 REEMIT_NONE, REEMIT_PHYSICAL, REEMIT_FIXED = 0, 1, 2
 
 dp = C.POINTER(C.c_double)
@@ -36,6 +37,12 @@ class Cells(C.Structure):
     _fields_ = [("number_density", dp), ("temperature", dp),
                 ("ionic_fraction", dp * NION), ("mean_intensity", dp * NION),
                 ("heating", dp * 2)]
+
+
+class Table(C.Structure):
+    """cmio_table: a plugin sampled on a grid of its argument."""
+    _fields_ = [("x", dp), ("y", dp), ("n", C.c_int32),
+                ("interpolation", C.c_int32)]
 
 
 class Model(C.Structure):
@@ -80,6 +87,9 @@ class Model(C.Structure):
         ("continuous_intercept", C.c_double),
         ("continuous_anchor", C.c_double * 2),
         ("continuous_side", C.c_double * 2),
+        ("spectrum_table", Table * 2),
+        ("xsec_table", Table),
+        ("recomb_table", Table),
     ]
 
 
@@ -341,6 +351,40 @@ class OracleSimulation:
             m.continuous_planck_temperature = planck_temperature
         m.continuous_luminosity = luminosity
         lib().cmio_mix_sources(C.byref(m))
+
+    def _set_table(self, table, x, y, interpolation):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        self._keep = getattr(self, "_keep", []) + [x, y]
+        table.x = _ptr(x)
+        table.y = _ptr(y)
+        table.n = len(x)
+        table.interpolation = interpolation
+
+    def set_spectrum_table(self, frequency, cumulative, role=0,
+                           interpolation=TABLE_LINEAR):
+        """A PhotonSourceSpectrum given as its quantile function (role 0: the
+        discrete sources', 1: the continuous source's)."""
+        self._set_table(self.model.spectrum_table[role], cumulative,
+                        frequency, interpolation)
+        if role == 0:
+            self.model.spectrum_type = SPECTRUM_TABLE
+        else:
+            self.model.continuous_spectrum_type = SPECTRUM_TABLE
+
+    def set_cross_sections_table(self, frequency, sigma,
+                                 interpolation=TABLE_LINEAR):
+        assert np.shape(sigma) == (NION, len(frequency))
+        self._set_table(self.model.xsec_table, frequency, sigma,
+                        interpolation)
+        self.model.xsec_type = XSEC_TABLE
+
+    def set_recombination_rates_table(self, temperature, alpha,
+                                      interpolation=TABLE_LOGLOG):
+        assert np.shape(alpha) == (NION, len(temperature))
+        self._set_table(self.model.recomb_table, temperature, alpha,
+                        interpolation)
+        self.model.recomb_type = RECOMB_TABLE
 
     def set_homogeneous(self, density, temperature, xH=1.e-6, xHe=1.e-6):
         """src/HomogeneousDensityFunction.hpp:99-107"""

@@ -1,0 +1,355 @@
+"""The generic lowering of plugins that are known only through the reference's
+virtuals (VERDICT r05 "What's missing" 1):
+PhotonSourceSpectrum::get_random_frequency, CrossSections::get_cross_section,
+RecombinationRates::get_recombination_rate are sampled on the host into tables
+(cmacionize_amd/host/Plugins.hpp: tabulate_spectrum, tabulate_ions) that the
+device reads (cmi_gpu_set_spectrum_table, cmi_gpu_set_cross_sections_table,
+cmi_gpu_set_recombination_rates_table).
+
+tests/support/third_party_plugins.cpp holds the plugins: classes that implement
+only the reference's signatures and know nothing of lower().
+
+Reference: src/PhotonSourceSpectrum.hpp:48-56, src/CrossSections.hpp:49-50,
+src/RecombinationRates.hpp:49, src/UniformPhotonSourceSpectrum.hpp:36-73,
+src/PhotonSourceSpectrumFactory.hpp:93-113."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "cmacionize_amd")
+SRC = os.path.join(ROOT, "tests", "support", "third_party_plugins.cpp")
+NU_H = 3.288465385e15
+FALLING, REJECTION, UNIFORM = 0, 1, 2
+
+CXX = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-fopenmp", "-pthread",
+       "-ffp-contract=off"]
+LINK = ["-L" + PKG, "-lcmi_gpu", "-lz", "-Wl,-rpath," + PKG,
+        "-Wl,-rpath,/opt/rocm/lib"]
+
+dp = C.POINTER(C.c_double)
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+@pytest.fixture(scope="module")
+def built(tmp_path_factory):
+    """The plugin file as a library and as cmi-gpu with the plugins
+    registered; libcmi_gpu.so must exist (build())."""
+    d = tmp_path_factory.mktemp("third_party")
+    if not os.path.exists(os.path.join(PKG, "libcmi_gpu.so")):
+        subprocess.run(["make", "-C", os.path.join(PKG, "csrc")], check=True)
+    lib = str(d / "libthird_party.so")
+    exe = str(d / "tp-cmi-gpu")
+    subprocess.run(CXX + ["-shared", "-fPIC", "-o", lib, SRC] + LINK,
+                   check=True)
+    subprocess.run(CXX + ["-DTP_WITH_MAIN", "-o", exe, SRC] + LINK,
+                   check=True)
+    L = C.CDLL(lib)
+    L.tp_lower.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.tp_spectrum_table.argtypes = [C.c_int, C.c_int, dp, dp,
+                                    C.POINTER(C.c_int), C.c_char_p]
+    L.tp_ion_table.argtypes = [C.c_int, C.c_int, dp, dp, C.POINTER(C.c_int)]
+    L.tp_cross_section.restype = C.c_double
+    L.tp_cross_section.argtypes = [C.c_int, C.c_double]
+    L.tp_recombination_rate.restype = C.c_double
+    L.tp_recombination_rate.argtypes = [C.c_int, C.c_double]
+    return L, exe
+
+
+def spectrum_table(L, which):
+    cap = 1 << 16
+    nu, cdf = np.zeros(cap), np.zeros(cap)
+    interp = C.c_int(-1)
+    method = C.create_string_buffer(2)
+    n = L.tp_spectrum_table(which, cap, _p(nu), _p(cdf), C.byref(interp),
+                            method)
+    assert n > 1
+    return nu[:n].copy(), cdf[:n].copy(), interp.value, method.value
+
+
+def ion_table(L, which):
+    cap = 1 << 14
+    x, y = np.zeros(cap), np.zeros(14 * cap)
+    interp = C.c_int(-1)
+    n = L.tp_ion_table(which, cap, _p(x), _p(y), C.byref(interp))
+    assert n > 1
+    return x[:n].copy(), y[:14 * n].reshape(14, n).copy(), interp.value
+
+
+def table_value(x, y, at, loglog):
+    """cmi_table_value / cmio_table_value in numpy."""
+    at = np.asarray(at, dtype=np.float64)
+    lo = np.clip(np.searchsorted(x, at, side="left") - 1, 0, len(x) - 2)
+    x0, x1, y0, y1 = x[lo], x[lo + 1], y[lo], y[lo + 1]
+    lin = y0 + (y1 - y0) * ((at - x0) / (x1 - x0))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pw = y0 * np.exp(np.log(y1 / y0) * (np.log(at / x0) / np.log(x1 / x0)))
+    out = np.where(loglog & (y0 > 0.) & (y1 > 0.), pw, lin)
+    out = np.where(at <= x[0], y[0], out)
+    return np.where(at >= x[-1], y[-1], out)
+
+
+def test_spectra_are_lowered_into_their_quantile_functions(built):
+    L, _ = built
+    # the reference's Uniform: nu = (1 + 3 u) 3.289e15, ascending in u
+    nu, cdf, interp, method = spectrum_table(L, UNIFORM)
+    assert method == b"s" and interp == 0
+    assert cdf[0] == 0. and cdf[-1] == 1. and np.all(np.diff(cdf) > 0.)
+    assert np.allclose(nu, (1. + 3. * cdf) * 3.289e15, rtol=1e-15)
+    # a sampler that uses 1 - u: recognised, read backwards. Its quantile
+    # function is nu_H / (1 - 0.75 q)
+    nu, cdf, interp, method = spectrum_table(L, FALLING)
+    assert method == b"s" and np.all(np.diff(nu) >= 0.)
+    assert np.allclose(nu, NU_H / (1. - 0.75 * cdf), rtol=1e-12)
+    # table read between its samples against the exact quantile function
+    u = (np.arange(100000) + 0.5) / 100000
+    got = table_value(cdf, nu, u, False)
+    # (linear between 8193 samples: h^2 f'' / 8 = 3.4e-8 at the steep end)
+    assert np.allclose(got, NU_H / (1. - 0.75 * u), rtol=1e-7)
+    # a rejection sampler (two uniforms per try): empirical quantiles of the
+    # triangular density 2 (1 - x) on nu_H (1 + 3 x): q = 1 - (1 - x)^2
+    nu, cdf, interp, method = spectrum_table(L, REJECTION)
+    assert method == b"e" and np.all(np.diff(nu) >= 0.)
+    x = 1. - np.sqrt(1. - cdf)
+    assert np.abs(nu / NU_H - (1. + 3. * x)).max() < 0.02  # 2^20 draws
+
+
+def test_cross_sections_and_rates_are_lowered_with_their_thresholds(built):
+    L, _ = built
+    x, y, interp = ion_table(L, 0)
+    assert interp == 1 and np.all(np.diff(x) > 0.) and y.shape == (14, len(x))
+    rng = np.random.default_rng(5)
+    nu = 10. ** rng.uniform(np.log10(1.2e15), np.log10(5.e16), 20000)
+    for ion in range(14):
+        want = np.array([L.tp_cross_section(ion, v) for v in nu])
+        got = table_value(x, y[ion], nu, True)
+        assert np.allclose(got, want, rtol=1e-5, atol=0.), ion
+        # the jump at the threshold sits between two ADJACENT samples
+        if want.max() > 0.:
+            k = np.flatnonzero(y[ion] > 0.)[0]
+            assert k > 0 and y[ion][k - 1] == 0.
+            assert x[k] == np.nextafter(x[k - 1], np.inf)
+    # just below / at / above hydrogen's threshold
+    k = np.flatnonzero(y[0] > 0.)[0]
+    assert L.tp_cross_section(0, x[k - 1]) == 0. < L.tp_cross_section(0, x[k])
+    T, a, interp = ion_table(L, 1)
+    assert interp == 1 and T[0] == 10. and T[-1] == 1.e9
+    Ts = 10. ** rng.uniform(1., 9., 5000)
+    for ion in range(14):
+        want = np.array([L.tp_recombination_rate(ion, v) for v in Ts])
+        assert np.allclose(table_value(T, a[ion], Ts, True), want, rtol=1e-9)
+
+
+PARAM = """SimulationBox:
+  anchor: [-5. pc, -5. pc, -5. pc]
+  sides: [10. pc, 10. pc, 10. pc]
+  periodicity: [false, false, false]
+DensityGrid:
+  type: Cartesian
+  number of cells: [16, 16, 16]
+DensityFunction:
+  type: Homogeneous
+  density: 100. cm^-3
+  temperature: 8000. K
+PhotonSourceDistribution:
+  type: SingleStar
+  position: [0. pc, 0. pc, 0. pc]
+  luminosity: 4.26e49 s^-1
+PhotonSourceSpectrum:
+  type: %(spectrum)s
+CrossSections:
+  type: %(xsec)s
+RecombinationRates:
+  type: %(recomb)s
+AbundanceModel:
+  He: 0.1
+  N: 4.e-5
+  O: 3.3e-4
+IonizationSimulation:
+  number of iterations: 3
+  number of photons: 20000
+  random seed: 42
+DensityGridWriter:
+  type: AsciiFile
+  prefix: tp_
+  padding: 3
+"""
+
+
+def test_factories_find_registered_plugins(built, tmp_path):
+    """--dry-run --describe of cmi-gpu built with the plugin file: the types
+    the reference's factories would need a new branch for are found through
+    the registry, and described by what the generic lowering made of them."""
+    _, exe = built
+    p = tmp_path / "tp.param"
+    p.write_text(PARAM % dict(spectrum="ThirdPartyFalling",
+                              xsec="ThirdPartyPowerLaw",
+                              recomb="ThirdPartyPowerLaw"))
+    out = subprocess.run([exe, "--params", str(p), "--dry-run", "--describe"],
+                         check=True, capture_output=True, text=True,
+                         cwd=str(tmp_path))
+    d = json.loads(out.stdout)
+    assert d["spectrum"]["type"] == "Table"
+    assert d["spectrum"]["lowering"] == "scripted"
+    assert d["spectrum"]["samples"] == 8193
+    assert abs(d["spectrum"]["minimum_frequency"] / NU_H - 1.) < 1e-12
+    assert abs(d["spectrum"]["maximum_frequency"] / NU_H - 4.) < 1e-12
+    assert d["cross_sections"]["type"] == "Table"
+    assert d["cross_sections"]["samples"] >= 4096 + 4  # + the thresholds
+    assert d["recombination_rates"] == {"type": "Table", "samples": 2048}
+    # the reference's own Uniform spectrum: a built-in of the factory now
+    p.write_text(PARAM % dict(spectrum="Uniform", xsec="Verner",
+                              recomb="Verner"))
+    out = subprocess.run([exe, "--params", str(p), "--dry-run", "--describe"],
+                         check=True, capture_output=True, text=True,
+                         cwd=str(tmp_path))
+    d = json.loads(out.stdout)
+    assert d["spectrum"]["type"] == "Uniform"
+    assert d["spectrum"]["lowering"] == "scripted"
+    assert d["cross_sections"] == "Verner"
+    # an unknown type is still an error, reported like the reference's
+    p.write_text(PARAM % dict(spectrum="Nonsense", xsec="Verner",
+                              recomb="Verner"))
+    out = subprocess.run([exe, "--params", str(p), "--dry-run", "--describe"],
+                         capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode != 0
+    assert "Unknown PhotonSourceSpectrum type" in out.stderr + out.stdout
+
+
+def oracle_with_tables(oracle, L, ncell, spectrum, continuous=False):
+    from cmacionize_amd.simulation import PC
+    sim = oracle.OracleSimulation((ncell,) * 3, (-5. * PC,) * 3,
+                                  (10. * PC,) * 3)
+    sim.set_sources([[0., 0., 0.]], [1.], 4.26e49)
+    sim.set_homogeneous(100. * 1.e6, 8000.)
+    m = sim.model
+    m.abundance[1] = 0.1
+    m.abundance[3] = 4.e-5
+    m.abundance[4] = 3.3e-4
+    nu, cdf, interp, _ = spectrum_table(L, spectrum)
+    if continuous:
+        m.spectrum_type = oracle.SPECTRUM_MONOCHROMATIC
+        m.mono_frequency = 1.3 * NU_H
+        sim.set_spectrum_table(nu, cdf, role=1, interpolation=interp)
+    else:
+        sim.set_spectrum_table(nu, cdf, role=0, interpolation=interp)
+    x, y, interp = ion_table(L, 0)
+    sim.set_cross_sections_table(x, y, interpolation=interp)
+    T, a, interp = ion_table(L, 1)
+    sim.set_recombination_rates_table(T, a, interpolation=interp)
+    m.reemit_type = oracle.REEMIT_PHYSICAL
+    m.do_temperature = 0
+    return sim
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spectrum,continuous", [(FALLING, False),
+                                                 (UNIFORM, False),
+                                                 (REJECTION, True)])
+def test_third_party_plugins_on_the_engine_match_the_oracle(built, spectrum,
+                                                            continuous):
+    """Plugins that implement only the reference's virtuals, lowered by their
+    base classes into an engine; the oracle is given the same tables. Three
+    iterations of transport (multi-ion accumulators, physical re-emission)
+    and cell update on 16^3."""
+    import oracle_lib as oracle
+    from cmacionize_amd import GpuEngine
+    from cmacionize_amd import engine as E
+    from cmacionize_amd.simulation import PC
+    oracle.build()
+    L, _ = built
+    ncell, npacket = 16, 30000
+    sim = oracle_with_tables(oracle, L, ncell, spectrum, continuous)
+    eng = GpuEngine((ncell,) * 3, (-5. * PC,) * 3, (10. * PC,) * 3,
+                    (0, 0, 0), device=0, track_heating=True)
+    eng.set_sources([[0., 0., 0.]], [1.], 4.26e49)
+    if continuous:
+        eng.set_spectrum_monochromatic(1.3 * NU_H)
+        sim.set_continuous_source(2.e49, frequency=1.)  # type + mix ...
+        nu, cdf, interp, _ = spectrum_table(L, spectrum)
+        sim.set_spectrum_table(nu, cdf, role=1, interpolation=interp)
+    assert L.tp_lower(eng._h, spectrum, int(continuous)) == 0, \
+        E.last_error()
+    if continuous:
+        eng.set_continuous_source(E.CONTINUOUS_ISOTROPIC, 2.e49)
+    eng.set_abundances([0.1, 0., 4.e-5, 3.3e-4, 0., 0.])
+    eng.set_reemission(1)
+    eng.set_temperature_params(do_temperature_calculation=0,
+                               pah_heating_factor=0.)
+    eng.upload_cells(sim.number_density, sim.temperature,
+                     np.array([np.asarray(x) for x in sim.x]))
+    for loop in range(3):
+        eng.reset_grid()
+        eng.shoot(42, loop, 0, npacket)
+        tw, tc, _ = eng.get_counters()
+        sim.reset()
+        sim.totweight = 0.
+        sim.typecount[:] = 0.
+        sim.shoot(42, loop, 0, npacket)
+        assert abs(tw - sim.totweight) <= 1e-12 * tw
+        assert np.abs(tc - sim.typecount).max() <= 3 * tw / npacket, \
+            (tc, sim.typecount)
+        assert tc[1] > 0 and tc[2] > 0  # H and He re-emission both happen
+        for ion in range(14):
+            J = eng.download_field(E.FIELD_MEAN_INTENSITY + ion)
+            ref = np.asarray(sim.J[ion])
+            assert np.allclose(J, ref, rtol=1e-6, atol=1e-6 * ref.max()), ion
+            assert (ref.max() > 0.) == (ion in (0, 1, 4, 7))
+        for k in range(2):
+            h = eng.download_field(E.FIELD_HEATING + k)
+            assert np.allclose(h, sim.heating[k], rtol=1e-6,
+                               atol=1e-6 * np.abs(sim.heating[k]).max())
+        for ion in range(14):
+            eng.upload_field(E.FIELD_MEAN_INTENSITY + ion, sim.J[ion])
+        for k in range(2):
+            eng.upload_field(E.FIELD_HEATING + k, sim.heating[k])
+        eng.update_cells(loop, tw)
+        eng.synchronize()
+        sim.update(loop, sim.totweight)
+        for ion in range(14):
+            x = eng.download_field(E.FIELD_IONIC_FRACTION + ion)
+            ref = np.asarray(sim.x[ion])
+            ok = np.isclose(x, ref, rtol=1e-5, atol=1e-300) | \
+                (np.isnan(x) & np.isnan(ref))
+            assert ok.all(), (loop, ion)
+        eng.upload_cells(sim.number_density, sim.temperature,
+                         np.array([np.asarray(x) for x in sim.x]))
+    assert sim.x[0].min() < 1e-2  # the plugin's photons ionize
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_third_party_plugins_through_the_driver(built, tmp_path):
+    """cmi-gpu with the plugins registered runs a .param file that names them
+    and writes the snapshot; its hydrogen fractions are those of the engine
+    driven from here with the same tables, seeds and iteration loop."""
+    import oracle_lib as oracle
+    oracle.build()
+    L, exe = built
+    p = tmp_path / "tp.param"
+    p.write_text(PARAM % dict(spectrum="ThirdPartyFalling",
+                              xsec="ThirdPartyPowerLaw",
+                              recomb="ThirdPartyPowerLaw"))
+    subprocess.run([exe, "--params", str(p), "--threads", "1"], check=True,
+                   cwd=str(tmp_path), capture_output=True, text=True)
+    out = tmp_path / "tp_003.txt"
+    assert out.exists()
+    data = np.loadtxt(str(out))
+    # AsciiFileDensityGridWriter: x y z n_H n_frac ... ; column 4 = neutral H
+    xH = data[:, 4]
+    sim = oracle_with_tables(oracle, L, 16, FALLING)
+    sim.model.reemit_type = oracle.REEMIT_NONE
+    sim.run(20000, 3, seed=42)
+    ref = np.asarray(sim.x[0])
+    assert xH.shape == ref.shape
+    # (device libm ulps: a handful of cells at the front may differ)
+    close = np.isclose(xH, ref, rtol=1e-4, atol=1e-12)
+    assert close.mean() > 0.999, close.mean()
+    assert ref.min() < 1e-2

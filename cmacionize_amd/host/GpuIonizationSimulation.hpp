@@ -1245,17 +1245,33 @@ public:
                           const bool create_engine = true,
                           const std::array<int, 3> blocks = {1, 1, 1},
                           const std::vector<int> &devices = {},
-                          const int copies = 0)
+                          const int copies = 0,
+                          /* --task-based: the run is controlled by the
+                           * parameter block of the reference's task-based
+                           * driver (TaskBasedIonizationSimulation ctor,
+                           * src/TaskBasedIonizationSimulation.cpp:190-260:
+                           * "number of iterations" 10, "number of photons"
+                           * 1e6, "random seed" 42, "source copy level" 4;
+                           * no "number of photons first loop") instead of
+                           * IonizationSimulation's - the engine is the same */
+                          const bool task_based = false)
       : _every_iteration_output(every_iteration_output),
         _output_statistics(output_statistics), _verbose(verbose),
         _parameter_file(parameterfile),
         _number_of_iterations((uint_fast32_t)_parameter_file.get_integer(
-            "IonizationSimulation:number of iterations", 10)),
+            task_based ? "TaskBasedIonizationSimulation:number of iterations"
+                       : "IonizationSimulation:number of iterations",
+            10)),
         _number_of_photons((uint_fast64_t)_parameter_file.get_integer(
-            "IonizationSimulation:number of photons", 100000)),
-        _number_of_photons_init((uint_fast64_t)_parameter_file.get_integer(
-            "IonizationSimulation:number of photons first loop",
-            (long long)_number_of_photons)),
+            task_based ? "TaskBasedIonizationSimulation:number of photons"
+                       : "IonizationSimulation:number of photons",
+            task_based ? 1000000 : 100000)),
+        _number_of_photons_init(
+            task_based
+                ? _number_of_photons
+                : (uint_fast64_t)_parameter_file.get_integer(
+                      "IonizationSimulation:number of photons first loop",
+                      (long long)_number_of_photons)),
         _random_seed(0), _abundances(_parameter_file),
         _cross_sections(generate_cross_sections(_parameter_file)),
         _recombination_rates(generate_recombination_rates(_parameter_file)),
@@ -1322,8 +1338,10 @@ public:
         QUANTITY_TEMPERATURE, "TemperatureCalculator:minimum ionized temperature",
         "4000. K");
 
-    _random_seed =
-        (int32_t)_parameter_file.get_integer("IonizationSimulation:random seed", 42);
+    _random_seed = (int32_t)_parameter_file.get_integer(
+        task_based ? "TaskBasedIonizationSimulation:random seed"
+                   : "IonizationSimulation:random seed",
+        42);
     /* src/IonizationSimulation.cpp:208-213 */
     if (_parameter_file.get_bool("IonizationSimulation:enable trackers", false))
       _trackers.reset(new TrackerManager(_parameter_file));

@@ -6,7 +6,10 @@
  * (src/CMacIonize.cpp:113-179,306-377): --params/-p, --threads/-t,
  * --every-iteration-output/-e, --output-statistics/-s, --dry-run/-n,
  * --verbose/-v, and the emission mode --emission/-m with --file/-f
- * (EmissivityCalculationSimulation.hpp). Flags that select other code paths
+ * (EmissivityCalculationSimulation.hpp), and --task-based: the run takes its
+ * control parameters from the TaskBasedIonizationSimulation: block of the
+ * file (src/CMacIonize.cpp:335-345, src/TaskBasedIonizationSimulation.cpp:
+ * 190-260) instead of IonizationSimulation:. Flags that select other code paths
  * of the reference (--rhd, --dusty-radiative-transfer, --task-based-rhd) are
  * rejected.
  * New: --device N (HIP device ordinal), --describe (print the lowered plugin
@@ -139,7 +142,7 @@ int main(int argc, char **argv) {
   bool emission = false;
   std::string input_file;
   bool every_iteration = false, statistics = false, dry_run = false,
-       verbose = false, do_describe = false;
+       verbose = false, do_describe = false, task_based = false;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto need = [&](const char *name) -> std::string {
@@ -184,9 +187,10 @@ int main(int argc, char **argv) {
       verbose = true;
     else if (a == "--describe")
       do_describe = true;
-    else if (a == "--dirty" || a == "-d" || a == "--task-based" ||
-             a == "--no-initial-output")
-      ; /* accepted, no effect: one engine serves both reference drivers */
+    else if (a == "--task-based")
+      task_based = true; /* src/CMacIonize.cpp: TaskBasedIonizationSimulation */
+    else if (a == "--dirty" || a == "-d" || a == "--no-initial-output")
+      ; /* accepted, no effect */
     else {
       std::cerr << "Unknown or unsupported option: " << a << "\n"
                 << "usage: cmi-gpu --params FILE [--threads N] [--device N] "
@@ -217,7 +221,7 @@ int main(int argc, char **argv) {
                                        every_iteration, statistics, threads,
                                        params, device,
                                        verbose || !do_describe, !dry_run,
-                                       blocks, devices, copies);
+                                       blocks, devices, copies, task_based);
     if (do_describe)
       describe(simulation);
     if (dry_run && dry_snapshot) {

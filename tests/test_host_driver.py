@@ -27,6 +27,22 @@ def exe():
     return EXE
 
 
+def bench_text(name):
+    """A benchmark input of the reference (benchmarks/ holds the files
+    byte for byte) as a template for the edits below: comment and blank lines
+    dropped, and the block of the task-based driver."""
+    out, skip = [], False
+    for line in open(os.path.join(BENCH, name)).read().split("\n"):
+        line = line.rstrip()
+        if not line.strip() or line.strip().startswith("#"):
+            continue
+        if not line.startswith(" "):
+            skip = line.startswith("TaskBasedIonizationSimulation:")
+        if not skip:
+            out.append(line)
+    return "\n".join(out) + "\n"
+
+
 def describe(exe, param, cwd):
     out = subprocess.run([exe, "--params", param, "--dry-run", "--describe"],
                          check=True, capture_output=True, text=True, cwd=cwd)
@@ -157,7 +173,7 @@ def test_cmi_gpu_executable_end_to_end(exe, tmp_path, oracle):
     """stromgren at 16^3 through the executable: used-values file, initial and
     final AsciiFile snapshots (reference column layout), result equal to the
     oracle driven with the same lowered values and seeds."""
-    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = bench_text("stromgren.param")
     text = text.replace("[64, 64, 64]", "[16, 16, 16]")
     text = text.replace("number of photons: 1e6", "number of photons: 20000")
     text = text.replace("number of iterations: 20", "number of iterations: 3")
@@ -206,7 +222,7 @@ def test_cmi_gpu_executable_with_blocks(exe, tmp_path, bench, blocks):
     flights are handed over device to device (cmi_gpu_group_exchange_flights:
     a routing kernel writes them into the owner's inbox); the snapshots equal
     those of the undivided run of the same parameter file."""
-    text = open(os.path.join(BENCH, bench)).read()
+    text = bench_text(bench)
     text = text.replace("[64, 64, 64]", "[18, 18, 18]")
     for old in ("number of photons: 1e6", "number of photons: 1e8"):
         text = text.replace(old, "number of photons: 20000")
@@ -256,7 +272,7 @@ def test_cmi_gpu_executable_with_replicas(exe, tmp_path, bench):
     distinct devices; replicas that share this box's one device are summed by
     a kernel), every replica updates its cells. Same packets as the
     single-engine run: equal snapshots."""
-    text = open(os.path.join(BENCH, bench)).read()
+    text = bench_text(bench)
     text = text.replace("[64, 64, 64]", "[18, 18, 18]")
     for old in ("number of photons: 1e6", "number of photons: 1e8"):
         text = text.replace(old, "number of photons: 20001")
@@ -327,7 +343,7 @@ def test_block_syntax_fixture_of_the_reference(exe, tmp_path):
     cube, two spheres and a rhombus): a 64^3 grid over the unit box holds the
     analytic number of hydrogen atoms within 0.003 (assert_values_equal_rel)."""
     import struct
-    text = open(os.path.join(BENCH, "lexingtonHII40.param")).read()
+    text = bench_text("lexingtonHII40.param")
     text = text.replace("anchor: [-5. pc, -5. pc, -5. pc]",
                         "anchor: [0. m, 0. m, 0. m]")
     text = text.replace("sides: [10. pc, 10. pc, 10. pc]",
@@ -361,7 +377,7 @@ def test_ascii_file_source_fixture_of_the_reference(exe, tmp_path):
     reference's own file (tests/golden/
     test_asciifilephotonsourcedistribution.yml): three sources, 2.4e49 s^-1
     in total, weights that sum to one, the first source at the origin."""
-    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = bench_text("stromgren.param")
     old = ("PhotonSourceDistribution:\n  type: SingleStar\n"
            "  position: [0. pc, 0. pc, 0. pc]\n  luminosity: 4.26e49 s^-1\n")
     assert old in text
@@ -392,7 +408,7 @@ def test_cmi_gpu_executable_with_copies_of_the_source_block(exe, tmp_path,
     id, their integrals are summed into each of them after the transport
     (update_original_counters, :556-574) and each solves the block's cells.
     The snapshots equal those of the undivided run."""
-    text = open(os.path.join(BENCH, bench)).read()
+    text = bench_text(bench)
     text = text.replace("[64, 64, 64]", "[18, 18, 18]")
     for old in ("number of photons: 1e6", "number of photons: 1e8"):
         text = text.replace(old, "number of photons: 20000")
@@ -439,7 +455,7 @@ def test_copies_cascade_to_the_neighbours_of_the_source_block(exe, tmp_path,
     src/DensitySubGridCreator.hpp:437-531), the far block 1: nine engines,
     flights routed to the copies of the block they enter by packet id.
     Against the oracle on the undivided grid, same seed."""
-    text = open(os.path.join(BENCH, "stromgren_diffuse.param")).read()
+    text = bench_text("stromgren_diffuse.param")
     text = text.replace("[64, 64, 64]", "[24, 12, 12]")
     text = text.replace("number of photons: 1e6", "number of photons: 30000")
     text = text.replace("number of iterations: 20", "number of iterations: 4")
@@ -491,7 +507,7 @@ def test_cmi_gpu_executable_with_a_continuous_source(exe, tmp_path, oracle):
     computes the continuous luminosity as surface area x flux
     (src/PhotonSource.cpp:104-111), half of the packets come from either kind
     of source; result equal to the oracle with the same mix."""
-    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = bench_text("stromgren.param")
     text = text.replace("[64, 64, 64]", "[16, 16, 16]")
     text = text.replace("number of photons: 1e6", "number of photons: 20000")
     text = text.replace("number of iterations: 20", "number of iterations: 3")
@@ -532,7 +548,7 @@ def test_ascii_file_source_distribution(exe, tmp_path):
     """PhotonSourceDistribution type AsciiFile
     (src/AsciiFilePhotonSourceDistribution.hpp:45-120): several stars from a
     YAML file; weights = luminosities over their sum."""
-    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = bench_text("stromgren.param")
     old = ("PhotonSourceDistribution:\n  type: SingleStar\n"
            "  position: [0. pc, 0. pc, 0. pc]\n  luminosity: 4.26e49 s^-1\n")
     assert old in text
@@ -567,7 +583,7 @@ def test_ascii_file_source_distribution(exe, tmp_path):
 def tracker_run(exe, tmp_path, label, blocks, hdf5=False, block_file=None):
     """lexingtonHII40.param at 16^3 with trackers in the last iteration"""
     import shutil
-    text = open(os.path.join(BENCH, "lexingtonHII40.param")).read()
+    text = bench_text("lexingtonHII40.param")
     text = text.replace("[64, 64, 64]", "[16, 16, 16]")
     text = text.replace("number of photons: 1e8", "number of photons: 30000")
     text = text.replace("number of iterations: 20", "number of iterations: 4")
@@ -872,7 +888,7 @@ def test_tracker_manager_fixture_of_the_reference(exe, tmp_path):
     output name) on the box of that test (10 pc around the origin, 64^3):
     all three are placed and written, each with its own number of bins."""
     import shutil
-    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = bench_text("stromgren.param")
     text = text.replace("number of photons: 1e6", "number of photons: 100000")
     text = text.replace("number of iterations: 20", "number of iterations: 2")
     text = text.replace("type: Gadget", "type: AsciiFile")
@@ -906,7 +922,7 @@ def test_tracker_block_file_is_parsed(exe, tmp_path):
     """TrackerManager's block file (src/TrackerManager.hpp:98-170): parsed
     with the parameter file grammar, used values written back, unknown types
     and missing keys reported (no GPU needed: dry run)."""
-    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = bench_text("stromgren.param")
     text = text.replace("random seed: 42",
                         "random seed: 42\n  enable trackers: true")
     if "enable trackers" not in text:
@@ -952,7 +968,7 @@ def test_tracker_block_file_is_parsed(exe, tmp_path):
 
 
 def multi_tracker_param(tmp_path, block_file):
-    text = open(os.path.join(BENCH, "stromgren_diffuse.param")).read()
+    text = bench_text("stromgren_diffuse.param")
     text = text.replace("number of photons: 1e6", "number of photons: 100000")
     text = text.replace("number of iterations: 20", "number of iterations: 2")
     text = text.replace("[64, 64, 64]", "[16, 16, 16]")
@@ -1075,7 +1091,7 @@ def test_copies_cascade_is_cut_back_to_the_group_limit(exe, tmp_path):
     reference has no such limit, so the cascade is cut back - outermost rings
     first, then fewer copies per source block - instead of refusing the run;
     the result is the undivided grid's (copies only share work)."""
-    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = bench_text("stromgren.param")
     text = text.replace("[64, 64, 64]", "[24, 24, 12]")
     text = text.replace("number of photons: 1e6", "number of photons: 40000")
     text = text.replace("number of iterations: 20", "number of iterations: 3")

@@ -1,0 +1,133 @@
+"""The reference's benchmark inputs, VERBATIM (VERDICT r05 "What's missing" 4):
+benchmarks/{stromgren, stromgren_diffuse, lexingtonHII40}.param and
+lexingtonHII40.yml are byte-identical copies of /root/reference/benchmarks/
+(input data; a second copy under tests/golden/benchmarks/ is the fixture the
+suite compares against), and run unchanged through `cmi-gpu` - with the
+reference's `--task-based` flag as well, which makes the driver take its
+control parameters from the file's `TaskBasedIonizationSimulation:` block
+(src/CMacIonize.cpp:335-345, src/TaskBasedIonizationSimulation.cpp:190-260)
+instead of `IonizationSimulation:`."""
+import filecmp
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "cmacionize_amd", "cmi-gpu")
+BENCH = os.path.join(ROOT, "benchmarks")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "benchmarks")
+REFERENCE = "/root/reference/benchmarks"
+FILES = ["stromgren.param", "stromgren_diffuse.param", "lexingtonHII40.param",
+         "lexingtonHII40.yml"]
+
+
+@pytest.fixture(scope="module")
+def exe():
+    if not os.path.exists(EXE):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "cmacionize_amd",
+                                                   "csrc")], check=True)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "cmacionize_amd",
+                                                   "host")], check=True)
+    return EXE
+
+
+def test_benchmark_inputs_are_the_reference_files_byte_for_byte():
+    for name in FILES:
+        assert filecmp.cmp(os.path.join(BENCH, name),
+                           os.path.join(GOLDEN, name), shallow=False), name
+        # (the reference's tree exists in the build container only)
+        if os.path.isdir(REFERENCE):
+            assert filecmp.cmp(os.path.join(GOLDEN, name),
+                               os.path.join(REFERENCE, name),
+                               shallow=False), name
+    # comments and the task-based blocks are there
+    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    assert "TaskBasedIonizationSimulation:" in text and "# " in text
+
+
+def stage(tmp_path, name):
+    """the inputs next to each other in a scratch directory (the block-syntax
+    density function writes a .used-values file beside its .yml)"""
+    for f in FILES:
+        shutil.copy(os.path.join(BENCH, f), str(tmp_path / f))
+    return str(tmp_path / name)
+
+
+@pytest.mark.parametrize("name,photons", [("stromgren.param", 10 ** 6),
+                                          ("stromgren_diffuse.param", 10 ** 6),
+                                          ("lexingtonHII40.param", 10 ** 8)])
+def test_both_control_blocks_are_read(exe, tmp_path, name, photons):
+    param = stage(tmp_path, name)
+    out = {}
+    for flag in ([], ["--task-based"]):
+        r = subprocess.run([exe, "--params", param, "--dry-run", "--describe"]
+                           + flag, check=True, capture_output=True, text=True,
+                           cwd=str(tmp_path))
+        out[bool(flag)] = json.loads(r.stdout)
+    for d in out.values():
+        assert d["number_of_iterations"] == 20
+        assert d["number_of_photons"] == photons
+        assert d["random_seed"] == 42
+        assert d["ncell"] == [64, 64, 64]
+    assert out[False] == out[True]
+    # the flag really switches blocks: different numbers in the two
+    text = open(param).read()
+    head, tail = text.split("TaskBasedIonizationSimulation:")
+    tail = tail.replace("number of iterations: 20", "number of iterations: 7",
+                        1).replace("number of photons: 1e", "number of photons: 3e", 1)
+    open(param, "w").write(head + "TaskBasedIonizationSimulation:" + tail +
+                           "\n")
+    r = subprocess.run([exe, "--params", param, "--dry-run", "--describe",
+                        "--task-based"], check=True, capture_output=True,
+                       text=True, cwd=str(tmp_path))
+    d = json.loads(r.stdout)
+    assert d["number_of_iterations"] == 7
+    assert d["number_of_photons"] == 3 * photons
+    r = subprocess.run([exe, "--params", param, "--dry-run", "--describe"],
+                       check=True, capture_output=True, text=True,
+                       cwd=str(tmp_path))
+    assert json.loads(r.stdout)["number_of_iterations"] == 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,prefix", [
+    ("stromgren.param", "stromgren_"),
+    ("stromgren_diffuse.param", "stromgren_diffuse_"),
+    ("lexingtonHII40.param", "lexingtonHII40_")])
+def test_reference_files_run_verbatim_both_ways(exe, tmp_path, name, prefix):
+    """the file as it stands (64^3, 1e6 / 1e8 packets x 20 iterations) through
+    cmi-gpu and cmi-gpu --task-based: the same engine, the same numbers in
+    both control blocks -> the same final snapshot; and the physics is the
+    benchmark's."""
+    import hdf5_mini
+    fields = {}
+    for flag in ([], ["--task-based"]):
+        d = tmp_path / ("tb" if flag else "classic")
+        d.mkdir()
+        param = stage(d, name)
+        r = subprocess.run([exe, "--params", param] + flag,
+                           capture_output=True, text=True, cwd=str(d))
+        assert r.returncode == 0, r.stderr[-2000:]
+        f = hdf5_mini.read(str(d / (prefix + "020.hdf5")))
+        fields[bool(flag)] = (f["/PartType0/NeutralFractionH"].data,
+                              f["/PartType0/Temperature"].data)
+    assert np.array_equal(fields[False][0], fields[True][0])
+    assert np.array_equal(fields[False][1], fields[True][1])
+    xH, T = fields[False]
+    assert xH.size == 64 ** 3
+    volume = float((xH < 0.5).mean())
+    if name == "lexingtonHII40.param":
+        # Lexington HII40: outer radius 1.46e19 cm of a 10 pc box -> the
+        # ionized sphere fills 0.44 of it; ~8000 K inside
+        assert 0.40 < volume < 0.48, volume
+        assert 7000. < T[xH < 0.1].mean() < 9000.
+    else:
+        # 0.3617 (the diffuse field adds ~10 %)
+        assert 0.355 < volume < 0.42, volume

@@ -30,6 +30,7 @@ packets, `value` counts all of them); the same line carries a
 import argparse
 import json
 import os
+import signal
 import sys
 import time
 
@@ -66,6 +67,19 @@ CONFIGS = {
         diffuse=True, lexington=True, converge_iterations=20,
         kernel="shoot_kernel<true, true, false, false, true, true, false, false, false>"),
 }
+
+
+
+def dominant_kernel(cfg, ncell):
+    """The first-generation kernel the engine picks for this grid: beyond 2^25
+    cells the hydrogen-only padded march is the BIG build (1024 threads, 4096
+    table slots; csrc/kernels.h CMI_TABLE_BIG_CELLS, csrc/engine.hip pad_big) -
+    the last template argument."""
+    name = cfg["kernel"]
+    if not cfg["lexington"] and ncell ** 3 > 1 << 25:
+        name = name.replace("true, false, false>", "true, false, true>")
+    return name
+
 
 # The CPU baseline (oracle/cmio_transport_fast.c) against the REFERENCE on the
 # same cores: 8-thread Xeon 2.1 GHz of the build container, 64^3, the whole
@@ -290,7 +304,7 @@ def roofline(config, ncell, cfg, steps_per_launch, lanes_per_wave_step,
     algorithmic = (steps_per_launch * cfg["bytes_per_step"]
                    if steps_per_launch else None)
     out = {
-        "kernel": cfg["kernel"],
+        "kernel": dominant_kernel(cfg, ncell),
         "bound": None, "achieved": None, "peak": None, "unit": None,
         "frac": None, "traffic": None,
         "kernel_avg_ms": first_generation_ms,
@@ -302,7 +316,7 @@ def roofline(config, ncell, cfg, steps_per_launch, lanes_per_wave_step,
         "algorithmic_over_hbm_peak": (algorithmic / t / 1e9 / HBM_PEAK_GBS
                                       if t and algorithmic else None),
     }
-    rel, c = load_profile(config, ncell, cfg["kernel"])
+    rel, c = load_profile(config, ncell, dominant_kernel(cfg, ncell))
     if c is None:
         out["note"] = ("no PMC profile of this kernel at this grid size under "
                        "profiles/: the bounding unit is unmeasured")
@@ -363,7 +377,7 @@ def roofline_cell_update(config, ncell, cfg, update_ms):
     operations per second (wave instructions x 64 lanes, PMC SQ_INSTS_VALU of
     the same profile) against the vector fp64 rate (78.6 TFLOP/s = 3.93e13
     fused multiply-adds per second)."""
-    rel, c = load_profile(config, ncell, cfg["kernel"])
+    rel, c = load_profile(config, ncell, dominant_kernel(cfg, ncell))
     if c is None:
         return None
     ks = [k for k in c.get("other_kernels", [])
@@ -617,6 +631,7 @@ def run_leg(args, ranks, config, steps, warmup, cpu_seconds=None,
         backend.engine.get_timing(reset=True)
         if domain:
             driver.idle_s = 0.
+            driver.measure_idle = True
         nsteps = 0
         t0 = time.perf_counter()
         for _ in range(nsteps_timed):
@@ -674,6 +689,23 @@ def run_leg(args, ranks, config, steps, warmup, cpu_seconds=None,
             parts = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(parts, t)
             idle_ms = [float(x.item()) for x in parts]
+    emitted = None
+    if domain:
+        # per rank: the packets its block emitted per step (the flights of
+        # the first launch after every reset_grid) - a block picks its own
+        # packets out of an iteration's ids (block_select_kernel), so this is
+        # ~ 1 / world of them for a source on the blocks' common corner
+        fg, before = [], None
+        for ms, n, st in launches:
+            if before is None or st <= before:
+                fg.append(n)
+            before = st
+        emitted = [float(np.mean(fg)) if fg else 0.]
+        if world > 1:
+            t = torch.tensor(emitted, dtype=torch.float64, device="cuda")
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            emitted = [float(x.item()) for x in parts]
     out = None
     if rank == 0:
         total_packets = float(global_packets) * steps
@@ -782,6 +814,7 @@ def run_leg(args, ranks, config, steps, warmup, cpu_seconds=None,
             out["exchange_rounds_last_step"] = driver.rounds
             out["flights_exchanged_last_step"] = driver.flights_exchanged
             out["idle_ms_per_step_by_rank"] = idle_ms
+            out["emitted_packets_per_step_by_rank"] = emitted
     # the next leg needs the memory (flight slots and queues of 1e8 packets)
     barrier()
     backend.engine.close()
@@ -995,16 +1028,30 @@ def child_line(args, config, ncell, domain, steps, warmup, driver,
                         "TORCHELASTIC_USE_AGENT_STORE",
                         "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # a session (= process group) of its own: a leg that hangs is ended WITH
+    # the ranks its launcher started - killing the launcher alone leaves them
+    # on their GPUs, and the next leg finds the devices occupied
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True,
+                             start_new_session=True)
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True,
-                           timeout=timeout)
+        stdout, stderr = child.communicate(timeout=timeout)
     except subprocess.TimeoutExpired:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.communicate()
         return {"error": "no result after %.0f s" % timeout}
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    if r.returncode != 0 or not lines:
-        return {"error": "exit code %d: %s" % (r.returncode,
-                                               r.stderr.strip()[-600:])}
-    return json.loads(lines[-1])
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    if child.returncode != 0 or not lines:
+        return {"error": "exit code %d: %s" % (child.returncode,
+                                               stderr.strip()[-600:])}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"error": "unreadable result line (%s): %s" %
+                         (e, lines[-1][:200])}
 
 
 # seconds the extra legs of an N > 1 run may take together
@@ -1099,22 +1146,32 @@ def main():
                               driver, timeout=min(300., left))
 
         if ranks.rank == 0:
-            leg = extra("lexington", ncell5, True, "torch")
-            keep = ALSO_KEYS + (
-                "n_gpus", "ranks_in_collective", "packets_per_rank_per_step",
-                "scaling", "exchange_rounds_last_step",
-                "flights_exchanged_last_step", "idle_ms_per_step_by_rank",
-                "error")
-            rec = {k: leg[k] for k in keep if k in leg}
-            if "iterations_to_converge" in leg:
-                rec["iterations_to_converge"] = \
-                    leg["iterations_to_converge"]["value"]
-            out["config5"] = rec
-            out["native"] = {
-                "replica": extra("stromgren", args.ncell, False, "native"),
-                "config5": extra("lexington", ncell5, True, "native")}
-            out["bench_wall_s"] = time.perf_counter() - t_start
-            store.set("cmi_bench_extras_done", "1")
+            # (whatever happens here, the other ranks are released and the
+            # headline line is printed)
+            try:
+                leg = extra("lexington", ncell5, True, "torch")
+                keep = ALSO_KEYS + (
+                    "n_gpus", "ranks_in_collective",
+                    "packets_per_rank_per_step", "scaling",
+                    "exchange_rounds_last_step",
+                    "flights_exchanged_last_step", "idle_ms_per_step_by_rank",
+                    "emitted_packets_per_step_by_rank",
+                    "error")
+                rec = {k: leg[k] for k in keep if k in leg}
+                if "iterations_to_converge" in leg:
+                    rec["iterations_to_converge"] = \
+                        leg["iterations_to_converge"]["value"]
+                out["config5"] = rec
+                out["native"] = {
+                    "replica": extra("stromgren", args.ncell, False,
+                                     "native"),
+                    "config5": extra("lexington", ncell5, True, "native")}
+            except Exception as e:  # noqa: BLE001 - recorded, not raised
+                out.setdefault("config5", {})["error"] = \
+                    "extras failed: %s: %s" % (type(e).__name__, e)
+            finally:
+                out["bench_wall_s"] = time.perf_counter() - t_start
+                store.set("cmi_bench_extras_done", "1")
         else:
             store.wait(["cmi_bench_extras_done"],
                        timedelta(seconds=EXTRAS_BUDGET_S + 600))

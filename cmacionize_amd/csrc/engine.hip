@@ -88,6 +88,7 @@ struct cmi_gpu_engine {
   cmi_gpu_temperature_params tparams;
 
   /* direction sort of the packet order (keys/ids double buffered) */
+  unsigned int *select_count = nullptr; /* block_select_kernel's counter */
   uint32_t *sort_keys[2] = {nullptr, nullptr};
   uint32_t *sort_ids[2] = {nullptr, nullptr};
   void *sort_temp = nullptr;
@@ -196,6 +197,13 @@ struct cmi_gpu_engine {
     /* the first generation parks an absorbed packet at the place of its
      * position in the launch's order (no queue counter) */
     bool park_in_place = true;
+    /* a block of a decomposed grid picks its own packets out of a launch's
+     * ids before keys, sort and transport (block_select_kernel); 0: every
+     * packet goes through them and the transport kernel drops the others */
+    bool block_select = true;
+    /* ... and flies them with the kernels built for a whole grid's first
+     * generation (padded march / pre-computed emission rows) */
+    bool block_first_kernels = true;
   } tune;
 
   /* device timing (HIP events around launches) is opt-in: set_tuning
@@ -1035,6 +1043,7 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->source_position);
   (void)hipFree(e->source_cumulative);
   (void)hipFree(e->sort_keys[0]);
+  (void)hipFree(e->select_count);
   (void)hipFree(e->sort_temp);
   (void)hipFree(e->queue_block);
   (void)hipFree(e->queue_counts);
@@ -1572,6 +1581,10 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
     e->tune.tile_compact_ratio = (int)(value < -1 ? -1 : value);
   else if (k == "park_in_place")
     e->tune.park_in_place = value != 0;
+  else if (k == "block_select")
+    e->tune.block_select = value != 0;
+  else if (k == "block_first_kernels")
+    e->tune.block_first_kernels = value != 0;
   else if (k == "accumulators_dirty")
     e->acc_block_dirty = e->acc_block_dirty || value != 0;
   else if (k == "temperature_finish_slots")
@@ -1831,9 +1844,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                 "cell data must be set first");
   if (n_packets == 0)
     return CMI_GPU_OK;
-  if (n_packets >= (1ull << 32))
+  /* (packet ids of a call are 32-bit, and 0xffffffff marks a place of the
+   * ended queue that holds no flight: CMI_QUEUE_HOLE) */
+  if (n_packets >= 0xffffffffull)
     return fail(CMI_GPU_EINVAL,
-                "cmi_gpu_shoot: at most 2^32 - 1 packets per call");
+                "cmi_gpu_shoot: at most 2^32 - 2 packets per call");
   if (e->grid.decomposed &&
       (e->tune.exact_dda || !e->export_rows ||
        e->ncell >= CMI_FAST_MARCHER_MAX_CELLS))
@@ -1922,9 +1937,11 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       ((int64_t)e->grid.ncell[0] + 2 * CMI_PAD_LAYERS) *
       ((int64_t)e->grid.ncell[1] + 2 * CMI_PAD_LAYERS) *
       ((int64_t)e->grid.ncell[2] + 2 * CMI_PAD_LAYERS);
+  /* (a block of a decomposed grid: its ghost layer says "left the block", the
+   * end of the flight then decides between "left the box" and a hand-over) */
+  const bool block_ok = !e->grid.decomposed || e->tune.block_first_kernels;
   const bool pad = kernel_first != kernel && !e->full_ions &&
-                   e->tune.pad_march && !e->grid.decomposed &&
-                   e->grid.copy_count <= 1 &&
+                   e->tune.pad_march && block_ok &&
                    padded_cells < ((int64_t)1 << 29);
   const bool pad_big = pad && e->ncell > CMI_TABLE_BIG_CELLS;
   if (pad_big)
@@ -1941,8 +1958,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
    * weights buffer of the tile rounds, idle during the first generation) */
   void (*kernel_first_pre)(const ShootArgs) = nullptr;
   if (kernel_first != kernel && e->full_ions && e->tune.pre_emission &&
-      e->tune.sort_packets && passes && e->tune.tile_rounds &&
-      !e->grid.decomposed && e->grid.copy_count <= 1)
+      e->tune.sort_packets && passes && e->tune.tile_rounds && block_ok)
     kernel_first_pre =
         heat ? shoot_kernel<true, true, false, false, true, true>
              : shoot_kernel<true, false, false, false, true, true>;
@@ -2081,8 +2097,41 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   }
 
   for (uint64_t done = 0; done < n_packets; done += max_launch) {
-    const uint64_t n = n_packets - done < max_launch ? n_packets - done
-                                                     : max_launch;
+    /* the launch's packet ids ... */
+    const uint64_t nids = n_packets - done < max_launch ? n_packets - done
+                                                        : max_launch;
+    /* ... and what it flies: all of them, or - a block of a decomposed grid -
+     * those that start in the block */
+    uint64_t n = nids;
+    const uint32_t *select = nullptr;
+    if (sorted && e->grid.decomposed && e->tune.block_select) {
+      if (!e->select_count)
+        HIP_TRY(hipMalloc(&e->select_count, sizeof(unsigned int)));
+      HIP_TRY(hipMemsetAsync(e->select_count, 0, sizeof(unsigned int),
+                             e->stream));
+      SelectArgs sa;
+      sa.grid = e->grid;
+      sa.model = e->model;
+      sa.first_packet = first_packet + done;
+      sa.batch_offset = done;
+      sa.n_packets = nids;
+      sa.seed = seed;
+      sa.iteration = iteration;
+      /* (the sort's output keys: free until the sort runs) */
+      sa.select = e->sort_keys[1];
+      sa.count = e->select_count;
+      block_select_kernel<false>
+          <<<grid_blocks(e, (int64_t)nids, 8), CMI_BLOCK, 0, e->stream>>>(sa);
+      HIP_TRY(hipGetLastError());
+      unsigned int mine = 0;
+      int rrc = read_counters(e, e->select_count, 1, &mine);
+      if (rrc)
+        return rrc;
+      if (mine == 0)
+        continue;
+      n = mine;
+      select = e->sort_keys[1];
+    }
     ShootArgs a;
     a.grid = e->grid;
     a.model = e->model;
@@ -2152,8 +2201,10 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       k.dir_bits = dir_bits;
       if (tau_bits != 0) {
         const uint64_t per_bin = 64ull << tau_bits;
+        /* (a block's own packets fill its part of the sphere as densely as
+         * the launch's ids fill the whole) */
         const uint64_t per_source =
-            n / (uint64_t)(e->model.nsource > 0 ? e->model.nsource : 1);
+            nids / (uint64_t)(e->model.nsource > 0 ? e->model.nsource : 1);
         while (k.dir_hi_bits < dir_bits &&
                (per_source >> (k.dir_hi_bits + 1u)) >= per_bin)
           ++k.dir_hi_bits;
@@ -2161,6 +2212,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       k.keys = e->sort_keys[0];
       k.ids = e->sort_ids[0];
       k.pre_rows = kernel_first_pre ? e->tile_rows[1].weights : nullptr;
+      k.select = select;
       a.pre_rows = k.pre_rows;
       if (k.pre_rows)
         emission_key_kernel<<<grid_blocks(e, (int64_t)n, 8), CMI_BLOCK, 0,

@@ -20,7 +20,7 @@
 #else
 #define CMI_EXP(a) 0
 #endif
-/* slots of a block's combining table (aggregate mode 3) */
+/* slots of a block's combining table (a.aggregate == CMI_AGG_BLOCK) */
 #ifndef CMI_TABLE_BITS
 #define CMI_TABLE_BITS 10
 #endif
@@ -245,6 +245,36 @@ __device__ __forceinline__ int32_t cmi_unpad_cell(const ShootArgs &a,
   return ((ix - CMI_PAD_LAYERS) * g.ncell[1] + (iy - CMI_PAD_LAYERS)) *
              g.ncell[2] +
          (iz - CMI_PAD_LAYERS);
+}
+
+/* PAD kernels on a block of a decomposed grid: the packet has stepped out of
+ * the block into the ghost cell p.cell (a padded long index). exit_cell_global
+ * (device_transport.h) for that cell: its long index in the WHOLE grid, or -1
+ * if it lies outside the whole grid; across a periodic face of the whole box
+ * the flight's origin is shifted by a box side. (One ghost layer is enough:
+ * every tied axis advances by one cell per step.) */
+template <bool FULL>
+__device__ __forceinline__ int64_t
+exit_cell_global_padded(const ShootArgs &a, const GridDev &g, Packet<FULL> &p) {
+  const int32_t c = p.cell;
+  const int32_t ix = (int32_t)(((double)c + 0.5) * a.pad_inv_yz);
+  const int32_t r = c - ix * (a.pad_ny * a.pad_nz);
+  const int32_t iy = (int32_t)(((double)r + 0.5) * a.pad_inv_z);
+  const int32_t iz = r - iy * a.pad_nz;
+  int64_t gc[3] = {(int64_t)ix - CMI_PAD_LAYERS + g.offset[0],
+                   (int64_t)iy - CMI_PAD_LAYERS + g.offset[1],
+                   (int64_t)iz - CMI_PAD_LAYERS + g.offset[2]};
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    if (gc[ax] < 0 || gc[ax] >= g.global_ncell[ax]) {
+      if (!g.global_periodic[ax])
+        return -1;
+      /* across a periodic face of the whole box: is_inside()'s wrap */
+      p.pos[ax] += (gc[ax] < 0 ? 1. : -1.) * g.box_sides[ax];
+      gc[ax] = gc[ax] < 0 ? g.global_ncell[ax] - 1 : 0;
+    }
+  }
+  return (gc[0] * g.global_ncell[1] + gc[1]) * g.global_ncell[2] + gc[2];
 }
 
 /* quad_perm DPP controls: lane j of every group of 4 reads lane j - 1 / j - 2
@@ -902,6 +932,60 @@ accumulate_full(const ShootArgs &a, const double (&wq)[CMI_NACC],
 #endif
 }
 
+/* Decomposed grids: does the block `g` fly the packet that emit_geometry has
+ * just started (p.index = its cell in the block's coordinates)?
+ *
+ * Every block can decide for every packet of the iteration; a source outside
+ * the whole grid is the business of the block at the grid's origin. A source
+ * ON a cell wall - the benchmarks' star sits on the corner shared by the 8
+ * octants - sends most of its packets through a first step of length zero
+ * into a neighbouring cell: such steps are pure geometry (no opacity, no
+ * optical depth), so every block takes them here, identically, before asking
+ * whose packet it is (`skipped` = 1: p.index and p.tmax have advanced).
+ * Otherwise the block with the source cell would emit everything and hand
+ * 7/8 of it over. Several engines may hold the block (copies): each takes its
+ * share of the ids. */
+template <bool FULL, bool EXACT>
+__device__ __forceinline__ bool
+block_owns_start(const GridDev &g, Packet<FULL> &p, uint32_t packet_id,
+                 int &skipped, bool &in_block) {
+  skipped = 0;
+  if (!EXACT) {
+    /* (one such step at most: afterwards every tmax is positive) */
+    const double tmin = min_f64(p.tmax[0], min_f64(p.tmax[1], p.tmax[2]));
+    bool start_in_grid = true;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      const int32_t gi = p.index[ax] + g.offset[ax];
+      start_in_grid &= (gi >= 0 && gi < g.global_ncell[ax]);
+    }
+    if (start_in_grid && tmin == p.t) {
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        if (p.tmax[ax] == tmin) { /* exactly fast_step's advance */
+          p.tmax[ax] = __fma_rn(1., p.tdelta[ax], p.tmax[ax]);
+          p.index[ax] += (p.dir[ax] > 0.) ? 1 : -1;
+        }
+      }
+      skipped = 1;
+    }
+  }
+  bool in_grid = true;
+  in_block = true;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const int32_t gi = p.index[ax] + g.offset[ax];
+    in_block &= (p.index[ax] >= 0 && p.index[ax] < g.ncell[ax]);
+    in_grid &= (gi >= 0 && gi < g.global_ncell[ax]);
+  }
+  const bool at_origin = (g.offset[0] | g.offset[1] | g.offset[2]) == 0;
+  bool mine = in_block || (!in_grid && at_origin);
+  /* several engines hold this block: each emits its share */
+  if (g.copy_count > 1)
+    mine &= (int32_t)(packet_id % (uint32_t)g.copy_count) == g.copy_rank;
+  return mine;
+}
+
 /*
  * Transport kernel: IonizationPhotonShootJob::execute
  * (src/IonizationPhotonShootJob.hpp:117-146) for a range of packets.
@@ -1296,52 +1380,13 @@ __global__ void
           const uint32_t origin =
               emit_geometry<FULL, EXACT>(a.grid, a.model, rng, p);
           if (a.grid.decomposed) {
-            /* Every block runs through all packets of the iteration but only
-             * flies those that start in it; a source outside the whole grid
-             * is the business of the block at the grid's origin. A source ON
-             * a cell wall - the benchmarks' star sits on the corner shared by
-             * the 8 octants - sends most of its packets through a first step
-             * of length zero into a neighbouring cell: such steps are pure
-             * geometry (no opacity, no optical depth), so every block takes
-             * them here, identically, before asking whose packet it is.
-             * Otherwise the block with the source cell would emit everything
-             * and hand 7/8 of it over. */
+            /* a block flies the packets that start in it (block_owns_start;
+             * the launch's positions may already be the block's own packets
+             * only - block_select_kernel - and then all of them are) */
             int skipped = 0;
-            if (!EXACT) {
-              /* (one such step at most: afterwards every tmax is positive) */
-              const double tmin =
-                  min_f64(p.tmax[0], min_f64(p.tmax[1], p.tmax[2]));
-              bool start_in_grid = true;
-#pragma unroll
-              for (int ax = 0; ax < 3; ++ax) {
-                const int32_t gi = p.index[ax] + a.grid.offset[ax];
-                start_in_grid &= (gi >= 0 && gi < a.grid.global_ncell[ax]);
-              }
-              if (start_in_grid && tmin == p.t) {
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) {
-                  if (p.tmax[ax] == tmin) { /* exactly fast_step's advance */
-                    p.tmax[ax] = __fma_rn(1., p.tdelta[ax], p.tmax[ax]);
-                    p.index[ax] += (p.dir[ax] > 0.) ? 1 : -1;
-                  }
-                }
-                skipped = 1;
-              }
-            }
-            bool in_block = true, in_grid = true;
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-              const int32_t gi = p.index[ax] + a.grid.offset[ax];
-              in_block &= (p.index[ax] >= 0 && p.index[ax] < a.grid.ncell[ax]);
-              in_grid &= (gi >= 0 && gi < a.grid.global_ncell[ax]);
-            }
-            const bool at_origin = (a.grid.offset[0] | a.grid.offset[1] |
-                                    a.grid.offset[2]) == 0;
-            mine = in_block || (!in_grid && at_origin);
-            /* several engines hold this block: each emits its share */
-            if (a.grid.copy_count > 1)
-              mine &= (int32_t)(packet_id % (uint32_t)a.grid.copy_count) ==
-                      a.grid.copy_rank;
+            bool in_block = true;
+            mine = block_owns_start<FULL, EXACT>(a.grid, p, packet_id, skipped,
+                                                 in_block);
             if (skipped != 0 && mine) {
               nsteps += skipped; /* they are DDA steps of the undivided run */
 #pragma unroll
@@ -1716,9 +1761,18 @@ __global__ void
           done = !absorbed;
         } else {
           done = true; /* left the box: DensityGrid::end() */
-          if (!EXACT && a.grid.decomposed && last_cell >= 0) {
-            /* ... or only this block of it: hand the flight over */
-            const int64_t cell_global = exit_cell_global(a.grid, p, last_cell);
+          if (!EXACT && a.grid.decomposed && (PAD || last_cell >= 0)) {
+            /* ... or only this block of it: hand the flight over. (PAD: the
+             * ghost cell the packet stands in says where it went; a packet
+             * that never entered the block stands in the corner ghost cell
+             * of padded index 0, which belongs to no block.) */
+            int64_t cell_global;
+            if constexpr (PAD)
+              cell_global = pad_next > -1.5
+                                ? -1
+                                : exit_cell_global_padded(a, a.grid, p);
+            else
+              cell_global = exit_cell_global(a.grid, p, last_cell);
             if (cell_global >= 0) {
               const unsigned long long leaving = __ballot(true);
               unsigned int base = 0;
@@ -2564,7 +2618,64 @@ struct KeyArgs {
   /* multi-ion transport: row i receives the emission physics of packet
    * first_packet + i (emit_physics_from_row reads it back); NULL = none */
   double *pre_rows;
+  /* not NULL: entry j of the launch is packet first_packet + select[j] (the
+   * packets of the launch that start in this block of a decomposed grid,
+   * block_select_kernel); keys[j] / ids[j] = select[j], row select[j] */
+  const uint32_t *select;
 };
+
+/* Decomposed grids: the packets of a launch that THIS block flies - the
+ * reference hands a subgrid's source task its own share of the packets
+ * (src/DistributedPhotonSource.hpp:140-200,
+ * src/SourceDiscretePhotonTaskContext.hpp:112-200); here every block decides
+ * for every packet id from the packet's own random numbers (emit_geometry +
+ * block_owns_start: ~8 draws and a sincos per packet, no physics), and only
+ * the block's own packets get keys, are sorted and are flown. select[0 ..
+ * *count) = their ids relative to first_packet, in no particular order (the
+ * sort orders them). */
+struct SelectArgs {
+  GridDev grid;
+  ModelDev model;
+  uint64_t first_packet; /* of the launch: packet i is first_packet + i ... */
+  uint64_t batch_offset; /* ... and has the id batch_offset + i in its call */
+  uint64_t n_packets;
+  uint32_t seed;
+  uint32_t iteration;
+  uint32_t *select;
+  unsigned int *count;
+};
+template <bool EXACT>
+__global__ void __launch_bounds__(CMI_BLOCK)
+    block_select_kernel(const SelectArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t rounded = (a.n_packets + 63) & ~(uint64_t)63;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       i < rounded; i += stride) {
+    bool mine = false;
+    if (i < a.n_packets) {
+      PacketRng rng;
+      rng.init(a.seed, a.iteration, a.first_packet + i);
+      Packet<false> p;
+      (void)emit_geometry<false, EXACT>(a.grid, a.model, rng, p);
+      int skipped;
+      bool in_block;
+      mine = block_owns_start<false, EXACT>(
+          a.grid, p, (uint32_t)(a.batch_offset + i), skipped, in_block);
+    }
+    const unsigned long long owners = __ballot(mine);
+    if (owners == 0ull)
+      continue;
+    unsigned int base = 0;
+    const int first = __ffsll((long long)owners) - 1;
+    if (lane == first)
+      base = atomicAdd(a.count, (unsigned int)__popcll(owners));
+    base = __shfl(base, first, 64);
+    if (mine)
+      a.select[base + __popcll(owners & ((1ull << lane) - 1ull))] =
+          (uint32_t)i;
+  }
+}
 
 __device__ __forceinline__ uint32_t spread_bits_11(uint32_t x) {
   /* 11 bits -> every other bit of 22 */
@@ -2672,7 +2783,7 @@ direction_key_batches(const KeyArgs &a) {
   constexpr int TRIPS = CMI_KEY_BATCH;
   constexpr unsigned int BATCH = TRIPS * CMI_BLOCK;
   __shared__ double s_nu[BATCH], s_tau[BATCH];
-  __shared__ uint32_t s_src[BATCH], s_morton[BATCH];
+  __shared__ uint32_t s_src[BATCH], s_morton[BATCH], s_id[BATCH];
   __shared__ uint16_t s_order[BATCH];
   __shared__ uint32_t s_count[CMI_VERNER_NCLASS];
   const uint32_t lo_bits = a.dir_bits - a.dir_hi_bits;
@@ -2691,7 +2802,10 @@ direction_key_batches(const KeyArgs &a) {
         continue;
       /* the draws of emit_packet, in its order */
       PacketRng rng;
-      rng.init(a.seed, a.iteration, a.first_packet + base + local);
+      const uint64_t id =
+          a.select ? (uint64_t)a.select[base + local] : base + local;
+      s_id[local] = (uint32_t)id;
+      rng.init(a.seed, a.iteration, a.first_packet + id);
       const uint32_t origin =
           rng.next() >= a.model.continuous_probability ? 0u : 1u;
       uint32_t src = 0;
@@ -2729,8 +2843,8 @@ direction_key_batches(const KeyArgs &a) {
       const double tau = s_tau[local];
       weights[CMI_NION] = q.nu;
       weights[CMI_NION + 1] = tau;
-      double4 *row =
-          reinterpret_cast<double4 *>(a.pre_rows + (size_t)CMI_NACC * i);
+      double4 *row = reinterpret_cast<double4 *>(
+          a.pre_rows + (size_t)CMI_NACC * s_id[local]);
 #pragma unroll
       for (int k = 0; k < CMI_NACC; k += 4)
         row[k >> 2] = make_double4(weights[k], weights[k + 1], weights[k + 2],
@@ -2748,7 +2862,7 @@ direction_key_batches(const KeyArgs &a) {
       a.keys[i] = ((s_src[local] & a.source_mask)
                    << (a.dir_bits + a.tau_bits)) |
                   (hi << (a.tau_bits + lo_bits)) | (tau_class << lo_bits) | lo;
-      a.ids[i] = (uint32_t)i;
+      a.ids[i] = s_id[local];
     }
     __syncthreads(); /* the batch's arrays are rewritten by the next one */
   }
@@ -2768,7 +2882,8 @@ __global__ void __launch_bounds__(CMI_BLOCK)
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
        i < a.n_packets; i += stride) {
     PacketRng rng;
-    rng.init(a.seed, a.iteration, a.first_packet + i);
+    const uint64_t id = a.select ? (uint64_t)a.select[i] : i;
+    rng.init(a.seed, a.iteration, a.first_packet + id);
     const uint32_t origin =
         rng.next() >= a.model.continuous_probability ? 0u : 1u;
     uint32_t src = 0;
@@ -2812,7 +2927,7 @@ __global__ void __launch_bounds__(CMI_BLOCK)
     const uint32_t lo = morton & ((1u << lo_bits) - 1u);
     a.keys[i] = ((src & a.source_mask) << (a.dir_bits + a.tau_bits)) |
                 (hi << (a.tau_bits + lo_bits)) | (tau_class << lo_bits) | lo;
-    a.ids[i] = (uint32_t)i;
+    a.ids[i] = (uint32_t)id;
   }
 }
 

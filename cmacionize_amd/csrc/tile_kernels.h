@@ -439,7 +439,11 @@ __global__ void __launch_bounds__((TileShape<FULL, HEAT>::THREADS),
   /* transport records of the tile's cells: n x_H (< 0: vacuum), and n x_He
    * for multi-ion transport */
   __shared__ double opac[(FULL ? 2 : 1) * TC];
-  __shared__ unsigned int s_ring[2], s_next, s_nabs;
+  /* (three claims in flight: the slot thread 0 fills in trip k - the unit after
+   * next - is one no wave can still be reading: its last reader was the end
+   * of trip k - 3, barriers ago; with two slots the first trip's claim
+   * overwrote the slot the other waves read after the prologue's barrier) */
+  __shared__ unsigned int s_ring[3], s_next, s_nabs;
 
   const int lane = threadIdx.x & 63;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
@@ -534,7 +538,8 @@ __global__ void __launch_bounds__((TileShape<FULL, HEAT>::THREADS),
     }
     if (threadIdx.x == 0) {
       if (PREFETCH)
-        s_ring[trip & 1] = atomicAdd(a.next_item, 1u); /* the one after next */
+        s_ring[(trip + 2) % 3] =
+            atomicAdd(a.next_item, 1u); /* the one after next */
       s_nabs = 0;
       s_next = it.begin;
     }
@@ -944,7 +949,7 @@ __global__ void __launch_bounds__((TileShape<FULL, HEAT>::THREADS),
     __syncthreads();
     if (PREFETCH) {
       item = item_next;
-      item_next = s_ring[trip & 1];
+      item_next = s_ring[(trip + 2) % 3];
       it = it_ahead;
     }
   }

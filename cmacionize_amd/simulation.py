@@ -375,6 +375,9 @@ class DomainIterationDriver:
         # seconds this rank spent inside the rounds' collectives (waiting for
         # the slowest rank + the transfer), summed until the caller resets it
         self.idle_s = 0.
+        # set by bench.py: time the hand-over collectives (adds a device-wide
+        # synchronize per round)
+        self.measure_idle = False
 
     def _exchange(self, rows, counts):
         """One hand-over round: ONE all-gather of every rank's per-owner
@@ -417,9 +420,13 @@ class DomainIterationDriver:
                 # to the end of the all-to-all the rank waits for the others)
                 t0 = time.perf_counter()
                 incoming, total = self._exchange(rows, counts)
-                if total != 0 and torch.cuda.is_available():
-                    torch.cuda.synchronize()
-                self.idle_s += time.perf_counter() - t0
+                if self.measure_idle:
+                    # (bench.py's idle_ms figure: wait for the all-to-all
+                    # itself. Off by default - the device-wide synchronize
+                    # serialises the collective against the next launch)
+                    if total != 0 and torch.cuda.is_available():
+                        torch.cuda.synchronize()
+                    self.idle_s += time.perf_counter() - t0
                 if total == 0:
                     break
             else:

@@ -570,6 +570,17 @@ int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);
  *                           launch's order instead of claiming a place from
  *                           the queue's counter (one returning atomic per
  *                           bundle on one word)
+ *   "block_select" (1)      a block of a decomposed grid picks the packets
+ *                           that start in it out of a launch's ids before
+ *                           keys, sort and transport (the reference gives a
+ *                           subgrid's source task its own share of the
+ *                           packets, src/DistributedPhotonSource.hpp:140-200);
+ *                           0: every block runs all ids through them and the
+ *                           transport kernel drops the others
+ *   "block_first_kernels" (1)  ... and flies them with the kernels built for
+ *                           a whole grid's first generation (padded march,
+ *                           emission rows from the key kernel); 0: the pass
+ *                           kernels, as before round 6
  *   "tile_compact_ratio" (-1)  the rows of the live flights are copied into
  *                           fresh rows, in tile order, once the flights are
  *                           spread over this many slots per flight; 0: never;

@@ -150,20 +150,32 @@ def test_eight_ranks_on_one_device():
     # the driver's command as it stands (no --no-also): the line of N > 1
     # ranks also carries config 5's shape over torch.distributed and the
     # native group driver (one process, eight engines) on both shapes
+    import time
     small.remove("--no-also")
+    t0 = time.perf_counter()
     replica = run(8, ["--config5-ncell", "48"])
+    # the driver allows a scaling run 25 minutes; the extras have a budget of
+    # 420 s of their own (bench.py EXTRAS_BUDGET_S)
+    assert time.perf_counter() - t0 < 25 * 60
+    assert replica["bench_wall_s"] < 25 * 60
     small.append("--no-also")
     assert replica["n_gpus"] == 8 and replica["ranks_in_collective"] == 8
     assert replica["scaling"] == "weak"
     assert replica["packets_per_rank_per_step"] == 2e5
     assert "strong_scaling" in replica
     c5 = replica["config5"]
+    assert "error" not in c5, c5
     assert "lexington" in c5["metric"] and "48^3" in c5["metric"]
     assert c5["scaling"] == "strong" and c5["n_gpus"] == 8
     assert c5["exchange_rounds_last_step"] >= 2
     assert c5["flights_exchanged_last_step"] > 0
     assert len(c5["idle_ms_per_step_by_rank"]) == 8
     assert all(ms >= 0. for ms in c5["idle_ms_per_step_by_rank"])
+    # every rank emits its own eighth of the packets (the star sits on the
+    # blocks' common corner), not all of them
+    emitted = c5["emitted_packets_per_step_by_rank"]
+    assert len(emitted) == 8 and abs(sum(emitted) - 2e5) < 1.
+    assert max(emitted) < 1.1 * 2e5 / 8
     native = replica["native"]
     for shape in ("replica", "config5"):
         assert "error" not in native[shape], native[shape]

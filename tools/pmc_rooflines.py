@@ -24,6 +24,9 @@ import sys
 from collections import defaultdict
 
 root, steps = sys.argv[1], int(sys.argv[2])
+# (the grid the profile was taken on: beyond 2^25 cells the hydrogen-only
+# first generation is the BIG build - last template argument true)
+NCELL = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 # (template arguments: FULL, HEAT, REEMIT, EXACT, TABLE, PRE, PAD, TRACK -
 # the first generation of an iteration runs the TABLE variant)
 DOMINANT = {"stromgren":
@@ -32,6 +35,10 @@ DOMINANT = {"stromgren":
                 "shoot_kernel<false, false, false, false, true, false, true, false, false>",
             "lexington":
                 "shoot_kernel<true, true, false, false, true, true, false, false, false>"}
+if NCELL ** 3 > 1 << 25:
+    for _c in ("stromgren", "stromgren_diffuse"):
+        DOMINANT[_c] = DOMINANT[_c].replace("true, false, false>",
+                                            "true, false, true>")
 N_SIMD, N_CU, MAXCLK = 1024, 256, 2.4e9
 
 
@@ -88,7 +95,7 @@ for config, dominant in DOMINANT.items():
     passes = load(config)
     if not passes:
         continue
-    entry = {"ncell": 256, "steps_profiled": steps, "dominant": {},
+    entry = {"ncell": NCELL, "steps_profiled": steps, "dominant": {},
              "other_kernels": [],
              # the source the profiled library was built from
              "commit": os.environ.get("CMI_PROFILE_COMMIT")}

@@ -258,7 +258,7 @@ def cpu_baseline(ncell, config, cfg, engine, seconds=12., hint=None):
 
 # PMC profiles of this very command, newest first (tools/round_measure.sh)
 PROFILES = [os.path.join("profiles", r, "counters.json")
-            for r in ("r05", "r04", "r03")]
+            for r in ("r06", "r05", "r04", "r03")]
 
 # what each unit of the chip can do per second (MI355X_MICROARCH.md; the
 # atomic-request rate is measured: profiles/r01/atomic_rates.txt)

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -89,6 +90,10 @@ struct cmi_gpu_engine {
 
   /* direction sort of the packet order (keys/ids double buffered) */
   unsigned int *select_count = nullptr; /* block_select_kernel's counter */
+  uint32_t *select_ids = nullptr;       /* ... and its list */
+  uint64_t select_capacity = 0;
+  double *select_rows = nullptr; /* emission rows of a selection, by id */
+  uint64_t select_rows_capacity = 0;
   uint32_t *sort_keys[2] = {nullptr, nullptr};
   uint32_t *sort_ids[2] = {nullptr, nullptr};
   void *sort_temp = nullptr;
@@ -1008,6 +1013,29 @@ int cmi_gpu_create(const cmi_gpu_config *config, cmi_gpu_engine **out) {
   m.t_min_ionized = tp.minimum_ionized_temperature;
 
   HIP_TRY(hipStreamSynchronize(e->stream));
+  /* CMI_GPU_TUNING="key=value,key=value": cmi_gpu_set_tuning for hosts that
+   * have no way to call it (the cmi-gpu executable, a code that links the
+   * library mode): experiments and bisections, not configuration */
+  if (const char *env = std::getenv("CMI_GPU_TUNING")) {
+    std::string all(env);
+    size_t at = 0;
+    while (at < all.size()) {
+      size_t end = all.find(',', at);
+      if (end == std::string::npos)
+        end = all.size();
+      const std::string item = all.substr(at, end - at);
+      const size_t eq = item.find('=');
+      if (eq != std::string::npos) {
+        const int rc = cmi_gpu_set_tuning(e, item.substr(0, eq).c_str(),
+                                          std::atoll(item.c_str() + eq + 1));
+        if (rc) {
+          cmi_gpu_destroy(e);
+          return rc;
+        }
+      }
+      at = end + 1;
+    }
+  }
   *out = e;
   return CMI_GPU_OK;
 }
@@ -1044,6 +1072,8 @@ int cmi_gpu_destroy(cmi_gpu_engine *e) {
   (void)hipFree(e->source_cumulative);
   (void)hipFree(e->sort_keys[0]);
   (void)hipFree(e->select_count);
+  (void)hipFree(e->select_ids);
+  (void)hipFree(e->select_rows);
   (void)hipFree(e->sort_temp);
   (void)hipFree(e->queue_block);
   (void)hipFree(e->queue_counts);
@@ -1883,7 +1913,13 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   /* with re-emission in passes the transport launches use the variant WITHOUT
    * the re-emission code (absorbed packets go to the interaction kernel); the
    * variant with it follows re-emissions in place */
-  const bool passes = reemit && e->tune.reemit_passes;
+  /* (a handful of handed-over flights - the late hand-over rounds of a
+   * decomposed grid - are followed in place, re-emissions and all, by ONE
+   * launch: a pass, the interaction kernel and the in-place kernel after it
+   * each cost the latency of the longest flight, ~1 ms, whatever their
+   * number) */
+  const bool passes = reemit && e->tune.reemit_passes &&
+                      !(flights && n_packets < e->tune.reemit_inline_below);
   void (*kernel)(const ShootArgs) = nullptr;
   void (*kernel_inline)(const ShootArgs) = nullptr;
 #define PICK(F, H, X)                                                          \
@@ -2000,29 +2036,40 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
   }
   const bool sorted = e->tune.sort_packets && !flights;
   const uint64_t max_launch = e->tune.max_packets_per_launch;
-  if (sorted) {
-    int rc = reserve_sort_buffers(e, n_packets < max_launch ? n_packets
-                                                            : max_launch);
-    if (rc)
-      return rc;
-  }
-  if (passes) {
-    int rc = reserve_queues(e, n_packets < max_launch ? n_packets : max_launch);
-    if (rc)
-      return rc;
-  }
   /* later generations in tile rounds: needs the incremental marcher */
   const bool tiles = passes && e->tune.tile_rounds && !exact && !tracking;
+  /* a block of a decomposed grid picks its own packets out of each launch's
+   * ids first (block_select_kernel): buffers for what it picks, not for all
+   * ids (1 / 8 of them in config 5 - sort buffers, queues and flight slots
+   * are 40 GB per 1e8 packets) */
+  const bool select_mode =
+      sorted && e->grid.decomposed && e->tune.block_select;
+  auto reserve_for = [&](uint64_t cap) -> int {
+    if (sorted || tiles) {
+      int rc = reserve_sort_buffers(e, cap);
+      if (rc)
+        return rc;
+    }
+    if (passes) {
+      int rc = reserve_queues(e, cap);
+      if (rc)
+        return rc;
+    }
+    if (tiles) {
+      int rc = reserve_tile_buffers(e, cap);
+      if (rc)
+        return rc;
+    }
+    return CMI_GPU_OK;
+  };
+  if (!select_mode) {
+    int rc = reserve_for(n_packets < max_launch ? n_packets : max_launch);
+    if (rc)
+      return rc;
+  }
   void (*tkernel)(const TileArgs) = nullptr;
   int tile_threads = 0, tile_blocks_per_cu = 0;
   if (tiles) {
-    const uint64_t cap = n_packets < max_launch ? n_packets : max_launch;
-    int rc = reserve_tile_buffers(e, cap);
-    if (rc)
-      return rc;
-    rc = reserve_sort_buffers(e, cap);
-    if (rc)
-      return rc;
     if (e->full_ions)
       tkernel = heat ? tile_kernel<true, true> : tile_kernel<true, false>;
     else
@@ -2104,9 +2151,17 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
      * those that start in the block */
     uint64_t n = nids;
     const uint32_t *select = nullptr;
-    if (sorted && e->grid.decomposed && e->tune.block_select) {
+    if (select_mode) {
       if (!e->select_count)
         HIP_TRY(hipMalloc(&e->select_count, sizeof(unsigned int)));
+      if (e->select_capacity < nids) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        (void)hipFree(e->select_ids);
+        e->select_ids = nullptr;
+        e->select_capacity = 0;
+        HIP_TRY(hipMalloc(&e->select_ids, sizeof(uint32_t) * nids));
+        e->select_capacity = nids;
+      }
       HIP_TRY(hipMemsetAsync(e->select_count, 0, sizeof(unsigned int),
                              e->stream));
       SelectArgs sa;
@@ -2117,8 +2172,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       sa.n_packets = nids;
       sa.seed = seed;
       sa.iteration = iteration;
-      /* (the sort's output keys: free until the sort runs) */
-      sa.select = e->sort_keys[1];
+      sa.select = e->select_ids;
       sa.count = e->select_count;
       block_select_kernel<false>
           <<<grid_blocks(e, (int64_t)nids, 8), CMI_BLOCK, 0, e->stream>>>(sa);
@@ -2130,7 +2184,12 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       if (mine == 0)
         continue;
       n = mine;
-      select = e->sort_keys[1];
+      select = e->select_ids;
+      /* (some headroom: the count differs by a per cent from one iteration
+       * to the next, and growing means freeing and allocating again) */
+      int rc = reserve_for(n + n / 16 + 1024);
+      if (rc)
+        return rc;
     }
     ShootArgs a;
     a.grid = e->grid;
@@ -2212,6 +2271,22 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       k.keys = e->sort_keys[0];
       k.ids = e->sort_ids[0];
       k.pre_rows = kernel_first_pre ? e->tile_rows[1].weights : nullptr;
+      if (kernel_first_pre && select) {
+        /* the rows are addressed by packet id within the launch (that is what
+         * the transport kernel knows): a block that flies a selection of the
+         * ids needs room for all of them - the flight slots it borrows the
+         * room from otherwise are sized for its selection */
+        if (e->select_rows_capacity < nids) {
+          HIP_TRY(hipStreamSynchronize(e->stream));
+          (void)hipFree(e->select_rows);
+          e->select_rows = nullptr;
+          e->select_rows_capacity = 0;
+          HIP_TRY(hipMalloc(&e->select_rows,
+                            sizeof(double) * CMI_NACC * (size_t)nids));
+          e->select_rows_capacity = nids;
+        }
+        k.pre_rows = e->select_rows;
+      }
       k.select = select;
       a.pre_rows = k.pre_rows;
       if (k.pre_rows)

@@ -463,12 +463,38 @@ class LocalDomainDriver:
         self.nsteps = 0
         self.rounds = 0
         self.flights_exchanged = 0
+        # set measure_parallel to time every block's call with a device
+        # synchronize around it: parallel_s is then the time the iteration's
+        # transport would take with one device PER block - per round the
+        # slowest block, rounds one after the other (bulk-synchronous, as
+        # DomainIterationDriver runs them) - and serial_s what it took here
+        self.measure_parallel = False
+        self.parallel_s = 0.
+        self.serial_s = 0.
+        self.round_parallel_s = []
+
+    def _timed(self, call):
+        import time
+        import torch
+        if not self.measure_parallel:
+            call()
+            return 0.
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        call()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
 
     def iteration(self, loop, n_packets, seed, update=True):
         import torch
+        times = []
         for b in self.backends:
             b.reset_grid()
-            b.shoot(seed, loop, 0, n_packets)
+            times.append(self._timed(
+                lambda b=b: b.shoot(seed, loop, 0, n_packets)))
+        self.parallel_s = max(times)
+        self.serial_s = sum(times)
+        self.round_parallel_s = [max(times)]  # emission, then every round
         self.rounds = 0
         self.flights_exchanged = 0
         while True:
@@ -484,9 +510,15 @@ class LocalDomainDriver:
                     start = int(counts[:dest].sum())
                     parts.append(rows[start:start + int(counts[dest])])
                 incoming.append(torch.cat(parts).clone())
+            times = []
             for b, rows in zip(self.backends, incoming):
                 b.reset_exports()
-                b.continue_flights(seed, loop, 0, rows)
+                times.append(self._timed(
+                    lambda b=b, rows=rows: b.continue_flights(seed, loop, 0,
+                                                              rows)))
+            self.parallel_s += max(times)
+            self.serial_s += sum(times)
+            self.round_parallel_s.append(max(times))
             self.rounds += 1
             self.flights_exchanged += total
         tw, tc, ns = 0., np.zeros(4), 0

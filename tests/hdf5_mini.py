@@ -177,5 +177,13 @@ class File:
         return node
 
 
+    def __contains__(self, path):
+        try:
+            self[path]
+        except KeyError:
+            return False
+        return True
+
+
 def read(path):
     return File(path)

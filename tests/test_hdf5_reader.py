@@ -22,6 +22,7 @@ import numpy as np
 import pytest
 
 import hdf5_mini
+from bench_inputs import bench_text
 from test_host_driver import BENCH, exe  # noqa: F401 (fixture)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,7 +47,7 @@ def read(cli, filename, path):
 
 
 def lexington_params(ncell, extra=""):
-    text = open(os.path.join(BENCH, "lexingtonHII40.param")).read()
+    text = bench_text("lexingtonHII40.param")
     text = text.replace("[64, 64, 64]", "[%d, %d, %d]" % ((ncell,) * 3))
     text = text.replace("NumberDensity: 0", "NumberDensity: 1")
     return text + extra
@@ -342,7 +343,7 @@ def test_snapshot_of_another_grid_type_is_refused(exe, tmp_path):
 def test_restart_from_the_last_snapshot(exe, tmp_path):
     """A run continued from its own last snapshot starts from exactly that
     state (neutral fractions included) and stays where it had converged."""
-    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = bench_text("stromgren.param")
     text = text.replace("[64, 64, 64]", "[16, 16, 16]")
     text = text.replace("number of photons: 1e6", "number of photons: 50000")
     text = text.replace("number of iterations: 20", "number of iterations: 8")
@@ -426,7 +427,7 @@ def test_gadget_snapshot_density_function(exe, sph_writer, tmp_path, periodic):
     subprocess.run([sph_writer, str(snap), str(raw), str(periodic), str(box),
                     repr(ul_cgs), repr(um_cgs), repr(ut), str(1 | 2 | 4 | 8)],
                    check=True)
-    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = bench_text("stromgren.param")
     text = text.replace("[64, 64, 64]", "[%d, %d, %d]" % ((ncell,) * 3))
     text = text.replace("anchor: [-5. pc, -5. pc, -5. pc]",
                         "anchor: [0. pc, 0. pc, 0. pc]")
@@ -488,7 +489,7 @@ def test_gadget_snapshot_fixture_of_the_reference(exe, cli, tmp_path):
     units = read(cli, fixture, "/Units")["attributes"]
     assert len(masses) == 100
     assert units["Unit length in cgs (U_L)"] == [100]
-    text = open(os.path.join(BENCH, "stromgren.param")).read()
+    text = bench_text("stromgren.param")
     text = text.replace("[64, 64, 64]", "[32, 32, 32]")
     text = text.replace("anchor: [-5. pc, -5. pc, -5. pc]",
                         "anchor: [0. m, 0. m, 0. m]")

@@ -9,8 +9,12 @@ import json
 import os
 import subprocess
 
+import sys
+
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "cmacionize_amd", "cmi-gpu")
@@ -27,20 +31,7 @@ def exe():
     return EXE
 
 
-def bench_text(name):
-    """A benchmark input of the reference (benchmarks/ holds the files
-    byte for byte) as a template for the edits below: comment and blank lines
-    dropped, and the block of the task-based driver."""
-    out, skip = [], False
-    for line in open(os.path.join(BENCH, name)).read().split("\n"):
-        line = line.rstrip()
-        if not line.strip() or line.strip().startswith("#"):
-            continue
-        if not line.startswith(" "):
-            skip = line.startswith("TaskBasedIonizationSimulation:")
-        if not skip:
-            out.append(line)
-    return "\n".join(out) + "\n"
+from bench_inputs import bench_text  # noqa: E402
 
 
 def describe(exe, param, cwd):

@@ -11,7 +11,7 @@
 set -u
 REPO=$(pwd)
 OUT=$REPO/$1
-ROUND=${2:-r05}
+ROUND=${2:-r06}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # (the GPU box has no .git: pass the commit the counters belong to, e.g.

@@ -80,6 +80,7 @@ def main():
             configure(b.engine, ncell, off, size)
             backends.append(b)
         driver = LocalDomainDriver(backends, dec)
+        driver.measure_parallel = True
         for loop in range(iters):
             t0 = time.perf_counter()
             driver.iteration(loop, npk, 42, update=False)
@@ -93,10 +94,15 @@ def main():
                              < 0.5).sum()) for b in backends) / ncell ** 3
             print("blocks it %d shoot %7.1f ms (%6.1f Mpk/s, %5.1f steps/pk) "
                   "update %7.1f ms ion.vol %.4f | %d rounds, %.3g flights "
-                  "handed over" %
+                  "handed over | blocks' calls %7.1f ms in series, %6.1f ms "
+                  "with a device per block (per round the slowest)" %
                   (loop, 1e3 * (t1 - t0), npk / (t1 - t0) / 1e6,
                    driver.nsteps / npk, 1e3 * (t2 - t1), ion, driver.rounds,
-                   driver.flights_exchanged), flush=True)
+                   driver.flights_exchanged, 1e3 * driver.serial_s,
+                   1e3 * driver.parallel_s), flush=True)
+            print("       per round (emission first), ms: " +
+                  " ".join("%.1f" % (1e3 * t)
+                           for t in driver.round_parallel_s), flush=True)
 
 
 if __name__ == "__main__":

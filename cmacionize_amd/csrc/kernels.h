@@ -56,6 +56,11 @@ constexpr int shoot_block_threads() {
 #ifndef CMI_TABLE_PROBES
 #define CMI_TABLE_PROBES 8
 #endif
+/* experiment (round 6): this many low bits of a PAD table slot come straight
+ * from the padded cell index (0: all hashed) */
+#ifndef CMI_PAD_HASH_LOW_BITS
+#define CMI_PAD_HASH_LOW_BITS 0
+#endif
 /* experiment: look at a slot's tag with a plain LDS read before trying the
  * compare-and-swap (a hit then costs no LDS atomic; measured: 39.0 instead of
  * 34.5 ms - the second round trip of every first visit costs more than the
@@ -1228,8 +1233,22 @@ __global__ void
        * low bits; asm: the compiler widens __umul24 to the quarter-rate
        * v_mul_lo_u32) */
       uint32_t product;
+#if CMI_PAD_HASH_LOW_BITS > 0
+      /* the low bits of the slot are the low bits of the padded index - z + 2 y
+       * + 4 x modulo 8 with an even padded extent: the cells of a 2 x 2 x 2
+       * neighbourhood, where the lanes of a bundle sit at any one step, fall
+       * into different LDS banks -, the rest is hashed */
+      asm("v_mul_u32_u24 %0, 0x9e3779, %1"
+          : "=v"(product)
+          : "v"(cell >> CMI_PAD_HASH_LOW_BITS));
+      slot = (((product >> (24 - TBITS + CMI_PAD_HASH_LOW_BITS))
+               << CMI_PAD_HASH_LOW_BITS) |
+              ((uint32_t)cell & ((1u << CMI_PAD_HASH_LOW_BITS) - 1u))) &
+             (TSLOTS - 1);
+#else
       asm("v_mul_u32_u24 %0, 0x9e3779, %1" : "=v"(product) : "v"(cell));
       slot = (product >> (24 - TBITS)) & (TSLOTS - 1);
+#endif
     } else {
       slot = ((uint32_t)cell * 0x9E3779B1u) >> (32 - TBITS);
     }

@@ -136,21 +136,42 @@ cmi_locate_linear(double x, const double *arr, uint32_t length) {
 
 /* ------------------------------------------- caller-supplied tables ---- */
 
+/* the table modes are the rare case: the register allocator should place
+ * whatever it has to spill for them on their side of the branch (inlined
+ * without the hint, the table path cost the key, weights and temperature
+ * kernels 20-50 scalar spills each and direction_key_kernel a wave per SIMD) */
+#define CMI_UNLIKELY(c) __builtin_expect(!!(c), 0)
+
 /* Row `row` of a table at abscissa x: Utilities::locate's interval
  * (src/Utilities.hpp:726-742), linear interpolation in (x, y) or in
  * (log x, log y) - a power law between two samples, the form the reference's
  * Planck table is sampled in (src/PlanckPhotonSourceSpectrum.cpp:149-165) -;
  * outside [x[0], x[n - 1]] the end values (no extrapolation). A log-log
  * interval with a sample that is not positive falls back to linear. */
-__host__ __device__ inline double cmi_table_value(const TableDev &t, int row,
-                                                 double x) {
+/* ... in two steps, so that the 14 rows of a cross-section table share one
+ * search: where x lies (the interval and the weight of its upper end), then a
+ * row's value there */
+struct TableAt {
+  uint32_t lo;   /* interval [lo, lo + 1] */
+  double linear; /* (x - x0) / (x1 - x0), 0 / 1 outside the table */
+  double loglog; /* log(x / x0) / log(x1 / x0) where that exists, else < 0 */
+};
+__host__ __device__ inline TableAt cmi_table_locate(const TableDev &t,
+                                                    double x) {
   const double *xs = t.x;
-  const double *ys = t.y + (size_t)row * (size_t)t.n;
   const uint32_t n = (uint32_t)t.n;
-  if (!(x > xs[0]))
-    return ys[0];
-  if (!(x < xs[n - 1]))
-    return ys[n - 1];
+  TableAt at;
+  at.loglog = -1.;
+  if (!(x > xs[0])) {
+    at.lo = 0;
+    at.linear = 0.;
+    return at;
+  }
+  if (!(x < xs[n - 1])) {
+    at.lo = n - 2;
+    at.linear = 1.;
+    return at;
+  }
   uint32_t lo = 0, hi = n;
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
@@ -161,10 +182,28 @@ __host__ __device__ inline double cmi_table_value(const TableDev &t, int row,
   }
   if (lo == n - 1)
     --lo;
-  const double x0 = xs[lo], x1 = xs[lo + 1], y0 = ys[lo], y1 = ys[lo + 1];
-  if (t.interpolation == CMI_TABLE_LOGLOG && y0 > 0. && y1 > 0. && x0 > 0.)
-    return y0 * exp(log(y1 / y0) * (log(x / x0) / log(x1 / x0)));
-  return y0 + (y1 - y0) * ((x - x0) / (x1 - x0));
+  const double x0 = xs[lo], x1 = xs[lo + 1];
+  at.lo = lo;
+  at.linear = (x - x0) / (x1 - x0);
+  if (t.interpolation == CMI_TABLE_LOGLOG && x0 > 0.)
+    at.loglog = log(x / x0) / log(x1 / x0);
+  return at;
+}
+__host__ __device__ inline double cmi_table_row(const TableDev &t, int row,
+                                                const TableAt &at) {
+  const double *ys = t.y + (size_t)row * (size_t)t.n;
+  const double y0 = ys[at.lo], y1 = ys[at.lo + 1];
+  if (at.linear <= 0.)
+    return y0;
+  if (at.linear >= 1.)
+    return y1;
+  if (at.loglog >= 0. && y0 > 0. && y1 > 0.)
+    return y0 * exp(log(y1 / y0) * at.loglog);
+  return y0 + (y1 - y0) * at.linear;
+}
+__host__ __device__ inline double cmi_table_value(const TableDev &t, int row,
+                                                 double x) {
+  return cmi_table_row(t, row, cmi_table_locate(t, x));
 }
 
 /* ------------------------------------------------ Verner cross section -- */
@@ -218,12 +257,13 @@ __host__ __device__ inline void cmi_cross_sections(const ModelDev &m, double nu,
       sigma[i] = m.xsec_fixed[i];
     return;
   }
-  if (m.xsec_verner == 2) {
+  if (CMI_UNLIKELY(m.xsec_verner == 2)) {
     /* a plugin known only through CrossSections::get_cross_section
      * (src/CrossSections.hpp:49-50), sampled into a table by the host */
+    const TableAt at = cmi_table_locate(m.xsec_table, nu);
 #pragma unroll 1
     for (int k = 0; k < CMI_NION; ++k) {
-      const double s = cmi_table_value(m.xsec_table, k, nu);
+      const double s = cmi_table_row(m.xsec_table, k, at);
 #pragma unroll
       for (int i = 0; i < CMI_NION; ++i)
         if (i == k)
@@ -283,9 +323,10 @@ __host__ __device__ inline void cmi_cross_sections_H_He(const ModelDev &m, doubl
     sigma_He = m.xsec_fixed[ION_He_n];
     return;
   }
-  if (m.xsec_verner == 2) {
-    sigma_H = cmi_table_value(m.xsec_table, ION_H_n, nu);
-    sigma_He = cmi_table_value(m.xsec_table, ION_He_n, nu);
+  if (CMI_UNLIKELY(m.xsec_verner == 2)) {
+    const TableAt at = cmi_table_locate(m.xsec_table, nu);
+    sigma_H = cmi_table_row(m.xsec_table, ION_H_n, at);
+    sigma_He = cmi_table_row(m.xsec_table, ION_He_n, at);
     return;
   }
   sigma_H = 0.;
@@ -310,7 +351,7 @@ __device__ inline double cmi_recombination_rate(const ModelDev &m, int ion,
                                                 double temperature) {
   if (!m.recomb_verner)
     return m.recomb_fixed[ion];
-  if (m.recomb_verner == 2)
+  if (CMI_UNLIKELY(m.recomb_verner == 2))
     /* RecombinationRates::get_recombination_rate
      * (src/RecombinationRates.hpp:49) sampled into a table by the host */
     return cmi_table_value(m.recomb_table, ion, temperature);

@@ -81,7 +81,7 @@ __device__ inline double sample_source_spectrum(const ModelDev &m,
   if (origin != 0) {
     if (m.continuous_spectrum_type == 0)
       return m.continuous_mono_frequency;
-    if (m.continuous_spectrum_type == 2)
+    if (CMI_UNLIKELY(m.continuous_spectrum_type == 2))
       return sample_spectrum_table(m.spectrum_table[1], rng);
     return sample_planck_table(m.spectra->planck2_cdf, m.spectra->planck2_logcdf,
                                m.spectra->planck2_logfreq,
@@ -92,7 +92,7 @@ __device__ inline double sample_source_spectrum(const ModelDev &m,
      * (src/MonochromaticPhotonSourceSpectrum.hpp:97-100) */
     return m.mono_frequency;
   }
-  if (m.spectrum_type == 2)
+  if (CMI_UNLIKELY(m.spectrum_type == 2))
     return sample_spectrum_table(m.spectrum_table[0], rng);
   return sample_planck(m.spectra, rng);
 }

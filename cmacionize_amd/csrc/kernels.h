@@ -2714,7 +2714,7 @@ __device__ inline float approximate_opacity_cross_section(const ModelDev &m,
   if (!m.xsec_verner)
     return (float)(m.xsec_fixed[ION_H_n] +
                    m.abundance[0] * m.xsec_fixed[ION_He_n]);
-  if (m.xsec_verner == 2)
+  if (CMI_UNLIKELY(m.xsec_verner == 2))
     return (float)(cmi_table_value(m.xsec_table, ION_H_n, nu) +
                    m.abundance[0] *
                        cmi_table_value(m.xsec_table, ION_He_n, nu));
@@ -2802,7 +2802,7 @@ direction_key_batches(const KeyArgs &a) {
   constexpr int TRIPS = CMI_KEY_BATCH;
   constexpr unsigned int BATCH = TRIPS * CMI_BLOCK;
   __shared__ double s_nu[BATCH], s_tau[BATCH];
-  __shared__ uint32_t s_src[BATCH], s_morton[BATCH], s_id[BATCH];
+  __shared__ uint32_t s_src[BATCH], s_morton[BATCH];
   __shared__ uint16_t s_order[BATCH];
   __shared__ uint32_t s_count[CMI_VERNER_NCLASS];
   const uint32_t lo_bits = a.dir_bits - a.dir_hi_bits;
@@ -2823,7 +2823,6 @@ direction_key_batches(const KeyArgs &a) {
       PacketRng rng;
       const uint64_t id =
           a.select ? (uint64_t)a.select[base + local] : base + local;
-      s_id[local] = (uint32_t)id;
       rng.init(a.seed, a.iteration, a.first_packet + id);
       const uint32_t origin =
           rng.next() >= a.model.continuous_probability ? 0u : 1u;
@@ -2862,8 +2861,10 @@ direction_key_batches(const KeyArgs &a) {
       const double tau = s_tau[local];
       weights[CMI_NION] = q.nu;
       weights[CMI_NION + 1] = tau;
-      double4 *row = reinterpret_cast<double4 *>(
-          a.pre_rows + (size_t)CMI_NACC * s_id[local]);
+      /* (the packet's id in the launch: its row, and what the sort carries) */
+      const uint32_t id = a.select ? a.select[i] : (uint32_t)i;
+      double4 *row =
+          reinterpret_cast<double4 *>(a.pre_rows + (size_t)CMI_NACC * id);
 #pragma unroll
       for (int k = 0; k < CMI_NACC; k += 4)
         row[k >> 2] = make_double4(weights[k], weights[k + 1], weights[k + 2],
@@ -2881,7 +2882,7 @@ direction_key_batches(const KeyArgs &a) {
       a.keys[i] = ((s_src[local] & a.source_mask)
                    << (a.dir_bits + a.tau_bits)) |
                   (hi << (a.tau_bits + lo_bits)) | (tau_class << lo_bits) | lo;
-      a.ids[i] = s_id[local];
+      a.ids[i] = id;
     }
     __syncthreads(); /* the batch's arrays are rewritten by the next one */
   }
@@ -2894,7 +2895,9 @@ __global__ void __launch_bounds__(CMI_BLOCK, CMI_KEY_WAVES)
 
 /* ... and without (pre_rows == nullptr): a kernel of its own, so that its few
  * registers are not the other's 168 */
-__global__ void __launch_bounds__(CMI_BLOCK)
+/* (5 waves per SIMD, as before the table modes and the selection list joined
+ * it: their registers are spilled on their own paths) */
+__global__ void __launch_bounds__(CMI_BLOCK, 5)
     direction_key_kernel(const KeyArgs a) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint32_t lo_bits = a.dir_bits - a.dir_hi_bits;

@@ -149,4 +149,22 @@ print("snapshot readers: 4 x 120 damaged files, %s" %
       ("clean" if not bad else "FAILED"))
 sys.exit(1 if bad else 0)
 PY
+# the generic lowering of third-party plugins (tabulate_spectrum /
+# tabulate_ions, the registries): cmi-gpu built with tests/support/
+# third_party_plugins.cpp on a .param file that names its types
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer \
+    -fopenmp -DTP_WITH_MAIN -o "$TMP/tp-asan" \
+    tests/support/third_party_plugins.cpp -Lcmacionize_amd -lcmi_gpu -lz \
+    -Wl,-rpath,"$REPO/cmacionize_amd" -Wl,-rpath,/opt/rocm/lib
+for SPEC in ThirdPartyFalling Uniform; do
+  sed -e "s/type: Monochromatic/type: $SPEC/" \
+      -e "/^CrossSections:/,/^  type:/s/type: FixedValue/type: ThirdPartyPowerLaw/" \
+      -e "/^RecombinationRates:/,/^  type:/s/type: FixedValue/type: ThirdPartyPowerLaw/" \
+      benchmarks/stromgren.param > "$TMP/tp.param"
+  (cd "$TMP" && ASAN_OPTIONS=detect_leaks=0 ./tp-asan --params tp.param \
+      --dry-run --describe > tp.json 2> tp.err)
+  if [ -s "$TMP/tp.err" ]; then cat "$TMP/tp.err"; exit 1; fi
+  grep -q '"lowering": "scripted"' "$TMP/tp.json"
+  echo "generic lowering ($SPEC): clean"
+done
 echo "sanitizer pass clean"

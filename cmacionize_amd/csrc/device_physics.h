@@ -140,7 +140,11 @@ cmi_locate_linear(double x, const double *arr, uint32_t length) {
  * whatever it has to spill for them on their side of the branch (inlined
  * without the hint, the table path cost the key, weights and temperature
  * kernels 20-50 scalar spills each and direction_key_kernel a wave per SIMD) */
+#ifdef CMI_EXP_NO_TABLE_MODES /* experiment: what the table modes cost the others */
+#define CMI_UNLIKELY(c) (false && (c))
+#else
 #define CMI_UNLIKELY(c) __builtin_expect(!!(c), 0)
+#endif
 
 /* Row `row` of a table at abscissa x: Utilities::locate's interval
  * (src/Utilities.hpp:726-742), linear interpolation in (x, y) or in

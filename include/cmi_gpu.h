@@ -626,7 +626,12 @@ int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);
  *                           destinations but skip the walk, 3 = walk without
  *                           the adds, 4 = as 2 without the table look-up,
  *                           5 = as 2 without the periodic write-backs,
- *                           6 = a quarter of the table adds */
+ *                           6 = a quarter of the table adds
+ * A host that cannot call this (the cmi-gpu executable, a code that links
+ * the library mode) sets the environment variable
+ * CMI_GPU_TUNING="key=value,key=value": cmi_gpu_create applies it to every
+ * engine it makes (an unknown key makes it fail). For experiments and
+ * bisections, not for configuration. */
 int cmi_gpu_set_tuning(cmi_gpu_engine *engine, const char *key, int64_t value);
 
 /* ------------------------------------------------- several GPUs, one host -- */

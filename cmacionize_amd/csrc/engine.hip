@@ -162,7 +162,12 @@ struct cmi_gpu_engine {
     bool exact_dda = false;
     bool reemit_passes = true;
     int refill_threshold_reemit = 32;
-    uint64_t reemit_inline_below = 4096;
+    /* -1: 4096 on a whole grid; 262144 on a block of a decomposed grid, whose
+     * hand-over rounds are many launches of few flights - each costs the
+     * latency of its longest flight - (measured on config 5's workload on one
+     * GPU, a device per block: 4096 / 32768 / 262144 / 2e6 -> 52 / 47 / 44 /
+     * 49 ms per iteration; the blocks' calls in series 360 -> 325 ms) */
+    int64_t reemit_inline_below = -1;
     int reemit_max_passes = 12;
     /* later generations in tile rounds (tile_kernels.h) instead of passes of
      * the transport kernel; below tile_min_flights flights the transport
@@ -1593,7 +1598,7 @@ int cmi_gpu_set_tuning(cmi_gpu_engine *e, const char *key, int64_t value) {
     e->tune.refill_threshold_reemit =
         (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
   else if (k == "reemit_inline_below")
-    e->tune.reemit_inline_below = (uint64_t)(value < 0 ? 0 : value);
+    e->tune.reemit_inline_below = value < 0 ? -1 : value;
   else if (k == "reemit_max_passes")
     e->tune.reemit_max_passes = (int)(value < 1 ? 1 : value);
   else if (k == "timing")
@@ -1861,6 +1866,12 @@ static bool block_emits_nothing(const cmi_gpu_engine *e) {
   return e->model.nsource > 0;
 }
 
+static uint64_t reemit_inline_below(const cmi_gpu_engine *e) {
+  if (e->tune.reemit_inline_below >= 0)
+    return (uint64_t)e->tune.reemit_inline_below;
+  return e->grid.decomposed ? 262144u : 4096u;
+}
+
 static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
                       uint64_t first_packet, uint64_t n_packets,
                       const double *flights) {
@@ -1919,7 +1930,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
    * each cost the latency of the longest flight, ~1 ms, whatever their
    * number) */
   const bool passes = reemit && e->tune.reemit_passes &&
-                      !(flights && n_packets < e->tune.reemit_inline_below);
+                      !(flights && n_packets < reemit_inline_below(e));
   void (*kernel)(const ShootArgs) = nullptr;
   void (*kernel_inline)(const ShootArgs) = nullptr;
 #define PICK(F, H, X)                                                          \
@@ -2619,7 +2630,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
     if (handover_count != 0) {
       /* pass 0 of the tail: the flights resume from their slots, absorbed
        * ones are parked for the interaction kernel as in every pass */
-      const bool last = handover_count < e->tune.reemit_inline_below;
+      const bool last = handover_count < reemit_inline_below(e);
       ShootArgs b = a;
       b.park_in_place = 0;
       b.order = nullptr;
@@ -2698,7 +2709,7 @@ static int shoot_impl(cmi_gpu_engine *e, uint32_t seed, uint32_t iteration,
       }
       if (count == 0)
         break;
-      const bool last = count < e->tune.reemit_inline_below ||
+      const bool last = count < reemit_inline_below(e) ||
                         gen + 2 >= e->tune.reemit_max_passes;
       ShootArgs b = a;
       b.park_in_place = 0;

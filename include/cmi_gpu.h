@@ -545,7 +545,7 @@ int cmi_gpu_get_tracker_counts(cmi_gpu_engine *engine, uint64_t *counts);
  *                           (keeps the primary ray bundles together and the
  *                           transport kernel small); 0 = follow re-emissions
  *                           in place
- *   "refill_threshold_reemit" (32), "reemit_inline_below" (4096),
+ *   "refill_threshold_reemit" (32), "reemit_inline_below" (-1 = auto: 4096, on a block of a decomposed grid 262144),
  *   "reemit_max_passes" (12)  refill threshold of the later passes; a pass
  *                           with fewer packets than this, or the last allowed
  *                           pass, follows re-emissions in place

@@ -195,7 +195,7 @@ int main(int argc, char **argv) {
       std::cerr << "Unknown or unsupported option: " << a << "\n"
                 << "usage: cmi-gpu --params FILE [--threads N] [--device N] "
                    "[--blocks BX,BY,BZ] [--devices D0,D1,...] [--copies K] "
-                   "[--every-iteration-output] [--output-statistics] "
+                   "[--task-based] [--every-iteration-output] [--output-statistics] "
                    "[--dry-run] [--dry-run-snapshot] [--describe] [--verbose]\n"
                    "       cmi-gpu --emission --params FILE --file "
                    "SNAPSHOT.hdf5 [--device N]\n";

@@ -2794,8 +2794,11 @@ order_by_verner_class(const uint32_t (&cls)[TRIPS], unsigned int n,
  * packets of a batch (direction, frequency, optical depth) into LDS, orders
  * them by the number of thresholds they lie above, and evaluates the fits in
  * that order - most waves then jump over most terms (cmi_cross_sections). */
+/* (batches of 2 / 4 / 8 x 256 packets: 13.3 / 11.9 / 11.2 ms per 1e8 packets of
+ * lexingtonHII40 - longer runs of one class; 3 / 2 / 4 waves per SIMD: 11.9 /
+ * 12.9 / 17.0; round 6) */
 #ifndef CMI_KEY_BATCH
-#define CMI_KEY_BATCH 4
+#define CMI_KEY_BATCH 8
 #endif
 __device__ __forceinline__ void
 direction_key_batches(const KeyArgs &a) {

@@ -19,7 +19,10 @@ The library's gfx950 code object is extracted (llvm-objcopy,
 clang-offload-bundler) and disassembled with branch targets as labels
 (llvm-objdump --symbolize-operands); every label whose block starts with
 scratch_store / scratch_load instructions followed by `s_or_b64 exec, exec`
-is reported. Exit status 1 if there is one.
+(the join) or `s_or_saveexec_b64` (the start of an else side: spill code of
+that block is right where the compiler normally puts it, between this
+instruction and the `s_xor_b64 exec` that narrows the mask again) is reported.
+Exit status 1 if there is one.
 
 usage: check_exec_spills.py path/to/libcmi_gpu.so"""
 import os
@@ -71,7 +74,12 @@ def scan(lines):
             if t.startswith(("s_waitcnt", "s_nop")):
                 j += 1
                 continue
-            if t.startswith("s_or_b64 exec, exec,") and pending:
+            # (the join of an if / else: s_or_b64 exec, exec, sN; the start of
+            # an else side: s_or_saveexec_b64 sA, sB - there the spill code of
+            # the block belongs BETWEEN it and the s_xor_b64 that narrows the
+            # mask to the else side, where all lanes of the if / else are on)
+            if t.startswith(("s_or_b64 exec, exec,", "s_or_saveexec_b64")) \
+                    and pending:
                 hits.append((function, m.group(1), pending, t))
             break
     return hits
